@@ -1,0 +1,184 @@
+/*
+ * flatgfa.h -- C ABI of the MI355X-native FlatGFA depth engine (libflatgfa.so).
+ *
+ * Part 1 is a drop-in for the reference's `flatgfa-c` crate (cucapra/pollen,
+ * flatgfa-c/src/lib.rs; its header is cbindgen-generated, flatgfa-c/build.rs:6-12):
+ * identical type names, function names, signatures, ownership and in-band error
+ * sentinels.  Part 2 is additive: the reference exposes its depth queries only
+ * as Rust functions (flatgfa/src/ops/depth.rs), so the entry points a binding
+ * for them would need are declared here, each citing the Rust item it replaces.
+ * Part 3 is the device-level surface used when the caller already owns HBM
+ * buffers (e.g. a torch tensor's data_ptr) and a HIP stream.
+ *
+ * All depth entry points run on the GPU through hand-written HIP kernels for
+ * gfx950.  There is no CPU fallback: without a usable HIP device they return
+ * FLATGFA_ERR_NO_DEVICE.
+ */
+#ifndef FLATGFA_H
+#define FLATGFA_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* libflatgfa.so is built with -fvisibility=hidden; only this header's functions are exported. */
+#pragma GCC visibility push(default)
+
+/* ------------------------------------------------------------------------ */
+/* Part 1 -- the flatgfa-c surface                                          */
+/* ------------------------------------------------------------------------ */
+
+/* flatgfa-c/src/lib.rs:16,31 -- opaque store, handed out as a raw pointer. */
+typedef struct CStore CStore;
+typedef CStore *flatgfa_t;
+
+/* flatgfa-c/src/lib.rs:36-40 -- borrowed, NOT NUL-terminated. */
+typedef struct flatgfa_string_t {
+    const uint8_t *data;
+    int len;
+} flatgfa_string_t;
+
+/* flatgfa-c/src/lib.rs:140-144 */
+typedef struct flatgfa_handle_t {
+    uint32_t segment_id;
+    bool is_forward;
+} flatgfa_handle_t;
+
+/* lib.rs:63 -- parse a GFA text file.  Where the reference aborts (missing or
+ * malformed file) this returns NULL and sets flatgfa_last_error(). */
+flatgfa_t flatgfa_parse(const char *filename);
+/* lib.rs:72 -- NULL-safe; also releases any device buffers the handle owns. */
+void flatgfa_free(flatgfa_t gfa);
+/* lib.rs:80 */
+uint32_t flatgfa_get_segment_count(flatgfa_t gfa);
+/* lib.rs:92 -- {NULL,0} when segment_id is out of range. */
+flatgfa_string_t flatgfa_get_seq(flatgfa_t gfa, uint32_t segment_id);
+/* lib.rs:105 */
+uint32_t flatgfa_path_count(flatgfa_t gfa);
+/* lib.rs:118 -- {NULL,0} when path_index is out of range. */
+flatgfa_string_t flatgfa_get_path_name(flatgfa_t gfa, uint32_t path_index);
+/* lib.rs:130 -- UINT32_MAX when path_index is out of range. */
+uint32_t flatgfa_get_path_step_count(flatgfa_t gfa, uint32_t path_index);
+/* lib.rs:149-154 -- false when either index is out of range. */
+bool flatgfa_get_step(flatgfa_t gfa, uintptr_t path_index, uintptr_t step_index, flatgfa_handle_t *out);
+
+/* ------------------------------------------------------------------------ */
+/* Part 2 -- additive: loaders, writers, and the depth queries              */
+/* ------------------------------------------------------------------------ */
+
+enum {
+    FLATGFA_OK = 0,
+    FLATGFA_ERR_ARG = -1,       /* NULL handle / bad argument */
+    FLATGFA_ERR_BOUNDS = -2,    /* a span or segment id is out of range (the reference panics) */
+    FLATGFA_ERR_NO_DEVICE = -3, /* no usable HIP device; there is no CPU fallback */
+    FLATGFA_ERR_HIP = -4,       /* a HIP runtime call failed; see flatgfa_last_error() */
+    FLATGFA_ERR_IO = -5,
+    FLATGFA_ERR_TOO_LARGE = -6  /* more than 2^32-1 steps */
+};
+
+/* Thread-local description of the last failure in this thread ("" if none). */
+const char *flatgfa_last_error(void);
+
+/* Parser::parse_mem on a caller buffer (flatgfa/src/parse.rs:77; flatgfa-py/src/lib.rs parse_bytes). */
+flatgfa_t flatgfa_parse_bytes(const uint8_t *data, size_t len);
+/* Parser::parse_stream semantics (parse.rs:24-74; what `fgfa` uses for stdin, cli/main.rs:110-113):
+ * an unterminated last line is kept and links are added before paths. */
+flatgfa_t flatgfa_parse_stream_bytes(const uint8_t *data, size_t len);
+/* file::view on a memory-mapped `.flatgfa` file, zero-copy (flatgfa/src/file.rs:185; cli/main.rs:99-100). */
+flatgfa_t flatgfa_load(const char *flatgfa_filename);
+/* file::dump (flatgfa/src/file.rs:290; cli/main.rs:197-201). */
+int flatgfa_write_flatgfa(flatgfa_t gfa, const char *filename);
+/* GFA text (flatgfa/src/print.rs:99-153).  *text is malloc'd; release with flatgfa_free_text. */
+int flatgfa_print_gfa(flatgfa_t gfa, char **text, size_t *len);
+void flatgfa_free_text(char *text);
+/* Deterministic synthetic graph; model 0 = pangenome walk, 1 = uniform. */
+flatgfa_t flatgfa_synth(uint64_t seed, uint32_t n_segs, uint32_t n_paths, uint32_t steps_per_path, int model,
+                        bool with_seq);
+
+/* Raw pool access in `.flatgfa` order (file.rs:14-27): 0 header, 1 segs, 2 paths, 3 links,
+ * 4 steps, 5 seq_data, 6 overlaps, 7 alignment, 8 name_data, 9 optional_data, 10 line_order.
+ * *data borrows from the handle and may be unaligned (the reference's PODs are repr(packed)). */
+int flatgfa_pool(flatgfa_t gfa, int pool_index, const void **data, uint64_t *len, uint64_t *elem_size);
+/* FlatGFA::find_path (flatgfa.rs:387): first path with this name, or -1. */
+int64_t flatgfa_find_path(flatgfa_t gfa, const uint8_t *name, size_t len);
+
+/* Number of visible HIP devices (0 if none). */
+int flatgfa_device_count(void);
+/* Copy the graph's structure-of-arrays image (steps, path spans, segment lengths) into the
+ * HBM of `device` and keep it resident until flatgfa_free.  Depth calls do this lazily on
+ * device 0 if it has not been done. */
+int flatgfa_to_device(flatgfa_t gfa, int device);
+
+/* seg_depth_with_uniq (ops/depth.rs:15-39) when uniq_out != NULL, seg_depth (depth.rs:45-56)
+ * when it is NULL.  Outputs are indexed by segment id, one uint64_t (Rust usize) each. */
+int flatgfa_seg_depth(flatgfa_t gfa, uint64_t *depth_out, uint64_t *uniq_out);
+/* path_depth + measure_path (ops/depth.rs:88-131) for the given path ids, in order. */
+int flatgfa_path_depth(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, uint64_t *length_out,
+                       double *mean_depth_out);
+/* The bytes `fgfa depth -d` prints: SegDepth::emit (ops/depth.rs:67-82; cli/cmds.rs:237-245). */
+int flatgfa_depth_table(flatgfa_t gfa, char **text, size_t *len);
+/* The bytes `fgfa depth [-r NAME]...` prints: PathDepth::emit (ops/depth.rs:143-160;
+ * cli/cmds.rs:256-284).  path_ids == NULL means all paths, in order. */
+int flatgfa_path_depth_table(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, char **text, size_t *len);
+/* format_float (ops/depth.rs:192-197); returns bytes written (no NUL). */
+int flatgfa_format_float(double x, int digits, char *out, int cap);
+
+/* ------------------------------------------------------------------------ */
+/* Part 3 -- device-level entry points (caller-owned HBM buffers)           */
+/* ------------------------------------------------------------------------ */
+
+/* The graph image the kernels read, all pointers in device memory:
+ *   steps       u32[n_steps]   Handle bits, (segment << 1) | orient   (flatgfa.rs:186-209)
+ *   path_begin  u32[n_paths]   Path.steps.start                        (flatgfa.rs:106)
+ *   path_end    u32[n_paths]   Path.steps.end
+ *   seg_len     u32[n_segs]    Segment::len() = seq.end - seq.start    (flatgfa.rs:86-88); may be
+ *                              NULL for node depth                                              */
+typedef struct flatgfa_dev_graph_t {
+    const uint32_t *steps;
+    uint64_t n_steps;
+    const uint32_t *path_begin;
+    const uint32_t *path_end;
+    uint32_t n_paths;
+    uint32_t n_segs;
+    const uint32_t *seg_len;
+} flatgfa_dev_graph_t;
+
+/* A prepared depth query over one resident graph image: owns the launch plan (how paths are cut
+ * into work items) and the scratch HBM the kernels need, on the device that is current when it
+ * is created.  `host_path_begin/host_path_end` are host copies of the span arrays (P entries each);
+ * pass NULL to have them copied back from the device.  Returns NULL on failure
+ * (flatgfa_last_error()); spans that are reversed or exceed n_steps are rejected here, where the
+ * reference would panic on the slice index (pool.rs:341-347). */
+typedef struct flatgfa_dev_plan flatgfa_dev_plan_t;
+flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t *g, const uint32_t *host_path_begin,
+                                            const uint32_t *host_path_end);
+void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *plan);
+
+/* Node depth on device: seg_depth_with_uniq (ops/depth.rs:15-39) when uniq_out != NULL, seg_depth
+ * (depth.rs:45-56) when NULL.  depth_out / uniq_out are u32[n_segs] in device memory.  Enqueues on
+ * `stream` (a hipStream_t; NULL = the default stream) and returns without synchronizing. */
+int flatgfa_dev_seg_depth(flatgfa_dev_plan_t *plan, uint32_t *depth_out, uint32_t *uniq_out, void *stream);
+/* Per-path sums on device given depth u32[n_segs] (measure_path, ops/depth.rs:116-131):
+ * length_out[k] = sum seg_len, weighted_out[k] = sum depth*seg_len over the steps of path
+ * path_ids[k] (u32[n_ids], device memory), both u64 wrapping like Rust usize.  The single f64
+ * division per path is left to the host. */
+int flatgfa_dev_path_sums(flatgfa_dev_plan_t *plan, const uint32_t *path_ids, uint32_t n_ids, const uint32_t *depth,
+                          uint64_t *length_out, uint64_t *weighted_out, void *stream);
+/* Synchronizes `stream`, then returns FLATGFA_OK, or FLATGFA_ERR_BOUNDS if any kernel since the
+ * last call saw a segment id >= n_segs or a path id >= n_paths. */
+int flatgfa_dev_status(flatgfa_dev_plan_t *plan, void *stream);
+
+/* Kernel-level timing for bench.py: when enabled, every kernel the library launches is bracketed
+ * by HIP events on its own stream; flatgfa_dev_profile_read synchronizes and returns, for up to
+ * `cap` kernels since the last read, the kernel name and elapsed milliseconds. */
+void flatgfa_dev_profile_enable(int on);
+int flatgfa_dev_profile_read(const char **names, float *ms, int cap);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLATGFA_H */

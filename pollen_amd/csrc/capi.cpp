@@ -1,0 +1,353 @@
+// extern "C" surface of libflatgfa.so: the flatgfa-c drop-in (Part 1 of include/flatgfa.h)
+// plus the additive loaders and depth queries (Part 2).  Device work is delegated to the
+// flatgfa_dev_* entry points in depth_device.hip through the HIP runtime API only.
+#include <hip/hip_runtime_api.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+
+#include "../../include/flatgfa.h"
+#include "device_common.hpp"
+#include "flatgfa_core.hpp"
+
+using fgfa_dev::set_error;
+
+// The opaque store (flatgfa-c/src/lib.rs:16-28): either a heap store built by the parser /
+// generator, or a borrowed view of a memory-mapped .flatgfa file.
+struct CStore {
+    fgfa::Store heap;
+    std::unique_ptr<fgfa::MappedFile> file;
+    fgfa::View view;
+
+    // Resident device image (structure of arrays), created on first use.
+    std::mutex op_mu;   // one depth query at a time per handle
+    std::mutex dev_mu;
+    bool on_device = false;
+    int device = 0;
+    uint32_t *d_steps = nullptr, *d_path_begin = nullptr, *d_path_end = nullptr, *d_seg_len = nullptr;
+    uint32_t *d_depth = nullptr, *d_uniq = nullptr;
+    std::vector<uint32_t> h_path_begin, h_path_end;
+    flatgfa_dev_plan_t *plan = nullptr;
+    hipStream_t stream = nullptr;
+
+    ~CStore() {
+        if (plan) flatgfa_dev_plan_destroy(plan);
+        for (uint32_t *p : {d_steps, d_path_begin, d_path_end, d_seg_len, d_depth, d_uniq})
+            if (p) (void)hipFree(p);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+#define CAPI_HIP(expr)                                                                      \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+            return FLATGFA_ERR_HIP;                                                         \
+        }                                                                                   \
+    } while (0)
+
+extern "C" {
+
+const char *flatgfa_last_error(void) { return fgfa_dev::last_error(); }
+
+// ------------------------------------------------------------- Part 1 ---
+
+static flatgfa_t parse_common(const uint8_t *data, size_t len, bool stream_mode) {
+    auto cs = std::make_unique<CStore>();
+    std::string err;
+    if (!fgfa::parse_gfa(data ? data : (const uint8_t *)"", len, &cs->heap, &err, stream_mode)) {
+        set_error(err);
+        return nullptr;
+    }
+    cs->view = cs->heap.view();
+    return cs.release();
+}
+
+flatgfa_t flatgfa_parse_bytes(const uint8_t *data, size_t len) { return parse_common(data, len, false); }
+flatgfa_t flatgfa_parse_stream_bytes(const uint8_t *data, size_t len) { return parse_common(data, len, true); }
+
+flatgfa_t flatgfa_parse(const char *filename) {
+    if (!filename) { set_error("flatgfa_parse: NULL filename"); return nullptr; }
+    fgfa::MappedFile f;
+    std::string err;
+    if (!f.open(filename, &err)) { set_error(err); return nullptr; }
+    return flatgfa_parse_bytes(f.data, f.size);
+}
+
+flatgfa_t flatgfa_load(const char *filename) {
+    if (!filename) { set_error("flatgfa_load: NULL filename"); return nullptr; }
+    auto cs = std::make_unique<CStore>();
+    cs->file = std::make_unique<fgfa::MappedFile>();
+    std::string err;
+    if (!cs->file->open(filename, &err) || !fgfa::view_flatgfa(cs->file->data, cs->file->size, &cs->view, &err)) {
+        set_error(err);
+        return nullptr;
+    }
+    return cs.release();
+}
+
+flatgfa_t flatgfa_synth(uint64_t seed, uint32_t n_segs, uint32_t n_paths, uint32_t steps_per_path, int model,
+                        bool with_seq) {
+    if (n_segs == 0 || (model != 0 && model != 1) || (uint64_t)n_paths * steps_per_path > 0xFFFFFFFFull ||
+        n_segs > 0x7FFFFFFFu) {
+        set_error("flatgfa_synth: bad shape");
+        return nullptr;
+    }
+    auto cs = std::make_unique<CStore>();
+    fgfa::synth_store(seed, n_segs, n_paths, steps_per_path, model, with_seq, &cs->heap);
+    cs->view = cs->heap.view();
+    return cs.release();
+}
+
+void flatgfa_free(flatgfa_t gfa) { delete gfa; }
+
+uint32_t flatgfa_get_segment_count(flatgfa_t gfa) { return (uint32_t)gfa->view.segs.len; }
+
+flatgfa_string_t flatgfa_get_seq(flatgfa_t gfa, uint32_t segment_id) {
+    flatgfa_string_t s{nullptr, 0};
+    const fgfa::View &v = gfa->view;
+    if (segment_id >= v.segs.len) return s;
+    fgfa::Span sp = v.segs[segment_id].seq;
+    s.data = v.seq_data.data + sp.start;
+    s.len = (int)sp.len();
+    return s;
+}
+
+uint32_t flatgfa_path_count(flatgfa_t gfa) { return (uint32_t)gfa->view.paths.len; }
+
+flatgfa_string_t flatgfa_get_path_name(flatgfa_t gfa, uint32_t path_index) {
+    flatgfa_string_t s{nullptr, 0};
+    const fgfa::View &v = gfa->view;
+    if (path_index >= v.paths.len) return s;
+    fgfa::Span sp = v.paths[path_index].name;
+    s.data = v.name_data.data + sp.start;
+    s.len = (int)sp.len();
+    return s;
+}
+
+uint32_t flatgfa_get_path_step_count(flatgfa_t gfa, uint32_t path_index) {
+    const fgfa::View &v = gfa->view;
+    if (path_index >= v.paths.len) return UINT32_MAX;
+    return v.paths[path_index].steps.len();
+}
+
+bool flatgfa_get_step(flatgfa_t gfa, uintptr_t path_index, uintptr_t step_index, flatgfa_handle_t *out) {
+    const fgfa::View &v = gfa->view;
+    if (path_index >= v.paths.len) return false;
+    fgfa::Span sp = v.paths[path_index].steps;
+    if (step_index >= sp.len()) return false;
+    fgfa::Handle h = v.steps[sp.start + step_index];
+    out->segment_id = h.segment();
+    out->is_forward = h.is_forward();
+    return true;
+}
+
+// ------------------------------------------------------------- Part 2 ---
+
+int flatgfa_pool(flatgfa_t gfa, int ix, const void **data, uint64_t *len, uint64_t *elem_size) {
+    if (!gfa || ix < 0 || ix > 10) { set_error("flatgfa_pool: bad argument"); return FLATGFA_ERR_ARG; }
+    if (data) *data = gfa->view.pool_data(ix);
+    if (len) *len = gfa->view.pool_len(ix);
+    if (elem_size) *elem_size = fgfa::kPoolElemSize[ix];
+    return FLATGFA_OK;
+}
+
+int64_t flatgfa_find_path(flatgfa_t gfa, const uint8_t *name, size_t len) {
+    if (!gfa) return -1;
+    return gfa->view.find_path(name, len);
+}
+
+int flatgfa_write_flatgfa(flatgfa_t gfa, const char *filename) {
+    if (!gfa || !filename) { set_error("flatgfa_write_flatgfa: NULL argument"); return FLATGFA_ERR_ARG; }
+    size_t n = fgfa::flatgfa_file_size(gfa->view);
+    std::vector<uint8_t> buf(n);
+    fgfa::dump_flatgfa(gfa->view, buf.data());
+    FILE *f = fopen(filename, "wb");
+    if (!f) { set_error(std::string("cannot create ") + filename); return FLATGFA_ERR_IO; }
+    size_t w = fwrite(buf.data(), 1, n, f);
+    if (fclose(f) != 0 || w != n) { set_error(std::string("short write to ") + filename); return FLATGFA_ERR_IO; }
+    return FLATGFA_OK;
+}
+
+static int give_text(const std::string &s, char **text, size_t *len) {
+    char *p = (char *)malloc(s.size() + 1);
+    if (!p) { set_error("out of memory"); return FLATGFA_ERR_IO; }
+    memcpy(p, s.data(), s.size());
+    p[s.size()] = 0;
+    *text = p;
+    if (len) *len = s.size();
+    return FLATGFA_OK;
+}
+
+int flatgfa_print_gfa(flatgfa_t gfa, char **text, size_t *len) {
+    if (!gfa || !text) { set_error("flatgfa_print_gfa: NULL argument"); return FLATGFA_ERR_ARG; }
+    std::string out, err;
+    if (!fgfa::print_gfa(gfa->view, &out, &err)) { set_error(err); return FLATGFA_ERR_BOUNDS; }
+    return give_text(out, text, len);
+}
+
+void flatgfa_free_text(char *text) { free(text); }
+
+int flatgfa_format_float(double x, int digits, char *out, int cap) {
+    std::string s = fgfa::format_float(x, digits);
+    int n = (int)std::min<size_t>(s.size(), cap > 0 ? (size_t)cap : 0);
+    memcpy(out, s.data(), (size_t)n);
+    return n;
+}
+
+// ---- device residency ----
+
+static int ensure_device(CStore *cs, int device) {
+    std::lock_guard<std::mutex> lk(cs->dev_mu);
+    if (cs->on_device) {
+        if (device >= 0 && device != cs->device) { set_error("graph is already resident on another device"); return FLATGFA_ERR_ARG; }
+        CAPI_HIP(hipSetDevice(cs->device));
+        return FLATGFA_OK;
+    }
+    if (device < 0) device = 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device is visible; the depth queries have no CPU fallback");
+        return FLATGFA_ERR_NO_DEVICE;
+    }
+    if (device >= ndev) { set_error("device index out of range"); return FLATGFA_ERR_ARG; }
+    const fgfa::View &v = cs->view;
+    if (v.steps.len > 0xFFFFFFFFull || v.segs.len > 0x80000000ull || v.paths.len > 0xFFFFFFFFull) {
+        set_error("graph too large for 32-bit ids");
+        return FLATGFA_ERR_TOO_LARGE;
+    }
+    CAPI_HIP(hipSetDevice(device));
+    cs->device = device;
+    CAPI_HIP(hipStreamCreateWithFlags(&cs->stream, hipStreamNonBlocking));
+    const size_t N = v.steps.len, P = v.paths.len, S = v.segs.len;
+    // AoS (packed, align-1) -> SoA.  Byte copies only: the file regions may be unaligned.
+    cs->h_path_begin.resize(P);
+    cs->h_path_end.resize(P);
+    for (size_t i = 0; i < P; ++i) {
+        cs->h_path_begin[i] = v.paths[i].steps.start;
+        cs->h_path_end[i] = v.paths[i].steps.end;
+    }
+    std::vector<uint32_t> seg_len(S);
+    for (size_t i = 0; i < S; ++i) seg_len[i] = v.segs[i].seq.len();
+    if (N) {
+        CAPI_HIP(hipMalloc(&cs->d_steps, N * 4));
+        CAPI_HIP(hipMemcpy(cs->d_steps, v.steps.data, N * 4, hipMemcpyHostToDevice));
+    }
+    if (P) {
+        CAPI_HIP(hipMalloc(&cs->d_path_begin, P * 4));
+        CAPI_HIP(hipMalloc(&cs->d_path_end, P * 4));
+        CAPI_HIP(hipMemcpy(cs->d_path_begin, cs->h_path_begin.data(), P * 4, hipMemcpyHostToDevice));
+        CAPI_HIP(hipMemcpy(cs->d_path_end, cs->h_path_end.data(), P * 4, hipMemcpyHostToDevice));
+    }
+    if (S) {
+        CAPI_HIP(hipMalloc(&cs->d_seg_len, S * 4));
+        CAPI_HIP(hipMemcpy(cs->d_seg_len, seg_len.data(), S * 4, hipMemcpyHostToDevice));
+        CAPI_HIP(hipMalloc(&cs->d_depth, S * 4));
+        CAPI_HIP(hipMalloc(&cs->d_uniq, S * 4));
+    }
+    flatgfa_dev_graph_t g{cs->d_steps, (uint64_t)N, cs->d_path_begin, cs->d_path_end, (uint32_t)P, (uint32_t)S, cs->d_seg_len};
+    cs->plan = flatgfa_dev_plan_create(&g, cs->h_path_begin.data(), cs->h_path_end.data());
+    if (!cs->plan) return FLATGFA_ERR_BOUNDS;
+    cs->on_device = true;
+    return FLATGFA_OK;
+}
+
+int flatgfa_to_device(flatgfa_t gfa, int device) {
+    if (!gfa) { set_error("flatgfa_to_device: NULL handle"); return FLATGFA_ERR_ARG; }
+    return ensure_device(gfa, device);
+}
+
+// Runs the node-depth kernels and leaves u32 results in cs->d_depth / cs->d_uniq.
+static int run_seg_depth(CStore *cs, bool want_uniq) {
+    int rc = ensure_device(cs, -1);
+    if (rc) return rc;
+    rc = flatgfa_dev_seg_depth(cs->plan, cs->d_depth, want_uniq ? cs->d_uniq : nullptr, cs->stream);
+    if (rc) return rc;
+    return flatgfa_dev_status(cs->plan, cs->stream);
+}
+
+static int fetch_widen(CStore *cs, const uint32_t *dev, uint64_t *out) {
+    const size_t S = cs->view.segs.len;
+    std::vector<uint32_t> tmp(S);
+    if (S) CAPI_HIP(hipMemcpy(tmp.data(), dev, S * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < S; ++i) out[i] = tmp[i];  // Vec<usize>
+    return FLATGFA_OK;
+}
+
+int flatgfa_seg_depth(flatgfa_t gfa, uint64_t *depth_out, uint64_t *uniq_out) {
+    if (!gfa || (!depth_out && gfa->view.segs.len)) { set_error("flatgfa_seg_depth: NULL argument"); return FLATGFA_ERR_ARG; }
+    std::lock_guard<std::mutex> op(gfa->op_mu);
+    int rc = run_seg_depth(gfa, uniq_out != nullptr);
+    if (rc) return rc;
+    rc = fetch_widen(gfa, gfa->d_depth, depth_out);
+    if (rc == FLATGFA_OK && uniq_out) rc = fetch_widen(gfa, gfa->d_uniq, uniq_out);
+    return rc;
+}
+
+int flatgfa_path_depth(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, uint64_t *length_out,
+                       double *mean_out) {
+    if (!gfa || (n_ids && (!path_ids || !length_out || !mean_out))) {
+        set_error("flatgfa_path_depth: NULL argument");
+        return FLATGFA_ERR_ARG;
+    }
+    for (uint32_t k = 0; k < n_ids; ++k)
+        if (path_ids[k] >= gfa->view.paths.len) { set_error("flatgfa_path_depth: path id out of range"); return FLATGFA_ERR_BOUNDS; }
+    // pass 1 over ALL paths (depth.rs:94-99), pass 2 over the requested ones (:104-108)
+    std::lock_guard<std::mutex> op(gfa->op_mu);
+    int rc = run_seg_depth(gfa, false);
+    if (rc || n_ids == 0) return rc;
+    uint32_t *d_ids = nullptr;
+    uint64_t *d_sums = nullptr;
+    CAPI_HIP(hipMalloc(&d_ids, (size_t)n_ids * 4));
+    hipError_t e = hipMalloc(&d_sums, (size_t)n_ids * 16);
+    if (e != hipSuccess) { (void)hipFree(d_ids); set_error("hipMalloc failed"); return FLATGFA_ERR_HIP; }
+    std::vector<uint64_t> sums((size_t)n_ids * 2);
+    rc = FLATGFA_OK;
+    if (hipMemcpyAsync(d_ids, path_ids, (size_t)n_ids * 4, hipMemcpyHostToDevice, gfa->stream) != hipSuccess) rc = FLATGFA_ERR_HIP;
+    if (!rc) rc = flatgfa_dev_path_sums(gfa->plan, d_ids, n_ids, gfa->d_depth, d_sums, d_sums + n_ids, gfa->stream);
+    if (!rc) rc = flatgfa_dev_status(gfa->plan, gfa->stream);
+    if (!rc && hipMemcpy(sums.data(), d_sums, (size_t)n_ids * 16, hipMemcpyDeviceToHost) != hipSuccess) rc = FLATGFA_ERR_HIP;
+    (void)hipFree(d_ids);
+    (void)hipFree(d_sums);
+    if (rc) return rc;
+    for (uint32_t k = 0; k < n_ids; ++k) {
+        length_out[k] = sums[k];
+        // the one floating-point operation on this path: depth.rs:129
+        mean_out[k] = (double)sums[n_ids + k] / (double)sums[k];
+    }
+    return FLATGFA_OK;
+}
+
+int flatgfa_depth_table(flatgfa_t gfa, char **text, size_t *len) {
+    if (!gfa || !text) { set_error("flatgfa_depth_table: NULL argument"); return FLATGFA_ERR_ARG; }
+    const size_t S = gfa->view.segs.len;
+    std::vector<uint64_t> d(S), u(S);
+    int rc = flatgfa_seg_depth(gfa, d.data(), u.data());
+    if (rc) return rc;
+    std::string out;
+    fgfa::emit_seg_depth(gfa->view, d.data(), u.data(), &out);
+    return give_text(out, text, len);
+}
+
+int flatgfa_path_depth_table(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, char **text, size_t *len) {
+    if (!gfa || !text) { set_error("flatgfa_path_depth_table: NULL argument"); return FLATGFA_ERR_ARG; }
+    std::vector<uint32_t> all;
+    if (!path_ids) {
+        all.resize(gfa->view.paths.len);
+        for (size_t i = 0; i < all.size(); ++i) all[i] = (uint32_t)i;
+        path_ids = all.data();
+        n_ids = (uint32_t)all.size();
+    }
+    std::vector<uint64_t> lens(n_ids);
+    std::vector<double> means(n_ids);
+    int rc = flatgfa_path_depth(gfa, path_ids, n_ids, lens.data(), means.data());
+    if (rc) return rc;
+    std::string out;
+    fgfa::emit_path_depth(gfa->view, path_ids, n_ids, lens.data(), means.data(), &out);
+    return give_text(out, text, len);
+}
+
+}  // extern "C"

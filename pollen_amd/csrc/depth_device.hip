@@ -1,0 +1,359 @@
+// HIP kernels + device-level C ABI for the FlatGFA depth queries on gfx950.
+//
+// Reference semantics (cucapra/pollen flatgfa/src/ops/depth.rs):
+//   depth[s] = number of steps, over all paths, whose handle's segment is s   (:25-29, :48-53)
+//   uniq[s]  = number of path entries that touch s at least once              (:30-34)
+//   path sums: length = sum seg_len, weighted = sum depth*seg_len per path    (:116-131)
+// All integer; results are order-independent sums, so they are bit-exact by construction.
+//
+// Data layout in HBM (structure of arrays): steps u32[N] (Handle bits), path_begin/path_end
+// u32[P], seg_len u32[S].  See DESIGN.md for the kernel-by-kernel roofline accounting.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/flatgfa.h"
+#include "device_common.hpp"
+
+namespace fgfa_dev {
+
+thread_local std::string g_last_error;
+void set_error(const std::string &s) { g_last_error = s; }
+const char *last_error() { return g_last_error.c_str(); }
+
+// ------------------------------------------------------------ profiling ---
+
+struct ProfRec {
+    const char *name;
+    hipEvent_t a, b;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+    hipStream_t s;
+    bool on;
+    ProfRec r;
+    ProfScope(const char *name, hipStream_t stream) : s(stream), on(g_prof_on) {
+        if (on) {
+            r.name = name;
+            (void)hipEventCreate(&r.a);
+            (void)hipEventCreate(&r.b);
+            (void)hipEventRecord(r.a, s);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(r.b, s);
+            std::lock_guard<std::mutex> lk(g_prof_mu);
+            g_prof.push_back(r);
+        }
+    }
+};
+
+// -------------------------------------------------------------- kernels ---
+
+// One work item = a contiguous piece [begin, end) of one path's step span.
+struct WorkItem {
+    uint32_t begin, end, path, flags;
+};
+
+constexpr int kScanThreads = 256;
+constexpr uint32_t kScanPiece = 16384;  // steps per work item of the flat depth scan
+
+// depth only (seg_depth, depth.rs:45-56): coalesced 4-byte step loads, one global atomic per step.
+__global__ __launch_bounds__(kScanThreads) void k_depth_scan(const uint32_t *__restrict__ steps,
+                                                              const WorkItem *__restrict__ items, uint32_t n_items,
+                                                              uint32_t n_segs, uint32_t *__restrict__ depth,
+                                                              uint32_t *__restrict__ status) {
+    for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const WorkItem w = items[it];
+        for (uint64_t i = (uint64_t)w.begin + threadIdx.x; i < w.end; i += kScanThreads) {
+            uint32_t seg = steps[i] >> 1;
+            if (seg < n_segs) atomicAdd(&depth[seg], 1u);
+            else *status = 1u;
+        }
+    }
+}
+
+// depth + uniq, one workgroup per (path, segment window): the path's "seen" bitset of
+// depth.rs:23-34 lives in LDS (one bit per segment of the window); a step whose bit was clear
+// bumps uniq.  Window 0 also accumulates depth.
+constexpr int kUniqThreads = 1024;
+constexpr uint32_t kWinWords = 32768;           // 128 KiB of LDS = 1,048,576 segments per window
+constexpr uint32_t kWinBits = kWinWords * 32u;
+
+__global__ __launch_bounds__(kUniqThreads) void k_depth_uniq_path(const uint32_t *__restrict__ steps,
+                                                                   const uint32_t *__restrict__ path_begin,
+                                                                   const uint32_t *__restrict__ path_end,
+                                                                   uint32_t n_paths, uint32_t n_segs,
+                                                                   uint32_t n_windows, uint32_t *__restrict__ depth,
+                                                                   uint32_t *__restrict__ uniq,
+                                                                   uint32_t *__restrict__ status) {
+    extern __shared__ uint32_t seen[];
+    const uint64_t total = (uint64_t)n_paths * n_windows;
+    for (uint64_t job = blockIdx.x; job < total; job += gridDim.x) {
+        const uint32_t p = (uint32_t)(job / n_windows);
+        const uint32_t win = (uint32_t)(job % n_windows);
+        const uint32_t lo = win * kWinBits;
+        const uint32_t nbits = min(kWinBits, n_segs - lo);
+        const uint32_t nwords = (nbits + 31u) >> 5;
+        for (uint32_t w = threadIdx.x; w < nwords; w += kUniqThreads) seen[w] = 0u;
+        __syncthreads();
+        const uint32_t b = path_begin[p], e = path_end[p];
+        for (uint64_t i = (uint64_t)b + threadIdx.x; i < e; i += kUniqThreads) {
+            const uint32_t seg = steps[i] >> 1;
+            if (seg >= n_segs) {
+                *status = 1u;
+                continue;
+            }
+            if (win == 0) atomicAdd(&depth[seg], 1u);
+            const uint32_t rel = seg - lo;  // wraps below the window; the compare rejects it
+            if (rel < nbits) {
+                const uint32_t bit = 1u << (rel & 31u);
+                const uint32_t old = atomicOr(&seen[rel >> 5], bit);
+                if (!(old & bit)) atomicAdd(&uniq[seg], 1u);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// measure_path (depth.rs:116-131): each block reduces one slice of one requested path.
+constexpr int kSumThreads = 256;
+
+__global__ __launch_bounds__(kSumThreads) void k_path_sums(const uint32_t *__restrict__ steps,
+                                                            const uint32_t *__restrict__ path_begin,
+                                                            const uint32_t *__restrict__ path_end, uint32_t n_paths,
+                                                            uint32_t n_segs, const uint32_t *__restrict__ seg_len,
+                                                            const uint32_t *__restrict__ path_ids, uint32_t n_ids,
+                                                            uint32_t split, const uint32_t *__restrict__ depth,
+                                                            unsigned long long *__restrict__ length_out,
+                                                            unsigned long long *__restrict__ weighted_out,
+                                                            uint32_t *__restrict__ status) {
+    __shared__ unsigned long long red[2][kSumThreads / 64];
+    const uint64_t total = (uint64_t)n_ids * split;
+    for (uint64_t job = blockIdx.x; job < total; job += gridDim.x) {
+        const uint32_t k = (uint32_t)(job / split), part = (uint32_t)(job % split);
+        const uint32_t p = path_ids[k];
+        unsigned long long len = 0, wsum = 0;
+        if (p < n_paths) {
+            const uint64_t b = path_begin[p], e = path_end[p];
+            const uint64_t n = e - b;
+            const uint64_t lo = b + n * part / split, hi = b + n * (part + 1) / split;
+            for (uint64_t i = lo + threadIdx.x; i < hi; i += kSumThreads) {
+                const uint32_t seg = steps[i] >> 1;
+                if (seg < n_segs) {
+                    const unsigned long long l = seg_len[seg];
+                    len += l;
+                    wsum += (unsigned long long)depth[seg] * l;
+                } else {
+                    *status = 1u;
+                }
+            }
+        } else if (threadIdx.x == 0 && part == 0) {
+            *status = 1u;
+        }
+        // wave64 shuffle reduction, then one LDS hop across the block's 4 waves
+        for (int off = 32; off > 0; off >>= 1) {
+            len += __shfl_down(len, off, 64);
+            wsum += __shfl_down(wsum, off, 64);
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) {
+            red[0][wave] = len;
+            red[1][wave] = wsum;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long a = 0, c = 0;
+            for (int w = 0; w < kSumThreads / 64; ++w) {
+                a += red[0][w];
+                c += red[1][w];
+            }
+            if (a) atomicAdd(&length_out[k], a);
+            if (c) atomicAdd(&weighted_out[k], c);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace fgfa_dev
+
+// ------------------------------------------------------------- the plan ---
+
+using namespace fgfa_dev;
+
+struct flatgfa_dev_plan {
+    flatgfa_dev_graph_t g;
+    int device = 0;
+    int n_cus = 256;
+    WorkItem *items = nullptr;  // flat-scan pieces
+    uint32_t n_items = 0;
+    uint32_t *status = nullptr;
+    uint32_t n_windows = 1;
+};
+
+#define HIP_TRY(expr, fail_stmt)                                                            \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+            fail_stmt;                                                                      \
+        }                                                                                   \
+    } while (0)
+
+extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t *g, const uint32_t *hb,
+                                                        const uint32_t *he) {
+    if (!g) { set_error("plan_create: NULL graph"); return nullptr; }
+    std::vector<uint32_t> cb, ce;
+    if (g->n_paths && (!hb || !he)) {
+        cb.resize(g->n_paths);
+        ce.resize(g->n_paths);
+        HIP_TRY(hipMemcpy(cb.data(), g->path_begin, (size_t)g->n_paths * 4, hipMemcpyDeviceToHost), return nullptr);
+        HIP_TRY(hipMemcpy(ce.data(), g->path_end, (size_t)g->n_paths * 4, hipMemcpyDeviceToHost), return nullptr);
+        hb = cb.data();
+        he = ce.data();
+    }
+    std::vector<WorkItem> items;
+    for (uint32_t p = 0; p < g->n_paths; ++p) {
+        if (hb[p] > he[p] || (uint64_t)he[p] > g->n_steps) {
+            set_error("plan_create: path " + std::to_string(p) + " has a step span outside the steps pool");
+            return nullptr;
+        }
+        for (uint64_t b = hb[p]; b < he[p]; b += kScanPiece)
+            items.push_back(WorkItem{(uint32_t)b, (uint32_t)std::min<uint64_t>(b + kScanPiece, he[p]), p, 0u});
+    }
+    auto *pl = new flatgfa_dev_plan();
+    pl->g = *g;
+    HIP_TRY(hipGetDevice(&pl->device), { delete pl; return nullptr; });
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, pl->device), { delete pl; return nullptr; });
+    pl->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    pl->n_items = (uint32_t)items.size();
+    pl->n_windows = g->n_segs ? (uint32_t)(((uint64_t)g->n_segs + kWinBits - 1) / kWinBits) : 1;
+    HIP_TRY(hipMalloc(&pl->status, 256), { delete pl; return nullptr; });
+    HIP_TRY(hipMemset(pl->status, 0, 256), { flatgfa_dev_plan_destroy(pl); return nullptr; });
+    if (!items.empty()) {
+        HIP_TRY(hipMalloc(&pl->items, items.size() * sizeof(WorkItem)), { flatgfa_dev_plan_destroy(pl); return nullptr; });
+        HIP_TRY(hipMemcpy(pl->items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice),
+                { flatgfa_dev_plan_destroy(pl); return nullptr; });
+    }
+    HIP_TRY(hipFuncSetAttribute((const void *)k_depth_uniq_path, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(kWinWords * 4)),
+            { flatgfa_dev_plan_destroy(pl); return nullptr; });
+    return pl;
+}
+
+extern "C" void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *pl) {
+    if (!pl) return;
+    if (pl->items) (void)hipFree(pl->items);
+    if (pl->status) (void)hipFree(pl->status);
+    delete pl;
+}
+
+extern "C" int flatgfa_dev_seg_depth(flatgfa_dev_plan_t *pl, uint32_t *depth_out, uint32_t *uniq_out, void *stream_) {
+    if (!pl || !depth_out) { set_error("dev_seg_depth: NULL argument"); return FLATGFA_ERR_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    const flatgfa_dev_graph_t &g = pl->g;
+    if (g.n_segs == 0) return FLATGFA_OK;
+    {
+        ProfScope ps("memset_outputs", stream);
+        HIP_TRY(hipMemsetAsync(depth_out, 0, (size_t)g.n_segs * 4, stream), return FLATGFA_ERR_HIP);
+        if (uniq_out) HIP_TRY(hipMemsetAsync(uniq_out, 0, (size_t)g.n_segs * 4, stream), return FLATGFA_ERR_HIP);
+    }
+    if (g.n_paths == 0 || pl->n_items == 0) return FLATGFA_OK;
+    if (!uniq_out) {
+        ProfScope ps("k_depth_scan", stream);
+        uint32_t grid = std::min<uint32_t>(pl->n_items, (uint32_t)pl->n_cus * 8u);
+        hipLaunchKernelGGL(k_depth_scan, dim3(grid), dim3(kScanThreads), 0, stream, g.steps, pl->items, pl->n_items,
+                           g.n_segs, depth_out, pl->status);
+    } else {
+        ProfScope ps("k_depth_uniq_path", stream);
+        uint64_t jobs = (uint64_t)g.n_paths * pl->n_windows;
+        uint32_t grid = (uint32_t)std::min<uint64_t>(jobs, (uint64_t)pl->n_cus * 64u);
+        hipLaunchKernelGGL(k_depth_uniq_path, dim3(grid), dim3(kUniqThreads), kWinWords * 4, stream, g.steps,
+                           g.path_begin, g.path_end, g.n_paths, g.n_segs, pl->n_windows, depth_out, uniq_out,
+                           pl->status);
+    }
+    HIP_TRY(hipGetLastError(), return FLATGFA_ERR_HIP);
+    return FLATGFA_OK;
+}
+
+extern "C" int flatgfa_dev_path_sums(flatgfa_dev_plan_t *pl, const uint32_t *path_ids, uint32_t n_ids,
+                                     const uint32_t *depth, uint64_t *length_out, uint64_t *weighted_out,
+                                     void *stream_) {
+    if (!pl || (n_ids && (!path_ids || !depth || !length_out || !weighted_out))) {
+        set_error("dev_path_sums: NULL argument");
+        return FLATGFA_ERR_ARG;
+    }
+    if (n_ids == 0) return FLATGFA_OK;
+    const flatgfa_dev_graph_t &g = pl->g;
+    if (!g.seg_len && g.n_segs) { set_error("dev_path_sums: graph image has no seg_len array"); return FLATGFA_ERR_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    {
+        ProfScope ps("memset_path_sums", stream);
+        HIP_TRY(hipMemsetAsync(length_out, 0, (size_t)n_ids * 8, stream), return FLATGFA_ERR_HIP);
+        HIP_TRY(hipMemsetAsync(weighted_out, 0, (size_t)n_ids * 8, stream), return FLATGFA_ERR_HIP);
+    }
+    uint32_t split = std::max<uint32_t>(1u, std::min<uint32_t>(64u, (uint32_t)(pl->n_cus * 16) / n_ids));
+    uint64_t jobs = (uint64_t)n_ids * split;
+    uint32_t grid = (uint32_t)std::min<uint64_t>(jobs, (uint64_t)pl->n_cus * 32u);
+    {
+        ProfScope ps("k_path_sums", stream);
+        hipLaunchKernelGGL(k_path_sums, dim3(grid), dim3(kSumThreads), 0, stream, g.steps, g.path_begin, g.path_end,
+                           g.n_paths, g.n_segs, g.seg_len, path_ids, n_ids, split, depth,
+                           (unsigned long long *)length_out, (unsigned long long *)weighted_out, pl->status);
+    }
+    HIP_TRY(hipGetLastError(), return FLATGFA_ERR_HIP);
+    return FLATGFA_OK;
+}
+
+extern "C" int flatgfa_dev_status(flatgfa_dev_plan_t *pl, void *stream_) {
+    if (!pl) return FLATGFA_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    uint32_t st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, pl->status, 4, hipMemcpyDeviceToHost, stream), return FLATGFA_ERR_HIP);
+    HIP_TRY(hipStreamSynchronize(stream), return FLATGFA_ERR_HIP);
+    if (st) {
+        HIP_TRY(hipMemsetAsync(pl->status, 0, 4, stream), return FLATGFA_ERR_HIP);
+        set_error("a step refers to a segment id (or a query to a path id) that is out of range");
+        return FLATGFA_ERR_BOUNDS;
+    }
+    return FLATGFA_OK;
+}
+
+extern "C" void flatgfa_dev_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+}
+
+extern "C" int flatgfa_dev_profile_read(const char **names, float *ms, int cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    int n = 0;
+    for (auto &r : g_prof) {
+        (void)hipEventSynchronize(r.b);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, r.a, r.b);
+        if (n < cap) {
+            names[n] = r.name;
+            ms[n] = t;
+            ++n;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+    return n;
+}
+
+extern "C" int flatgfa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}

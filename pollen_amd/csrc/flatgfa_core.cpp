@@ -1,0 +1,569 @@
+// Host-side FlatGFA: pools, GFA text parser, .flatgfa container, emitters.
+// See flatgfa_core.hpp for the reference citations.
+#include "flatgfa_core.hpp"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+
+namespace fgfa {
+
+const size_t kPoolElemSize[11] = {1, sizeof(Segment), sizeof(Path), sizeof(Link), sizeof(Handle), 1,
+                                  sizeof(Span), 4, 1, 1, 1};
+const char *const kPoolName[11] = {"header", "segs", "paths", "links", "steps", "seq_data",
+                                   "overlaps", "alignment", "name_data", "optional_data", "line_order"};
+
+size_t View::pool_len(int ix) const {
+    switch (ix) {
+        case pHeader: return header.len;
+        case pSegs: return segs.len;
+        case pPaths: return paths.len;
+        case pLinks: return links.len;
+        case pSteps: return steps.len;
+        case pSeqData: return seq_data.len;
+        case pOverlaps: return overlaps.len;
+        case pAlignment: return alignment.len;
+        case pNameData: return name_data.len;
+        case pOptionalData: return optional_data.len;
+        case pLineOrder: return line_order.len;
+    }
+    return 0;
+}
+
+const void *View::pool_data(int ix) const {
+    switch (ix) {
+        case pHeader: return header.data;
+        case pSegs: return segs.data;
+        case pPaths: return paths.data;
+        case pLinks: return links.data;
+        case pSteps: return steps.data;
+        case pSeqData: return seq_data.data;
+        case pOverlaps: return overlaps.data;
+        case pAlignment: return alignment.data;
+        case pNameData: return name_data.data;
+        case pOptionalData: return optional_data.data;
+        case pLineOrder: return line_order.data;
+    }
+    return nullptr;
+}
+
+int64_t View::find_path(const uint8_t *name, size_t n) const {
+    for (size_t i = 0; i < paths.len; ++i) {
+        Span s = paths[i].name;
+        if (s.len() == n && (n == 0 || memcmp(name_data.data + s.start, name, n) == 0)) return (int64_t)i;
+    }
+    return -1;
+}
+
+template <class T>
+static Pool<T> pool_of(const std::vector<T> &v) {
+    Pool<T> p;
+    p.data = v.data();
+    p.len = v.size();
+    return p;
+}
+
+View Store::view() const {
+    View v;
+    v.header = pool_of(header);
+    v.segs = pool_of(segs);
+    v.paths = pool_of(paths);
+    v.links = pool_of(links);
+    v.steps = pool_of(steps);
+    v.seq_data = pool_of(seq_data);
+    v.overlaps = pool_of(overlaps);
+    v.alignment = pool_of(alignment);
+    v.name_data = pool_of(name_data);
+    v.optional_data = pool_of(optional_data);
+    v.line_order = pool_of(line_order);
+    return v;
+}
+
+// ---------------------------------------------------------------- NameMap ---
+
+void NameMap::insert(uint64_t name, uint32_t id) {
+    // `name - 1` wraps for name == 0, as release-mode Rust does (namemap.rs:20).
+    uint64_t nm1 = name - 1;
+    if (nm1 == sequential_max_ && nm1 == id) {
+        sequential_max_ += 1;
+    } else {
+        others_[name] = id;
+    }
+}
+
+bool NameMap::get(uint64_t name, uint32_t *id) const {
+    if (name <= sequential_max_) {
+        *id = (uint32_t)(name - 1);
+        return true;
+    }
+    auto it = others_.find(name);
+    if (it == others_.end()) return false;
+    *id = it->second;
+    return true;
+}
+
+// ----------------------------------------------------------------- parser ---
+
+namespace {
+
+struct Cursor {
+    const uint8_t *p;
+    const uint8_t *e;
+    bool empty() const { return p == e; }
+    size_t size() const { return (size_t)(e - p); }
+};
+
+// gfaline.rs:153-158 (atoi FromRadix10: leading digits, wrapping arithmetic)
+bool parse_num(Cursor *c, uint64_t *out) {
+    const uint8_t *s = c->p;
+    uint64_t v = 0;
+    while (s < c->e && *s >= '0' && *s <= '9') v = v * 10 + (uint64_t)(*s++ - '0');
+    if (s == c->p) return false;
+    c->p = s;
+    *out = v;
+    return true;
+}
+
+bool parse_byte(Cursor *c, uint8_t b) {
+    if (c->empty() || *c->p != b) return false;
+    c->p++;
+    return true;
+}
+
+// gfaline.rs:128-142
+Cursor parse_field(Cursor *c) {
+    const uint8_t *t = (const uint8_t *)memchr(c->p, '\t', c->size());
+    Cursor f{c->p, t ? t : c->e};
+    c->p = t ? t + 1 : c->e;
+    return f;
+}
+
+bool parse_orient(Cursor *c, uint32_t *orient) {
+    if (c->empty()) return false;
+    if (*c->p == '+') *orient = 0;
+    else if (*c->p == '-') *orient = 1;
+    else return false;
+    c->p++;
+    return true;
+}
+
+// gfaline.rs:174-198; ops are appended to `out`.
+bool parse_align(Cursor *c, std::vector<uint32_t> *out, const char **why) {
+    while (!c->empty() && *c->p >= '0' && *c->p <= '9') {
+        uint64_t len;
+        parse_num(c, &len);
+        len &= 0xFFFFFFFFull;  // parse_num::<u32>
+        if (c->empty()) { *why = "alignment: missing opcode"; return false; }
+        uint32_t op;
+        switch (*c->p) {
+            case 'M': op = kMatch; break;
+            case 'N': op = kGap; break;
+            case 'D': op = kDeletion; break;
+            case 'I': op = kInsertion; break;
+            default: *why = "expected align op"; return false;
+        }
+        if (len & ~0xFFull) { *why = "length too large"; return false; }  // flatgfa.rs:228
+        out->push_back(((uint32_t)len << 8) | op);
+        c->p++;
+    }
+    return true;
+}
+
+bool make_handle(uint32_t seg, bool forward, Handle *h, const char **why) {
+    if (seg & 0x80000000u) { *why = "index too large"; return false; }  // flatgfa.rs:194
+    h->bits = (seg << 1) | (forward ? 0u : 1u);
+    return true;
+}
+
+}  // namespace
+
+bool parse_gfa(const uint8_t *buf, size_t n, Store *st, std::string *err, bool stream_mode) {
+    *st = Store();
+    NameMap names;
+    std::vector<Cursor> deferred;
+    auto fail = [&](const char *why, size_t lineno) {
+        *err = std::string("parse error (line ") + std::to_string(lineno) + "): " + why;
+        return false;
+    };
+
+    // MemchrSplit (memfile.rs:51-63): a last line with no '\n' is never yielded.
+    size_t pos = 0, lineno = 0;
+    while (pos < n) {
+        const uint8_t *nl = (const uint8_t *)memchr(buf + pos, '\n', n - pos);
+        if (!nl) {
+            if (!stream_mode) break;
+            nl = buf + n;  // BufRead::split yields the unterminated tail (parse.rs:32)
+        }
+        Cursor line{buf + pos, nl};
+        pos = (size_t)(nl - buf) + 1;
+        ++lineno;
+        if (line.empty()) return fail("empty line", lineno);  // parse.rs:83 indexes line[0]
+        uint8_t kind = *line.p;
+        if (kind == 'P' || kind == 'L') {
+            st->line_order.push_back(kind == 'P' ? kPath : kLink);
+            deferred.push_back(line);
+            continue;
+        }
+        if (line.size() < 2 || line.p[1] != '\t') return fail("expected marker and tab", lineno);
+        Cursor rest{line.p + 2, line.e};
+        if (kind == 'H') {
+            st->line_order.push_back(kHeader);
+            if (!st->header.empty()) return fail("more than one header", lineno);  // flatgfa.rs:444
+            st->header.assign(rest.p, rest.e);
+        } else if (kind == 'S') {
+            uint64_t name;
+            if (!parse_num(&rest, &name)) return fail("expected number", lineno);
+            if (!parse_byte(&rest, '\t')) return fail("expected byte", lineno);
+            Cursor seq = parse_field(&rest);
+            st->line_order.push_back(kSegment);
+            Segment s;
+            s.name = name;
+            s.seq.start = (uint32_t)st->seq_data.size();
+            st->seq_data.insert(st->seq_data.end(), seq.p, seq.e);
+            s.seq.end = (uint32_t)st->seq_data.size();
+            s.optional.start = (uint32_t)st->optional_data.size();
+            st->optional_data.insert(st->optional_data.end(), rest.p, rest.e);
+            s.optional.end = (uint32_t)st->optional_data.size();
+            uint32_t id = (uint32_t)st->segs.size();
+            st->segs.push_back(s);
+            names.insert(name, id);
+        } else {
+            return fail("unhandled line kind", lineno);
+        }
+    }
+
+    // "Unwind" the deferred links and paths in file order (parse.rs:108-123).
+    size_t dn = 0;
+    if (stream_mode)  // parse_stream unwinds links first, then paths (parse.rs:63-72)
+        std::stable_partition(deferred.begin(), deferred.end(), [](const Cursor &c) { return *c.p == 'L'; });
+    for (Cursor line : deferred) {
+        ++dn;
+        if (line.size() < 2 || line.p[1] != '\t') return fail("expected marker and tab (deferred)", dn);
+        Cursor rest{line.p + 2, line.e};
+        const char *why = "";
+        if (*line.p == 'L') {
+            uint64_t from_name, to_name;
+            uint32_t fo, to;
+            if (!parse_num(&rest, &from_name) || !parse_byte(&rest, '\t') || !parse_orient(&rest, &fo) ||
+                !parse_byte(&rest, '\t') || !parse_num(&rest, &to_name) || !parse_byte(&rest, '\t') ||
+                !parse_orient(&rest, &to) || !parse_byte(&rest, '\t'))
+                return fail("malformed link", dn);
+            size_t a0 = st->alignment.size();
+            std::vector<uint32_t> ops;
+            if (!parse_align(&rest, &ops, &why)) return fail(why, dn);
+            if (!rest.empty()) return fail("expected end of line", dn);
+            uint32_t fid, tid;
+            Link l;
+            Handle fh, th;
+            if (!names.get(from_name, &fid) || !make_handle(fid, fo == 0, &fh, &why)) return fail("link: unknown segment", dn);
+            if (!names.get(to_name, &tid) || !make_handle(tid, to == 0, &th, &why)) return fail("link: unknown segment", dn);
+            st->alignment.insert(st->alignment.end(), ops.begin(), ops.end());
+            l.from = fh.bits;
+            l.to = th.bits;
+            l.overlap.start = (uint32_t)a0;
+            l.overlap.end = (uint32_t)st->alignment.size();
+            st->links.push_back(l);
+        } else {
+            Cursor name = parse_field(&rest);
+            Cursor steps = parse_field(&rest);
+            // parse_maybe_overlap_list, gfaline.rs:102-125
+            std::vector<std::vector<uint32_t>> ovs;
+            if (!(rest.size() == 1 && *rest.p == '*')) {
+                while (!rest.empty()) {
+                    ovs.emplace_back();
+                    if (!parse_align(&rest, &ovs.back(), &why)) return fail(why, dn);
+                    if (!rest.empty() && !parse_byte(&rest, ',')) return fail("expected byte", dn);
+                }
+            }
+            // StepsParser, gfaline.rs:200-263.  The byte that stops the scan is
+            // consumed before `rest()` is examined (parse.rs:155).
+            Path p;
+            p.steps.start = (uint32_t)st->steps.size();
+            const uint8_t *s = steps.p;
+            uint64_t seg = 0;
+            bool want_seg = true;
+            while (s < steps.e) {
+                uint8_t b = *s++;
+                if (want_seg) {
+                    if (b == '+' || b == '-') {
+                        want_seg = false;
+                        uint32_t id;
+                        Handle h;
+                        if (!names.get(seg, &id)) return fail("path: unknown segment", dn);
+                        if (!make_handle(id, b == '+', &h, &why)) return fail(why, dn);
+                        st->steps.push_back(h);
+                    } else if (b >= '0' && b <= '9') {
+                        seg = seg * 10 + (uint64_t)(b - '0');
+                    } else {
+                        break;
+                    }
+                } else {
+                    if (b == ',') {
+                        want_seg = true;
+                        seg = 0;
+                    } else {
+                        break;
+                    }
+                }
+            }
+            if (s != steps.e) return fail("path steps: trailing bytes", dn);
+            p.steps.end = (uint32_t)st->steps.size();
+            p.overlaps.start = (uint32_t)st->overlaps.size();
+            for (auto &ops : ovs) {
+                Span a;
+                a.start = (uint32_t)st->alignment.size();
+                st->alignment.insert(st->alignment.end(), ops.begin(), ops.end());
+                a.end = (uint32_t)st->alignment.size();
+                st->overlaps.push_back(a);
+            }
+            p.overlaps.end = (uint32_t)st->overlaps.size();
+            p.name.start = (uint32_t)st->name_data.size();
+            st->name_data.insert(st->name_data.end(), name.p, name.e);
+            p.name.end = (uint32_t)st->name_data.size();
+            st->paths.push_back(p);
+        }
+    }
+    return true;
+}
+
+// ------------------------------------------------------ .flatgfa container ---
+
+bool view_flatgfa(const uint8_t *data, size_t n, View *out, std::string *err) {
+    if (n < sizeof(Toc)) { *err = "flatgfa file: shorter than its table of contents"; return false; }
+    Toc toc;
+    memcpy(&toc, data, sizeof toc);
+    if (toc.magic != kMagic) { *err = "flatgfa file: bad magic number"; return false; }
+    size_t off = sizeof(Toc);
+    const void *ptr[11];
+    for (int i = 0; i < 11; ++i) {
+        const TocSize &sz = toc.pool[i];
+        if (sz.len > sz.capacity) { *err = "flatgfa file: len > capacity"; return false; }
+        unsigned __int128 bytes = (unsigned __int128)sz.capacity * kPoolElemSize[i];
+        if (bytes > (unsigned __int128)(n - off)) {
+            *err = std::string("flatgfa file: region out of bounds: ") + kPoolName[i];
+            return false;
+        }
+        ptr[i] = data + off;
+        off += (size_t)bytes;
+    }
+    *out = View();
+    out->header = {(const uint8_t *)ptr[pHeader], (size_t)toc.pool[pHeader].len};
+    out->segs = {(const Segment *)ptr[pSegs], (size_t)toc.pool[pSegs].len};
+    out->paths = {(const Path *)ptr[pPaths], (size_t)toc.pool[pPaths].len};
+    out->links = {(const Link *)ptr[pLinks], (size_t)toc.pool[pLinks].len};
+    out->steps = {(const Handle *)ptr[pSteps], (size_t)toc.pool[pSteps].len};
+    out->seq_data = {(const uint8_t *)ptr[pSeqData], (size_t)toc.pool[pSeqData].len};
+    out->overlaps = {(const Span *)ptr[pOverlaps], (size_t)toc.pool[pOverlaps].len};
+    out->alignment = {(const uint32_t *)ptr[pAlignment], (size_t)toc.pool[pAlignment].len};
+    out->name_data = {(const uint8_t *)ptr[pNameData], (size_t)toc.pool[pNameData].len};
+    out->optional_data = {(const uint8_t *)ptr[pOptionalData], (size_t)toc.pool[pOptionalData].len};
+    out->line_order = {(const uint8_t *)ptr[pLineOrder], (size_t)toc.pool[pLineOrder].len};
+    return true;
+}
+
+size_t flatgfa_file_size(const View &v) {
+    size_t total = sizeof(Toc);
+    for (int i = 0; i < 11; ++i) total += v.pool_len(i) * kPoolElemSize[i];
+    return total;
+}
+
+void dump_flatgfa(const View &v, uint8_t *buf) {
+    Toc toc;
+    toc.magic = kMagic;
+    for (int i = 0; i < 11; ++i) toc.pool[i] = TocSize{v.pool_len(i), v.pool_len(i)};
+    memcpy(buf, &toc, sizeof toc);
+    size_t off = sizeof toc;
+    for (int i = 0; i < 11; ++i) {
+        size_t bytes = v.pool_len(i) * kPoolElemSize[i];
+        if (bytes) memcpy(buf + off, v.pool_data(i), bytes);
+        off += bytes;
+    }
+}
+
+// ------------------------------------------------------------ GFA printer ---
+
+namespace {
+
+void put_u64(std::string *o, uint64_t v) {
+    char b[24];
+    int n = snprintf(b, sizeof b, "%llu", (unsigned long long)v);
+    o->append(b, (size_t)n);
+}
+
+void put_alignment(const View &v, Span a, std::string *o) {
+    static const char letters[4] = {'M', 'N', 'D', 'I'};  // print.rs:14-23
+    if (a.start == a.end) o->append("0M");
+    for (uint32_t i = a.start; i < a.end; ++i) {
+        uint32_t op = v.alignment[i];
+        put_u64(o, op >> 8);
+        o->push_back(letters[op & 3]);
+    }
+}
+
+void put_handle(const View &v, uint32_t bits, std::string *o) {
+    put_u64(o, v.segs[bits >> 1].name);
+    o->push_back((bits & 1) ? '-' : '+');
+}
+
+bool put_seg(const View &v, size_t i, std::string *o) {
+    const Segment &s = v.segs[i];
+    o->append("S\t");
+    put_u64(o, s.name);
+    o->push_back('\t');
+    o->append((const char *)v.seq_data.data + s.seq.start, s.seq.len());
+    if (s.optional.start != s.optional.end) {
+        o->push_back('\t');
+        o->append((const char *)v.optional_data.data + s.optional.start, s.optional.len());
+    }
+    o->push_back('\n');
+    return true;
+}
+
+bool put_path(const View &v, size_t i, std::string *o, std::string *err) {
+    const Path &p = v.paths[i];
+    o->append("P\t");
+    o->append((const char *)v.name_data.data + p.name.start, p.name.len());
+    o->push_back('\t');
+    if (p.steps.start == p.steps.end) { *err = "print: path with no steps"; return false; }  // print.rs:48 steps[0]
+    for (uint32_t k = p.steps.start; k < p.steps.end; ++k) {
+        if (k != p.steps.start) o->push_back(',');
+        put_handle(v, v.steps[k].bits, o);
+    }
+    o->push_back('\t');
+    if (p.overlaps.start == p.overlaps.end) {
+        o->push_back('*');
+    } else {
+        for (uint32_t k = p.overlaps.start; k < p.overlaps.end; ++k) {
+            if (k != p.overlaps.start) o->push_back(',');
+            put_alignment(v, v.overlaps[k], o);
+        }
+    }
+    o->push_back('\n');
+    return true;
+}
+
+void put_link(const View &v, size_t i, std::string *o) {
+    const Link &l = v.links[i];
+    o->append("L\t");
+    put_u64(o, v.segs[l.from >> 1].name);
+    o->append((l.from & 1) ? "\t-\t" : "\t+\t");
+    put_u64(o, v.segs[l.to >> 1].name);
+    o->append((l.to & 1) ? "\t-\t" : "\t+\t");
+    put_alignment(v, l.overlap, o);
+    o->push_back('\n');
+}
+
+void put_header(const View &v, std::string *o) {
+    o->append("H\t");
+    o->append((const char *)v.header.data, v.header.len);
+    o->push_back('\n');
+}
+
+}  // namespace
+
+bool print_gfa(const View &v, std::string *o, std::string *err) {
+    if (v.line_order.len == 0) {  // write_normalized, print.rs:134-150
+        if (v.header.len) put_header(v, o);
+        for (size_t i = 0; i < v.segs.len; ++i) put_seg(v, i, o);
+        for (size_t i = 0; i < v.paths.len; ++i)
+            if (!put_path(v, i, o, err)) return false;
+        for (size_t i = 0; i < v.links.len; ++i) put_link(v, i, o);
+        return true;
+    }
+    size_t si = 0, pi = 0, li = 0;  // write_preserved, print.rs:99-131
+    for (size_t k = 0; k < v.line_order.len; ++k) {
+        switch (v.line_order[k]) {
+            case kHeader:
+                if (!v.header.len) { *err = "print: empty header"; return false; }
+                put_header(v, o);
+                break;
+            case kSegment:
+                if (si >= v.segs.len) { *err = "print: too few segments"; return false; }
+                put_seg(v, si++, o);
+                break;
+            case kPath:
+                if (pi >= v.paths.len) { *err = "print: too few paths"; return false; }
+                if (!put_path(v, pi++, o, err)) return false;
+                break;
+            case kLink:
+                if (li >= v.links.len) { *err = "print: too few links"; return false; }
+                put_link(v, li++, o);
+                break;
+            default:
+                *err = "print: bad line kind";
+                return false;
+        }
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- emitters ---
+
+std::string format_float(double x, int digits) {
+    char buf[512];
+    int n;
+    // Rust's Display spells these "NaN" / "inf" / "-inf".
+    if (std::isnan(x)) n = snprintf(buf, sizeof buf, "NaN");
+    else if (std::isinf(x)) n = snprintf(buf, sizeof buf, x > 0 ? "inf" : "-inf");
+    else n = snprintf(buf, sizeof buf, "%.*f", digits, x);  // glibc: correctly rounded, like Rust
+    while (n > 0 && buf[n - 1] == '0') --n;
+    while (n > 0 && buf[n - 1] == '.') --n;
+    return std::string(buf, (size_t)n);
+}
+
+void emit_seg_depth(const View &v, const uint64_t *depth, const uint64_t *uniq, std::string *out) {
+    out->append("#node.id\tdepth\tdepth.uniq\n");
+    out->reserve(out->size() + v.segs.len * 16);
+    char line[96];
+    for (size_t i = 0; i < v.segs.len; ++i) {
+        uint32_t name = (uint32_t)v.segs[i].name;  // `seg.name as u32`, depth.rs:71
+        int n = snprintf(line, sizeof line, "%u\t%llu\t%llu\n", name, (unsigned long long)depth[i],
+                         (unsigned long long)uniq[i]);
+        out->append(line, (size_t)n);
+    }
+}
+
+void emit_path_depth(const View &v, const uint32_t *path_ids, size_t n, const uint64_t *lengths,
+                     const double *means, std::string *out) {
+    out->append("#path\tstart\tend\tmean.depth\n");
+    for (size_t k = 0; k < n; ++k) {
+        const Path &p = v.paths[path_ids[k]];
+        out->append((const char *)v.name_data.data + p.name.start, p.name.len());
+        out->append("\t0\t");
+        put_u64(out, lengths[k]);
+        out->push_back('\t');
+        out->append(format_float(means[k], 2));
+        out->push_back('\n');
+    }
+}
+
+// ------------------------------------------------------------- mapped file ---
+
+bool MappedFile::open(const char *path, std::string *err) {
+    int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { *err = std::string("cannot open ") + path; return false; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { ::close(fd); *err = std::string("cannot stat ") + path; return false; }
+    size = (size_t)sb.st_size;
+    if (size == 0) {
+        data = (const uint8_t *)"";
+        ::close(fd);
+        return true;
+    }
+    void *m = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) { size = 0; *err = std::string("cannot mmap ") + path; return false; }
+    data = (const uint8_t *)m;
+    return true;
+}
+
+MappedFile::~MappedFile() {
+    if (data && size) munmap((void *)data, size);
+}
+
+}  // namespace fgfa

@@ -1,0 +1,166 @@
+// FlatGFA host-side data model for the MI355X depth engine.
+//
+// Re-creates, from scratch, the reference's flat-array pangenome graph
+// (cucapra/pollen flatgfa/src/flatgfa.rs, pool.rs, file.rs, parse.rs) as far
+// as the depth path needs it: byte-compatible PODs, the eleven pools, the GFA
+// text parser, the zero-copy `.flatgfa` container, and the odgi-style emitters.
+// Device code lives in depth_device.hip; this header is plain C++17.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace fgfa {
+
+// ---- PODs: byte-compatible with the reference (all repr(packed), align 1) ----
+#pragma pack(push, 1)
+// pool.rs:80-86
+struct Span {
+    uint32_t start, end;
+    uint32_t len() const { return end - start; }
+};
+// flatgfa.rs:71-82
+struct Segment {
+    uint64_t name;
+    Span seq;
+    Span optional;
+};
+// flatgfa.rs:99-112
+struct Path {
+    Span name;
+    Span steps;
+    Span overlaps;
+};
+// flatgfa.rs:121-133
+struct Link {
+    uint32_t from, to;
+    Span overlap;
+};
+// flatgfa.rs:186-209 -- (segment << 1) | orient; Forward = 0, Backward = 1
+struct Handle {
+    uint32_t bits;
+    uint32_t segment() const { return bits >> 1; }
+    bool is_forward() const { return (bits & 1u) == 0; }
+};
+// file.rs:29-38, 12-27
+struct TocSize {
+    uint64_t len, capacity;
+};
+struct Toc {
+    uint64_t magic;
+    TocSize pool[11];
+};
+#pragma pack(pop)
+static_assert(sizeof(Span) == 8 && sizeof(Segment) == 24 && sizeof(Path) == 24, "layout");
+static_assert(sizeof(Link) == 16 && sizeof(Handle) == 4 && sizeof(Toc) == 184, "layout");
+
+constexpr uint64_t kMagic = 0xB1011054ull;  // file.rs:9
+// flatgfa.rs:262-269
+enum LineKind : uint8_t { kHeader = 0, kSegment = 1, kPath = 2, kLink = 3 };
+// flatgfa.rs:213-221 with the letter mapping of gfaline.rs:178-184 / print.rs:14-23
+enum AlignOpcode : uint8_t { kMatch = 0, kGap = 1, kInsertion = 2, kDeletion = 3 };
+
+// The pool order inside a .flatgfa file (file.rs:14-27).
+enum PoolIx { pHeader, pSegs, pPaths, pLinks, pSteps, pSeqData, pOverlaps, pAlignment, pNameData, pOptionalData, pLineOrder };
+extern const size_t kPoolElemSize[11];
+extern const char *const kPoolName[11];
+
+template <class T>
+struct Pool {
+    const T *data = nullptr;
+    size_t len = 0;
+    const T &operator[](size_t i) const { return data[i]; }
+    const T *begin() const { return data; }
+    const T *end() const { return data + len; }
+};
+
+// A borrowed view of a whole graph: flatgfa.rs:19-67.
+struct View {
+    Pool<uint8_t> header;
+    Pool<Segment> segs;
+    Pool<Path> paths;
+    Pool<Link> links;
+    Pool<Handle> steps;
+    Pool<uint8_t> seq_data;
+    Pool<Span> overlaps;
+    Pool<uint32_t> alignment;
+    Pool<uint8_t> name_data;
+    Pool<uint8_t> optional_data;
+    Pool<uint8_t> line_order;
+
+    size_t pool_len(int ix) const;
+    const void *pool_data(int ix) const;
+    // flatgfa.rs:387-394
+    int64_t find_path(const uint8_t *name, size_t n) const;
+};
+
+// An owning heap store (the reference's HeapGFAStore, flatgfa.rs:428-552).
+struct Store {
+    std::vector<uint8_t> header;
+    std::vector<Segment> segs;
+    std::vector<Path> paths;
+    std::vector<Link> links;
+    std::vector<Handle> steps;
+    std::vector<uint8_t> seq_data;
+    std::vector<Span> overlaps;
+    std::vector<uint32_t> alignment;
+    std::vector<uint8_t> name_data;
+    std::vector<uint8_t> optional_data;
+    std::vector<uint8_t> line_order;
+    View view() const;
+};
+
+// namemap.rs:7-33
+class NameMap {
+  public:
+    void insert(uint64_t name, uint32_t id);
+    // false where the reference would panic on a missing key
+    bool get(uint64_t name, uint32_t *id) const;
+
+  private:
+    uint64_t sequential_max_ = 0;
+    std::unordered_map<uint64_t, uint32_t> others_;
+};
+
+// Parser::parse_mem (parse.rs:77-159).  Returns false and sets `err` exactly
+// where the reference panics.  With `stream_mode` it follows Parser::parse_stream
+// (parse.rs:24-74, used for stdin) instead: a final line without '\n' is kept, and
+// all deferred links are added before all deferred paths.
+bool parse_gfa(const uint8_t *buf, size_t n, Store *out, std::string *err, bool stream_mode = false);
+
+// file::view (file.rs:163-213).  `data` must outlive the view.
+bool view_flatgfa(const uint8_t *data, size_t n, View *out, std::string *err);
+// file::size / file::dump with Toc::full (file.rs:82-98, 290-313)
+size_t flatgfa_file_size(const View &v);
+void dump_flatgfa(const View &v, uint8_t *buf);
+
+// print.rs:99-153 (preserved order when line_order is non-empty, else normalized)
+bool print_gfa(const View &v, std::string *out, std::string *err);
+
+// ops/depth.rs:192-197
+std::string format_float(double x, int digits);
+// ops/depth.rs:67-82
+void emit_seg_depth(const View &v, const uint64_t *depth, const uint64_t *uniq, std::string *out);
+// ops/depth.rs:143-160
+void emit_path_depth(const View &v, const uint32_t *path_ids, size_t n, const uint64_t *lengths,
+                     const double *means, std::string *out);
+
+// The synthetic-graph generator of SURVEY.md 8(d) (spec: oracle/synth.py).
+// model 0 = pangenome, 1 = uniform.
+void synth_store(uint64_t seed, uint32_t S, uint32_t P, uint32_t L, int model, bool with_seq, Store *out);
+
+// A read-only memory-mapped file (memfile.rs:7-10).
+struct MappedFile {
+    const uint8_t *data = nullptr;
+    size_t size = 0;
+    bool open(const char *path, std::string *err);
+    ~MappedFile();
+    MappedFile() = default;
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
+};
+
+}  // namespace fgfa

@@ -1,0 +1,130 @@
+"""Device-level depth queries on caller-owned HBM buffers (Part 3 of include/flatgfa.h).
+
+torch is used for what it is good at here -- device memory, streams, torch.distributed -- and
+nothing else: the tensors below are plain int32 buffers whose ``data_ptr()`` goes straight
+into the C ABI; every kernel that runs is a hand-written HIP kernel in libflatgfa.so.
+
+Handles are u32 in the reference (flatgfa.rs:186-209); they are carried in torch.int32
+tensors because u32 and i32 have the same bits and wrapping add, and int32 is what RCCL and
+every torch op accept.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .flatgfa import FlatGFAError, _check
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _as_i32(a: np.ndarray):
+    torch = _torch()
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint32).view(np.int32))
+
+
+class DeviceGraph:
+    """The structure-of-arrays graph image resident in one GPU's HBM."""
+
+    def __init__(self, steps: np.ndarray, path_begin: np.ndarray, path_end: np.ndarray, n_segs: int,
+                 seg_len: Optional[np.ndarray] = None, device: str = "cuda:0"):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise FlatGFAError("no HIP device is visible; pollen_amd has no CPU fallback", -3)
+        self.device = torch.device(device)
+        self.n_steps = int(len(steps))
+        self.n_paths = int(len(path_begin))
+        self.n_segs = int(n_segs)
+        self.h_path_begin = np.ascontiguousarray(path_begin, dtype=np.uint32)
+        self.h_path_end = np.ascontiguousarray(path_end, dtype=np.uint32)
+        with torch.cuda.device(self.device):
+            self.steps = _as_i32(steps).to(self.device)
+            self.path_begin = _as_i32(self.h_path_begin).to(self.device)
+            self.path_end = _as_i32(self.h_path_end).to(self.device)
+            self.seg_len = None if seg_len is None else _as_i32(seg_len).to(self.device)
+            torch.cuda.synchronize(self.device)
+
+    def c_struct(self) -> _lib.flatgfa_dev_graph_t:
+        return _lib.flatgfa_dev_graph_t(
+            self.steps.data_ptr() if self.n_steps else None, self.n_steps,
+            self.path_begin.data_ptr() if self.n_paths else None,
+            self.path_end.data_ptr() if self.n_paths else None, self.n_paths, self.n_segs,
+            self.seg_len.data_ptr() if self.seg_len is not None and self.n_segs else None)
+
+
+class DepthPlan:
+    """A prepared depth query (flatgfa_dev_plan_t): launch plan + scratch HBM for one DeviceGraph."""
+
+    def __init__(self, graph: DeviceGraph):
+        torch = _torch()
+        self.graph = graph
+        with torch.cuda.device(graph.device):
+            g = graph.c_struct()
+            self._p = ctypes.c_void_p(_lib.lib().flatgfa_dev_plan_create(
+                ctypes.byref(g), graph.h_path_begin.ctypes.data if graph.n_paths else None,
+                graph.h_path_end.ctypes.data if graph.n_paths else None))
+        if not self._p.value:
+            raise FlatGFAError("dev_plan_create", -2)
+
+    def close(self) -> None:
+        if getattr(self, "_p", None) is not None and self._p.value:
+            _lib.lib().flatgfa_dev_plan_destroy(self._p)
+            self._p = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self) -> int:
+        return _torch().cuda.current_stream(self.graph.device).cuda_stream
+
+    def seg_depth(self, depth_out, uniq_out=None) -> None:
+        """Enqueue node depth (+ unique depth when `uniq_out` is given) on torch's current stream.
+        Outputs are int32 CUDA tensors of n_segs elements (u32 bits)."""
+        torch = _torch()
+        S = self.graph.n_segs
+        for t in (depth_out, uniq_out):
+            if t is not None:
+                assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous() and t.numel() == S
+        with torch.cuda.device(self.graph.device):
+            _check(_lib.lib().flatgfa_dev_seg_depth(self._p, depth_out.data_ptr() if S else None,
+                                                    uniq_out.data_ptr() if (uniq_out is not None and S) else None,
+                                                    self._stream()), "dev_seg_depth")
+
+    def path_sums(self, path_ids, depth, length_out, weighted_out) -> None:
+        """Enqueue measure_path's integer sums for `path_ids` (int32 CUDA tensor); outputs are
+        int64 CUDA tensors (u64 bits)."""
+        torch = _torch()
+        n = int(path_ids.numel())
+        assert path_ids.dtype == torch.int32 and length_out.dtype == torch.int64 and weighted_out.dtype == torch.int64
+        assert length_out.numel() == n and weighted_out.numel() == n
+        with torch.cuda.device(self.graph.device):
+            _check(_lib.lib().flatgfa_dev_path_sums(self._p, path_ids.data_ptr() if n else None, n,
+                                                    depth.data_ptr() if self.graph.n_segs else None,
+                                                    length_out.data_ptr() if n else None,
+                                                    weighted_out.data_ptr() if n else None, self._stream()),
+                   "dev_path_sums")
+
+    def status(self) -> None:
+        """Synchronize the current stream and raise if a kernel saw an out-of-range id."""
+        with _torch().cuda.device(self.graph.device):
+            _check(_lib.lib().flatgfa_dev_status(self._p, self._stream()), "dev_status")
+
+
+def profile_enable(on: bool) -> None:
+    _lib.lib().flatgfa_dev_profile_enable(1 if on else 0)
+
+
+def profile_read(cap: int = 4096) -> List[Tuple[str, float]]:
+    names = (ctypes.c_char_p * cap)()
+    ms = (ctypes.c_float * cap)()
+    n = _lib.lib().flatgfa_dev_profile_read(names, ms, cap)
+    return [(names[i].decode(), float(ms[i])) for i in range(n)]

@@ -1,0 +1,224 @@
+"""Host-side mirror of the reference's FlatGFA interface for the depth path, over the C ABI.
+
+Names and argument meaning follow the reference (cucapra/pollen):
+  parse / parse_bytes / load / write_flatgfa / write_gfa      flatgfa-py/flatgfa.pyi:80-93
+  seg_depth / seg_depth_with_uniq / path_depth                flatgfa/src/ops/depth.rs:15,45,88
+  depth_table / path_depth_table  (`fgfa depth [-d] [-r P]`)  flatgfa/src/cli/cmds.rs:234-285
+
+Every depth method runs the HIP kernels in libflatgfa.so; there is no Python or CPU
+implementation of them in this package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Iterable, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import _lib
+from ._lib import flatgfa_handle_t
+
+# Packed reference layouts (flatgfa.rs:71-82, 99-112, 121-133; pool.rs:80-86).
+SEG_DT = np.dtype([("name", "<u8"), ("seq_start", "<u4"), ("seq_end", "<u4"),
+                   ("opt_start", "<u4"), ("opt_end", "<u4")])
+PATH_DT = np.dtype([("name_start", "<u4"), ("name_end", "<u4"), ("steps_start", "<u4"),
+                    ("steps_end", "<u4"), ("ov_start", "<u4"), ("ov_end", "<u4")])
+LINK_DT = np.dtype([("from_", "<u4"), ("to", "<u4"), ("ov_start", "<u4"), ("ov_end", "<u4")])
+SPAN_DT = np.dtype([("start", "<u4"), ("end", "<u4")])
+POOLS = ["header", "segs", "paths", "links", "steps", "seq_data", "overlaps", "alignment",
+         "name_data", "optional_data", "line_order"]
+_POOL_DT = {"header": np.dtype("u1"), "segs": SEG_DT, "paths": PATH_DT, "links": LINK_DT,
+            "steps": np.dtype("<u4"), "seq_data": np.dtype("u1"), "overlaps": SPAN_DT,
+            "alignment": np.dtype("<u4"), "name_data": np.dtype("u1"),
+            "optional_data": np.dtype("u1"), "line_order": np.dtype("u1")}
+
+ERR_BOUNDS = -2
+ERR_NO_DEVICE = -3
+
+
+class FlatGFAError(RuntimeError):
+    def __init__(self, what: str, code: int = 0):
+        super().__init__(f"{what}: {_lib.last_error()}" + (f" (code {code})" if code else ""))
+        self.code = code
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise FlatGFAError(what, rc)
+
+
+def _take_text(ptr: ctypes.c_void_p, n: ctypes.c_size_t) -> bytes:
+    out = ctypes.string_at(ptr.value, n.value) if ptr.value else b""
+    _lib.lib().flatgfa_free_text(ptr)
+    return out
+
+
+class FlatGFA:
+    """An owned graph handle (`flatgfa_t`).  Freed on garbage collection or `close()`."""
+
+    def __init__(self, handle: int):
+        if not handle:
+            raise FlatGFAError("cannot create FlatGFA")
+        self._h = ctypes.c_void_p(handle)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().flatgfa_free(self._h)
+            self._h = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- flatgfa-c accessors (flatgfa-c/src/lib.rs:80-172) ----
+    @property
+    def segment_count(self) -> int:
+        return _lib.lib().flatgfa_get_segment_count(self._h)
+
+    @property
+    def path_count(self) -> int:
+        return _lib.lib().flatgfa_path_count(self._h)
+
+    def get_seq(self, segment_id: int) -> Optional[bytes]:
+        s = _lib.lib().flatgfa_get_seq(self._h, segment_id)
+        return None if not s.data and s.len == 0 and segment_id >= self.segment_count else ctypes.string_at(s.data, s.len)
+
+    def get_path_name(self, path_index: int) -> Optional[bytes]:
+        if path_index >= self.path_count:
+            s = _lib.lib().flatgfa_get_path_name(self._h, path_index)
+            assert not s.data and s.len == 0
+            return None
+        s = _lib.lib().flatgfa_get_path_name(self._h, path_index)
+        return ctypes.string_at(s.data, s.len)
+
+    def get_path_step_count(self, path_index: int) -> int:
+        return _lib.lib().flatgfa_get_path_step_count(self._h, path_index)
+
+    def get_step(self, path_index: int, step_index: int) -> Optional[Tuple[int, bool]]:
+        out = flatgfa_handle_t()
+        ok = _lib.lib().flatgfa_get_step(self._h, path_index, step_index, ctypes.byref(out))
+        return (out.segment_id, bool(out.is_forward)) if ok else None
+
+    def find_path(self, name: bytes) -> Optional[int]:
+        i = _lib.lib().flatgfa_find_path(self._h, name, len(name))
+        return None if i < 0 else int(i)
+
+    # ---- pools ----
+    def pool(self, name: str) -> np.ndarray:
+        """A copy of one pool as a numpy array in the reference's packed layout."""
+        ix = POOLS.index(name)
+        data, n, es = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint64()
+        _check(_lib.lib().flatgfa_pool(self._h, ix, ctypes.byref(data), ctypes.byref(n), ctypes.byref(es)), "pool")
+        dt = _POOL_DT[name]
+        assert dt.itemsize == es.value
+        if n.value == 0:
+            return np.zeros(0, dtype=dt)
+        raw = ctypes.string_at(data.value, n.value * es.value)
+        return np.frombuffer(raw, dtype=dt).copy()
+
+    def soa(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+        """The structure-of-arrays image the kernels read: (steps, path_begin, path_end, seg_len)."""
+        paths, segs = self.pool("paths"), self.pool("segs")
+        return (self.pool("steps"), np.ascontiguousarray(paths["steps_start"]),
+                np.ascontiguousarray(paths["steps_end"]),
+                (segs["seq_end"] - segs["seq_start"]).astype(np.uint32))
+
+    # ---- writers (flatgfa-py: write_flatgfa / write_gfa / str) ----
+    def write_flatgfa(self, filename: str) -> None:
+        _check(_lib.lib().flatgfa_write_flatgfa(self._h, os.fsencode(filename)), "write_flatgfa")
+
+    def gfa_text(self) -> bytes:
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(_lib.lib().flatgfa_print_gfa(self._h, ctypes.byref(p), ctypes.byref(n)), "print_gfa")
+        return _take_text(p, n)
+
+    def write_gfa(self, filename: str) -> None:
+        with open(filename, "wb") as f:
+            f.write(self.gfa_text())
+
+    def __str__(self) -> str:
+        return self.gfa_text().decode(errors="replace")
+
+    # ---- depth queries (HIP) ----
+    def to_device(self, device: int = 0) -> None:
+        _check(_lib.lib().flatgfa_to_device(self._h, device), "to_device")
+
+    def seg_depth_with_uniq(self) -> Tuple[np.ndarray, np.ndarray]:
+        """ops/depth.rs:15-39 -> (depths, uniq_depths), uint64, indexed by segment id."""
+        S = self.segment_count
+        d, u = np.zeros(S, np.uint64), np.zeros(S, np.uint64)
+        _check(_lib.lib().flatgfa_seg_depth(self._h, d.ctypes.data, u.ctypes.data), "seg_depth_with_uniq")
+        return d, u
+
+    def seg_depth(self) -> np.ndarray:
+        """ops/depth.rs:45-56"""
+        d = np.zeros(self.segment_count, np.uint64)
+        _check(_lib.lib().flatgfa_seg_depth(self._h, d.ctypes.data, None), "seg_depth")
+        return d
+
+    def path_depth(self, path_ids: Optional[Sequence[int]] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """ops/depth.rs:88-111 -> (path_lengths uint64, mean depths float64) for `path_ids`
+        (default: all paths, in order)."""
+        ids = np.arange(self.path_count, dtype=np.uint32) if path_ids is None \
+            else np.ascontiguousarray(path_ids, dtype=np.uint32)
+        ln, mean = np.zeros(len(ids), np.uint64), np.zeros(len(ids), np.float64)
+        _check(_lib.lib().flatgfa_path_depth(self._h, ids.ctypes.data, len(ids), ln.ctypes.data, mean.ctypes.data),
+               "path_depth")
+        return ln, mean
+
+    def depth_table(self) -> bytes:
+        """The bytes `fgfa depth -d` prints."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(_lib.lib().flatgfa_depth_table(self._h, ctypes.byref(p), ctypes.byref(n)), "depth_table")
+        return _take_text(p, n)
+
+    def path_depth_table(self, names: Optional[Iterable[bytes]] = None) -> bytes:
+        """The bytes `fgfa depth [-r NAME]...` prints; unknown names are dropped (cmds.rs:270-274)."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        if names is None:
+            rc = _lib.lib().flatgfa_path_depth_table(self._h, None, 0, ctypes.byref(p), ctypes.byref(n))
+        else:
+            found = [self.find_path(nm) for nm in names]
+            ids = np.array([i for i in found if i is not None] + [0], dtype=np.uint32)
+            rc = _lib.lib().flatgfa_path_depth_table(self._h, ids.ctypes.data, len(ids) - 1, ctypes.byref(p),
+                                                     ctypes.byref(n))
+        _check(rc, "path_depth_table")
+        return _take_text(p, n)
+
+
+def parse(filename: Union[str, os.PathLike]) -> FlatGFA:
+    """Parse a GFA text file (flatgfa_parse, flatgfa-c/src/lib.rs:63)."""
+    return FlatGFA(_lib.lib().flatgfa_parse(os.fsencode(filename)))
+
+
+def parse_bytes(gfa: bytes) -> FlatGFA:
+    return FlatGFA(_lib.lib().flatgfa_parse_bytes(gfa, len(gfa)))
+
+
+def parse_stream_bytes(gfa: bytes) -> FlatGFA:
+    return FlatGFA(_lib.lib().flatgfa_parse_stream_bytes(gfa, len(gfa)))
+
+
+def load(filename: Union[str, os.PathLike]) -> FlatGFA:
+    """Map a binary `.flatgfa` file (file::view, flatgfa/src/file.rs:185)."""
+    return FlatGFA(_lib.lib().flatgfa_load(os.fsencode(filename)))
+
+
+def synth(seed: int, n_segs: int, n_paths: int, steps_per_path: int, model: str = "pangenome",
+          with_seq: bool = False) -> FlatGFA:
+    """The deterministic synthetic graph of SURVEY.md 8(d)."""
+    m = {"pangenome": 0, "uniform": 1}[model]
+    return FlatGFA(_lib.lib().flatgfa_synth(seed, n_segs, n_paths, steps_per_path, m, with_seq))
+
+
+def format_float(x: float, digits: int) -> str:
+    buf = ctypes.create_string_buffer(600)
+    n = _lib.lib().flatgfa_format_float(x, digits, buf, 600)
+    return buf.raw[:n].decode()
+
+
+def device_count() -> int:
+    return _lib.lib().flatgfa_device_count()

@@ -1,0 +1,87 @@
+"""Path-sharded node depth across the GPUs of one node.
+
+depth and uniq are sums over paths of per-path contributions (ops/depth.rs:25-36), and paths
+are independent, so each rank owns a contiguous group of WHOLE paths (never splitting a path
+keeps uniq a plain sum), computes its partial vectors with the HIP kernels, and one sum
+all-reduce of the per-segment vector(s) combines them -- RCCL over xGMI under
+torch.distributed's "nccl" backend.  The message is only 4*S (or 8*S) bytes, so the collective
+is latency-bound and is issued once, on the fused [depth | uniq] buffer.
+
+Nothing here computes depth on the host: `local_fn` is the HIP path in production
+(DepthPlan.seg_depth); tests inject a stand-in to exercise the partition + reduce logic on CPU
+under gloo.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+
+def shard_paths(path_begin: np.ndarray, path_end: np.ndarray, world: int) -> List[Tuple[int, int]]:
+    """Cut paths [0, P) into `world` contiguous groups of whole paths with near-equal step
+    counts.  Returns [(lo, hi)] per rank (hi exclusive; groups may be empty).
+
+    Greedy on the prefix sum: rank r ends at the first path whose cumulative step count
+    reaches (r+1)/world of the total, which bounds every rank's load by ideal + one path."""
+    P = int(len(path_begin))
+    lens = (np.asarray(path_end, dtype=np.int64) - np.asarray(path_begin, dtype=np.int64))
+    if (lens < 0).any():
+        raise ValueError("reversed path span")
+    # ends[k] = steps in paths [0, k); a cut at k puts ends[k] steps to its left
+    ends = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    total = int(ends[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        k = int(np.searchsorted(ends, target, side="left"))  # first k with ends[k] >= target
+        k = min(k, P)
+        if k > 0 and abs(int(ends[k - 1]) - target) <= abs(int(ends[k]) - target):
+            k -= 1  # the cut just before is at least as close to the target
+        cuts.append(min(max(k, cuts[-1]), P))
+    cuts.append(P)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def local_slice(steps: np.ndarray, path_begin: np.ndarray, path_end: np.ndarray, lo: int, hi: int
+                ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """The sub-image rank-local kernels read: only the steps its paths span, with rebased spans.
+    Works for arbitrary (even overlapping) spans by taking the covering range."""
+    if hi <= lo:
+        z = np.zeros(0, dtype=np.uint32)
+        return z, z.copy(), z.copy()
+    b = np.asarray(path_begin[lo:hi], dtype=np.uint32)
+    e = np.asarray(path_end[lo:hi], dtype=np.uint32)
+    s0, s1 = int(b.min()), int(e.max())
+    return (np.ascontiguousarray(steps[s0:s1]), (b - np.uint32(s0)).astype(np.uint32),
+            (e - np.uint32(s0)).astype(np.uint32))
+
+
+class ShardedDepth:
+    """seg_depth_with_uniq over a path-sharded graph: local HIP partials + one sum all-reduce."""
+
+    def __init__(self, n_segs: int, local_fn: Callable, device, with_uniq: bool = True, group=None):
+        import torch
+        self.torch = torch
+        self.n_segs = int(n_segs)
+        self.local_fn = local_fn
+        self.with_uniq = with_uniq
+        self.group = group
+        k = 2 if with_uniq else 1
+        # one fused buffer so that a single collective carries both vectors
+        self.buf = torch.zeros(k * self.n_segs, dtype=torch.int32, device=device)
+
+    @property
+    def depth(self):
+        return self.buf[: self.n_segs]
+
+    @property
+    def uniq(self):
+        return self.buf[self.n_segs:] if self.with_uniq else None
+
+    def run(self) -> None:
+        """One step: local partials into the fused buffer, then the all-reduce (if world > 1)."""
+        import torch.distributed as dist
+        self.local_fn(self.depth, self.uniq)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)

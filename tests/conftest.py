@@ -1,0 +1,28 @@
+import glob
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_gfas():
+    return sorted(glob.glob(os.path.join(GOLDEN, "*.gfa")))
+
+
+def fixture_id(path):
+    return os.path.basename(path)[:-4]
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

@@ -1,0 +1,217 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the oracle.
+
+Bit-exact everywhere (integer work); the one f64 division per path must also match exactly
+because both sides divide the same two integers.  Run with `-m gpu` on an MI355X.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pollen_amd as pa
+from conftest import GOLDEN, ROOT, fixture_id, golden_gfas
+from oracle import flatgfa_oracle as fo
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
+
+
+def read(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def pools_of(g: pa.FlatGFA) -> fo.Pools:
+    return fo.Pools(**{n: g.pool(n) for n in fo.POOL_ORDER})
+
+
+def check_graph(g: pa.FlatGFA, pools: fo.Pools, path_ids=None):
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    d, u = g.seg_depth_with_uniq()
+    assert d.dtype == np.uint64 and (d == want_d).all(), "depth"
+    assert (u == want_u).all(), "uniq"
+    assert (g.seg_depth() == want_d).all(), "seg_depth"
+    want_len, want_mean = fo.path_depth(pools, path_ids)
+    ln, mean = g.path_depth(path_ids)
+    assert (ln == want_len).all(), "path lengths"
+    assert mean.tobytes() == want_mean.tobytes(), "mean depth (bitwise, NaN included)"
+
+
+@pytest.mark.parametrize("gfa", golden_gfas(), ids=fixture_id)
+def test_fixtures_match_oracle_and_golden(gfa):
+    g = pa.parse(gfa)
+    pools = fo.parse_gfa(read(gfa))
+    check_graph(g, pools)
+    # the text boundary: byte-identical to slow_odgi's table and to the oracle's emitters
+    assert g.depth_table() == read(gfa[:-4] + ".depth.tsv")
+    assert g.path_depth_table() == fo.fgfa_depth(pools, False)
+
+
+def test_known_answers():
+    # flatgfa-sh/README.md:31-36,51-59,267-270 (stand-ins) and slow_odgi/README.md:144-178
+    g = pa.parse(os.path.join(GOLDEN, "standin_note5.gfa"))
+    assert g.depth_table() == b"#node.id\tdepth\tdepth.uniq\n1\t2\t2\n2\t0\t0\n3\t2\t2\n4\t2\t2\n"
+    assert g.path_depth_table() == b"#path\tstart\tend\tmean.depth\n5\t0\t13\t2\n5-\t0\t13\t2\n"
+    assert g.path_depth_table([b"zzz", b"5-"]) == b"#path\tstart\tend\tmean.depth\n5-\t0\t13\t2\n"
+    assert g.path_depth_table([b"zzz"]) == b"#path\tstart\tend\tmean.depth\n"
+    g = pa.parse(os.path.join(GOLDEN, "standin_k.gfa"))
+    assert g.path_depth_table() == b"#path\tstart\tend\tmean.depth\nx\t0\t50\t1.9\ny\t0\t50\t1.9\n"
+    g = pa.parse(os.path.join(GOLDEN, "kat_slow_odgi_readme.gfa"))
+    d, u = g.seg_depth_with_uniq()
+    assert d.tolist() == [2, 0, 4, 2] and u.tolist() == [2, 0, 3, 2]
+
+
+def test_cli_depth_is_byte_identical():
+    for name in ("standin_note5", "ref_ex2", "edge_names_loops"):
+        gfa = os.path.join(GOLDEN, name + ".gfa")
+        pools = fo.parse_gfa(read(gfa))
+        out = subprocess.run([FGFA, "-I", gfa, "depth", "-d"], capture_output=True, check=True).stdout
+        assert out == read(os.path.join(GOLDEN, name + ".depth.tsv"))
+        out = subprocess.run([FGFA, "-I", gfa, "depth"], capture_output=True, check=True).stdout
+        assert out == fo.fgfa_depth(pools, False)
+    gfa = os.path.join(GOLDEN, "edge_names_loops.gfa")
+    out = subprocess.run([FGFA, "-I", gfa, "depth", "-r", "gamma", "-r", "nope", "-r", "alpha"],
+                         capture_output=True, check=True).stdout
+    assert out == fo.fgfa_depth(fo.parse_gfa(read(gfa)), False, [b"gamma", b"nope", b"alpha"])
+
+
+def test_flatgfa_file_input(tmp_path):
+    g = pa.synth(3, 5000, 40, 2000, "pangenome", True)
+    f = tmp_path / "s.flatgfa"
+    g.write_flatgfa(str(f))
+    h = pa.load(str(f))  # zero-copy view of an unaligned file image
+    check_graph(h, pools_of(g))
+    out = subprocess.run([FGFA, "-i", str(f), "depth", "-d"], capture_output=True, check=True).stdout
+    assert out == fo.fgfa_depth(pools_of(g), True)
+
+
+EDGE_TEXTS = [
+    b"",                                               # no segments, no paths
+    b"S\t1\tACGT\n",                                   # segments but no paths
+    b"S\t1\tACGT\nP\te\t\t*\n",                        # a path with zero steps (mean = NaN)
+    b"S\t1\tACGT\nS\t2\tA\nP\te\t\t*\nP\tp\t2+,2-,2+\t*\nP\tq\t1+\t*\n",
+    b"S\t7\tAC\nP\ta\t7+\t*\nP\ta\t7-\t*\n",           # duplicate path names are distinct paths
+    b"S\t1\t*\nP\tp\t1+,1+\t*\n",
+]
+
+
+@pytest.mark.parametrize("text", EDGE_TEXTS, ids=range(len(EDGE_TEXTS)))
+def test_edge_graphs(text):
+    g = pa.parse_bytes(text)
+    pools = fo.parse_gfa(text)
+    check_graph(g, pools)
+    assert g.depth_table() == fo.fgfa_depth(pools, True)
+    assert g.path_depth_table() == fo.fgfa_depth(pools, False)
+
+
+SHAPES = [
+    # seed, S, P, L, model
+    (1, 1, 1, 1, "pangenome"),
+    (2, 1, 7, 1000, "pangenome"),          # every step on one segment: worst-case contention
+    (3, 31, 3, 64, "uniform"),
+    (4, 33, 5, 65, "pangenome"),
+    (5, 1000, 1, 100_000, "pangenome"),    # one long path
+    (6, 100_000, 2000, 50, "pangenome"),   # many short paths
+    (7, 100_000, 3, 1, "uniform"),
+    (8, 65_537, 257, 1023, "uniform"),
+    (9, 1_048_576, 8, 20_000, "pangenome"),  # exactly one LDS window
+    (10, 1_048_577, 8, 20_000, "uniform"),   # one segment past it: two windows
+    (11, 2_500_000, 6, 30_000, "uniform"),   # three windows
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"S{s[1]}_P{s[2]}_L{s[3]}_{s[4]}" for s in SHAPES])
+def test_synthetic_shapes(shape):
+    seed, S, P, L, model = shape
+    g = pa.synth(seed, S, P, L, model, False)
+    pools = pools_of(g)
+    ids = None if P <= 64 else np.arange(P - 1, -1, -7, dtype=np.uint32)  # reversed, strided subset
+    check_graph(g, pools, ids)
+
+
+def test_arbitrary_and_overlapping_spans(tmp_path):
+    # The Path type allows any spans: overlapping, nested, out of order, gaps.
+    pools = synth.pools(12, 500, 4, 1000, "pangenome")
+    pools.paths["steps_start"] = [100, 0, 3500, 100]
+    pools.paths["steps_end"] = [2100, 4000, 3500, 2100]
+    f = tmp_path / "spans.flatgfa"
+    f.write_bytes(fo.dump_flatgfa(pools))
+    check_graph(pa.load(str(f)), pools, np.array([3, 3, 0, 2, 1], dtype=np.uint32))
+
+
+def test_out_of_range_ids_are_errors(tmp_path):
+    pools = synth.pools(13, 100, 2, 50, "pangenome")
+    bad = fo.Pools(**{n: getattr(pools, n).copy() for n in fo.POOL_ORDER})
+    bad.steps[77] = (100 << 1) | 1  # segment id == n_segs
+    f = tmp_path / "badseg.flatgfa"
+    f.write_bytes(fo.dump_flatgfa(bad))
+    g = pa.load(str(f))
+    with pytest.raises(pa.FlatGFAError) as e:
+        g.seg_depth_with_uniq()
+    assert e.value.code == -2
+    with pytest.raises(pa.FlatGFAError):
+        g.seg_depth()
+    bad = fo.Pools(**{n: getattr(pools, n).copy() for n in fo.POOL_ORDER})
+    bad.paths["steps_end"][1] = 101  # span past the steps pool
+    f = tmp_path / "badspan.flatgfa"
+    f.write_bytes(fo.dump_flatgfa(bad))
+    with pytest.raises(pa.FlatGFAError):
+        pa.load(str(f)).seg_depth()
+    with pytest.raises(pa.FlatGFAError):
+        pa.synth(1, 10, 2, 5).path_depth([0, 2])  # path id out of range
+
+
+def test_cfgS_matches_slow_odgi_golden():
+    # BASELINE.json configs[1]: 10k segments / 1M steps on one MI355X, bit-exact vs slow_odgi
+    g = pa.synth(1, 10_000, 100, 10_000, "pangenome", True)
+    assert g.depth_table() == read(os.path.join(GOLDEN, "synth_cfgS.depth.tsv"))
+    check_graph(g, pools_of(g))
+
+
+@pytest.mark.parametrize("model", ["pangenome", "uniform"])
+def test_cfgL_full_size(model):
+    # BASELINE.json configs[2]: 1M segments / 100M steps.  Checked against the oracle (a few
+    # seconds of CPU) and through size-independent properties.
+    S, P, L = 1_000_000, 1000, 100_000
+    g = pa.synth(1, S, P, L, model, False)
+    d, u = g.seg_depth_with_uniq()
+    assert int(d.sum()) == P * L                       # every step counted once
+    assert (u <= d).all() and (u <= P).all() and ((d > 0) == (u > 0)).all()
+    pools = pools_of(g)
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    assert (d == want_d).all() and (u == want_u).all()
+    ln, mean = g.path_depth()
+    want_ln, want_mean = fo.path_depth(pools)
+    assert (ln == want_ln).all() and mean.tobytes() == want_mean.tobytes()
+
+
+def test_repeat_calls_are_idempotent():
+    g = pa.synth(21, 20_000, 50, 4000, "pangenome", False)
+    a = g.seg_depth_with_uniq()
+    for _ in range(3):
+        b = g.seg_depth_with_uniq()
+        assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    assert (g.seg_depth() == a[0]).all()
+
+
+def test_linearity_over_path_subsets():
+    # depth and uniq are sums of per-path contributions: computing two disjoint path groups
+    # separately and adding must equal the whole (this is what multi-GPU sharding relies on).
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    from pollen_amd.sharded import local_slice, shard_paths
+    import torch
+    g = pa.synth(22, 30_000, 37, 3000, "pangenome", False)
+    steps, pb, pe, _ = g.soa()
+    whole_d, whole_u = g.seg_depth_with_uniq()
+    acc = torch.zeros(2 * 30_000, dtype=torch.int32, device="cuda:0")
+    for lo, hi in shard_paths(pb, pe, 3):
+        s, b, e = local_slice(steps, pb, pe, lo, hi)
+        plan = DepthPlan(DeviceGraph(s, b, e, 30_000))
+        part = torch.zeros_like(acc)
+        plan.seg_depth(part[:30_000], part[30_000:])
+        plan.status()
+        acc += part
+    got = acc.cpu().numpy().view(np.uint32)
+    assert (got[:30_000] == whole_d).all() and (got[30_000:] == whole_u).all()

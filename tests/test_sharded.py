@@ -1,0 +1,101 @@
+"""Multi-GPU path sharding, exercised on CPU: the partition logic directly, and the
+partial -> all-reduce combination under torch.distributed's gloo backend with world_size 2.
+The per-rank partials come from the oracle here (test stand-in for the HIP kernels); the
+partition, buffer fusion and collective are the product code in pollen_amd/sharded.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from oracle import flatgfa_oracle as fo
+from oracle import synth
+from pollen_amd.sharded import ShardedDepth, local_slice, shard_paths
+
+
+def test_shard_paths_covers_and_balances():
+    rng = np.random.default_rng(5)
+    for world in (1, 2, 3, 4, 8):
+        for P in (0, 1, 2, 7, 8, 100, 1000):
+            lens = rng.integers(0, 5000, size=P)
+            pb = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint32) if P else np.zeros(0, np.uint32)
+            pe = (pb + lens).astype(np.uint32)
+            cuts = shard_paths(pb, pe, world)
+            assert len(cuts) == world and cuts[0][0] == 0 and cuts[-1][1] == P
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))          # contiguous, whole paths
+            loads = [int(lens[lo:hi].sum()) for lo, hi in cuts]
+            assert sum(loads) == int(lens.sum())
+            if P:
+                assert max(loads) <= lens.sum() / world + lens.max()          # ideal + one path
+
+
+def test_shard_paths_equal_paths_split_evenly():
+    pb = (np.arange(1000) * 100_000).astype(np.uint32)
+    pe = pb + 100_000
+    for world in (2, 4, 8):
+        cuts = shard_paths(pb, pe, world)
+        assert [hi - lo for lo, hi in cuts] == [1000 // world] * world
+
+
+def test_local_slice_rebases_spans():
+    p = synth.pools(3, 200, 6, 50, "pangenome")
+    pb, pe = p.paths["steps_start"], p.paths["steps_end"]
+    s, b, e = local_slice(p.steps, pb, pe, 2, 5)
+    assert len(s) == 150 and b.tolist() == [0, 50, 100] and e.tolist() == [50, 100, 150]
+    assert (s == p.steps[100:250]).all()
+    s, b, e = local_slice(p.steps, pb, pe, 3, 3)
+    assert len(s) == 0 and len(b) == 0
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, seed, S, P, L, model, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pools = synth.pools(seed, S, P, L, model)
+        pb, pe = pools.paths["steps_start"], pools.paths["steps_end"]
+        lo, hi = shard_paths(pb, pe, world)[rank]
+        steps, b, e = local_slice(pools.steps, pb, pe, lo, hi)
+        sub = fo.Pools(**{n: getattr(pools, n) for n in fo.POOL_ORDER})
+        sub.steps = steps
+        paths = np.zeros(hi - lo, dtype=fo.PATH_DT)
+        paths["steps_start"], paths["steps_end"] = b, e
+        sub.paths = paths
+
+        def local_fn(depth, uniq):  # stand-in for DepthPlan.seg_depth on this rank's shard
+            d, u = fo.seg_depth_with_uniq(sub)
+            depth.copy_(torch.from_numpy(d.astype(np.uint32).view(np.int32)))
+            uniq.copy_(torch.from_numpy(u.astype(np.uint32).view(np.int32)))
+
+        op = ShardedDepth(S, local_fn, device="cpu", with_uniq=True)
+        op.run()
+        op.run()  # a second step must not accumulate
+        want_d, want_u = fo.seg_depth_with_uniq(pools)
+        ok = (op.depth.numpy().view(np.uint32) == want_d).all() and (op.uniq.numpy().view(np.uint32) == want_u).all()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape", [(1, 5000, 9, 700, "pangenome"), (2, 300, 2, 1000, "uniform"), (3, 64, 1, 10, "uniform")])
+def test_gloo_world2_allreduce_matches_unsharded(shape):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, *shape, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, True), (1, True)]
