@@ -12,12 +12,15 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
 
 #include "../../include/flatgfa.h"
+#include "depth_fast.hpp"
 #include "device_common.hpp"
+#include "prof.hpp"
 
 namespace fgfa_dev {
 
@@ -27,34 +30,15 @@ const char *last_error() { return g_last_error.c_str(); }
 
 // ------------------------------------------------------------ profiling ---
 
-struct ProfRec {
-    const char *name;
-    hipEvent_t a, b;
-};
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 
-struct ProfScope {
-    hipStream_t s;
-    bool on;
-    ProfRec r;
-    ProfScope(const char *name, hipStream_t stream) : s(stream), on(g_prof_on) {
-        if (on) {
-            r.name = name;
-            (void)hipEventCreate(&r.a);
-            (void)hipEventCreate(&r.b);
-            (void)hipEventRecord(r.a, s);
-        }
-    }
-    ~ProfScope() {
-        if (on) {
-            (void)hipEventRecord(r.b, s);
-            std::lock_guard<std::mutex> lk(g_prof_mu);
-            g_prof.push_back(r);
-        }
-    }
-};
+bool prof_enabled() { return g_prof_on; }
+void prof_push(const ProfRec &r) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(r);
+}
 
 // -------------------------------------------------------------- kernels ---
 
@@ -197,6 +181,7 @@ struct flatgfa_dev_plan {
     uint32_t n_items = 0;
     uint32_t *status = nullptr;
     uint32_t n_windows = 1;
+    FastPlan fast;  // the bucketed two-kernel path, used whenever the graph is eligible
 };
 
 #define HIP_TRY(expr, fail_stmt)                                                            \
@@ -247,21 +232,29 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
     HIP_TRY(hipFuncSetAttribute((const void *)k_depth_uniq_path, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)(kWinWords * 4)),
             { flatgfa_dev_plan_destroy(pl); return nullptr; });
+    // FLATGFA_DEPTH_PATH=atomic forces the simple global-atomic kernels (used by the tests to
+    // cover both device paths); anything else lets eligibility decide.
+    const char *force = getenv("FLATGFA_DEPTH_PATH");
+    if (!(force && std::string(force) == "atomic")) {
+        if (!fast_plan_create(pl->g, hb, he, &pl->fast)) { flatgfa_dev_plan_destroy(pl); return nullptr; }
+    }
     return pl;
 }
 
 extern "C" void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *pl) {
     if (!pl) return;
+    fast_plan_destroy(&pl->fast);
     if (pl->items) (void)hipFree(pl->items);
     if (pl->status) (void)hipFree(pl->status);
     delete pl;
 }
 
 extern "C" int flatgfa_dev_seg_depth(flatgfa_dev_plan_t *pl, uint32_t *depth_out, uint32_t *uniq_out, void *stream_) {
-    if (!pl || !depth_out) { set_error("dev_seg_depth: NULL argument"); return FLATGFA_ERR_ARG; }
+    if (!pl || (!depth_out && pl->g.n_segs)) { set_error("dev_seg_depth: NULL argument"); return FLATGFA_ERR_ARG; }
     hipStream_t stream = (hipStream_t)stream_;
     const flatgfa_dev_graph_t &g = pl->g;
     if (g.n_segs == 0) return FLATGFA_OK;
+    if (pl->fast.eligible) return fast_seg_depth(pl->fast, g, depth_out, uniq_out, pl->status, stream);
     {
         ProfScope ps("memset_outputs", stream);
         HIP_TRY(hipMemsetAsync(depth_out, 0, (size_t)g.n_segs * 4, stream), return FLATGFA_ERR_HIP);

@@ -1,0 +1,620 @@
+// The bucketed node-depth path for gfx950: two kernels, no global atomics on the data path.
+//
+//   k_scan   (pass 1)  persistent workgroups (one per CU), each pulling whole paths from a
+//            queue.  Every wave streams a contiguous span of the path's steps with 16-byte
+//            loads (4 handles per lane, 4 tiles in flight), detects maximal +1 runs of segment
+//            ids, and turns each run into ONE range record (start id, length) instead of
+//            `length` histogram updates.  For unique depth the path's "seen" bitset of
+//            ops/depth.rs:23-34 lives in LDS (1 bit per segment); when the path ends, the
+//            set-bit runs of the bitset become range records of a second kind and the bitset
+//            is left zeroed.  A record goes straight to the bucket of its 4096-segment window:
+//            buckets are split into one private sub-bucket per workgroup, so the append cursor
+//            is an LDS counter and no global atomic is needed; each workgroup's writes stay on
+//            its own XCD's L2 until the line is full.
+//   k_accum  (pass 2)  one workgroup per window: applies the window's records as +1/-1 pairs
+//            to two LDS difference arrays, prefix-sums them, and writes depth/uniq with
+//            coalesced 16-byte stores.  It also zeroes the counts it consumed, so the scratch
+//            is clean for the next call without any memset.
+//
+// Exactness: every step lies in exactly one run, so it contributes +1 to exactly one depth
+// record; every (path, segment) pair that occurs sets exactly one bit, which lies in exactly
+// one uniq record.  Sums of +1s are order-independent, hence the results equal
+// ops/depth.rs:15-39 bit for bit under any scheduling.  Runs are cut at ids that are multiples
+// of 2048, so a record never crosses a window.  Sub-buckets have a fixed capacity; a record
+// that does not fit is applied to a global difference array with atomics instead (slow, still
+// exact) and k_accum folds that array in.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "depth_fast.hpp"
+#include "device_common.hpp"
+#include "prof.hpp"
+
+namespace fgfa_dev {
+namespace {
+
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
+constexpr uint32_t kRunBits = 11;  // runs are cut at ids that are multiples of 2048
+constexpr uint32_t kRunSpan = 1u << kRunBits;
+constexpr uint32_t kWinBits = 12;  // accumulation window: 4096 segment ids = 128 bitset words
+constexpr uint32_t kWin = 1u << kWinBits;
+constexpr uint32_t kWinWords = kWin / 32;
+constexpr uint32_t kMaxWin = 512;  // LDS cursor table entries
+constexpr uint32_t kLdsLimit = 160 * 1024;
+constexpr int kAccThreads = 1024;
+
+// diagnostic ablations (FLATGFA_DEBUG_SKIP, results are then wrong by construction)
+constexpr uint32_t kDbgNoStore = 1, kDbgNoScanOut = 2, kDbgNoBitset = 4, kDbgNoTiles = 8;
+// the ablation checks exist only in the DBG instantiation of the kernel
+#define FGFA_SKIP(bit) (DBG && (A.dbg & (bit)))
+
+struct ScanArgs {
+    const uint32_t *steps;
+    const uint32_t *path_begin;
+    const uint32_t *path_end;
+    const uint32_t *order;  // paths, longest first
+    uint32_t n_paths, n_segs, n_win, n_words, n_slots;
+    uint32_t *work_counter;
+    uint32_t *counts;   // [n_win][n_slots]
+    uint32_t *buckets;  // [n_win + 1][n_slots][cap]; window n_win is a write sink
+    uint32_t cap;
+    uint32_t stride;    // n_slots * cap: elements between consecutive windows (< 2^30 in total)
+    uint32_t sink;      // n_win * stride
+    int *ovf_d;
+    int *ovf_u;
+    uint32_t *ovf_flag;
+    uint32_t *status;
+    uint32_t dbg;
+};
+
+// A record whose sub-bucket is full: apply it to the global difference array instead.
+__device__ __noinline__ void overflow_apply(int *arr, uint32_t *flag, uint32_t id, uint32_t len) {
+    flag[id >> kWinBits] = 1u;
+    atomicAdd(&arr[id], 1);
+    if ((id & (kWin - 1)) + len < kWin) atomicAdd(&arr[id + len], -1);
+}
+__device__ __forceinline__ void overflow_record(const ScanArgs &A, uint32_t id, uint32_t len, uint32_t kind) {
+    overflow_apply(kind ? A.ovf_u : A.ovf_d, A.ovf_flag, id, len);  // by value: A stays in SGPRs
+}
+
+// Reserve the next slot of this workgroup's sub-bucket for window (id >> 12); LDS atomic.
+__device__ __forceinline__ uint32_t reserve(uint32_t *bcur, bool e, uint32_t id) {
+    return e ? atomicAdd(&bcur[id >> kWinBits], 1u) : 0u;
+}
+
+// Store a record at slot `pos` of this workgroup's sub-bucket of window (id >> 12).  Branch
+// free: lanes with nothing to store (or no room) write to the sink window.  Returns whether
+// the record still has to take the overflow route.
+template <bool DBG>
+__device__ __forceinline__ bool put(const ScanArgs &A, uint32_t *mine, bool e, uint32_t pos, uint32_t id,
+                                    uint32_t lenm1, uint32_t kind) {
+    const bool ok = e && pos < A.cap;
+    // the bucket array holds fewer than 2^30 records, so a 32-bit byte offset from a uniform base suffices
+    const uint32_t boff = (ok ? (id >> kWinBits) * A.stride + pos : A.sink) << 2;
+    if (!FGFA_SKIP(kDbgNoStore))
+        *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(mine) + boff) =
+            (id & (kWin - 1)) | (lenm1 << kWinBits) | (kind << 24);
+    return e && !ok;
+}
+
+__device__ __forceinline__ uint32_t clamp_id(const ScanArgs &A, uint32_t id) {
+    if (id >= A.n_segs) {
+        *A.status = 1u;
+        return 0u;
+    }
+    return id;
+}
+
+// Wave-uniform walk state: the id of the step before the next one, and the start id of the
+// run that step belongs to.
+struct Walk {
+    uint32_t prev, rs;
+};
+
+// 256 steps, four consecutive ones per lane (lane i holds steps 4i..4i+3 of the tile).
+template <bool UNIQ, bool DBG>
+__device__ __forceinline__ void tile_full(const ScanArgs &A, Walk &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
+                                          int lane, uint4 v) {
+    uint32_t a0 = v.x >> 1, a1 = v.y >> 1, a2 = v.z >> 1, a3 = v.w >> 1;
+    if (max(max(a0, a1), max(a2, a3)) >= A.n_segs) {
+        a0 = clamp_id(A, a0);
+        a1 = clamp_id(A, a1);
+        a2 = clamp_id(A, a2);
+        a3 = clamp_id(A, a3);
+    }
+    uint32_t prev = __builtin_amdgcn_update_dpp(0u, a3, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    if (lane == 0) prev = w.prev;
+    const bool s0 = (a0 != prev + 1) | ((a0 & (kRunSpan - 1)) == 0);
+    const bool s1 = (a1 != a0 + 1) | ((a1 & (kRunSpan - 1)) == 0);
+    const bool s2 = (a2 != a1 + 1) | ((a2 & (kRunSpan - 1)) == 0);
+    const bool s3 = (a3 != a2 + 1) | ((a3 & (kRunSpan - 1)) == 0);
+    if (UNIQ && !FGFA_SKIP(kDbgNoBitset)) {
+        if (!(s1 | s2 | s3) && (a0 >> 5) == (a3 >> 5)) {
+            atomicOr(&seen[a0 >> 5], 0xFu << (a0 & 31));
+        } else {
+            atomicOr(&seen[a0 >> 5], 1u << (a0 & 31));
+            atomicOr(&seen[a1 >> 5], 1u << (a1 & 31));
+            atomicOr(&seen[a2 >> 5], 1u << (a2 & 31));
+            atomicOr(&seen[a3 >> 5], 1u << (a3 & 31));
+        }
+    }
+    // start id of the run in progress when this lane's first step arrives
+    const bool any = s0 | s1 | s2 | s3;
+    const uint32_t last_start = s3 ? a3 : (s2 ? a2 : (s1 ? a1 : a0));
+    const unsigned long long below = __ballot(any) & ((1ull << lane) - 1ull);
+    const int src = below ? 63 - __builtin_clzll(below) : lane;
+    const uint32_t from_below = __shfl(last_start, src, 64);
+    const uint32_t rs = below ? from_below : w.rs;
+    // a run ends wherever the next one starts: emit (start, length) of the run that just ended
+    const uint32_t len0 = prev - rs + 1;
+    const uint32_t rsA = s0 ? a0 : rs;
+    const uint32_t rsB = s1 ? a1 : rsA;
+    const uint32_t rsC = s2 ? a2 : rsB;
+    const uint32_t rsD = s3 ? a3 : rsC;
+    const bool e0 = s0 && len0 != 0;
+    const uint32_t p0 = reserve(bcur, e0, rs);
+    const uint32_t p1 = reserve(bcur, s1, rsA);
+    const uint32_t p2 = reserve(bcur, s2, rsB);
+    const uint32_t p3 = reserve(bcur, s3, rsC);
+    const bool o0 = put<DBG>(A, mine, e0, p0, rs, len0 - 1, 0u);
+    const bool o1 = put<DBG>(A, mine, s1, p1, rsA, a0 - rsA, 0u);
+    const bool o2 = put<DBG>(A, mine, s2, p2, rsB, a1 - rsB, 0u);
+    const bool o3 = put<DBG>(A, mine, s3, p3, rsC, a2 - rsC, 0u);
+    if (__ballot(o0 | o1 | o2 | o3)) {  // rare: a sub-bucket is full
+        if (o0) overflow_record(A, rs, len0, 0u);
+        if (o1) overflow_record(A, rsA, a0 - rsA + 1, 0u);
+        if (o2) overflow_record(A, rsB, a1 - rsB + 1, 0u);
+        if (o3) overflow_record(A, rsC, a2 - rsC + 1, 0u);
+    }
+    w.prev = __builtin_amdgcn_readlane(a3, 63);
+    w.rs = __builtin_amdgcn_readlane(rsD, 63);
+}
+
+// Up to 64 consecutive steps, one per lane (heads, tails and short spans).
+template <bool UNIQ>
+__device__ __forceinline__ void tile_narrow(const ScanArgs &A, Walk &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
+                                            int lane, uint64_t t, uint32_t count) {
+    const bool valid = (uint32_t)lane < count;
+    const uint32_t id = valid ? clamp_id(A, A.steps[t + lane] >> 1) : 0u;
+    uint32_t prev = __builtin_amdgcn_update_dpp(0u, id, 0x138, 0xf, 0xf, false);
+    if (lane == 0) prev = w.prev;
+    const bool s = valid && ((id != prev + 1) | ((id & (kRunSpan - 1)) == 0));
+    if (UNIQ && valid) atomicOr(&seen[id >> 5], 1u << (id & 31));
+    const unsigned long long m = __ballot(s);
+    const unsigned long long below = m & ((1ull << lane) - 1ull);
+    const int src = below ? 63 - __builtin_clzll(below) : lane;
+    const uint32_t from_below = __shfl(id, src, 64);
+    const uint32_t rs = below ? from_below : w.rs;
+    const uint32_t len = prev - rs + 1;
+    const bool e = s && len != 0;
+    if (put<false>(A, mine, e, reserve(bcur, e, rs), rs, len - 1, 0u)) overflow_record(A, rs, len, 0u);
+    w.prev = __shfl(id, (int)count - 1, 64);
+    if (m) w.rs = __shfl(id, 63 - __builtin_clzll(m), 64);
+}
+
+// One wave's share of one path: steps [lo, hi), of which [t0, t0 + 256 * nfull) are whole,
+// 16-byte-aligned tiles read through `src`.
+struct Span {
+    uint64_t lo, hi, t0, nfull;
+    const uint4 *src;
+};
+
+__device__ __forceinline__ Span make_span(const ScanArgs &A, uint32_t job, int wave, int lane) {
+    Span s;
+    s.lo = s.hi = s.t0 = s.nfull = 0;
+    s.src = nullptr;
+    if (job < A.n_paths) {
+        const uint32_t p = A.order[job];
+        const uint64_t b = A.path_begin[p], e = A.path_end[p], n = e - b;
+        // contiguous span per wave, a whole number of tiles
+        const uint64_t per = ((n + kWaves - 1) / kWaves + 255) / 256 * 256;
+        s.lo = min(b + per * wave, e);
+        s.hi = min(s.lo + per, e);
+        s.t0 = min(s.lo + ((4 - (s.lo & 3)) & 3), s.hi);
+        s.nfull = (s.hi - s.t0) / 256;
+        s.src = reinterpret_cast<const uint4 *>(A.steps + s.t0) + lane;
+    }
+    return s;
+}
+
+// Streaming loads of steps: each handle is read exactly once, so keep it out of the way of
+// the bucket lines that the L2 is write-combining.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_tile(const uint4 *p) {
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// The runs of set bits of one bitset word become uniq records at consecutive slots from `pos`.
+template <bool DBG>
+__device__ __forceinline__ void put_word_runs(const ScanArgs &A, uint32_t *mine, uint32_t x, uint32_t id0,
+                                              uint32_t pos) {
+    while (x) {
+        const uint32_t tz = __builtin_ctz(x);
+        const uint32_t y = x >> tz;
+        const uint32_t run = (y == 0xFFFFFFFFu) ? 32u : (uint32_t)__builtin_ctz(~y);
+        x &= ~(((run == 32u) ? 0xFFFFFFFFu : ((1u << run) - 1u)) << tz);
+        if (pos < A.cap) {
+            if (!FGFA_SKIP(kDbgNoStore))
+                mine[(id0 >> kWinBits) * A.stride + pos] = ((id0 + tz) & (kWin - 1)) | ((run - 1) << kWinBits) | (1u << 24);
+        } else {
+            overflow_record(A, id0 + tz, run, 1u);
+        }
+        ++pos;
+    }
+}
+
+__device__ __forceinline__ uint32_t word_runs(uint32_t x) { return __builtin_popcount(x & ~(x << 1)); }
+
+template <bool UNIQ, bool DBG>
+__global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
+    extern __shared__ uint32_t lds[];
+    // layout: [bcur: kMaxWin][seen: n_words]
+    uint32_t *bcur = lds;
+    uint32_t *seen = lds + kMaxWin;
+    __shared__ uint32_t next_job;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;  // this workgroup's sub-bucket of window 0
+    for (uint32_t i = threadIdx.x; i < kMaxWin; i += kThreads) bcur[i] = 0u;
+    if (UNIQ)
+        for (uint32_t i = threadIdx.x; i < A.n_words; i += kThreads) seen[i] = 0u;
+    if (threadIdx.x == 0) next_job = atomicAdd(A.work_counter, 1u);
+    __syncthreads();
+    uint32_t job = next_job;
+    __syncthreads();
+
+    // The first tiles of a path are requested before the previous path's bitset is scanned
+    // out, so that their latency hides behind that phase.
+    Span sp = make_span(A, job, wave, lane);
+    uint4 r0 = {}, r1 = {}, r2 = {}, r3 = {};
+    uint32_t first_raw = 0;
+#define FGFA_PRELOAD()                                              \
+    do {                                                            \
+        if (sp.lo < sp.hi) first_raw = A.steps[sp.lo];              \
+        if (sp.nfull > 0) r0 = load_tile(sp.src);                   \
+        if (sp.nfull > 1) r1 = load_tile(sp.src + 64);              \
+        if (sp.nfull > 2) r2 = load_tile(sp.src + 128);             \
+        if (sp.nfull > 3) r3 = load_tile(sp.src + 192);             \
+    } while (0)
+    FGFA_PRELOAD();
+
+    while (job < A.n_paths) {
+        if (threadIdx.x == 0) next_job = atomicAdd(A.work_counter, 1u);  // consumed after the barrier below
+        if (sp.lo < sp.hi) {
+            const uint32_t first = clamp_id(A, first_raw >> 1);
+            Walk w;
+            w.prev = first - 1;  // the first step then continues a (so far empty) run that starts at it
+            w.rs = first;
+            if (sp.t0 > sp.lo) tile_narrow<UNIQ>(A, w, seen, bcur, mine, lane, sp.lo, (uint32_t)(sp.t0 - sp.lo));
+            // four tiles (4 KiB per wave, 64 KiB per CU) stay in flight
+#pragma unroll 4
+            for (uint64_t i = 0; i < sp.nfull; ++i) {
+                const uint4 cur = r0;
+                r0 = r1;
+                r1 = r2;
+                r2 = r3;
+                if (i + 4 < sp.nfull) r3 = load_tile(sp.src + (i + 4) * 64);
+                if (!FGFA_SKIP(kDbgNoTiles)) tile_full<UNIQ, DBG>(A, w, seen, bcur, mine, lane, cur);
+                else if (cur.x == 0x7FFFFFFFu) *A.status = 2u;
+            }
+            uint64_t t = sp.t0 + sp.nfull * 256;
+            while (t < sp.hi) {
+                const uint32_t cnt = (uint32_t)min((uint64_t)64, sp.hi - t);
+                tile_narrow<UNIQ>(A, w, seen, bcur, mine, lane, t, cnt);
+                t += cnt;
+            }
+            // close the run still open at the end of the span
+            const bool last = lane == 0;
+            if (put<false>(A, mine, last, reserve(bcur, last, w.rs), w.rs, w.prev - w.rs, 0u))
+                overflow_record(A, w.rs, w.prev - w.rs + 1, 0u);
+        }
+        __syncthreads();  // every wave's bits are in; next_job is visible
+        job = next_job;
+        sp = make_span(A, job, wave, lane);
+        FGFA_PRELOAD();
+        if (UNIQ) {
+            // Scan-out: every lane owns `wpl` consecutive bitset words (1024 lanes cover the whole
+            // bitset; a window's 128 words belong to 128/wpl neighbouring lanes).  One counting
+            // sweep gives each lane its number of set-bit runs; a wave prefix sum and ONE LDS
+            // atomic per window reserve the slots; a second sweep writes the records and leaves
+            // the words zeroed.
+            if (!FGFA_SKIP(kDbgNoScanOut)) {
+                const uint32_t wpl = A.n_words >> 10;  // 4, 8, 16 or 32
+                uint32_t *my = seen + threadIdx.x * wpl;
+                uint32_t c = 0;
+                for (uint32_t k = 0; k < wpl; k += 4) {
+                    const uint4 x = *reinterpret_cast<const uint4 *>(my + k);
+                    c += word_runs(x.x) + word_runs(x.y) + word_runs(x.z) + word_runs(x.w);
+                }
+                if (__ballot(c != 0)) {
+                    uint32_t incl = c;
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t t = __shfl_up(incl, off, 64);
+                        if (lane >= off) incl += t;
+                    }
+                    const int group = (int)(kWinWords / wpl);  // lanes per window: 32 .. 4
+                    const int g0 = lane & ~(group - 1);
+                    const uint32_t upto_prev_group = __shfl(incl, g0 ? g0 - 1 : 0, 64);
+                    const uint32_t before = g0 ? upto_prev_group : 0u;
+                    const uint32_t group_total = __shfl(incl, g0 + group - 1, 64) - before;
+                    const uint32_t win = (threadIdx.x * wpl) / kWinWords;
+                    uint32_t base = 0;
+                    if (lane == g0 && group_total) base = atomicAdd(&bcur[win], group_total);
+                    base = __shfl(base, g0, 64);
+                    uint32_t pos = base + (incl - c) - before;
+                    if (c) {
+                        const uint32_t id0 = (threadIdx.x * wpl) << 5;
+                        for (uint32_t k = 0; k < wpl; k += 4) {
+                            const uint4 x = *reinterpret_cast<const uint4 *>(my + k);
+                            if ((x.x | x.y | x.z | x.w) == 0) continue;
+                            *reinterpret_cast<uint4 *>(my + k) = make_uint4(0u, 0u, 0u, 0u);
+                            put_word_runs<DBG>(A, mine, x.x, id0 + (k << 5), pos);
+                            pos += word_runs(x.x);
+                            put_word_runs<DBG>(A, mine, x.y, id0 + ((k + 1) << 5), pos);
+                            pos += word_runs(x.y);
+                            put_word_runs<DBG>(A, mine, x.z, id0 + ((k + 2) << 5), pos);
+                            pos += word_runs(x.z);
+                            put_word_runs<DBG>(A, mine, x.w, id0 + ((k + 3) << 5), pos);
+                            pos += word_runs(x.w);
+                        }
+                    }
+                }
+            } else {
+                for (uint32_t j = threadIdx.x; j < A.n_words; j += kThreads) seen[j] = 0u;
+            }
+            __syncthreads();  // the bitset is clean before the next path sets bits
+        }
+    }
+#undef FGFA_PRELOAD
+    // publish how many records this workgroup left in each window's sub-bucket
+    __syncthreads();
+    for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads)
+        A.counts[(size_t)wdw * A.n_slots + blockIdx.x] = bcur[wdw];
+}
+
+// ------------------------------------------------------------------ pass 2 ---
+
+struct AccArgs {
+    uint32_t n_segs, n_win, n_slots, cap;
+    uint32_t *counts;
+    const uint32_t *buckets;
+    int *ovf_d;
+    int *ovf_u;
+    uint32_t *ovf_flag;
+    uint32_t *work_counter;
+    uint32_t *depth_out;
+    uint32_t *uniq_out;
+};
+
+template <bool UNIQ>
+__device__ __forceinline__ void apply_record(int *dd, int *ud, uint32_t rec) {
+    const uint32_t rel = rec & (kWin - 1), len = ((rec >> kWinBits) & (kWin - 1)) + 1;
+    int *arr = (UNIQ && ((rec >> 24) & 1u)) ? ud : dd;
+    atomicAdd(&arr[rel], 1);
+    atomicAdd(&arr[rel + len], -1);  // rel + len <= 4096; slot 4096 is a sink
+}
+
+// inclusive prefix sum of 4096 ints held 4 per thread by 1024 threads; returns this thread's
+// four prefix values.
+__device__ __forceinline__ int4 block_scan4(const int *arr, int *wave_tot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int4 v = *reinterpret_cast<const int4 *>(arr + 4 * tid);
+    v.y += v.x;
+    v.z += v.y;
+    v.w += v.z;
+    int incl = v.w;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int add = incl - v.w;
+    for (int k = 0; k < wave; ++k) add += wave_tot[k];
+    __syncthreads();
+    v.x += add;
+    v.y += add;
+    v.z += add;
+    v.w += add;
+    return v;
+}
+
+__device__ __forceinline__ void store4(uint32_t *out, uint32_t i0, uint32_t nvalid, int4 v) {
+    if (i0 + 3 < nvalid) {
+        *reinterpret_cast<uint4 *>(out + i0) = make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
+    } else {
+        const int a[4] = {v.x, v.y, v.z, v.w};
+        for (uint32_t k = 0; k < 4; ++k)
+            if (i0 + k < nvalid) out[i0 + k] = (uint32_t)a[k];
+    }
+}
+
+template <bool UNIQ>
+__global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
+    __shared__ __attribute__((aligned(16))) int dd[kWin + 64];
+    __shared__ __attribute__((aligned(16))) int ud[UNIQ ? kWin + 64 : 64];
+    __shared__ int wave_tot[kAccThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t win = blockIdx.x, w0 = win * kWin;
+    const uint32_t nvalid = min(kWin, A.n_segs - w0);
+    const bool ovf = A.ovf_flag[win] != 0;
+    for (uint32_t i = tid; i < kWin + 64; i += kAccThreads) {
+        int d0 = 0, u0 = 0;
+        if (ovf && i < nvalid) {
+            d0 = A.ovf_d[w0 + i];
+            A.ovf_d[w0 + i] = 0;
+            if (UNIQ) {
+                u0 = A.ovf_u[w0 + i];
+                A.ovf_u[w0 + i] = 0;
+            }
+        }
+        dd[i] = d0;
+        if (UNIQ) ud[i] = u0;
+    }
+    __syncthreads();
+    if (ovf && tid == 0) A.ovf_flag[win] = 0u;
+    // Drain the window's sub-buckets: each wave takes four of them per round so that four
+    // independent 16-byte loads per lane are in flight.
+    constexpr uint32_t kAccWaves = kAccThreads / 64;
+    const uint32_t *cnt_base = A.counts + (size_t)win * A.n_slots;
+    for (uint32_t s0 = wave; s0 < A.n_slots; s0 += 4 * kAccWaves) {
+        uint32_t cnt[4];
+        const uint32_t *bk[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t s = s0 + k * kAccWaves;
+            cnt[k] = s < A.n_slots ? min(cnt_base[s], A.cap) : 0u;
+            bk[k] = A.buckets + ((size_t)win * A.n_slots + (s < A.n_slots ? s : 0u)) * A.cap;
+        }
+        const uint32_t max4 = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3])) >> 2;
+        for (uint32_t i = lane; i < max4; i += 64) {
+            uint4 r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i < (cnt[k] >> 2)) r[k] = reinterpret_cast<const uint4 *>(bk[k])[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i < (cnt[k] >> 2)) {
+                    apply_record<UNIQ>(dd, ud, r[k].x);
+                    apply_record<UNIQ>(dd, ud, r[k].y);
+                    apply_record<UNIQ>(dd, ud, r[k].z);
+                    apply_record<UNIQ>(dd, ud, r[k].w);
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t rest = (cnt[k] & ~3u) + lane;
+            if (rest < cnt[k]) apply_record<UNIQ>(dd, ud, bk[k][rest]);
+        }
+    }
+    __syncthreads();
+    // the scratch is clean for the next call
+    for (uint32_t s = tid; s < A.n_slots; s += kAccThreads) A.counts[(size_t)win * A.n_slots + s] = 0u;
+    if (win == 0 && tid == 0) *A.work_counter = 0u;
+    const uint32_t i0 = 4 * tid;
+    store4(A.depth_out + w0, i0, nvalid, block_scan4(dd, wave_tot));
+    if (UNIQ) store4(A.uniq_out + w0, i0, nvalid, block_scan4(ud, wave_tot));
+}
+
+uint32_t scan_lds_bytes(uint32_t n_words) { return (kMaxWin + n_words) * 4u; }
+
+#define FAST_TRY(expr)                                                                      \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+            return false;                                                                   \
+        }                                                                                   \
+    } while (0)
+
+}  // namespace
+
+bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp) {
+    *fp = FastPlan();
+    if (g.n_segs == 0 || g.n_paths == 0 || g.n_steps == 0) return true;
+    if ((reinterpret_cast<uintptr_t>(g.steps) & 15u) != 0) return true;  // 16-byte step loads
+    const uint32_t n_win = (g.n_segs + kWin - 1) / kWin;
+    if (n_win > kMaxWin) return true;
+    // the scan-out gives each of the 1024 lanes 4, 8, 16 or 32 consecutive bitset words
+    uint32_t wpl = 4;
+    while (wpl < 32 && (uint64_t)wpl * kThreads * 32 < g.n_segs) wpl *= 2;
+    if ((uint64_t)wpl * kThreads * 32 < g.n_segs) return true;  // more than 1,048,576 segments: bitset too big
+    const uint32_t n_words = wpl * kThreads;
+    if (scan_lds_bytes(n_words) + 64 > kLdsLimit) return true;  // the "seen" bitset must fit one CU's LDS
+    hipDeviceProp_t prop;
+    int dev = 0;
+    FAST_TRY(hipGetDevice(&dev));
+    FAST_TRY(hipGetDeviceProperties(&prop, dev));
+    fp->n_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+    fp->n_slots = fp->n_cus;
+    fp->n_win = n_win;
+    fp->n_words = n_words;
+    fp->lds_bytes_uniq = scan_lds_bytes(n_words);
+    fp->lds_bytes_depth = scan_lds_bytes(0);
+    // Worst case is one depth record per step plus one uniq record per step; 25% headroom for
+    // skew.  Record slots are addressed with 32-bit element offsets, so the whole bucket array
+    // (one extra sink window included) must stay below 2^30 elements; beyond that the capacity
+    // is trimmed and the overflow route absorbs the worst case.
+    const uint64_t slots = (uint64_t)n_win * fp->n_slots;
+    uint64_t cap = (2 * g.n_steps + slots - 1) / slots;
+    cap = cap + cap / 4 + 256;
+    const uint64_t max_cap = ((1ull << 30) - 1) / ((uint64_t)(n_win + 1) * fp->n_slots);
+    cap = std::min(cap, max_cap);
+    if (const char *forced = getenv("FLATGFA_BUCKET_CAP")) cap = strtoull(forced, nullptr, 10);  // tests: force overflow
+    cap = std::min<uint64_t>(std::max<uint64_t>(cap & ~3ull, 4), max_cap & ~3ull);
+    if (cap < 4) return true;
+    fp->cap = (uint32_t)cap;
+    if (const char *d = getenv("FLATGFA_DEBUG_SKIP")) fp->dbg = (uint32_t)strtoul(d, nullptr, 10);
+    std::vector<uint32_t> order(g.n_paths);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return he[a] - hb[a] > he[b] - hb[b]; });
+    FAST_TRY(hipMalloc(&fp->counts, slots * 4));
+    FAST_TRY(hipMemset(fp->counts, 0, slots * 4));
+    FAST_TRY(hipMalloc(&fp->buckets, (slots + fp->n_slots) * cap * 4));
+    FAST_TRY(hipMalloc(&fp->ovf_d, ((size_t)g.n_segs + 1) * 4));
+    FAST_TRY(hipMalloc(&fp->ovf_u, ((size_t)g.n_segs + 1) * 4));
+    FAST_TRY(hipMemset(fp->ovf_d, 0, ((size_t)g.n_segs + 1) * 4));
+    FAST_TRY(hipMemset(fp->ovf_u, 0, ((size_t)g.n_segs + 1) * 4));
+    FAST_TRY(hipMalloc(&fp->ovf_flag, (size_t)n_win * 4));
+    FAST_TRY(hipMemset(fp->ovf_flag, 0, (size_t)n_win * 4));
+    FAST_TRY(hipMalloc(&fp->order, (size_t)g.n_paths * 4));
+    FAST_TRY(hipMemcpy(fp->order, order.data(), (size_t)g.n_paths * 4, hipMemcpyHostToDevice));
+    FAST_TRY(hipMalloc(&fp->work_counter, 256));
+    FAST_TRY(hipMemset(fp->work_counter, 0, 256));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_uniq));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_uniq));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_depth));
+    fp->eligible = true;
+    return true;
+}
+
+void fast_plan_destroy(FastPlan *fp) {
+    for (void *p : {(void *)fp->counts, (void *)fp->buckets, (void *)fp->ovf_d, (void *)fp->ovf_u, (void *)fp->ovf_flag,
+                    (void *)fp->order, (void *)fp->work_counter})
+        if (p) (void)hipFree(p);
+    *fp = FastPlan();
+}
+
+int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
+                   uint32_t *status, hipStream_t stream) {
+    const uint32_t stride = fp.n_slots * fp.cap;
+    ScanArgs sa{g.steps, g.path_begin, g.path_end, fp.order, g.n_paths, g.n_segs, fp.n_win,
+                uniq_out ? fp.n_words : 0u, fp.n_slots, fp.work_counter, fp.counts, fp.buckets, fp.cap, stride,
+                fp.n_win * stride, fp.ovf_d, fp.ovf_u, fp.ovf_flag, status, fp.dbg};
+    AccArgs aa{g.n_segs, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.buckets, fp.ovf_d, fp.ovf_u, fp.ovf_flag,
+               fp.work_counter, depth_out, uniq_out};
+    const uint32_t grid = std::min<uint32_t>(g.n_paths, fp.n_slots);  // one persistent workgroup per CU
+    if (uniq_out) {
+        {
+            ProfScope ps("k_scan<uniq>", stream);
+            if (fp.dbg) hipLaunchKernelGGL((k_scan<true, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_uniq, stream, sa);
+            else hipLaunchKernelGGL((k_scan<true, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_uniq, stream, sa);
+        }
+        {
+            ProfScope ps("k_accum<uniq>", stream);
+            hipLaunchKernelGGL(k_accum<true>, dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
+        }
+    } else {
+        {
+            ProfScope ps("k_scan<depth>", stream);
+            hipLaunchKernelGGL((k_scan<false, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_depth, stream, sa);
+        }
+        {
+            ProfScope ps("k_accum<depth>", stream);
+            hipLaunchKernelGGL(k_accum<false>, dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
+        }
+    }
+    if (hipGetLastError() != hipSuccess) {
+        set_error("fast_seg_depth: kernel launch failed");
+        return FLATGFA_ERR_HIP;
+    }
+    return FLATGFA_OK;
+}
+
+}  // namespace fgfa_dev

@@ -18,6 +18,20 @@ pytestmark = pytest.mark.gpu
 FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
+@pytest.fixture(params=["auto", "atomic", "tinycap"])
+def device_path(request, monkeypatch):
+    """Runs a test once per device path: the bucketed two-kernel path (default), the simple
+    global-atomic kernels, and the bucketed path with 8-record buckets so that nearly every
+    record takes the overflow route.  The variables are read when a graph becomes resident."""
+    monkeypatch.delenv("FLATGFA_DEPTH_PATH", raising=False)
+    monkeypatch.delenv("FLATGFA_BUCKET_CAP", raising=False)
+    if request.param == "atomic":
+        monkeypatch.setenv("FLATGFA_DEPTH_PATH", "atomic")
+    elif request.param == "tinycap":
+        monkeypatch.setenv("FLATGFA_BUCKET_CAP", "8")
+    return request.param
+
+
 def read(path):
     with open(path, "rb") as f:
         return f.read()
@@ -40,7 +54,7 @@ def check_graph(g: pa.FlatGFA, pools: fo.Pools, path_ids=None):
 
 
 @pytest.mark.parametrize("gfa", golden_gfas(), ids=fixture_id)
-def test_fixtures_match_oracle_and_golden(gfa):
+def test_fixtures_match_oracle_and_golden(gfa, device_path):
     g = pa.parse(gfa)
     pools = fo.parse_gfa(read(gfa))
     check_graph(g, pools)
@@ -98,7 +112,7 @@ EDGE_TEXTS = [
 
 
 @pytest.mark.parametrize("text", EDGE_TEXTS, ids=range(len(EDGE_TEXTS)))
-def test_edge_graphs(text):
+def test_edge_graphs(text, device_path):
     g = pa.parse_bytes(text)
     pools = fo.parse_gfa(text)
     check_graph(g, pools)
@@ -123,7 +137,7 @@ SHAPES = [
 
 
 @pytest.mark.parametrize("shape", SHAPES, ids=[f"S{s[1]}_P{s[2]}_L{s[3]}_{s[4]}" for s in SHAPES])
-def test_synthetic_shapes(shape):
+def test_synthetic_shapes(shape, device_path):
     seed, S, P, L, model = shape
     g = pa.synth(seed, S, P, L, model, False)
     pools = pools_of(g)
@@ -131,7 +145,7 @@ def test_synthetic_shapes(shape):
     check_graph(g, pools, ids)
 
 
-def test_arbitrary_and_overlapping_spans(tmp_path):
+def test_arbitrary_and_overlapping_spans(tmp_path, device_path):
     # The Path type allows any spans: overlapping, nested, out of order, gaps.
     pools = synth.pools(12, 500, 4, 1000, "pangenome")
     pools.paths["steps_start"] = [100, 0, 3500, 100]
@@ -141,7 +155,7 @@ def test_arbitrary_and_overlapping_spans(tmp_path):
     check_graph(pa.load(str(f)), pools, np.array([3, 3, 0, 2, 1], dtype=np.uint32))
 
 
-def test_out_of_range_ids_are_errors(tmp_path):
+def test_out_of_range_ids_are_errors(tmp_path, device_path):
     pools = synth.pools(13, 100, 2, 50, "pangenome")
     bad = fo.Pools(**{n: getattr(pools, n).copy() for n in fo.POOL_ORDER})
     bad.steps[77] = (100 << 1) | 1  # segment id == n_segs
@@ -187,7 +201,7 @@ def test_cfgL_full_size(model):
     assert (ln == want_ln).all() and mean.tobytes() == want_mean.tobytes()
 
 
-def test_repeat_calls_are_idempotent():
+def test_repeat_calls_are_idempotent(device_path):
     g = pa.synth(21, 20_000, 50, 4000, "pangenome", False)
     a = g.seg_depth_with_uniq()
     for _ in range(3):
