@@ -79,13 +79,10 @@ __device__ __noinline__ void overflow_apply(int *arr, uint32_t *flag, uint32_t i
     atomicAdd(&arr[id], 1);
     if ((id & (kWin - 1)) + len < kWin) atomicAdd(&arr[id + len], -1);
 }
+// kind: 0 = depth, 1 = uniq, 2 = both
 __device__ __forceinline__ void overflow_record(const ScanArgs &A, uint32_t id, uint32_t len, uint32_t kind) {
-    overflow_apply(kind ? A.ovf_u : A.ovf_d, A.ovf_flag, id, len);  // by value: A stays in SGPRs
-}
-
-// Reserve the next slot of this workgroup's sub-bucket for window (id >> 12); LDS atomic.
-__device__ __forceinline__ uint32_t reserve(uint32_t *bcur, bool e, uint32_t id) {
-    return e ? atomicAdd(&bcur[id >> kWinBits], 1u) : 0u;
+    if (kind != 1u) overflow_apply(A.ovf_d, A.ovf_flag, id, len);  // by value: A stays in SGPRs
+    if (kind != 0u) overflow_apply(A.ovf_u, A.ovf_flag, id, len);
 }
 
 // Store a record at slot `pos` of this workgroup's sub-bucket of window (id >> 12).  Branch
@@ -111,16 +108,121 @@ __device__ __forceinline__ uint32_t clamp_id(const ScanArgs &A, uint32_t id) {
     return id;
 }
 
-// Wave-uniform walk state: the id of the step before the next one, and the start id of the
-// run that step belongs to.
-struct Walk {
-    uint32_t prev, rs;
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Per-wave state: the run queue (LDS, kQCap entries of (start id << 11) | (len - 1)), how many
+// entries it holds, the id of the step before the next one, and the start id of the run that
+// step belongs to.  `fill`, `prev` and `rs` are wave-uniform.
+struct Wave {
+    uint32_t *q;
+    uint32_t fill, prev, rs;
+    int lane;
 };
+
+__device__ __forceinline__ void enqueue(Wave &w, bool e, uint32_t rec) {
+    const unsigned long long m = __ballot(e);
+    if (e) w.q[w.fill + lane_rank(m)] = rec;
+    w.fill += (uint32_t)__builtin_popcountll(m);
+}
+
+// Claim a run longer than 64 segments word by word; the newly claimed bits of each word become
+// uniq records.  Rare (a perfectly linear stretch of the path), hence out of line.
+__device__ __noinline__ void claim_long_run(uint32_t *seen, uint32_t *mine, uint32_t *bcur, uint32_t cap, uint32_t stride,
+                                            int *ovf_u, uint32_t *ovf_flag, uint32_t id, uint32_t len) {
+    uint32_t cur = id, left = len;
+    while (left) {
+        const uint32_t b = cur & 31u, n = min(left, 32u - b);
+        const uint32_t mw = ((n == 32u) ? 0xFFFFFFFFu : ((1u << n) - 1u)) << b;
+        uint32_t nb = mw & ~atomicOr(&seen[cur >> 5], mw);
+        const uint32_t id0 = cur & ~31u;
+        while (nb) {
+            const uint32_t tz = __builtin_ctz(nb);
+            const uint32_t y = nb >> tz;
+            const uint32_t run = (y == 0xFFFFFFFFu) ? 32u : (uint32_t)__builtin_ctz(~y);
+            nb &= ~(((run == 32u) ? 0xFFFFFFFFu : ((1u << run) - 1u)) << tz);
+            const uint32_t rid = id0 + tz;
+            const uint32_t pos = atomicAdd(&bcur[rid >> kWinBits], 1u);
+            if (pos < cap) mine[(rid >> kWinBits) * stride + pos] = (rid & (kWin - 1)) | ((run - 1) << kWinBits) | (1u << 24);
+            else overflow_apply(ovf_u, ovf_flag, rid, run);
+        }
+        cur += n;
+        left -= n;
+    }
+}
+
+// Emit up to 64 queued runs, one per lane.  Each run becomes one depth record.  For unique
+// depth the lane claims the run's segments in the path's "seen" bitset with returning LDS ORs
+// (a run of up to 64 segments spans at most three words): the bits that were still clear are
+// exactly the (path, segment) pairs this run is the first to touch.  If all of them were
+// clear the depth record doubles as the uniq record (kind 2); otherwise every stretch of newly
+// claimed segments gets a uniq record of its own (usually none or one).
+template <bool UNIQ, bool DBG>
+__device__ __forceinline__ void emit_chunk(const ScanArgs &A, uint32_t *seen, uint32_t *bcur, uint32_t *mine, bool valid,
+                                           uint32_t rec) {
+    const uint32_t id = rec >> kRunBits, len = (rec & (kRunSpan - 1)) + 1, win = id >> kWinBits;
+    uint32_t kind = 0;
+    unsigned long long xr = 0;  // bit k set <=> segment id + k was newly claimed and still needs a uniq record
+    bool slow = false;
+    if (UNIQ && !FGFA_SKIP(kDbgNoBitset)) {
+        const uint32_t bit0 = id & 31u, w0 = id >> 5;
+        const bool fast = valid && len <= 64u;
+        slow = valid && !fast;
+        const unsigned long long ones = (len >= 64u) ? ~0ull : ((1ull << len) - 1ull);
+        const unsigned long long m01 = fast ? (ones << bit0) : 0ull;
+        const uint32_t m2 = (fast && bit0) ? (uint32_t)(ones >> (64u - bit0)) : 0u;
+        const uint32_t lo = (uint32_t)m01, mid = (uint32_t)(m01 >> 32);
+        const uint32_t old_lo = lo ? atomicOr(&seen[w0], lo) : 0u;
+        const uint32_t old_mid = mid ? atomicOr(&seen[w0 + 1], mid) : 0u;
+        const uint32_t old_2 = m2 ? atomicOr(&seen[w0 + 2], m2) : 0u;
+        const unsigned long long nb01 = m01 & ~(((unsigned long long)old_mid << 32) | old_lo);
+        const uint32_t nb2 = m2 & ~old_2;
+        const unsigned long long x = (nb01 >> bit0) | (bit0 ? ((unsigned long long)nb2 << (64u - bit0)) : 0ull);
+        const bool allnew = fast && x == ones;
+        kind = allnew ? 2u : 0u;
+        xr = allnew ? 0ull : x;
+    }
+    const uint32_t pos = valid ? atomicAdd(&bcur[win], 1u) : 0u;
+    const bool o0 = put<DBG>(A, mine, valid, pos, id, len - 1, kind);
+    if (__ballot(o0) && o0) overflow_record(A, id, len, kind);  // rare: the sub-bucket is full
+    if (UNIQ) {
+        while (__ballot(xr != 0ull)) {
+            const bool e = xr != 0ull;
+            const uint32_t tz = e ? (uint32_t)__builtin_ctzll(xr) : 0u;
+            const unsigned long long y = xr >> tz;
+            const uint32_t run = (~y == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~y);
+            xr &= ~(((run >= 64u) ? ~0ull : ((1ull << run) - 1ull)) << tz);
+            const uint32_t p = e ? atomicAdd(&bcur[win], 1u) : 0u;
+            const bool o1 = put<DBG>(A, mine, e, p, id + tz, run - 1, 1u);
+            if (__ballot(o1) && o1) overflow_record(A, id + tz, run, 1u);
+        }
+        if (__ballot(slow) && slow) claim_long_run(seen, mine, bcur, A.cap, A.stride, A.ovf_u, A.ovf_flag, id, len);
+    }
+}
+
+constexpr uint32_t kQCap = 320;  // 63 left over + up to 256 from one tile
+
+// Emit whole chunks of 64 queued runs (all of them when `all`), keeping the rest at the front.
+template <bool UNIQ, bool DBG>
+__device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine, bool all) {
+    while (w.fill >= 64u || (all && w.fill)) {
+        const uint32_t n = min(w.fill, 64u);
+        const bool valid = (uint32_t)w.lane < n;
+        const uint32_t rec = valid ? w.q[w.lane] : 0u;
+        emit_chunk<UNIQ, DBG>(A, seen, bcur, mine, valid, rec);
+        const uint32_t rest = w.fill - n;
+        for (uint32_t i = w.lane; i < rest; i += 64) {  // ds ops of one wave execute in order
+            const uint32_t t = w.q[n + i];
+            w.q[i] = t;
+        }
+        w.fill = rest;
+    }
+}
 
 // 256 steps, four consecutive ones per lane (lane i holds steps 4i..4i+3 of the tile).
 template <bool UNIQ, bool DBG>
-__device__ __forceinline__ void tile_full(const ScanArgs &A, Walk &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
-                                          int lane, uint4 v) {
+__device__ __forceinline__ void tile_full(const ScanArgs &A, Wave &w, uint4 v) {
     uint32_t a0 = v.x >> 1, a1 = v.y >> 1, a2 = v.z >> 1, a3 = v.w >> 1;
     if (max(max(a0, a1), max(a2, a3)) >= A.n_segs) {
         a0 = clamp_id(A, a0);
@@ -129,71 +231,46 @@ __device__ __forceinline__ void tile_full(const ScanArgs &A, Walk &w, uint32_t *
         a3 = clamp_id(A, a3);
     }
     uint32_t prev = __builtin_amdgcn_update_dpp(0u, a3, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    if (lane == 0) prev = w.prev;
+    if (w.lane == 0) prev = w.prev;
     const bool s0 = (a0 != prev + 1) | ((a0 & (kRunSpan - 1)) == 0);
     const bool s1 = (a1 != a0 + 1) | ((a1 & (kRunSpan - 1)) == 0);
     const bool s2 = (a2 != a1 + 1) | ((a2 & (kRunSpan - 1)) == 0);
     const bool s3 = (a3 != a2 + 1) | ((a3 & (kRunSpan - 1)) == 0);
-    if (UNIQ && !FGFA_SKIP(kDbgNoBitset)) {
-        if (!(s1 | s2 | s3) && (a0 >> 5) == (a3 >> 5)) {
-            atomicOr(&seen[a0 >> 5], 0xFu << (a0 & 31));
-        } else {
-            atomicOr(&seen[a0 >> 5], 1u << (a0 & 31));
-            atomicOr(&seen[a1 >> 5], 1u << (a1 & 31));
-            atomicOr(&seen[a2 >> 5], 1u << (a2 & 31));
-            atomicOr(&seen[a3 >> 5], 1u << (a3 & 31));
-        }
-    }
     // start id of the run in progress when this lane's first step arrives
     const bool any = s0 | s1 | s2 | s3;
     const uint32_t last_start = s3 ? a3 : (s2 ? a2 : (s1 ? a1 : a0));
-    const unsigned long long below = __ballot(any) & ((1ull << lane) - 1ull);
-    const int src = below ? 63 - __builtin_clzll(below) : lane;
+    const unsigned long long below = __ballot(any) & ((1ull << w.lane) - 1ull);
+    const int src = below ? 63 - __builtin_clzll(below) : w.lane;
     const uint32_t from_below = __shfl(last_start, src, 64);
     const uint32_t rs = below ? from_below : w.rs;
-    // a run ends wherever the next one starts: emit (start, length) of the run that just ended
+    // a run ends wherever the next one starts: queue (start, length) of the run that just ended
     const uint32_t len0 = prev - rs + 1;
     const uint32_t rsA = s0 ? a0 : rs;
     const uint32_t rsB = s1 ? a1 : rsA;
     const uint32_t rsC = s2 ? a2 : rsB;
     const uint32_t rsD = s3 ? a3 : rsC;
-    const bool e0 = s0 && len0 != 0;
-    const uint32_t p0 = reserve(bcur, e0, rs);
-    const uint32_t p1 = reserve(bcur, s1, rsA);
-    const uint32_t p2 = reserve(bcur, s2, rsB);
-    const uint32_t p3 = reserve(bcur, s3, rsC);
-    const bool o0 = put<DBG>(A, mine, e0, p0, rs, len0 - 1, 0u);
-    const bool o1 = put<DBG>(A, mine, s1, p1, rsA, a0 - rsA, 0u);
-    const bool o2 = put<DBG>(A, mine, s2, p2, rsB, a1 - rsB, 0u);
-    const bool o3 = put<DBG>(A, mine, s3, p3, rsC, a2 - rsC, 0u);
-    if (__ballot(o0 | o1 | o2 | o3)) {  // rare: a sub-bucket is full
-        if (o0) overflow_record(A, rs, len0, 0u);
-        if (o1) overflow_record(A, rsA, a0 - rsA + 1, 0u);
-        if (o2) overflow_record(A, rsB, a1 - rsB + 1, 0u);
-        if (o3) overflow_record(A, rsC, a2 - rsC + 1, 0u);
-    }
+    enqueue(w, s0 && len0 != 0, (rs << kRunBits) | (len0 - 1));
+    enqueue(w, s1, (rsA << kRunBits) | (a0 - rsA));
+    enqueue(w, s2, (rsB << kRunBits) | (a1 - rsB));
+    enqueue(w, s3, (rsC << kRunBits) | (a2 - rsC));
     w.prev = __builtin_amdgcn_readlane(a3, 63);
     w.rs = __builtin_amdgcn_readlane(rsD, 63);
 }
 
 // Up to 64 consecutive steps, one per lane (heads, tails and short spans).
-template <bool UNIQ>
-__device__ __forceinline__ void tile_narrow(const ScanArgs &A, Walk &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
-                                            int lane, uint64_t t, uint32_t count) {
-    const bool valid = (uint32_t)lane < count;
-    const uint32_t id = valid ? clamp_id(A, A.steps[t + lane] >> 1) : 0u;
+__device__ __forceinline__ void tile_narrow(const ScanArgs &A, Wave &w, uint64_t t, uint32_t count) {
+    const bool valid = (uint32_t)w.lane < count;
+    const uint32_t id = valid ? clamp_id(A, A.steps[t + w.lane] >> 1) : 0u;
     uint32_t prev = __builtin_amdgcn_update_dpp(0u, id, 0x138, 0xf, 0xf, false);
-    if (lane == 0) prev = w.prev;
+    if (w.lane == 0) prev = w.prev;
     const bool s = valid && ((id != prev + 1) | ((id & (kRunSpan - 1)) == 0));
-    if (UNIQ && valid) atomicOr(&seen[id >> 5], 1u << (id & 31));
     const unsigned long long m = __ballot(s);
-    const unsigned long long below = m & ((1ull << lane) - 1ull);
-    const int src = below ? 63 - __builtin_clzll(below) : lane;
+    const unsigned long long below = m & ((1ull << w.lane) - 1ull);
+    const int src = below ? 63 - __builtin_clzll(below) : w.lane;
     const uint32_t from_below = __shfl(id, src, 64);
     const uint32_t rs = below ? from_below : w.rs;
     const uint32_t len = prev - rs + 1;
-    const bool e = s && len != 0;
-    if (put<false>(A, mine, e, reserve(bcur, e, rs), rs, len - 1, 0u)) overflow_record(A, rs, len, 0u);
+    enqueue(w, s && len != 0, (rs << kRunBits) | (len - 1));
     w.prev = __shfl(id, (int)count - 1, 64);
     if (m) w.rs = __shfl(id, 63 - __builtin_clzll(m), 64);
 }
@@ -223,155 +300,111 @@ __device__ __forceinline__ Span make_span(const ScanArgs &A, uint32_t job, int w
     return s;
 }
 
-// Streaming loads of steps: each handle is read exactly once, so keep it out of the way of
-// the bucket lines that the L2 is write-combining.
+// Streaming loads of steps.  Each handle is read exactly once (nontemporal: keep it out of the
+// way of the bucket lines the L2 is write-combining).  The loads are issued as inline asm and
+// waited for with explicit counted s_waitcnt, because hipcc otherwise drains vmcnt to 0 at the
+// top of the tile loop and loses the prefetch depth.  On gfx950 vmcnt counts loads and stores
+// in issue order, so "at most N outstanding" with N <= the number of loads issued after the one
+// we need is always sufficient; record stores issued in between only make the wait stricter.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 load_tile(const uint4 *p) {
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
+__device__ __forceinline__ void load_tile_async(u32x4 &r, const uint4 *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r) : "v"(p) : "memory");
 }
-
-// The runs of set bits of one bitset word become uniq records at consecutive slots from `pos`.
-template <bool DBG>
-__device__ __forceinline__ void put_word_runs(const ScanArgs &A, uint32_t *mine, uint32_t x, uint32_t id0,
-                                              uint32_t pos) {
-    while (x) {
-        const uint32_t tz = __builtin_ctz(x);
-        const uint32_t y = x >> tz;
-        const uint32_t run = (y == 0xFFFFFFFFu) ? 32u : (uint32_t)__builtin_ctz(~y);
-        x &= ~(((run == 32u) ? 0xFFFFFFFFu : ((1u << run) - 1u)) << tz);
-        if (pos < A.cap) {
-            if (!FGFA_SKIP(kDbgNoStore))
-                mine[(id0 >> kWinBits) * A.stride + pos] = ((id0 + tz) & (kWin - 1)) | ((run - 1) << kWinBits) | (1u << 24);
-        } else {
-            overflow_record(A, id0 + tz, run, 1u);
-        }
-        ++pos;
-    }
+// Waits until tile data `r` has landed; `younger` = how many tile loads were issued after it.
+__device__ __forceinline__ void wait_tile(u32x4 &r, uint64_t younger) {
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(r)::"memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(r)::"memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(r)::"memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r)::"memory");
 }
-
-__device__ __forceinline__ uint32_t word_runs(uint32_t x) { return __builtin_popcount(x & ~(x << 1)); }
 
 template <bool UNIQ, bool DBG>
 __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     extern __shared__ uint32_t lds[];
-    // layout: [bcur: kMaxWin][seen: n_words]
+    // layout: [bcur: kMaxWin][queues: kWaves * kQCap][seen: n_words]
     uint32_t *bcur = lds;
-    uint32_t *seen = lds + kMaxWin;
+    uint32_t *seen = lds + kMaxWin + kWaves * kQCap;
     __shared__ uint32_t next_job;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the span math on the scalar unit
     uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;  // this workgroup's sub-bucket of window 0
+    Wave w;
+    w.q = lds + kMaxWin + wave * kQCap;
+    w.fill = 0;
+    w.lane = lane;
     for (uint32_t i = threadIdx.x; i < kMaxWin; i += kThreads) bcur[i] = 0u;
     if (UNIQ)
         for (uint32_t i = threadIdx.x; i < A.n_words; i += kThreads) seen[i] = 0u;
     if (threadIdx.x == 0) next_job = atomicAdd(A.work_counter, 1u);
     __syncthreads();
-    uint32_t job = next_job;
+    uint32_t job = __builtin_amdgcn_readfirstlane(next_job);
     __syncthreads();
 
-    // The first tiles of a path are requested before the previous path's bitset is scanned
-    // out, so that their latency hides behind that phase.
+    // The first tiles of a path are requested while the previous path is being wrapped up.
     Span sp = make_span(A, job, wave, lane);
-    uint4 r0 = {}, r1 = {}, r2 = {}, r3 = {};
+    u32x4 r0 = {}, r1 = {}, r2 = {}, r3 = {};
     uint32_t first_raw = 0;
 #define FGFA_PRELOAD()                                              \
     do {                                                            \
         if (sp.lo < sp.hi) first_raw = A.steps[sp.lo];              \
-        if (sp.nfull > 0) r0 = load_tile(sp.src);                   \
-        if (sp.nfull > 1) r1 = load_tile(sp.src + 64);              \
-        if (sp.nfull > 2) r2 = load_tile(sp.src + 128);             \
-        if (sp.nfull > 3) r3 = load_tile(sp.src + 192);             \
+        if (sp.nfull > 0) load_tile_async(r0, sp.src);              \
+        if (sp.nfull > 1) load_tile_async(r1, sp.src + 64);         \
+        if (sp.nfull > 2) load_tile_async(r2, sp.src + 128);        \
+        if (sp.nfull > 3) load_tile_async(r3, sp.src + 192);        \
     } while (0)
+    // one tile: wait for its data, re-issue its register for the tile four ahead, process it
+#define FGFA_TILE(R, K)                                                                   \
+    if (i + (K) < sp.nfull) {                                                             \
+        wait_tile(R, sp.nfull - 1 - (i + (K)));                                           \
+        const uint4 cur = make_uint4(R.x, R.y, R.z, R.w);                                 \
+        if (i + (K) + 4 < sp.nfull) load_tile_async(R, sp.src + (i + (K) + 4) * 64);      \
+        if (!FGFA_SKIP(kDbgNoTiles)) {                                                    \
+            tile_full<UNIQ, DBG>(A, w, cur);                                              \
+            drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);                              \
+        } else if (cur.x == 0x7FFFFFFFu) {                                                \
+            *A.status = 2u;                                                               \
+        }                                                                                 \
+    }
     FGFA_PRELOAD();
 
     while (job < A.n_paths) {
         if (threadIdx.x == 0) next_job = atomicAdd(A.work_counter, 1u);  // consumed after the barrier below
         if (sp.lo < sp.hi) {
             const uint32_t first = clamp_id(A, first_raw >> 1);
-            Walk w;
             w.prev = first - 1;  // the first step then continues a (so far empty) run that starts at it
             w.rs = first;
-            if (sp.t0 > sp.lo) tile_narrow<UNIQ>(A, w, seen, bcur, mine, lane, sp.lo, (uint32_t)(sp.t0 - sp.lo));
+            if (sp.t0 > sp.lo) tile_narrow(A, w, sp.lo, (uint32_t)(sp.t0 - sp.lo));
             // four tiles (4 KiB per wave, 64 KiB per CU) stay in flight
-#pragma unroll 4
-            for (uint64_t i = 0; i < sp.nfull; ++i) {
-                const uint4 cur = r0;
-                r0 = r1;
-                r1 = r2;
-                r2 = r3;
-                if (i + 4 < sp.nfull) r3 = load_tile(sp.src + (i + 4) * 64);
-                if (!FGFA_SKIP(kDbgNoTiles)) tile_full<UNIQ, DBG>(A, w, seen, bcur, mine, lane, cur);
-                else if (cur.x == 0x7FFFFFFFu) *A.status = 2u;
+#pragma unroll 1
+            for (uint64_t i = 0; i < sp.nfull; i += 4) {
+                FGFA_TILE(r0, 0)
+                FGFA_TILE(r1, 1)
+                FGFA_TILE(r2, 2)
+                FGFA_TILE(r3, 3)
             }
             uint64_t t = sp.t0 + sp.nfull * 256;
             while (t < sp.hi) {
                 const uint32_t cnt = (uint32_t)min((uint64_t)64, sp.hi - t);
-                tile_narrow<UNIQ>(A, w, seen, bcur, mine, lane, t, cnt);
+                tile_narrow(A, w, t, cnt);
                 t += cnt;
+                drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);
             }
             // close the run still open at the end of the span
-            const bool last = lane == 0;
-            if (put<false>(A, mine, last, reserve(bcur, last, w.rs), w.rs, w.prev - w.rs, 0u))
-                overflow_record(A, w.rs, w.prev - w.rs + 1, 0u);
+            enqueue(w, lane == 0, (w.rs << kRunBits) | (w.prev - w.rs));
+            drain<UNIQ, DBG>(A, w, seen, bcur, mine, true);
         }
-        __syncthreads();  // every wave's bits are in; next_job is visible
-        job = next_job;
+        __syncthreads();  // every wave is done with this path's bitset; next_job is visible
+        job = __builtin_amdgcn_readfirstlane(next_job);
         sp = make_span(A, job, wave, lane);
         FGFA_PRELOAD();
         if (UNIQ) {
-            // Scan-out: every lane owns `wpl` consecutive bitset words (1024 lanes cover the whole
-            // bitset; a window's 128 words belong to 128/wpl neighbouring lanes).  One counting
-            // sweep gives each lane its number of set-bit runs; a wave prefix sum and ONE LDS
-            // atomic per window reserve the slots; a second sweep writes the records and leaves
-            // the words zeroed.
-            if (!FGFA_SKIP(kDbgNoScanOut)) {
-                const uint32_t wpl = A.n_words >> 10;  // 4, 8, 16 or 32
-                uint32_t *my = seen + threadIdx.x * wpl;
-                uint32_t c = 0;
-                for (uint32_t k = 0; k < wpl; k += 4) {
-                    const uint4 x = *reinterpret_cast<const uint4 *>(my + k);
-                    c += word_runs(x.x) + word_runs(x.y) + word_runs(x.z) + word_runs(x.w);
-                }
-                if (__ballot(c != 0)) {
-                    uint32_t incl = c;
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const uint32_t t = __shfl_up(incl, off, 64);
-                        if (lane >= off) incl += t;
-                    }
-                    const int group = (int)(kWinWords / wpl);  // lanes per window: 32 .. 4
-                    const int g0 = lane & ~(group - 1);
-                    const uint32_t upto_prev_group = __shfl(incl, g0 ? g0 - 1 : 0, 64);
-                    const uint32_t before = g0 ? upto_prev_group : 0u;
-                    const uint32_t group_total = __shfl(incl, g0 + group - 1, 64) - before;
-                    const uint32_t win = (threadIdx.x * wpl) / kWinWords;
-                    uint32_t base = 0;
-                    if (lane == g0 && group_total) base = atomicAdd(&bcur[win], group_total);
-                    base = __shfl(base, g0, 64);
-                    uint32_t pos = base + (incl - c) - before;
-                    if (c) {
-                        const uint32_t id0 = (threadIdx.x * wpl) << 5;
-                        for (uint32_t k = 0; k < wpl; k += 4) {
-                            const uint4 x = *reinterpret_cast<const uint4 *>(my + k);
-                            if ((x.x | x.y | x.z | x.w) == 0) continue;
-                            *reinterpret_cast<uint4 *>(my + k) = make_uint4(0u, 0u, 0u, 0u);
-                            put_word_runs<DBG>(A, mine, x.x, id0 + (k << 5), pos);
-                            pos += word_runs(x.x);
-                            put_word_runs<DBG>(A, mine, x.y, id0 + ((k + 1) << 5), pos);
-                            pos += word_runs(x.y);
-                            put_word_runs<DBG>(A, mine, x.z, id0 + ((k + 2) << 5), pos);
-                            pos += word_runs(x.z);
-                            put_word_runs<DBG>(A, mine, x.w, id0 + ((k + 3) << 5), pos);
-                            pos += word_runs(x.w);
-                        }
-                    }
-                }
-            } else {
-                for (uint32_t j = threadIdx.x; j < A.n_words; j += kThreads) seen[j] = 0u;
-            }
-            __syncthreads();  // the bitset is clean before the next path sets bits
+            uint4 *sv = reinterpret_cast<uint4 *>(seen);
+            for (uint32_t i = threadIdx.x; i < A.n_words / 4; i += kThreads) sv[i] = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();  // the bitset is clean before the next path claims bits
         }
     }
 #undef FGFA_PRELOAD
+#undef FGFA_TILE
     // publish how many records this workgroup left in each window's sub-bucket
     __syncthreads();
     for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads)
@@ -395,9 +428,15 @@ struct AccArgs {
 template <bool UNIQ>
 __device__ __forceinline__ void apply_record(int *dd, int *ud, uint32_t rec) {
     const uint32_t rel = rec & (kWin - 1), len = ((rec >> kWinBits) & (kWin - 1)) + 1;
-    int *arr = (UNIQ && ((rec >> 24) & 1u)) ? ud : dd;
-    atomicAdd(&arr[rel], 1);
-    atomicAdd(&arr[rel + len], -1);  // rel + len <= 4096; slot 4096 is a sink
+    const uint32_t kind = (rec >> 24) & 3u;  // 0 depth, 1 uniq, 2 both
+    if (!UNIQ || kind != 1u) {
+        atomicAdd(&dd[rel], 1);
+        atomicAdd(&dd[rel + len], -1);  // rel + len <= 4096; slot 4096 is a sink
+    }
+    if (UNIQ && kind != 0u) {
+        atomicAdd(&ud[rel], 1);
+        atomicAdd(&ud[rel + len], -1);
+    }
 }
 
 // inclusive prefix sum of 4096 ints held 4 per thread by 1024 threads; returns this thread's
@@ -502,7 +541,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     if (UNIQ) store4(A.uniq_out + w0, i0, nvalid, block_scan4(ud, wave_tot));
 }
 
-uint32_t scan_lds_bytes(uint32_t n_words) { return (kMaxWin + n_words) * 4u; }
+uint32_t scan_lds_bytes(uint32_t n_words) { return (kMaxWin + kWaves * kQCap + n_words) * 4u; }
 
 #define FAST_TRY(expr)                                                                      \
     do {                                                                                    \
@@ -521,11 +560,8 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     if ((reinterpret_cast<uintptr_t>(g.steps) & 15u) != 0) return true;  // 16-byte step loads
     const uint32_t n_win = (g.n_segs + kWin - 1) / kWin;
     if (n_win > kMaxWin) return true;
-    // the scan-out gives each of the 1024 lanes 4, 8, 16 or 32 consecutive bitset words
-    uint32_t wpl = 4;
-    while (wpl < 32 && (uint64_t)wpl * kThreads * 32 < g.n_segs) wpl *= 2;
-    if ((uint64_t)wpl * kThreads * 32 < g.n_segs) return true;  // more than 1,048,576 segments: bitset too big
-    const uint32_t n_words = wpl * kThreads;
+    if (g.n_segs > (1u << 21)) return true;  // a queued run is (start id << 11) | (len - 1)
+    const uint32_t n_words = ((g.n_segs + 31) / 32 + 4 + 3) & ~3u;  // one word of slack for the two-word claim
     if (scan_lds_bytes(n_words) + 64 > kLdsLimit) return true;  // the "seen" bitset must fit one CU's LDS
     hipDeviceProp_t prop;
     int dev = 0;
