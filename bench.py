@@ -137,8 +137,17 @@ def main():
     roofline = None
     if dom:
         achieved = B / (kern_avg_ms[dom] * 1e-3) / 1e9
+        # HBM bytes per launch of the dominant kernel from the PMC counters: they need separate
+        # rocprofv3 --pmc passes (tools/profile_round.sh), so the committed summary is quoted here.
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
+            if tj.get("workload") == args.workload and dom in tj["kernels"]:
+                traffic = tj["kernels"][dom]["hbm_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "kernel_avg_ms": round(kern_avg_ms[dom], 5), "algorithmic_bytes": B,
                     "all_kernels_ms_per_step": round(device_ms_per_step, 5),
                     "kernels_avg_ms": {k: round(v, 5) for k, v in kern_avg_ms.items()}}
