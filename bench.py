@@ -34,6 +34,7 @@ WORKLOADS = {
     "cfgL": (1_000_000, 1000, 100_000, "pangenome"),
     "cfgL-uniform": (1_000_000, 1000, 100_000, "uniform"),
     "cfgL-short": (1_000_000, 100_000, 1000, "pangenome"),
+    "cfgL-fewlong": (1_000_000, 100, 1_000_000, "pangenome"),
     "cfgS": (10_000, 100, 10_000, "pangenome"),
 }
 

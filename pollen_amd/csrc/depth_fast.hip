@@ -47,6 +47,7 @@ constexpr uint32_t kWin = 1u << kWinBits;
 constexpr uint32_t kWinWords = kWin / 32;
 constexpr uint32_t kMaxWin = 512;  // LDS cursor table entries
 constexpr uint32_t kLdsLimit = 160 * 1024;
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr int kAccThreads = 1024;
 
 // diagnostic ablations (FLATGFA_DEBUG_SKIP, results are then wrong by construction)
@@ -56,10 +57,9 @@ constexpr uint32_t kDbgNoStore = 1, kDbgNoScanOut = 2, kDbgNoBitset = 4, kDbgNoT
 
 struct ScanArgs {
     const uint32_t *steps;
-    const uint32_t *path_begin;
-    const uint32_t *path_end;
-    const uint32_t *order;  // paths, longest first
-    uint32_t n_paths, n_segs, n_win, n_words, n_slots;
+    const uint4 *items;  // work queue, longest first: {begin, end, piece slot or kNoSlot, unused}
+    uint32_t *piece_bits;  // [n_piece_slots][n_words]: "seen" bitsets of the pieces of split paths
+    uint32_t n_items, n_segs, n_win, n_words, n_slots;
     uint32_t *work_counter;
     uint32_t *counts;   // [n_win][n_slots]
     uint32_t *buckets;  // [n_win + 1][n_slots][cap]; window n_win is a write sink
@@ -280,15 +280,18 @@ __device__ __forceinline__ void tile_narrow(const ScanArgs &A, Wave &w, uint64_t
 struct Span {
     uint64_t lo, hi, t0, nfull;
     const uint4 *src;
+    uint32_t slot;  // where to leave the bitset when this is a piece of a split path
 };
 
 __device__ __forceinline__ Span make_span(const ScanArgs &A, uint32_t job, int wave, int lane) {
     Span s;
     s.lo = s.hi = s.t0 = s.nfull = 0;
     s.src = nullptr;
-    if (job < A.n_paths) {
-        const uint32_t p = A.order[job];
-        const uint64_t b = A.path_begin[p], e = A.path_end[p], n = e - b;
+    s.slot = kNoSlot;
+    if (job < A.n_items) {
+        const uint4 it = A.items[job];
+        const uint64_t b = it.x, e = it.y, n = e - b;
+        s.slot = it.z;
         // contiguous span per wave, a whole number of tiles
         const uint64_t per = ((n + kWaves - 1) / kWaves + 255) / 256 * 256;
         s.lo = min(b + per * wave, e);
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     }
     FGFA_PRELOAD();
 
-    while (job < A.n_paths) {
+    while (job < A.n_items) {
         if (threadIdx.x == 0) next_job = atomicAdd(A.work_counter, 1u);  // consumed after the barrier below
         if (sp.lo < sp.hi) {
             const uint32_t first = clamp_id(A, first_raw >> 1);
@@ -394,11 +397,18 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             drain<UNIQ, DBG>(A, w, seen, bcur, mine, true);
         }
         __syncthreads();  // every wave is done with this path's bitset; next_job is visible
+        const uint32_t done_slot = sp.slot;
         job = __builtin_amdgcn_readfirstlane(next_job);
         sp = make_span(A, job, wave, lane);
         FGFA_PRELOAD();
         if (UNIQ) {
             uint4 *sv = reinterpret_cast<uint4 *>(seen);
+            if (done_slot != kNoSlot) {
+                // a piece of a split path: other pieces may have claimed the same segments, so
+                // the bitset is kept for k_merge to find the duplicates
+                uint4 *dst = reinterpret_cast<uint4 *>(A.piece_bits + (size_t)done_slot * A.n_words);
+                for (uint32_t i = threadIdx.x; i < A.n_words / 4; i += kThreads) dst[i] = sv[i];
+            }
             for (uint32_t i = threadIdx.x; i < A.n_words / 4; i += kThreads) sv[i] = make_uint4(0u, 0u, 0u, 0u);
             __syncthreads();  // the bitset is clean before the next path claims bits
         }
@@ -409,6 +419,45 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     __syncthreads();
     for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads)
         A.counts[(size_t)wdw * A.n_slots + blockIdx.x] = bcur[wdw];
+}
+
+// ------------------------------------------------------------------ merge ---
+// A path longer than the piece length is scanned as several pieces by different workgroups,
+// each with its own bitset, so a segment touched by two pieces of one path has been counted
+// twice in uniq.  For every split path this kernel walks the pieces' bitsets in order and
+// takes one back for every bit that an earlier piece already had (negative range updates on
+// the overflow difference array, which k_accum folds in).
+struct MergeArgs {
+    const uint32_t *piece_bits;
+    const uint2 *split;  // per split path: {first piece slot, number of pieces}
+    uint32_t n_split, n_words, n_segs;
+    int *ovf_u;
+    uint32_t *ovf_flag;
+};
+
+__global__ __launch_bounds__(256) void k_merge(const MergeArgs A) {
+    const uint32_t chunks = (A.n_words + 255) / 256;
+    for (uint32_t job = blockIdx.x; job < A.n_split * chunks; job += gridDim.x) {
+        const uint2 sp = A.split[job / chunks];
+        const uint32_t w = (job % chunks) * 256 + threadIdx.x;
+        if (w >= A.n_words) continue;
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < sp.y; ++k) {
+            const uint32_t bits = A.piece_bits[(size_t)(sp.x + k) * A.n_words + w];
+            uint32_t dup = bits & acc;
+            acc |= bits;
+            while (dup) {
+                const uint32_t tz = __builtin_ctz(dup);
+                const uint32_t y = dup >> tz;
+                const uint32_t run = (y == 0xFFFFFFFFu) ? 32u : (uint32_t)__builtin_ctz(~y);
+                dup &= ~(((run == 32u) ? 0xFFFFFFFFu : ((1u << run) - 1u)) << tz);
+                const uint32_t id = (w << 5) + tz;
+                A.ovf_flag[id >> kWinBits] = 1u;
+                atomicAdd(&A.ovf_u[id], -1);
+                if ((id & (kWin - 1)) + run < kWin) atomicAdd(&A.ovf_u[id + run], 1);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------ pass 2 ---
@@ -587,9 +636,33 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     if (cap < 4) return true;
     fp->cap = (uint32_t)cap;
     if (const char *d = getenv("FLATGFA_DEBUG_SKIP")) fp->dbg = (uint32_t)strtoul(d, nullptr, 10);
-    std::vector<uint32_t> order(g.n_paths);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return he[a] - hb[a] > he[b] - hb[b]; });
+    // Work items: whole paths, except that a path longer than `piece` steps is cut into pieces so
+    // that graphs with few long paths still fill the chip.  Pieces carry a slot for their bitset.
+    uint64_t piece = std::max<uint64_t>(65536, (g.n_steps + 2ull * fp->n_cus - 1) / (2ull * fp->n_cus));
+    if (const char *forced = getenv("FLATGFA_PIECE_STEPS")) piece = std::max<uint64_t>(256, strtoull(forced, nullptr, 10));
+    piece = (piece + 255) & ~255ull;
+    std::vector<uint4> items;
+    std::vector<uint2> split;
+    uint32_t n_piece_slots = 0;
+    for (uint32_t p = 0; p < g.n_paths; ++p) {
+        const uint64_t b = hb[p], e = he[p], n = e - b;
+        if (n == 0) continue;
+        if (n <= piece) {
+            items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
+        } else {
+            const uint32_t k = (uint32_t)((n + piece - 1) / piece);
+            split.push_back(make_uint2(n_piece_slots, k));
+            for (uint32_t j = 0; j < k; ++j) {
+                const uint64_t pb = b + n * j / k, pe = b + n * (j + 1) / k;
+                items.push_back(make_uint4((uint32_t)pb, (uint32_t)pe, n_piece_slots + j, p));
+            }
+            n_piece_slots += k;
+        }
+    }
+    std::stable_sort(items.begin(), items.end(), [](const uint4 &a, const uint4 &b) { return a.y - a.x > b.y - b.x; });
+    fp->n_items = (uint32_t)items.size();
+    fp->n_split = (uint32_t)split.size();
+    if (items.empty()) return true;
     FAST_TRY(hipMalloc(&fp->counts, slots * 4));
     FAST_TRY(hipMemset(fp->counts, 0, slots * 4));
     FAST_TRY(hipMalloc(&fp->buckets, (slots + fp->n_slots) * cap * 4));
@@ -599,8 +672,13 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     FAST_TRY(hipMemset(fp->ovf_u, 0, ((size_t)g.n_segs + 1) * 4));
     FAST_TRY(hipMalloc(&fp->ovf_flag, (size_t)n_win * 4));
     FAST_TRY(hipMemset(fp->ovf_flag, 0, (size_t)n_win * 4));
-    FAST_TRY(hipMalloc(&fp->order, (size_t)g.n_paths * 4));
-    FAST_TRY(hipMemcpy(fp->order, order.data(), (size_t)g.n_paths * 4, hipMemcpyHostToDevice));
+    FAST_TRY(hipMalloc(&fp->items, items.size() * sizeof(uint4)));
+    FAST_TRY(hipMemcpy(fp->items, items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    if (n_piece_slots) {
+        FAST_TRY(hipMalloc(&fp->piece_bits, (size_t)n_piece_slots * n_words * 4));
+        FAST_TRY(hipMalloc(&fp->split, split.size() * sizeof(uint2)));
+        FAST_TRY(hipMemcpy(fp->split, split.data(), split.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    }
     FAST_TRY(hipMalloc(&fp->work_counter, 256));
     FAST_TRY(hipMemset(fp->work_counter, 0, 256));
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_uniq));
@@ -612,7 +690,7 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
 
 void fast_plan_destroy(FastPlan *fp) {
     for (void *p : {(void *)fp->counts, (void *)fp->buckets, (void *)fp->ovf_d, (void *)fp->ovf_u, (void *)fp->ovf_flag,
-                    (void *)fp->order, (void *)fp->work_counter})
+                    (void *)fp->items, (void *)fp->piece_bits, (void *)fp->split, (void *)fp->work_counter})
         if (p) (void)hipFree(p);
     *fp = FastPlan();
 }
@@ -620,17 +698,24 @@ void fast_plan_destroy(FastPlan *fp) {
 int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
                    uint32_t *status, hipStream_t stream) {
     const uint32_t stride = fp.n_slots * fp.cap;
-    ScanArgs sa{g.steps, g.path_begin, g.path_end, fp.order, g.n_paths, g.n_segs, fp.n_win,
+    ScanArgs sa{g.steps, reinterpret_cast<const uint4 *>(fp.items), fp.piece_bits, fp.n_items, g.n_segs, fp.n_win,
                 uniq_out ? fp.n_words : 0u, fp.n_slots, fp.work_counter, fp.counts, fp.buckets, fp.cap, stride,
                 fp.n_win * stride, fp.ovf_d, fp.ovf_u, fp.ovf_flag, status, fp.dbg};
     AccArgs aa{g.n_segs, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.buckets, fp.ovf_d, fp.ovf_u, fp.ovf_flag,
                fp.work_counter, depth_out, uniq_out};
-    const uint32_t grid = std::min<uint32_t>(g.n_paths, fp.n_slots);  // one persistent workgroup per CU
+    const uint32_t grid = std::min<uint32_t>(fp.n_items, fp.n_slots);  // one persistent workgroup per CU
     if (uniq_out) {
         {
             ProfScope ps("k_scan<uniq>", stream);
             if (fp.dbg) hipLaunchKernelGGL((k_scan<true, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_uniq, stream, sa);
             else hipLaunchKernelGGL((k_scan<true, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_uniq, stream, sa);
+        }
+        if (fp.n_split) {
+            MergeArgs ma{fp.piece_bits, reinterpret_cast<const uint2 *>(fp.split), fp.n_split, fp.n_words, g.n_segs,
+                         fp.ovf_u, fp.ovf_flag};
+            const uint32_t jobs = fp.n_split * ((fp.n_words + 255) / 256);
+            ProfScope ps("k_merge", stream);
+            hipLaunchKernelGGL(k_merge, dim3(std::min<uint32_t>(jobs, fp.n_cus * 8u)), dim3(256), 0, stream, ma);
         }
         {
             ProfScope ps("k_accum<uniq>", stream);

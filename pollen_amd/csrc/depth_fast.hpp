@@ -22,7 +22,11 @@ struct FastPlan {
     int *ovf_d = nullptr;          // int[n_segs + 1], zero between calls
     int *ovf_u = nullptr;
     uint32_t *ovf_flag = nullptr;  // u32[n_win]
-    uint32_t *order = nullptr;     // path ids, longest first (work queue order)
+    void *items = nullptr;         // uint4[n_items] work queue: whole paths and pieces of long paths
+    uint32_t n_items = 0;
+    uint32_t *piece_bits = nullptr;  // bitsets left behind by the pieces of split paths
+    void *split = nullptr;         // uint2[n_split] {first piece slot, pieces} per split path
+    uint32_t n_split = 0;
     uint32_t *work_counter = nullptr;
 };
 

@@ -18,13 +18,16 @@ pytestmark = pytest.mark.gpu
 FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
-@pytest.fixture(params=["auto", "atomic", "tinycap"])
+@pytest.fixture(params=["auto", "atomic", "tinycap", "pieces"])
 def device_path(request, monkeypatch):
     """Runs a test once per device path: the bucketed two-kernel path (default), the simple
     global-atomic kernels, and the bucketed path with 8-record buckets so that nearly every
     record takes the overflow route.  The variables are read when a graph becomes resident."""
     monkeypatch.delenv("FLATGFA_DEPTH_PATH", raising=False)
     monkeypatch.delenv("FLATGFA_BUCKET_CAP", raising=False)
+    monkeypatch.delenv("FLATGFA_PIECE_STEPS", raising=False)
+    if request.param == "pieces":   # every path longer than 512 steps is scanned as several pieces + k_merge
+        monkeypatch.setenv("FLATGFA_PIECE_STEPS", "512")
     if request.param == "atomic":
         monkeypatch.setenv("FLATGFA_DEPTH_PATH", "atomic")
     elif request.param == "tinycap":
@@ -133,6 +136,8 @@ SHAPES = [
     (9, 1_048_576, 8, 20_000, "pangenome"),  # exactly one LDS window
     (10, 1_048_577, 8, 20_000, "uniform"),   # one segment past it: two windows
     (11, 2_500_000, 6, 30_000, "uniform"),   # three windows
+    (12, 50_000, 3, 700_001, "pangenome"),   # few long paths: split into pieces by default
+    (13, 3_000, 2, 400_000, "uniform"),      # pieces of one path revisit the same segments heavily
 ]
 
 
