@@ -421,49 +421,14 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         A.counts[(size_t)wdw * A.n_slots + blockIdx.x] = bcur[wdw];
 }
 
-// ------------------------------------------------------------------ merge ---
-// A path longer than the piece length is scanned as several pieces by different workgroups,
-// each with its own bitset, so a segment touched by two pieces of one path has been counted
-// twice in uniq.  For every split path this kernel walks the pieces' bitsets in order and
-// takes one back for every bit that an earlier piece already had (negative range updates on
-// the overflow difference array, which k_accum folds in).
-struct MergeArgs {
-    const uint32_t *piece_bits;
-    const uint2 *split;  // per split path: {first piece slot, number of pieces}
-    uint32_t n_split, n_words, n_segs;
-    int *ovf_u;
-    uint32_t *ovf_flag;
-};
-
-__global__ __launch_bounds__(256) void k_merge(const MergeArgs A) {
-    const uint32_t chunks = (A.n_words + 255) / 256;
-    for (uint32_t job = blockIdx.x; job < A.n_split * chunks; job += gridDim.x) {
-        const uint2 sp = A.split[job / chunks];
-        const uint32_t w = (job % chunks) * 256 + threadIdx.x;
-        if (w >= A.n_words) continue;
-        uint32_t acc = 0;
-        for (uint32_t k = 0; k < sp.y; ++k) {
-            const uint32_t bits = A.piece_bits[(size_t)(sp.x + k) * A.n_words + w];
-            uint32_t dup = bits & acc;
-            acc |= bits;
-            while (dup) {
-                const uint32_t tz = __builtin_ctz(dup);
-                const uint32_t y = dup >> tz;
-                const uint32_t run = (y == 0xFFFFFFFFu) ? 32u : (uint32_t)__builtin_ctz(~y);
-                dup &= ~(((run == 32u) ? 0xFFFFFFFFu : ((1u << run) - 1u)) << tz);
-                const uint32_t id = (w << 5) + tz;
-                A.ovf_flag[id >> kWinBits] = 1u;
-                atomicAdd(&A.ovf_u[id], -1);
-                if ((id & (kWin - 1)) + run < kWin) atomicAdd(&A.ovf_u[id + run], 1);
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------ pass 2 ---
 
 struct AccArgs {
     uint32_t n_segs, n_win, n_slots, cap;
+    // split paths (see fast_plan_create): the bitsets their pieces left behind
+    const uint32_t *piece_bits;
+    const uint2 *split;  // per split path: {first piece slot, number of pieces}
+    uint32_t n_split, n_words;
     uint32_t *counts;
     const uint32_t *buckets;
     int *ovf_d;
@@ -547,6 +512,39 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     }
     __syncthreads();
     if (ovf && tid == 0) A.ovf_flag[win] = 0u;
+    if (UNIQ && A.n_split) {
+        // A path longer than the piece length was scanned as several pieces by different
+        // workgroups, each with its own bitset, so a segment touched by two pieces of one path
+        // was counted twice in uniq.  Walk the pieces' bitsets for this window in order and take
+        // one back for every bit an earlier piece of the same path already had.
+        const uint32_t word = tid & (kWinWords - 1), grp = tid / kWinWords;  // 128 words x 8 paths at a time
+        const uint32_t gw = win * kWinWords + word;
+        if (gw < A.n_words) {
+            for (uint32_t s = grp; s < A.n_split; s += kAccThreads / kWinWords) {
+                const uint2 sp = A.split[s];
+                const uint32_t *base = A.piece_bits + (size_t)sp.x * A.n_words + gw;
+                uint32_t acc = 0;
+                for (uint32_t k0 = 0; k0 < sp.y; k0 += 8) {
+                    uint32_t b[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) b[j] = (k0 + j < sp.y) ? base[(size_t)(k0 + j) * A.n_words] : 0u;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        uint32_t dup = b[j] & acc;
+                        acc |= b[j];
+                        while (dup) {
+                            const uint32_t tz = __builtin_ctz(dup);
+                            const uint32_t y = dup >> tz;
+                            const uint32_t run = (y == 0xFFFFFFFFu) ? 32u : (uint32_t)__builtin_ctz(~y);
+                            dup &= ~(((run == 32u) ? 0xFFFFFFFFu : ((1u << run) - 1u)) << tz);
+                            atomicAdd(&ud[(word << 5) + tz], -1);
+                            atomicAdd(&ud[(word << 5) + tz + run], 1);
+                        }
+                    }
+                }
+            }
+        }
+    }
     // Drain the window's sub-buckets: each wave takes four of them per round so that four
     // independent 16-byte loads per lane are in flight.
     constexpr uint32_t kAccWaves = kAccThreads / 64;
@@ -701,7 +699,8 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
     ScanArgs sa{g.steps, reinterpret_cast<const uint4 *>(fp.items), fp.piece_bits, fp.n_items, g.n_segs, fp.n_win,
                 uniq_out ? fp.n_words : 0u, fp.n_slots, fp.work_counter, fp.counts, fp.buckets, fp.cap, stride,
                 fp.n_win * stride, fp.ovf_d, fp.ovf_u, fp.ovf_flag, status, fp.dbg};
-    AccArgs aa{g.n_segs, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.buckets, fp.ovf_d, fp.ovf_u, fp.ovf_flag,
+    AccArgs aa{g.n_segs, fp.n_win, fp.n_slots, fp.cap, fp.piece_bits, reinterpret_cast<const uint2 *>(fp.split),
+               uniq_out ? fp.n_split : 0u, fp.n_words, fp.counts, fp.buckets, fp.ovf_d, fp.ovf_u, fp.ovf_flag,
                fp.work_counter, depth_out, uniq_out};
     const uint32_t grid = std::min<uint32_t>(fp.n_items, fp.n_slots);  // one persistent workgroup per CU
     if (uniq_out) {
@@ -709,13 +708,6 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
             ProfScope ps("k_scan<uniq>", stream);
             if (fp.dbg) hipLaunchKernelGGL((k_scan<true, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_uniq, stream, sa);
             else hipLaunchKernelGGL((k_scan<true, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_uniq, stream, sa);
-        }
-        if (fp.n_split) {
-            MergeArgs ma{fp.piece_bits, reinterpret_cast<const uint2 *>(fp.split), fp.n_split, fp.n_words, g.n_segs,
-                         fp.ovf_u, fp.ovf_flag};
-            const uint32_t jobs = fp.n_split * ((fp.n_words + 255) / 256);
-            ProfScope ps("k_merge", stream);
-            hipLaunchKernelGGL(k_merge, dim3(std::min<uint32_t>(jobs, fp.n_cus * 8u)), dim3(256), 0, stream, ma);
         }
         {
             ProfScope ps("k_accum<uniq>", stream);
