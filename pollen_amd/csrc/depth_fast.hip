@@ -122,7 +122,7 @@ struct Wave {
 };
 
 __device__ __forceinline__ void enqueue(Wave &w, bool e, uint32_t rec) {
-    const unsigned long long m = __ballot(e);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(e);
     if (e) w.q[w.fill + lane_rank(m)] = rec;
     w.fill += (uint32_t)__builtin_popcountll(m);
 }
@@ -185,9 +185,9 @@ __device__ __forceinline__ void emit_chunk(const ScanArgs &A, uint32_t *seen, ui
     }
     const uint32_t pos = valid ? atomicAdd(&bcur[win], 1u) : 0u;
     const bool o0 = put<DBG>(A, mine, valid, pos, id, len - 1, kind);
-    if (__ballot(o0) && o0) overflow_record(A, id, len, kind);  // rare: the sub-bucket is full
+    if (__builtin_amdgcn_ballot_w64(o0) && o0) overflow_record(A, id, len, kind);  // rare: the sub-bucket is full
     if (UNIQ) {
-        while (__ballot(xr != 0ull)) {
+        while (__builtin_amdgcn_ballot_w64(xr != 0ull)) {
             const bool e = xr != 0ull;
             const uint32_t tz = e ? (uint32_t)__builtin_ctzll(xr) : 0u;
             const unsigned long long y = xr >> tz;
@@ -195,9 +195,9 @@ __device__ __forceinline__ void emit_chunk(const ScanArgs &A, uint32_t *seen, ui
             xr &= ~(((run >= 64u) ? ~0ull : ((1ull << run) - 1ull)) << tz);
             const uint32_t p = e ? atomicAdd(&bcur[win], 1u) : 0u;
             const bool o1 = put<DBG>(A, mine, e, p, id + tz, run - 1, 1u);
-            if (__ballot(o1) && o1) overflow_record(A, id + tz, run, 1u);
+            if (__builtin_amdgcn_ballot_w64(o1) && o1) overflow_record(A, id + tz, run, 1u);
         }
-        if (__ballot(slow) && slow) claim_long_run(seen, mine, bcur, A.cap, A.stride, A.ovf_u, A.ovf_flag, id, len);
+        if (__builtin_amdgcn_ballot_w64(slow) && slow) claim_long_run(seen, mine, bcur, A.cap, A.stride, A.ovf_u, A.ovf_flag, id, len);
     }
 }
 
@@ -239,7 +239,7 @@ __device__ __forceinline__ void tile_full(const ScanArgs &A, Wave &w, uint4 v) {
     // start id of the run in progress when this lane's first step arrives
     const bool any = s0 | s1 | s2 | s3;
     const uint32_t last_start = s3 ? a3 : (s2 ? a2 : (s1 ? a1 : a0));
-    const unsigned long long below = __ballot(any) & ((1ull << w.lane) - 1ull);
+    const unsigned long long below = __builtin_amdgcn_ballot_w64(any) & ((1ull << w.lane) - 1ull);
     const int src = below ? 63 - __builtin_clzll(below) : w.lane;
     const uint32_t from_below = __shfl(last_start, src, 64);
     const uint32_t rs = below ? from_below : w.rs;
@@ -264,7 +264,7 @@ __device__ __forceinline__ void tile_narrow(const ScanArgs &A, Wave &w, uint64_t
     uint32_t prev = __builtin_amdgcn_update_dpp(0u, id, 0x138, 0xf, 0xf, false);
     if (w.lane == 0) prev = w.prev;
     const bool s = valid && ((id != prev + 1) | ((id & (kRunSpan - 1)) == 0));
-    const unsigned long long m = __ballot(s);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
     const unsigned long long below = m & ((1ull << w.lane) - 1ull);
     const int src = below ? 63 - __builtin_clzll(below) : w.lane;
     const uint32_t from_below = __shfl(id, src, 64);
