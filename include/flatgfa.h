@@ -123,6 +123,26 @@ int flatgfa_depth_table(flatgfa_t gfa, char **text, size_t *len);
 /* The bytes `fgfa depth [-r NAME]...` prints: PathDepth::emit (ops/depth.rs:143-160;
  * cli/cmds.rs:256-284).  path_ids == NULL means all paths, in order. */
 int flatgfa_path_depth_table(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, char **text, size_t *len);
+/* odgi-style node depth restricted to a subset of paths (`odgi depth -d -s FILE`,
+ * slow_odgi/slow_odgi/depth.py:12; tests/turnt.toml:31-44).  The reference's Rust `-d` ignores
+ * `-r`; this closes that gap.  path_ids may repeat: each occurrence counts as its own path. */
+int flatgfa_seg_depth_subset(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, uint64_t *depth_out,
+                             uint64_t *uniq_out);
+/* Path-pair overlap (slow_odgi/slow_odgi/overlap.py:6-32; `odgi overlap -R FILE`):
+ * touch_out[k * path_count + j] = 1 iff path j touches query path query_ids[k]. */
+int flatgfa_path_overlaps(flatgfa_t gfa, const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out);
+/* The bytes `slow_odgi overlap --paths FILE` prints for these query paths (overlap.py:17-32). */
+int flatgfa_overlap_table(flatgfa_t gfa, const uint32_t *query_ids, uint32_t n_q, char **text, size_t *len);
+/* interval_depth (flatgfa/src/ops/window_depth.rs:176-180): mean depth of each [start,end) interval
+ * (base pairs along path `path_index`, sorted) -- node depth from the GPU, the f64 accumulation of
+ * assign_depths (:116-147) on the host in the reference's order. */
+int flatgfa_interval_depth(flatgfa_t gfa, uint32_t path_index, const uint64_t *starts, const uint64_t *ends,
+                           uint64_t n_intervals, double *depth_out);
+/* The bytes `fgfa window-depth PATH SIZE` prints (window_depth.rs:183-200, cli/cmds.rs:488-496). */
+int flatgfa_window_depth_table(flatgfa_t gfa, uint32_t path_index, uint64_t window, char **text, size_t *len);
+/* The bytes `fgfa depth -b FILE.bed` prints (window_depth.rs:203-211, cli/cmds.rs:246-255); the BED
+ * text is parsed as flatbed.rs:125-158 does. */
+int flatgfa_bed_depth_table(flatgfa_t gfa, const uint8_t *bed, size_t bed_len, char **text, size_t *len);
 /* format_float (ops/depth.rs:192-197); returns bytes written (no NUL). */
 int flatgfa_format_float(double x, int digits, char *out, int cap);
 
@@ -167,6 +187,12 @@ int flatgfa_dev_seg_depth(flatgfa_dev_plan_t *plan, uint32_t *depth_out, uint32_
  * division per path is left to the host. */
 int flatgfa_dev_path_sums(flatgfa_dev_plan_t *plan, const uint32_t *path_ids, uint32_t n_ids, const uint32_t *depth,
                           uint64_t *length_out, uint64_t *weighted_out, void *stream);
+/* Path-pair overlap on device (slow_odgi/slow_odgi/overlap.py:6-14): touch_out[k * n_paths + j] = 1
+ * iff path j is a different path from path_ids[k] and the two share at least one ORIENTED handle.
+ * query_ids u32[n_q] and touch_out u8[n_q * n_paths] are device memory.  The per-path handle
+ * bitsets are built on the first call and kept with the plan. */
+int flatgfa_dev_path_overlaps(flatgfa_dev_plan_t *plan, const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out,
+                              void *stream);
 /* Synchronizes `stream`, then returns FLATGFA_OK, or FLATGFA_ERR_BOUNDS if any kernel since the
  * last call saw a segment id >= n_segs or a path id >= n_paths. */
 int flatgfa_dev_status(flatgfa_dev_plan_t *plan, void *stream);

@@ -422,6 +422,13 @@ def lib() -> ctypes.CDLL:
                                                 ctypes.POINTER(ctypes.c_uint64)]
         _LIB.oracle_emit_path_depth.restype = ctypes.c_void_p
         _LIB.oracle_free.argtypes = [ctypes.c_void_p]
+        _LIB.oracle_path_touches.argtypes = [u8p, ctypes.c_uint64, u32p, ctypes.c_uint64, ctypes.c_uint64,
+                                             u32p, ctypes.c_uint64, u8p]
+        _LIB.oracle_emit_overlap.argtypes = [u8p, u8p, ctypes.c_uint64, u32p, ctypes.c_uint64, u64p, u8p,
+                                             ctypes.POINTER(ctypes.c_uint64)]
+        _LIB.oracle_emit_overlap.restype = ctypes.c_void_p
+        _LIB.oracle_interval_depth.argtypes = [u8p, ctypes.c_uint64, u32p, ctypes.c_uint64, u8p, ctypes.c_uint64,
+                                               u64p, ctypes.c_uint32, u64p, u64p, ctypes.c_uint64, f64p]
     return _LIB
 
 
@@ -518,3 +525,105 @@ def fgfa_depth(p: Pools, seg_depth_flag: bool = False, path_names: Optional[List
         ids = np.array([i for i in found if i is not None], dtype=np.uint32)
     ln, dp = path_depth(p, ids)
     return emit_path_depth(p, ids, ln, dp)
+
+
+# --------------------------------------------------------------------------
+# rows next to the depth path: overlap (slow_odgi/overlap.py), subset depth (slow_odgi/depth.py:12),
+# window / interval depth (flatgfa/src/ops/window_depth.rs)
+# --------------------------------------------------------------------------
+
+def path_touches(p: Pools, query_ids) -> np.ndarray:
+    paths, steps = _c(p.paths), _c(p.steps)
+    ids = np.ascontiguousarray(query_ids, dtype=np.uint32)
+    out = np.zeros((len(ids), len(paths)), dtype=np.uint8)
+    rc = lib().oracle_path_touches(_ptr(paths), len(paths), _ptr(steps), len(steps), len(p.segs), _ptr(ids), len(ids),
+                                   _ptr(out) if out.size else None)
+    if rc:
+        raise ParseError(f"oracle_path_touches rc={rc}")
+    return out
+
+
+def overlap_table(p: Pools, query_names: List[bytes]) -> bytes:
+    """The bytes `slow_odgi overlap --paths FILE` prints."""
+    ids = []
+    for nm in query_names:
+        i = find_path(p, nm)
+        if i is None:
+            raise ParseError("query path not in graph")  # overlap.py:21 asserts
+        ids.append(i)
+    ids = np.array(ids, dtype=np.uint32)
+    touch = path_touches(p, ids)
+    ln, _ = path_depth(p, ids)  # len(pathseq[ip]) == the path's length in base pairs
+    paths, names = _c(p.paths), _c(p.name_data)
+    n = ctypes.c_uint64(0)
+    ptr = lib().oracle_emit_overlap(_ptr(paths), _ptr(names), len(paths), _ptr(ids), len(ids), _ptr(ln),
+                                    _ptr(touch) if touch.size else None, ctypes.byref(n))
+    out = ctypes.string_at(ptr, n.value)
+    lib().oracle_free(ptr)
+    return out
+
+
+def seg_depth_subset(p: Pools, path_ids) -> Tuple[np.ndarray, np.ndarray]:
+    """slow_odgi/depth.py:12: only crossings on the listed paths count (each listed path once per listing)."""
+    sub = Pools(**{n: getattr(p, n) for n in POOL_ORDER})
+    sub.paths = np.ascontiguousarray(p.paths[np.asarray(path_ids, dtype=np.intp)])
+    return seg_depth_with_uniq(sub)
+
+
+def interval_depth(p: Pools, path_id: int, starts, ends) -> np.ndarray:
+    paths, steps, segs = _c(p.paths), _c(p.steps), _c(p.segs)
+    d = seg_depth(p)
+    st = np.ascontiguousarray(starts, dtype=np.uint64)
+    en = np.ascontiguousarray(ends, dtype=np.uint64)
+    out = np.zeros(len(st), dtype=np.float64)
+    rc = lib().oracle_interval_depth(_ptr(paths), len(paths), _ptr(steps), len(steps), _ptr(segs), len(segs), _ptr(d),
+                                     int(path_id), _ptr(st), _ptr(en), len(st), _ptr(out))
+    if rc:
+        raise ParseError(f"oracle_interval_depth rc={rc}")
+    return out
+
+
+def parse_bed(buf: bytes):
+    """flatbed.rs:125-158 (+ memfile.rs:51-63): [(name, start, end)]."""
+    out = []
+    for line in _memchr_split(buf):
+        if line.startswith(b"#"):
+            continue
+        name, rest = _parse_field(line)
+        start, rest = _parse_num(rest)
+        if not rest:
+            raise ParseError("BED: index out of bounds")
+        end, _ = _parse_num(rest[1:])
+        out.append((name, start, end))
+    return out
+
+
+def _emit_intervals(rows, depths) -> bytes:
+    """IntervalDepth::emit, window_depth.rs:158-170"""
+    return b"".join(b"%s\t%d\t%d\t%s\n" % (nm, s, e, format_float(float(d), 4).encode())
+                    for (nm, s, e), d in zip(rows, depths))
+
+
+def window_depth_table(p: Pools, path_name: bytes, window: int) -> bytes:
+    """cmds::window_depth, cli/cmds.rs:488-496 + window_depth.rs:183-200"""
+    pid = find_path(p, path_name)
+    if pid is None or window <= 0:
+        raise ParseError("path not found / bad window")
+    ln, _ = path_depth(p, [pid])
+    rows, pos = [], 0
+    while pos < int(ln[0]):
+        e = min(pos + window, int(ln[0]))
+        rows.append((path_name, pos, e))
+        pos = e
+    return _emit_intervals(rows, interval_depth(p, pid, [r[1] for r in rows], [r[2] for r in rows]))
+
+
+def bed_depth_table(p: Pools, bed: bytes) -> bytes:
+    """cmds::depth -b, cli/cmds.rs:246-255 + window_depth.rs:203-211"""
+    rows = parse_bed(bed)
+    if not rows:
+        raise ParseError("BED: no intervals")
+    pid = find_path(p, rows[0][0])
+    if pid is None:
+        raise ParseError("path not found in graph")
+    return _emit_intervals(rows, interval_depth(p, pid, [r[1] for r in rows], [r[2] for r in rows]))

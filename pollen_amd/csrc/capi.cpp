@@ -350,4 +350,132 @@ int flatgfa_path_depth_table(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n
     return give_text(out, text, len);
 }
 
+// ---- f1: path-pair overlap (slow_odgi/overlap.py) ----
+
+int flatgfa_path_overlaps(flatgfa_t gfa, const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out) {
+    if (!gfa || (n_q && (!query_ids || !touch_out))) { set_error("flatgfa_path_overlaps: NULL argument"); return FLATGFA_ERR_ARG; }
+    const size_t P = gfa->view.paths.len;
+    for (uint32_t k = 0; k < n_q; ++k)
+        if (query_ids[k] >= P) { set_error("flatgfa_path_overlaps: path id out of range"); return FLATGFA_ERR_BOUNDS; }
+    if (n_q == 0 || P == 0) return FLATGFA_OK;
+    std::lock_guard<std::mutex> op(gfa->op_mu);
+    int rc = ensure_device(gfa, -1);
+    if (rc) return rc;
+    uint32_t *d_q = nullptr;
+    uint8_t *d_t = nullptr;
+    CAPI_HIP(hipMalloc(&d_q, (size_t)n_q * 4));
+    if (hipMalloc(&d_t, (size_t)n_q * P) != hipSuccess) { (void)hipFree(d_q); set_error("hipMalloc failed"); return FLATGFA_ERR_HIP; }
+    rc = FLATGFA_OK;
+    if (hipMemcpyAsync(d_q, query_ids, (size_t)n_q * 4, hipMemcpyHostToDevice, gfa->stream) != hipSuccess) rc = FLATGFA_ERR_HIP;
+    if (!rc) rc = flatgfa_dev_path_overlaps(gfa->plan, d_q, n_q, d_t, gfa->stream);
+    if (!rc) rc = flatgfa_dev_status(gfa->plan, gfa->stream);
+    if (!rc && hipMemcpy(touch_out, d_t, (size_t)n_q * P, hipMemcpyDeviceToHost) != hipSuccess) rc = FLATGFA_ERR_HIP;
+    (void)hipFree(d_q);
+    (void)hipFree(d_t);
+    return rc;
+}
+
+int flatgfa_overlap_table(flatgfa_t gfa, const uint32_t *query_ids, uint32_t n_q, char **text, size_t *len) {
+    if (!gfa || !text) { set_error("flatgfa_overlap_table: NULL argument"); return FLATGFA_ERR_ARG; }
+    const size_t P = gfa->view.paths.len;
+    std::vector<uint8_t> touch((size_t)n_q * P);
+    int rc = flatgfa_path_overlaps(gfa, query_ids, n_q, touch.data());
+    if (rc) return rc;
+    std::vector<uint64_t> plen(n_q);  // len(pathseq[ip]): the path's length in base pairs
+    for (uint32_t k = 0; k < n_q; ++k) plen[k] = fgfa::path_length(gfa->view, query_ids[k]);
+    std::string out;
+    fgfa::emit_overlap(gfa->view, query_ids, n_q, plen.data(), touch.data(), &out);
+    return give_text(out, text, len);
+}
+
+// ---- f2: window / interval depth (ops/window_depth.rs) ----
+
+int flatgfa_interval_depth(flatgfa_t gfa, uint32_t path_index, const uint64_t *starts, const uint64_t *ends,
+                           uint64_t n, double *depth_out) {
+    if (!gfa || (n && (!starts || !ends || !depth_out))) { set_error("flatgfa_interval_depth: NULL argument"); return FLATGFA_ERR_ARG; }
+    if (path_index >= gfa->view.paths.len) { set_error("flatgfa_interval_depth: path id out of range"); return FLATGFA_ERR_BOUNDS; }
+    std::vector<uint64_t> depth(gfa->view.segs.len);
+    int rc = flatgfa_seg_depth(gfa, depth.data(), nullptr);  // interval_depth calls seg_depth, window_depth.rs:177
+    if (rc) return rc;
+    std::vector<fgfa::BedEntry> win(n);
+    for (uint64_t i = 0; i < n; ++i) win[i] = fgfa::BedEntry{0u, 0u, starts[i], ends[i]};
+    fgfa::interval_depth(gfa->view, depth.data(), path_index, win.data(), n, depth_out);
+    return FLATGFA_OK;
+}
+
+static int bed_depth_common(flatgfa_t gfa, uint32_t path_index, const fgfa::Bed &bed, char **text, size_t *len) {
+    std::vector<uint64_t> depth(gfa->view.segs.len);
+    int rc = flatgfa_seg_depth(gfa, depth.data(), nullptr);
+    if (rc) return rc;
+    std::vector<double> out(bed.entries.size());
+    fgfa::interval_depth(gfa->view, depth.data(), path_index, bed.entries.data(), bed.entries.size(), out.data());
+    std::string s;
+    fgfa::emit_interval_depth(bed, out.data(), &s);
+    return give_text(s, text, len);
+}
+
+int flatgfa_window_depth_table(flatgfa_t gfa, uint32_t path_index, uint64_t window, char **text, size_t *len) {
+    if (!gfa || !text) { set_error("flatgfa_window_depth_table: NULL argument"); return FLATGFA_ERR_ARG; }
+    if (path_index >= gfa->view.paths.len) { set_error("window depth: path not found"); return FLATGFA_ERR_BOUNDS; }
+    if (window == 0) { set_error("window depth: window size must be positive"); return FLATGFA_ERR_ARG; }  // div_ceil by zero panics
+    const fgfa::Path &p = gfa->view.paths[path_index];
+    fgfa::Bed bed;
+    fgfa::make_windows(gfa->view.name_data.data + p.name.start, p.name.len(), 0, fgfa::path_length(gfa->view, path_index),
+                       window, &bed);
+    return bed_depth_common(gfa, path_index, bed, text, len);
+}
+
+int flatgfa_bed_depth_table(flatgfa_t gfa, const uint8_t *bed_text, size_t bed_len, char **text, size_t *len) {
+    if (!gfa || !text || (bed_len && !bed_text)) { set_error("flatgfa_bed_depth_table: NULL argument"); return FLATGFA_ERR_ARG; }
+    fgfa::Bed bed;
+    std::string err;
+    if (!fgfa::parse_bed(bed_text, bed_len, &bed, &err)) { set_error(err); return FLATGFA_ERR_BOUNDS; }
+    if (bed.entries.empty()) { set_error("BED: no intervals"); return FLATGFA_ERR_BOUNDS; }  // entries.all()[0] panics
+    // all intervals are taken to lie on the path named by the first entry (window_depth.rs:204-210)
+    const fgfa::BedEntry &e0 = bed.entries[0];
+    int64_t path = gfa->view.find_path(bed.name_data.data() + e0.name_start, e0.name_end - e0.name_start);
+    if (path < 0) { set_error("BED: path not found in graph"); return FLATGFA_ERR_BOUNDS; }
+    return bed_depth_common(gfa, (uint32_t)path, bed, text, len);
+}
+
+// ---- f3: node depth over a subset of paths (odgi depth -d -s) ----
+
+int flatgfa_seg_depth_subset(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, uint64_t *depth_out,
+                             uint64_t *uniq_out) {
+    if (!gfa || (n_ids && !path_ids) || (!depth_out && gfa->view.segs.len)) {
+        set_error("flatgfa_seg_depth_subset: NULL argument");
+        return FLATGFA_ERR_ARG;
+    }
+    const size_t P = gfa->view.paths.len, S = gfa->view.segs.len;
+    for (uint32_t k = 0; k < n_ids; ++k)
+        if (path_ids[k] >= P) { set_error("flatgfa_seg_depth_subset: path id out of range"); return FLATGFA_ERR_BOUNDS; }
+    std::lock_guard<std::mutex> op(gfa->op_mu);
+    int rc = ensure_device(gfa, -1);
+    if (rc) return rc;
+    // a prepared query over the same resident steps, with only the chosen paths' spans
+    std::vector<uint32_t> hb(n_ids), he(n_ids);
+    for (uint32_t k = 0; k < n_ids; ++k) {
+        hb[k] = gfa->h_path_begin[path_ids[k]];
+        he[k] = gfa->h_path_end[path_ids[k]];
+    }
+    uint32_t *d_b = nullptr, *d_e = nullptr;
+    if (n_ids) {
+        CAPI_HIP(hipMalloc(&d_b, (size_t)n_ids * 4));
+        if (hipMalloc(&d_e, (size_t)n_ids * 4) != hipSuccess) { (void)hipFree(d_b); set_error("hipMalloc failed"); return FLATGFA_ERR_HIP; }
+        (void)hipMemcpy(d_b, hb.data(), (size_t)n_ids * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(d_e, he.data(), (size_t)n_ids * 4, hipMemcpyHostToDevice);
+    }
+    flatgfa_dev_graph_t g{gfa->d_steps, (uint64_t)gfa->view.steps.len, d_b, d_e, n_ids, (uint32_t)S, gfa->d_seg_len};
+    flatgfa_dev_plan_t *plan = flatgfa_dev_plan_create(&g, hb.data(), he.data());
+    rc = plan ? FLATGFA_OK : FLATGFA_ERR_HIP;
+    if (!rc) rc = flatgfa_dev_seg_depth(plan, gfa->d_depth, uniq_out ? gfa->d_uniq : nullptr, gfa->stream);
+    if (!rc) rc = flatgfa_dev_status(plan, gfa->stream);
+    if (!rc) rc = fetch_widen(gfa, gfa->d_depth, depth_out);
+    if (!rc && uniq_out) rc = fetch_widen(gfa, gfa->d_uniq, uniq_out);
+    if (plan) flatgfa_dev_plan_destroy(plan);
+    if (d_b) (void)hipFree(d_b);
+    if (d_e) (void)hipFree(d_e);
+    return rc;
+}
+
 }  // extern "C"

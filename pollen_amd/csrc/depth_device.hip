@@ -182,7 +182,12 @@ struct flatgfa_dev_plan {
     uint32_t *status = nullptr;
     uint32_t n_windows = 1;
     FastPlan fast;  // the bucketed two-kernel path, used whenever the graph is eligible
+    uint32_t *overlap_bits = nullptr;  // per-path oriented-handle bitsets (built on first overlap query)
 };
+
+extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int n_cus, uint32_t **bits_cache,
+                                              const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out,
+                                              uint32_t *status, hipStream_t stream);
 
 #define HIP_TRY(expr, fail_stmt)                                                            \
     do {                                                                                    \
@@ -244,6 +249,7 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
 extern "C" void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *pl) {
     if (!pl) return;
     fast_plan_destroy(&pl->fast);
+    if (pl->overlap_bits) (void)hipFree(pl->overlap_bits);
     if (pl->items) (void)hipFree(pl->items);
     if (pl->status) (void)hipFree(pl->status);
     delete pl;
@@ -305,6 +311,13 @@ extern "C" int flatgfa_dev_path_sums(flatgfa_dev_plan_t *pl, const uint32_t *pat
     }
     HIP_TRY(hipGetLastError(), return FLATGFA_ERR_HIP);
     return FLATGFA_OK;
+}
+
+extern "C" int flatgfa_dev_path_overlaps(flatgfa_dev_plan_t *pl, const uint32_t *query_ids, uint32_t n_q,
+                                         uint8_t *touch_out, void *stream_) {
+    if (!pl || (n_q && (!query_ids || !touch_out))) { set_error("dev_path_overlaps: NULL argument"); return FLATGFA_ERR_ARG; }
+    return flatgfa_dev_path_overlaps_impl(&pl->g, pl->n_cus, &pl->overlap_bits, query_ids, n_q, touch_out, pl->status,
+                                          (hipStream_t)stream_);
 }
 
 extern "C" int flatgfa_dev_status(flatgfa_dev_plan_t *pl, void *stream_) {

@@ -2,7 +2,8 @@
 // (cucapra/pollen flatgfa/src/cli/main.rs:9-55, cmds.rs:16-97,217-285), built on the C ABI:
 //
 //   fgfa [-i FILE.flatgfa | -I FILE.gfa] [-o OUT.flatgfa] [-O OUT.gfa] [COMMAND]
-//   COMMAND: toc [-b] | paths | stats -S | depth [-d] [-r NAME]...
+//   COMMAND: toc [-b] | paths | stats -S | depth [-d] [-r NAME]... [-b FILE.bed] [-s PATHS]
+//            | window-depth PATH SIZE | overlap --paths FILE
 //
 // With no -i/-I the GFA text is read from stdin; with no COMMAND the graph is written out
 // (-o binary, -O text, otherwise text on stdout).  `depth` output is byte-identical to the
@@ -20,6 +21,25 @@
 static int die(const char *what) {
     fprintf(stderr, "fgfa: %s: %s\n", what, flatgfa_last_error());
     return 1;
+}
+
+// One name per line (blank lines skipped), as slow_odgi's parse_paths does.
+static bool read_names(const char *file, std::vector<std::string> *out) {
+    FILE *f = fopen(file, "rb");
+    if (!f) return false;
+    std::string cur;
+    int c;
+    while ((c = fgetc(f)) != EOF) {
+        if (c == '\n') {
+            if (!cur.empty()) out->push_back(cur);
+            cur.clear();
+        } else if (c != '\r') {
+            cur.push_back((char)c);
+        }
+    }
+    if (!cur.empty()) out->push_back(cur);
+    fclose(f);
+    return true;
 }
 
 static void write_all(const char *p, size_t n) {
@@ -106,17 +126,55 @@ int main(int argc, char **argv) {
     } else if (cmd == "depth") {
         bool seg_depth = false;
         std::vector<std::string> names;
+        const char *bed = nullptr, *subset = nullptr;
         for (; i < argc; ++i) {
             std::string a = argv[i];
             if (a == "-d" || a == "--graph-depth-table") seg_depth = true;
             else if (a == "-r" && i + 1 < argc) names.push_back(argv[++i]);
-            else if (a == "-b" || a == "--bed-input") { fprintf(stderr, "fgfa: depth -b is not built yet\n"); flatgfa_free(g); return 2; }
+            else if ((a == "-b" || a == "--bed-input") && i + 1 < argc) bed = argv[++i];
+            else if ((a == "-s" || a == "--subset-paths") && i + 1 < argc) subset = argv[++i];  // odgi depth -d -s
             else { fprintf(stderr, "fgfa: depth: unknown option %s\n", a.c_str()); flatgfa_free(g); return 2; }
         }
         char *text = nullptr;
         size_t n = 0;
-        if (seg_depth) {
+        if (seg_depth && subset) {
+            // node depth over the listed paths only (slow_odgi depth --paths, depth.py:12)
+            std::vector<std::string> want;
+            if (!read_names(subset, &want)) { fprintf(stderr, "fgfa: cannot read %s\n", subset); flatgfa_free(g); return 1; }
+            std::vector<uint32_t> ids;
+            for (auto &nm : want) {
+                int64_t id = flatgfa_find_path(g, (const uint8_t *)nm.data(), nm.size());
+                if (id >= 0) ids.push_back((uint32_t)id);
+            }
+            uint32_t S = flatgfa_get_segment_count(g);
+            std::vector<uint64_t> d(S), u(S);
+            uint32_t dummy = 0;
+            rc = flatgfa_seg_depth_subset(g, ids.empty() ? &dummy : ids.data(), (uint32_t)ids.size(), d.data(), u.data());
+            if (!rc) {
+                std::string out = "#node.id\tdepth\tdepth.uniq\n";
+                const void *segs;
+                uint64_t ns;
+                flatgfa_pool(g, 1, &segs, &ns, nullptr);
+                char line[96];
+                for (uint32_t k = 0; k < S; ++k) {
+                    uint64_t name;
+                    memcpy(&name, (const char *)segs + (size_t)k * 24, 8);
+                    out.append(line, (size_t)snprintf(line, sizeof line, "%u\t%llu\t%llu\n", (uint32_t)name,
+                                                      (unsigned long long)d[k], (unsigned long long)u[k]));
+                }
+                write_all(out.data(), out.size());
+            }
+        } else if (seg_depth) {
             rc = flatgfa_depth_table(g, &text, &n);
+        } else if (bed) {
+            std::string btext;
+            FILE *bf = fopen(bed, "rb");
+            if (!bf) { fprintf(stderr, "fgfa: cannot open %s\n", bed); flatgfa_free(g); return 1; }
+            char tmp[1 << 16];
+            size_t r;
+            while ((r = fread(tmp, 1, sizeof tmp, bf)) > 0) btext.append(tmp, r);
+            fclose(bf);
+            rc = flatgfa_bed_depth_table(g, (const uint8_t *)btext.data(), btext.size(), &text, &n);
         } else if (names.empty()) {
             rc = flatgfa_path_depth_table(g, nullptr, 0, &text, &n);
         } else {
@@ -130,6 +188,34 @@ int main(int argc, char **argv) {
             rc = flatgfa_path_depth_table(g, ids.empty() ? &dummy : ids.data(), (uint32_t)ids.size(), &text, &n);
         }
         if (rc) rc = die("depth");
+        else write_all(text, n);
+        flatgfa_free_text(text);
+    } else if (cmd == "window-depth") {
+        // cli/cmds.rs:477-496: fgfa window-depth PATH SIZE
+        if (i + 1 >= argc) { fprintf(stderr, "usage: fgfa window-depth PATH SIZE\n"); flatgfa_free(g); return 2; }
+        std::string pname = argv[i];
+        int64_t id = flatgfa_find_path(g, (const uint8_t *)pname.data(), pname.size());
+        char *text = nullptr;
+        size_t n = 0;
+        if (id < 0) { fprintf(stderr, "fgfa: path not found\n"); rc = 1; }
+        else if (flatgfa_window_depth_table(g, (uint32_t)id, strtoull(argv[i + 1], nullptr, 10), &text, &n)) rc = die("window-depth");
+        else write_all(text, n);
+        flatgfa_free_text(text);
+    } else if (cmd == "overlap") {
+        // slow_odgi overlap --paths FILE (slow_odgi/__main__.py:93-101)
+        if (i + 1 >= argc || strcmp(argv[i], "--paths")) { fprintf(stderr, "usage: fgfa overlap --paths FILE\n"); flatgfa_free(g); return 2; }
+        std::vector<std::string> want;
+        if (!read_names(argv[i + 1], &want)) { fprintf(stderr, "fgfa: cannot read %s\n", argv[i + 1]); flatgfa_free(g); return 1; }
+        std::vector<uint32_t> ids;
+        for (auto &nm : want) {
+            int64_t id = flatgfa_find_path(g, (const uint8_t *)nm.data(), nm.size());
+            if (id < 0) { fprintf(stderr, "fgfa: overlap: path %s is not in the graph\n", nm.c_str()); flatgfa_free(g); return 1; }
+            ids.push_back((uint32_t)id);
+        }
+        char *text = nullptr;
+        size_t n = 0;
+        uint32_t dummy = 0;
+        if (flatgfa_overlap_table(g, ids.empty() ? &dummy : ids.data(), (uint32_t)ids.size(), &text, &n)) rc = die("overlap");
         else write_all(text, n);
         flatgfa_free_text(text);
     } else {

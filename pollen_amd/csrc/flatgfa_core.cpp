@@ -387,13 +387,13 @@ void dump_flatgfa(const View &v, uint8_t *buf) {
 
 // ------------------------------------------------------------ GFA printer ---
 
-namespace {
-
-void put_u64(std::string *o, uint64_t v) {
+static void put_u64(std::string *o, uint64_t v) {
     char b[24];
     int n = snprintf(b, sizeof b, "%llu", (unsigned long long)v);
     o->append(b, (size_t)n);
 }
+
+namespace {
 
 void put_alignment(const View &v, Span a, std::string *o) {
     static const char letters[4] = {'M', 'N', 'D', 'I'};  // print.rs:14-23
@@ -564,6 +564,123 @@ bool MappedFile::open(const char *path, std::string *err) {
 
 MappedFile::~MappedFile() {
     if (data && size) munmap((void *)data, size);
+}
+
+}  // namespace fgfa
+
+// ------------------------------------------------- window / interval depth ---
+// Host side of flatgfa/src/ops/window_depth.rs: node depth comes from the GPU; the f64
+// accumulation is order-dependent, so it is done here exactly in the reference's order.
+
+namespace fgfa {
+
+bool parse_bed(const uint8_t *buf, size_t n, Bed *out, std::string *err) {
+    *out = Bed();
+    size_t pos = 0;
+    while (pos < n) {  // MemchrSplit: an unterminated last line is dropped (memfile.rs:51-63)
+        const uint8_t *nl = (const uint8_t *)memchr(buf + pos, '\n', n - pos);
+        if (!nl) break;
+        const uint8_t *p = buf + pos, *e = nl;
+        pos = (size_t)(nl - buf) + 1;
+        if (p < e && *p == '#') continue;  // flatbed.rs:141-143
+        const uint8_t *t = (const uint8_t *)memchr(p, '\t', (size_t)(e - p));
+        const uint8_t *name_end = t ? t : e;
+        const uint8_t *q = t ? t + 1 : e;
+        uint64_t start = 0, end = 0;
+        const uint8_t *s = q;
+        while (s < e && *s >= '0' && *s <= '9') start = start * 10 + (uint64_t)(*s++ - '0');
+        if (s == q) { *err = "BED: expected number"; return false; }
+        if (s >= e) { *err = "BED: line ends after the start column"; return false; }  // rest[1..] panics
+        const uint8_t *r = s + 1;
+        s = r;
+        while (s < e && *s >= '0' && *s <= '9') end = end * 10 + (uint64_t)(*s++ - '0');
+        if (s == r) { *err = "BED: expected number"; return false; }
+        BedEntry be;
+        be.name_start = (uint32_t)out->name_data.size();
+        out->name_data.insert(out->name_data.end(), p, name_end);
+        be.name_end = (uint32_t)out->name_data.size();
+        be.start = start;
+        be.end = end;
+        out->entries.push_back(be);
+    }
+    return true;
+}
+
+void make_windows(const uint8_t *name, size_t name_len, uint64_t start, uint64_t end, uint64_t size, Bed *out) {
+    *out = Bed();
+    out->name_data.assign(name, name + name_len);
+    for (uint64_t pos = start; pos < end;) {  // window_depth.rs:41-51
+        const uint64_t e = std::min(pos + size, end);
+        out->entries.push_back(BedEntry{0u, (uint32_t)name_len, pos, e});
+        pos = e;
+    }
+}
+
+uint64_t path_length(const View &v, uint32_t path) {  // window_depth.rs:69-77
+    uint64_t total = 0;
+    const Span sp = v.paths[path].steps;
+    for (uint32_t i = sp.start; i < sp.end; ++i) total += v.segs[v.steps[i].segment()].seq.len();
+    return total;
+}
+
+void interval_depth(const View &v, const uint64_t *seg_depth, uint32_t path, const BedEntry *win, size_t n_win, double *out) {
+    for (size_t i = 0; i < n_win; ++i) out[i] = 0.0;
+    size_t cur = 0;
+    uint64_t pos = 0;
+    const Span sp = v.paths[path].steps;
+    for (uint32_t i = sp.start; i < sp.end; ++i) {  // weighted_depths, window_depth.rs:84-103
+        const uint32_t seg = v.steps[i].segment();
+        const uint64_t len = v.segs[seg].seq.len();
+        const uint64_t r0 = pos, r1 = pos + len;
+        pos = r1;
+        const double sdepth = (double)(seg_depth[seg] * len);
+        while (cur < n_win) {  // assign_depths, window_depth.rs:116-147
+            const uint64_t w0 = win[cur].start, w1 = win[cur].end;
+            const uint64_t o0 = std::max(w0, r0), o1 = std::min(w1, r1);
+            if (o1 > o0) {
+                const double amt = (double)(o1 - o0) / (double)(r1 - r0);
+                out[cur] += (sdepth * amt) / (double)(w1 - w0);
+            }
+            if (w1 > r1) break;
+            cur += 1;
+        }
+    }
+}
+
+void emit_interval_depth(const Bed &bed, const double *depths, std::string *out) {  // window_depth.rs:158-170
+    for (size_t i = 0; i < bed.entries.size(); ++i) {
+        const BedEntry &e = bed.entries[i];
+        out->append((const char *)bed.name_data.data() + e.name_start, e.name_end - e.name_start);
+        out->push_back('\t');
+        put_u64(out, e.start);
+        out->push_back('\t');
+        put_u64(out, e.end);
+        out->push_back('\t');
+        out->append(format_float(depths[i], 4));
+        out->push_back('\n');
+    }
+}
+
+void emit_overlap(const View &v, const uint32_t *query_ids, size_t n_q, const uint64_t *path_len, const uint8_t *touch,
+                  std::string *out) {  // slow_odgi/overlap.py:17-32
+    bool header = false;
+    for (size_t k = 0; k < n_q; ++k) {
+        const Path &ip = v.paths[query_ids[k]];
+        for (size_t j = 0; j < v.paths.len; ++j) {
+            if (!touch[k * v.paths.len + j]) continue;
+            if (!header) {
+                out->append("#path\tstart\tend\tpath.touched\n");
+                header = true;
+            }
+            out->append((const char *)v.name_data.data + ip.name.start, ip.name.len());
+            out->append("\t0\t");
+            put_u64(out, path_len[k]);
+            out->push_back('\t');
+            const Path &q = v.paths[j];
+            out->append((const char *)v.name_data.data + q.name.start, q.name.len());
+            out->push_back('\n');
+        }
+    }
 }
 
 }  // namespace fgfa

@@ -148,6 +148,28 @@ void emit_seg_depth(const View &v, const uint64_t *depth, const uint64_t *uniq, 
 void emit_path_depth(const View &v, const uint32_t *path_ids, size_t n, const uint64_t *lengths,
                      const double *means, std::string *out);
 
+// A parsed BED file (flatgfa/src/flatbed.rs:9-25,125-158).
+struct BedEntry {
+    uint32_t name_start, name_end;
+    uint64_t start, end;
+};
+struct Bed {
+    std::vector<uint8_t> name_data;
+    std::vector<BedEntry> entries;
+};
+bool parse_bed(const uint8_t *buf, size_t n, Bed *out, std::string *err);
+// Windows{name, start, end, size}.as_bed(), window_depth.rs:22-57
+void make_windows(const uint8_t *name, size_t name_len, uint64_t start, uint64_t end, uint64_t size, Bed *out);
+// window_depth.rs:69-77
+uint64_t path_length(const View &v, uint32_t path);
+// weighted_depths + assign_depths, window_depth.rs:84-147 (f64, reference order of operations)
+void interval_depth(const View &v, const uint64_t *seg_depth, uint32_t path, const BedEntry *win, size_t n_win, double *out);
+// IntervalDepth::emit, window_depth.rs:158-170
+void emit_interval_depth(const Bed &bed, const double *depths, std::string *out);
+// slow_odgi/slow_odgi/overlap.py:17-32
+void emit_overlap(const View &v, const uint32_t *query_ids, size_t n_q, const uint64_t *path_len, const uint8_t *touch,
+                  std::string *out);
+
 // The synthetic-graph generator of SURVEY.md 8(d) (spec: oracle/synth.py).
 // model 0 = pangenome, 1 = uniform.
 void synth_store(uint64_t seed, uint32_t S, uint32_t P, uint32_t L, int model, bool with_seq, Store *out);

@@ -84,7 +84,10 @@ class FlatGFA:
 
     def get_seq(self, segment_id: int) -> Optional[bytes]:
         s = _lib.lib().flatgfa_get_seq(self._h, segment_id)
-        return None if not s.data and s.len == 0 and segment_id >= self.segment_count else ctypes.string_at(s.data, s.len)
+        if segment_id >= self.segment_count:
+            assert not s.data and s.len == 0
+            return None
+        return ctypes.string_at(s.data, s.len)
 
     def get_path_name(self, path_index: int) -> Optional[bytes]:
         if path_index >= self.path_count:
@@ -186,6 +189,71 @@ class FlatGFA:
             rc = _lib.lib().flatgfa_path_depth_table(self._h, ids.ctypes.data, len(ids) - 1, ctypes.byref(p),
                                                      ctypes.byref(n))
         _check(rc, "path_depth_table")
+        return _take_text(p, n)
+
+
+    # ---- the rows next to the depth path ----
+    def _ids(self, paths) -> np.ndarray:
+        """Path ids from a list of ids or names; unknown names raise (slow_odgi asserts, overlap.py:21)."""
+        out = []
+        for p in paths:
+            if isinstance(p, (bytes, bytearray)):
+                i = self.find_path(bytes(p))
+                if i is None:
+                    raise FlatGFAError(f"path {bytes(p)!r} not found")
+                out.append(i)
+            else:
+                out.append(int(p))
+        return np.ascontiguousarray(out, dtype=np.uint32)
+
+    def seg_depth_subset(self, paths) -> Tuple[np.ndarray, np.ndarray]:
+        """Node depth counting only `paths` (`odgi depth -d -s`, slow_odgi/depth.py:12)."""
+        ids = self._ids(paths)
+        S = self.segment_count
+        d, u = np.zeros(S, np.uint64), np.zeros(S, np.uint64)
+        _check(_lib.lib().flatgfa_seg_depth_subset(self._h, ids.ctypes.data if len(ids) else None, len(ids),
+                                                   d.ctypes.data, u.ctypes.data), "seg_depth_subset")
+        return d, u
+
+    def path_overlaps(self, queries) -> np.ndarray:
+        """touch[k, j] = path j touches query k (slow_odgi/overlap.py:6-14)."""
+        ids = self._ids(queries)
+        t = np.zeros((len(ids), self.path_count), np.uint8)
+        _check(_lib.lib().flatgfa_path_overlaps(self._h, ids.ctypes.data if len(ids) else None, len(ids),
+                                                t.ctypes.data if t.size else None), "path_overlaps")
+        return t
+
+    def overlap_table(self, queries) -> bytes:
+        """The bytes `slow_odgi overlap --paths FILE` prints."""
+        ids = self._ids(queries)
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(_lib.lib().flatgfa_overlap_table(self._h, ids.ctypes.data if len(ids) else None, len(ids),
+                                                ctypes.byref(p), ctypes.byref(n)), "overlap_table")
+        return _take_text(p, n)
+
+    def interval_depth(self, path, starts, ends) -> np.ndarray:
+        """ops/window_depth.rs:176-180"""
+        (pid,) = self._ids([path])
+        st = np.ascontiguousarray(starts, dtype=np.uint64)
+        en = np.ascontiguousarray(ends, dtype=np.uint64)
+        out = np.zeros(len(st), np.float64)
+        _check(_lib.lib().flatgfa_interval_depth(self._h, int(pid), st.ctypes.data, en.ctypes.data, len(st),
+                                                 out.ctypes.data), "interval_depth")
+        return out
+
+    def window_depth_table(self, path, window: int) -> bytes:
+        """The bytes `fgfa window-depth PATH SIZE` prints."""
+        (pid,) = self._ids([path])
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(_lib.lib().flatgfa_window_depth_table(self._h, int(pid), window, ctypes.byref(p), ctypes.byref(n)),
+               "window_depth_table")
+        return _take_text(p, n)
+
+    def bed_depth_table(self, bed: bytes) -> bytes:
+        """The bytes `fgfa depth -b FILE.bed` prints."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        _check(_lib.lib().flatgfa_bed_depth_table(self._h, bed, len(bed), ctypes.byref(p), ctypes.byref(n)),
+               "bed_depth_table")
         return _take_text(p, n)
 
 

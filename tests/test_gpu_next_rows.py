@@ -1,0 +1,118 @@
+"""HIP parity for the rows next to the depth path: path-pair overlap (f1), window /
+BED interval depth (f2), subset-paths node depth (f3) -- product (C ABI) vs oracle and goldens."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import pollen_amd as pa
+from conftest import GOLDEN, ROOT, fixture_id, golden_gfas
+from oracle import flatgfa_oracle as fo
+
+pytestmark = pytest.mark.gpu
+FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
+
+
+def read(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def pools_of(g):
+    return fo.Pools(**{n: g.pool(n) for n in fo.POOL_ORDER})
+
+
+@pytest.mark.parametrize("gfa", golden_gfas(), ids=fixture_id)
+def test_overlap_fixtures(gfa):
+    g = pa.parse(gfa)
+    names = [g.get_path_name(i) for i in range(g.path_count)]
+    assert g.overlap_table(names) == read(gfa[:-4] + ".overlap.tsv")      # slow_odgi golden
+    pools = fo.parse_gfa(read(gfa))
+    assert (g.path_overlaps(list(range(g.path_count))) == fo.path_touches(pools, np.arange(g.path_count))).all()
+
+
+def test_overlap_known_answer_and_errors():
+    g = pa.parse(os.path.join(GOLDEN, "kat_slow_odgi_readme.gfa"))
+    assert g.path_overlaps([b"x", b"y", b"z"]).tolist() == [[0, 1, 1], [1, 0, 0], [1, 0, 0]]
+    assert g.overlap_table([b"y"]) == b"#path\tstart\tend\tpath.touched\ny\t0\t8\tx\n"
+    assert g.overlap_table([]) == b""
+    with pytest.raises(pa.FlatGFAError):
+        g.overlap_table([b"nope"])
+    with pytest.raises(pa.FlatGFAError):
+        g.path_overlaps([7])
+
+
+@pytest.mark.parametrize("shape", [(1, 5000, 40, 300, "pangenome"), (2, 100_000, 64, 2000, "uniform"),
+                                   (3, 1_300_000, 12, 5000, "pangenome"), (4, 70, 9, 50, "uniform")])
+def test_overlap_synthetic(shape):
+    seed, S, P, L, model = shape
+    g = pa.synth(seed, S, P, L, model, False)
+    q = np.arange(P - 1, -1, -3, dtype=np.uint32)
+    assert (g.path_overlaps(q) == fo.path_touches(pools_of(g), q)).all()
+
+
+def test_overlap_cfgL():
+    # BASELINE.json configs[4]: path-pair overlap on the 1M-segment / 100M-step graph
+    g = pa.synth(1, 1_000_000, 1000, 100_000, "pangenome", False)
+    q = np.arange(0, 1000, 37, dtype=np.uint32)
+    got = g.path_overlaps(q)
+    assert (got == fo.path_touches(pools_of(g), q)).all()
+    assert (got[np.arange(len(q)), q] == 0).all()      # a path never touches itself
+
+
+@pytest.mark.parametrize("name", ["kat_slow_odgi_readme", "ref_ex1", "ref_ex2", "edge_names_loops"])
+def test_subset_depth_matches_slow_odgi(name, tmp_path):
+    gfa = os.path.join(GOLDEN, name + ".gfa")
+    g = pa.parse(gfa)
+    want = read(os.path.join(GOLDEN, name + ".depth_subset.tsv"))
+    paths_file = os.path.join(GOLDEN, name + ".subset.paths")
+    names = [ln.strip().encode() for ln in open(paths_file) if ln.strip()]
+    d, u = g.seg_depth_subset(names)
+    assert fo.emit_seg_depth(fo.parse_gfa(read(gfa)), d, u) == want
+    out = subprocess.run([FGFA, "-I", gfa, "depth", "-d", "-s", paths_file], capture_output=True, check=True).stdout
+    assert out == want
+
+
+def test_subset_depth_synthetic():
+    g = pa.synth(5, 60_000, 120, 3000, "pangenome", False)
+    pools = pools_of(g)
+    ids = [3, 3, 119, 0, 57]          # a repeated id counts as its own path entry
+    d, u = g.seg_depth_subset(ids)
+    wd, wu = fo.seg_depth_subset(pools, ids)
+    assert (d == wd).all() and (u == wu).all()
+    d, u = g.seg_depth_subset([])
+    assert not d.any() and not u.any()
+    full = g.seg_depth_with_uniq()     # the resident plan is untouched by subset queries
+    wd, wu = fo.seg_depth_with_uniq(pools)
+    assert (full[0] == wd).all() and (full[1] == wu).all()
+
+
+def test_window_and_bed_depth_known_answers(tmp_path):
+    # flatgfa-sh/README.md:282-294 (stand-in for note5.gfa)
+    gfa = os.path.join(GOLDEN, "standin_note5.gfa")
+    g = pa.parse(gfa)
+    want = b"5\t0\t4\t2\n5\t4\t8\t2\n5\t8\t12\t2\n5\t12\t13\t2\n"
+    assert g.window_depth_table(b"5", 4) == want
+    bed = b"#path\tstart\tend\n5\t0\t4\n5\t4\t8\n5\t8\t12\n5\t12\t13\n"
+    assert g.bed_depth_table(bed) == want
+    (tmp_path / "w.bed").write_bytes(bed)
+    assert subprocess.run([FGFA, "-I", gfa, "depth", "-b", str(tmp_path / "w.bed")], capture_output=True, check=True).stdout == want
+    assert subprocess.run([FGFA, "-I", gfa, "window-depth", "5", "4"], capture_output=True, check=True).stdout == want
+    for bad in (b"", b"zzz\t0\t4\n", b"5\tx\t4\n"):
+        with pytest.raises(pa.FlatGFAError):
+            g.bed_depth_table(bad)
+    with pytest.raises(pa.FlatGFAError):
+        g.window_depth_table(b"5", 0)
+
+
+@pytest.mark.parametrize("window", [1, 7, 64, 1000, 10**9])
+def test_window_depth_synthetic_matches_oracle_bitwise(window):
+    g = pa.synth(6, 20_000, 30, 4000, "pangenome", True)
+    pools = pools_of(g)
+    assert g.window_depth_table(b"p7", window) == fo.window_depth_table(pools, b"p7", window)
+    ln, _ = fo.path_depth(pools, [7])
+    edges = np.unique(np.concatenate([[0, int(ln[0])], np.random.default_rng(window).integers(0, int(ln[0]), 50)]))
+    got = g.interval_depth(b"p7", edges[:-1], edges[1:])
+    want = fo.interval_depth(pools, 7, edges[:-1], edges[1:])
+    assert got.tobytes() == want.tobytes()       # f64 accumulated in the reference's order: bit-identical
