@@ -73,6 +73,28 @@ class FlatGFA:
         except Exception:
             pass
 
+    # ---- flatgfa-py style list views (flatgfa-py/flatgfa.pyi:80-88) ----
+    def _views(self):
+        from . import views
+        if getattr(self, "_pools_cache", None) is None:
+            self._pools_cache = views._Pools(self)
+        return views, self._pools_cache
+
+    @property
+    def segments(self):
+        v, p = self._views()
+        return v.SegmentList(p)
+
+    @property
+    def paths(self):
+        v, p = self._views()
+        return v.PathList(p)
+
+    @property
+    def links(self):
+        v, p = self._views()
+        return v.LinkList(p)
+
     # ---- flatgfa-c accessors (flatgfa-c/src/lib.rs:80-172) ----
     @property
     def segment_count(self) -> int:
