@@ -304,21 +304,45 @@ __device__ __forceinline__ Span make_span(const ScanArgs &A, uint32_t job, int w
 }
 
 // Streaming loads of steps.  Each handle is read exactly once (nontemporal: keep it out of the
-// way of the bucket lines the L2 is write-combining).  The loads are issued as inline asm and
-// waited for with explicit counted s_waitcnt, because hipcc otherwise drains vmcnt to 0 at the
-// top of the tile loop and loses the prefetch depth.  On gfx950 vmcnt counts loads and stores
-// in issue order, so "at most N outstanding" with N <= the number of loads issued after the one
-// we need is always sufficient; record stores issued in between only make the wait stricter.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void load_tile_async(u32x4 &r, const uint4 *p) {
-    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(r) : "v"(p) : "memory");
+// way of the bucket lines the L2 is write-combining).  Four tiles per wave are kept in flight
+// across loop iterations.  hipcc cannot express that: it drains vmcnt to 0 at the top of the
+// loop, and an inline-asm load into a compiler-allocated register is unsafe because the compiler
+// may copy the register (to rotate it through the loop) while the load is still in flight.  So
+// the landing registers are four fixed quads, v[112:127], which the compiler is told are
+// clobbered and never otherwise allocates (the kernel needs < 100 VGPRs; 128 is the budget of a
+// 1024-thread workgroup).  tools/check_pinned_vgprs.py checks the generated ISA for exactly that
+// (run by `make check` and by the CPU test suite).
+// A tile is taken out of its quad by v_movs issued after a counted s_waitcnt: on gfx950 vmcnt
+// counts loads and stores in issue order, so "at most N outstanding" with N <= the number of
+// tile loads issued after the one we need is always sufficient; record stores issued in between
+// only make the wait stricter.
+#define FGFA_LOAD_Q(Q, A, B, C, D, p) \
+    asm volatile("global_load_dwordx4 " Q ", %0, off nt" ::"v"(p) : "memory", A, B, C, D)
+#define FGFA_TAKE_Q(A, B, C, D, cur)                                                                  \
+    asm volatile("v_mov_b32 %0, " A "\n\tv_mov_b32 %1, " B "\n\tv_mov_b32 %2, " C "\n\tv_mov_b32 %3, " D \
+                 : "=v"(cur.x), "=v"(cur.y), "=v"(cur.z), "=v"(cur.w)::"memory")
+template <int SLOT>
+__device__ __forceinline__ void load_tile_async(const uint4 *p) {
+    if (SLOT == 0) FGFA_LOAD_Q("v[112:115]", "v112", "v113", "v114", "v115", p);
+    if (SLOT == 1) FGFA_LOAD_Q("v[116:119]", "v116", "v117", "v118", "v119", p);
+    if (SLOT == 2) FGFA_LOAD_Q("v[120:123]", "v120", "v121", "v122", "v123", p);
+    if (SLOT == 3) FGFA_LOAD_Q("v[124:127]", "v124", "v125", "v126", "v127", p);
 }
-// Waits until tile data `r` has landed; `younger` = how many tile loads were issued after it.
-__device__ __forceinline__ void wait_tile(u32x4 &r, uint64_t younger) {
-    if (younger >= 3) asm volatile("s_waitcnt vmcnt(3)" : "+v"(r)::"memory");
-    else if (younger == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(r)::"memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" : "+v"(r)::"memory");
-    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r)::"memory");
+// Waits until at most `younger` (capped at 3) of this wave's memory operations are outstanding.
+__device__ __forceinline__ void wait_tiles(uint64_t younger) {
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+template <int SLOT>
+__device__ __forceinline__ uint4 take_tile() {
+    uint4 cur;
+    if (SLOT == 0) FGFA_TAKE_Q("v112", "v113", "v114", "v115", cur);
+    if (SLOT == 1) FGFA_TAKE_Q("v116", "v117", "v118", "v119", cur);
+    if (SLOT == 2) FGFA_TAKE_Q("v120", "v121", "v122", "v123", cur);
+    if (SLOT == 3) FGFA_TAKE_Q("v124", "v125", "v126", "v127", cur);
+    return cur;
 }
 
 template <bool UNIQ, bool DBG>
@@ -345,22 +369,21 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
 
     // The first tiles of a path are requested while the previous path is being wrapped up.
     Span sp = make_span(A, job, wave, lane);
-    u32x4 r0 = {}, r1 = {}, r2 = {}, r3 = {};
     uint32_t first_raw = 0;
 #define FGFA_PRELOAD()                                              \
     do {                                                            \
         if (sp.lo < sp.hi) first_raw = A.steps[sp.lo];              \
-        if (sp.nfull > 0) load_tile_async(r0, sp.src);              \
-        if (sp.nfull > 1) load_tile_async(r1, sp.src + 64);         \
-        if (sp.nfull > 2) load_tile_async(r2, sp.src + 128);        \
-        if (sp.nfull > 3) load_tile_async(r3, sp.src + 192);        \
+        if (sp.nfull > 0) load_tile_async<0>(sp.src);               \
+        if (sp.nfull > 1) load_tile_async<1>(sp.src + 64);          \
+        if (sp.nfull > 2) load_tile_async<2>(sp.src + 128);         \
+        if (sp.nfull > 3) load_tile_async<3>(sp.src + 192);         \
     } while (0)
     // one tile: wait for its data, re-issue its register for the tile four ahead, process it
-#define FGFA_TILE(R, K)                                                                   \
+#define FGFA_TILE(K)                                                                      \
     if (i + (K) < sp.nfull) {                                                             \
-        wait_tile(R, sp.nfull - 1 - (i + (K)));                                           \
-        const uint4 cur = make_uint4(R.x, R.y, R.z, R.w);                                 \
-        if (i + (K) + 4 < sp.nfull) load_tile_async(R, sp.src + (i + (K) + 4) * 64);      \
+        wait_tiles(sp.nfull - 1 - (i + (K)));                                             \
+        const uint4 cur = take_tile<K>();                                                 \
+        if (i + (K) + 4 < sp.nfull) load_tile_async<K>(sp.src + (i + (K) + 4) * 64);      \
         if (!FGFA_SKIP(kDbgNoTiles)) {                                                    \
             tile_full<UNIQ, DBG>(A, w, cur);                                              \
             drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);                              \
@@ -380,10 +403,10 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             // four tiles (4 KiB per wave, 64 KiB per CU) stay in flight
 #pragma unroll 1
             for (uint64_t i = 0; i < sp.nfull; i += 4) {
-                FGFA_TILE(r0, 0)
-                FGFA_TILE(r1, 1)
-                FGFA_TILE(r2, 2)
-                FGFA_TILE(r3, 3)
+                FGFA_TILE(0)
+                FGFA_TILE(1)
+                FGFA_TILE(2)
+                FGFA_TILE(3)
             }
             uint64_t t = sp.t0 + sp.nfull * 256;
             while (t < sp.hi) {
@@ -415,6 +438,8 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     }
 #undef FGFA_PRELOAD
 #undef FGFA_TILE
+#undef FGFA_LOAD_Q
+#undef FGFA_TAKE_Q
     // publish how many records this workgroup left in each window's sub-bucket
     __syncthreads();
     for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads)

@@ -50,3 +50,15 @@ def test_no_oracle_in_product():
                 if "oracle" in open(os.path.join(d, f), errors="replace").read().replace("oracle/synth.py", ""):
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_pinned_landing_registers_are_private():
+    """k_scan's in-flight step tiles land in fixed VGPRs; nothing else in the generated ISA may
+    touch them (tools/check_pinned_vgprs.py, also `make -C pollen_amd/csrc check`)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_pinned_vgprs.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

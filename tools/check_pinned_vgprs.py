@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Build-time check for depth_fast.hip's pinned landing registers.
+
+k_scan keeps four 16-byte step units in flight in the fixed VGPR quads v[112:127]
+(see the comment above load_unit_async in pollen_amd/csrc/depth_fast.hip).  That is only sound if
+nothing else in the kernel touches those registers.  This script compiles the file to gfx950
+assembly and checks, for every k_scan instantiation and every function it can call:
+
+  * the only instructions that mention v112..v127 are `global_load_dwordx4 v[Q:Q+3], ..., off nt`
+    (as the destination) and `v_mov_b32 vN, v1xx` (as the source);
+  * the kernel's VGPR budget stays at or under 128 (a 1024-thread workgroup needs 4 waves/SIMD).
+
+Usage: check_pinned_vgprs.py [path/to/depth_fast.hip]      exit status 0 = ok
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "..", "pollen_amd", "csrc", "depth_fast.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+PINNED = set(range(112, 128))
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+OK_LOAD = re.compile(r"^global_load_dwordx4 v\[(112|116|120|124):(115|119|123|127)\], v\[\d+:\d+\], off nt$")
+OK_TAKE = re.compile(r"^v_mov_b32(_e32)? v(\d+), v(\d+)$")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def main():
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "depth_fast.s")
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                               SRC, "-o", asm], stderr=subprocess.DEVNULL)
+        lines = open(asm).read().splitlines()
+    bad, n_load, n_take, func = [], 0, 0, "?"
+    budgets = {}
+    for ln in lines:
+        s = ln.split(";")[0].strip()
+        if s.endswith(":") and not s.startswith("."):
+            func = s[:-1]
+            continue
+        m = re.match(r"\.amdhsa_next_free_vgpr\s+(\d+)", s)
+        if m:
+            budgets[func] = int(m.group(1))
+            continue
+        if not s or s.startswith("."):
+            continue
+        touched = regs_of(s) & PINNED
+        if not touched:
+            continue
+        if OK_LOAD.match(s):
+            n_load += 1
+            continue
+        m = OK_TAKE.match(s)
+        if m and int(m.group(3)) in PINNED and int(m.group(2)) not in PINNED:
+            n_take += 1
+            continue
+        bad.append(f"{func}: {s}")
+    for name, v in budgets.items():
+        if "k_scan" in name and v > 128:
+            bad.append(f"{name}: {v} VGPRs > 128")
+    if n_load == 0 or n_take == 0:
+        bad.append("no pinned loads/takes found -- did the kernel change?")
+    if bad:
+        print("pinned-VGPR check FAILED:\n  " + "\n  ".join(bad[:20]))
+        return 1
+    print(f"pinned-VGPR check ok: {n_load} loads, {n_take} takes, nothing else touches v112..v127; "
+          f"k_scan budgets {sorted(set(v for k, v in budgets.items() if 'k_scan' in k))}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
