@@ -40,18 +40,23 @@ namespace {
 
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
-constexpr uint32_t kRunBits = 11;  // runs are cut at ids that are multiples of 2048
+constexpr uint32_t kRunBits = 11;  // a queued run is (start id << 11) | (len - 1)
 constexpr uint32_t kRunSpan = 1u << kRunBits;
+// Where runs are cut: depth-only runs at ids that are multiples of 2048 (a record never crosses a
+// window); with unique depth at multiples of 32, so that a run lies inside ONE word of the "seen"
+// bitset and is claimed with a single returning LDS OR.
+template <bool UNIQ>
+constexpr uint32_t kCutMask = UNIQ ? 31u : kRunSpan - 1u;
 constexpr uint32_t kWinBits = 12;  // accumulation window: 4096 segment ids = 128 bitset words
 constexpr uint32_t kWin = 1u << kWinBits;
 constexpr uint32_t kWinWords = kWin / 32;
-constexpr uint32_t kMaxWin = 512;  // LDS cursor table entries
+constexpr uint32_t kMaxWin = 256;  // LDS cursor table entries (the bitset limit keeps n_win below this)
 constexpr uint32_t kLdsLimit = 160 * 1024;
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr int kAccThreads = 1024;
 
 // diagnostic ablations (FLATGFA_DEBUG_SKIP, results are then wrong by construction)
-constexpr uint32_t kDbgNoStore = 1, kDbgNoScanOut = 2, kDbgNoBitset = 4, kDbgNoTiles = 8;
+constexpr uint32_t kDbgNoStore = 1, kDbgNoBitset = 4, kDbgNoTiles = 8;
 // the ablation checks exist only in the DBG instantiation of the kernel
 #define FGFA_SKIP(bit) (DBG && (A.dbg & (bit)))
 
@@ -114,10 +119,11 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long m) {
 
 // Per-wave state: the run queue (LDS, kQCap entries of (start id << 11) | (len - 1)), how many
 // entries it holds, the id of the step before the next one, and the start id of the run that
-// step belongs to.  `fill`, `prev` and `rs` are wave-uniform.
+// step belongs to; and the queue of partially new claims (see emit_chunk).  `fill`, `pfill`,
+// `prev` and `rs` are wave-uniform.
 struct Wave {
-    uint32_t *q;
-    uint32_t fill, prev, rs;
+    uint32_t *q, *pq;
+    uint32_t fill, pfill, prev, rs;
     int lane;
 };
 
@@ -127,81 +133,71 @@ __device__ __forceinline__ void enqueue(Wave &w, bool e, uint32_t rec) {
     w.fill += (uint32_t)__builtin_popcountll(m);
 }
 
-// Claim a run longer than 64 segments word by word; the newly claimed bits of each word become
-// uniq records.  Rare (a perfectly linear stretch of the path), hence out of line.
-__device__ __noinline__ void claim_long_run(uint32_t *seen, uint32_t *mine, uint32_t *bcur, uint32_t cap, uint32_t stride,
-                                            int *ovf_u, uint32_t *ovf_flag, uint32_t id, uint32_t len) {
-    uint32_t cur = id, left = len;
-    while (left) {
-        const uint32_t b = cur & 31u, n = min(left, 32u - b);
-        const uint32_t mw = ((n == 32u) ? 0xFFFFFFFFu : ((1u << n) - 1u)) << b;
-        uint32_t nb = mw & ~atomicOr(&seen[cur >> 5], mw);
-        const uint32_t id0 = cur & ~31u;
-        while (nb) {
-            const uint32_t tz = __builtin_ctz(nb);
-            const uint32_t y = nb >> tz;
-            const uint32_t run = (y == 0xFFFFFFFFu) ? 32u : (uint32_t)__builtin_ctz(~y);
-            nb &= ~(((run == 32u) ? 0xFFFFFFFFu : ((1u << run) - 1u)) << tz);
-            const uint32_t rid = id0 + tz;
-            const uint32_t pos = atomicAdd(&bcur[rid >> kWinBits], 1u);
-            if (pos < cap) mine[(rid >> kWinBits) * stride + pos] = (rid & (kWin - 1)) | ((run - 1) << kWinBits) | (1u << 24);
-            else overflow_apply(ovf_u, ovf_flag, rid, run);
-        }
-        cur += n;
-        left -= n;
-    }
+constexpr uint32_t kQCap = 320;  // 63 left over + up to 256 from one tile
+constexpr uint32_t kPCap = 192;  // 63 left over + up to 2 x 64 from one chunk of claims
+
+__device__ __forceinline__ void push_partial(Wave &w, bool e, uint32_t ent) {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(e);
+    if (e) w.pq[w.pfill + lane_rank(m)] = ent;
+    w.pfill += (uint32_t)__builtin_popcountll(m);
 }
 
 // Emit up to 64 queued runs, one per lane.  Each run becomes one depth record.  For unique
-// depth the lane claims the run's segments in the path's "seen" bitset with returning LDS ORs
-// (a run of up to 64 segments spans at most three words): the bits that were still clear are
-// exactly the (path, segment) pairs this run is the first to touch.  If all of them were
-// clear the depth record doubles as the uniq record (kind 2); otherwise every stretch of newly
-// claimed segments gets a uniq record of its own (usually none or one).
+// depth the lane claims the run's segments in the path's "seen" bitset with ONE returning LDS OR
+// (runs are cut at multiples of 32, so a run lies inside one word): the bits that were still
+// clear are exactly the (path, segment) pairs this run is the first to touch.  If all of them
+// were clear the depth record doubles as the uniq record (kind 2), if none was there is nothing
+// to add.  The rare claim that is partly new is parked, as (word, half, 16 new bits), on a second
+// queue; that queue is turned into uniq records 64 entries at a time, so its bit-stretch loop
+// runs with all lanes busy instead of once per chunk for a lane or two.
 template <bool UNIQ, bool DBG>
-__device__ __forceinline__ void emit_chunk(const ScanArgs &A, uint32_t *seen, uint32_t *bcur, uint32_t *mine, bool valid,
-                                           uint32_t rec) {
-    const uint32_t id = rec >> kRunBits, len = (rec & (kRunSpan - 1)) + 1, win = id >> kWinBits;
+__device__ __forceinline__ void emit_chunk(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
+                                           bool valid, uint32_t rec) {
+    const uint32_t id = rec >> kRunBits, lenm1 = rec & (kRunSpan - 1), win = id >> kWinBits;
     uint32_t kind = 0;
-    unsigned long long xr = 0;  // bit k set <=> segment id + k was newly claimed and still needs a uniq record
-    bool slow = false;
     if (UNIQ && !FGFA_SKIP(kDbgNoBitset)) {
-        const uint32_t bit0 = id & 31u, w0 = id >> 5;
-        const bool fast = valid && len <= 64u;
-        slow = valid && !fast;
-        const unsigned long long ones = (len >= 64u) ? ~0ull : ((1ull << len) - 1ull);
-        const unsigned long long m01 = fast ? (ones << bit0) : 0ull;
-        const uint32_t m2 = (fast && bit0) ? (uint32_t)(ones >> (64u - bit0)) : 0u;
-        const uint32_t lo = (uint32_t)m01, mid = (uint32_t)(m01 >> 32);
-        const uint32_t old_lo = lo ? atomicOr(&seen[w0], lo) : 0u;
-        const uint32_t old_mid = mid ? atomicOr(&seen[w0 + 1], mid) : 0u;
-        const uint32_t old_2 = m2 ? atomicOr(&seen[w0 + 2], m2) : 0u;
-        const unsigned long long nb01 = m01 & ~(((unsigned long long)old_mid << 32) | old_lo);
-        const uint32_t nb2 = m2 & ~old_2;
-        const unsigned long long x = (nb01 >> bit0) | (bit0 ? ((unsigned long long)nb2 << (64u - bit0)) : 0ull);
-        const bool allnew = fast && x == ones;
-        kind = allnew ? 2u : 0u;
-        xr = allnew ? 0ull : x;
+        const uint32_t mask = valid ? (0xFFFFFFFFu >> (31u - lenm1)) << (id & 31u) : 0u;
+        const uint32_t old = mask ? atomicOr(&seen[id >> 5], mask) : 0u;
+        const uint32_t nb = mask & ~old;
+        kind = (nb == mask) ? 2u : 0u;
+        const uint32_t part = (nb == mask) ? 0u : nb;
+        const uint32_t word = (id >> 5) << 17;
+        push_partial(w, (part & 0xFFFFu) != 0u, word | (part & 0xFFFFu));
+        push_partial(w, (part >> 16) != 0u, word | 0x10000u | (part >> 16));
     }
     const uint32_t pos = valid ? atomicAdd(&bcur[win], 1u) : 0u;
-    const bool o0 = put<DBG>(A, mine, valid, pos, id, len - 1, kind);
-    if (__builtin_amdgcn_ballot_w64(o0) && o0) overflow_record(A, id, len, kind);  // rare: the sub-bucket is full
-    if (UNIQ) {
-        while (__builtin_amdgcn_ballot_w64(xr != 0ull)) {
-            const bool e = xr != 0ull;
-            const uint32_t tz = e ? (uint32_t)__builtin_ctzll(xr) : 0u;
-            const unsigned long long y = xr >> tz;
-            const uint32_t run = (~y == 0ull) ? 64u : (uint32_t)__builtin_ctzll(~y);
-            xr &= ~(((run >= 64u) ? ~0ull : ((1ull << run) - 1ull)) << tz);
-            const uint32_t p = e ? atomicAdd(&bcur[win], 1u) : 0u;
-            const bool o1 = put<DBG>(A, mine, e, p, id + tz, run - 1, 1u);
-            if (__builtin_amdgcn_ballot_w64(o1) && o1) overflow_record(A, id + tz, run, 1u);
-        }
-        if (__builtin_amdgcn_ballot_w64(slow) && slow) claim_long_run(seen, mine, bcur, A.cap, A.stride, A.ovf_u, A.ovf_flag, id, len);
-    }
+    const bool o0 = put<DBG>(A, mine, valid, pos, id, lenm1, kind);
+    if (__builtin_amdgcn_ballot_w64(o0) && o0) overflow_record(A, id, lenm1 + 1, kind);  // rare: the sub-bucket is full
 }
 
-constexpr uint32_t kQCap = 320;  // 63 left over + up to 256 from one tile
+// Turn whole chunks of 64 parked claims (all of them when `all`) into uniq records: one per
+// stretch of new bits.
+template <bool DBG>
+__device__ __forceinline__ void drain_partial(const ScanArgs &A, Wave &w, uint32_t *bcur, uint32_t *mine, bool all) {
+    while (w.pfill >= 64u || (all && w.pfill)) {
+        const uint32_t n = min(w.pfill, 64u);
+        const bool valid = (uint32_t)w.lane < n;
+        const uint32_t ent = valid ? w.pq[w.lane] : 0u;
+        const uint32_t rest = w.pfill - n;
+        for (uint32_t i = w.lane; i < rest; i += 64) {  // ds ops of one wave execute in order
+            const uint32_t t = w.pq[n + i];
+            w.pq[i] = t;
+        }
+        w.pfill = rest;
+        const uint32_t base = ((ent >> 17) << 5) | ((ent >> 12) & 16u);  // first segment of the half word
+        const uint32_t win = base >> kWinBits;
+        uint32_t m = ent & 0xFFFFu;
+        while (__builtin_amdgcn_ballot_w64(m != 0u)) {
+            const bool e = m != 0u;
+            const uint32_t tz = e ? (uint32_t)__builtin_ctz(m) : 0u;
+            const uint32_t run = (uint32_t)__builtin_ctz(~(m >> tz));  // m has 16 bits: ~(m >> tz) is never 0
+            m &= ~(((1u << run) - 1u) << tz);
+            const uint32_t p = e ? atomicAdd(&bcur[win], 1u) : 0u;
+            const bool o1 = put<DBG>(A, mine, e, p, base + tz, run - 1u, 1u);
+            if (__builtin_amdgcn_ballot_w64(o1) && o1) overflow_record(A, base + tz, run, 1u);
+        }
+    }
+}
 
 // Emit whole chunks of 64 queued runs (all of them when `all`), keeping the rest at the front.
 template <bool UNIQ, bool DBG>
@@ -210,14 +206,16 @@ __device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen
         const uint32_t n = min(w.fill, 64u);
         const bool valid = (uint32_t)w.lane < n;
         const uint32_t rec = valid ? w.q[w.lane] : 0u;
-        emit_chunk<UNIQ, DBG>(A, seen, bcur, mine, valid, rec);
+        emit_chunk<UNIQ, DBG>(A, w, seen, bcur, mine, valid, rec);
         const uint32_t rest = w.fill - n;
         for (uint32_t i = w.lane; i < rest; i += 64) {  // ds ops of one wave execute in order
             const uint32_t t = w.q[n + i];
             w.q[i] = t;
         }
         w.fill = rest;
+        if (UNIQ) drain_partial<DBG>(A, w, bcur, mine, false);
     }
+    if (UNIQ && all) drain_partial<DBG>(A, w, bcur, mine, true);
 }
 
 // 256 steps, four consecutive ones per lane (lane i holds steps 4i..4i+3 of the tile).
@@ -232,10 +230,10 @@ __device__ __forceinline__ void tile_full(const ScanArgs &A, Wave &w, uint4 v) {
     }
     uint32_t prev = __builtin_amdgcn_update_dpp(0u, a3, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     if (w.lane == 0) prev = w.prev;
-    const bool s0 = (a0 != prev + 1) | ((a0 & (kRunSpan - 1)) == 0);
-    const bool s1 = (a1 != a0 + 1) | ((a1 & (kRunSpan - 1)) == 0);
-    const bool s2 = (a2 != a1 + 1) | ((a2 & (kRunSpan - 1)) == 0);
-    const bool s3 = (a3 != a2 + 1) | ((a3 & (kRunSpan - 1)) == 0);
+    const bool s0 = (a0 != prev + 1) | ((a0 & kCutMask<UNIQ>) == 0);
+    const bool s1 = (a1 != a0 + 1) | ((a1 & kCutMask<UNIQ>) == 0);
+    const bool s2 = (a2 != a1 + 1) | ((a2 & kCutMask<UNIQ>) == 0);
+    const bool s3 = (a3 != a2 + 1) | ((a3 & kCutMask<UNIQ>) == 0);
     // start id of the run in progress when this lane's first step arrives
     const bool any = s0 | s1 | s2 | s3;
     const uint32_t last_start = s3 ? a3 : (s2 ? a2 : (s1 ? a1 : a0));
@@ -258,12 +256,13 @@ __device__ __forceinline__ void tile_full(const ScanArgs &A, Wave &w, uint4 v) {
 }
 
 // Up to 64 consecutive steps, one per lane (heads, tails and short spans).
+template <bool UNIQ>
 __device__ __forceinline__ void tile_narrow(const ScanArgs &A, Wave &w, uint64_t t, uint32_t count) {
     const bool valid = (uint32_t)w.lane < count;
     const uint32_t id = valid ? clamp_id(A, A.steps[t + w.lane] >> 1) : 0u;
     uint32_t prev = __builtin_amdgcn_update_dpp(0u, id, 0x138, 0xf, 0xf, false);
     if (w.lane == 0) prev = w.prev;
-    const bool s = valid && ((id != prev + 1) | ((id & (kRunSpan - 1)) == 0));
+    const bool s = valid && ((id != prev + 1) | ((id & kCutMask<UNIQ>) == 0));
     const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
     const unsigned long long below = m & ((1ull << w.lane) - 1ull);
     const int src = below ? 63 - __builtin_clzll(below) : w.lane;
@@ -348,16 +347,17 @@ __device__ __forceinline__ uint4 take_tile() {
 template <bool UNIQ, bool DBG>
 __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     extern __shared__ uint32_t lds[];
-    // layout: [bcur: kMaxWin][queues: kWaves * kQCap][seen: n_words]
+    // layout: [bcur: kMaxWin][run queues: kWaves * kQCap][partial-claim queues: kWaves * kPCap][seen: n_words]
     uint32_t *bcur = lds;
-    uint32_t *seen = lds + kMaxWin + kWaves * kQCap;
+    uint32_t *seen = lds + kMaxWin + kWaves * (kQCap + kPCap);
     __shared__ uint32_t next_job;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the span math on the scalar unit
     uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;  // this workgroup's sub-bucket of window 0
     Wave w;
     w.q = lds + kMaxWin + wave * kQCap;
-    w.fill = 0;
+    w.pq = lds + kMaxWin + kWaves * kQCap + wave * kPCap;
+    w.fill = w.pfill = 0;
     w.lane = lane;
     for (uint32_t i = threadIdx.x; i < kMaxWin; i += kThreads) bcur[i] = 0u;
     if (UNIQ)
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             const uint32_t first = clamp_id(A, first_raw >> 1);
             w.prev = first - 1;  // the first step then continues a (so far empty) run that starts at it
             w.rs = first;
-            if (sp.t0 > sp.lo) tile_narrow(A, w, sp.lo, (uint32_t)(sp.t0 - sp.lo));
+            if (sp.t0 > sp.lo) tile_narrow<UNIQ>(A, w, sp.lo, (uint32_t)(sp.t0 - sp.lo));
             // four tiles (4 KiB per wave, 64 KiB per CU) stay in flight
 #pragma unroll 1
             for (uint64_t i = 0; i < sp.nfull; i += 4) {
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             uint64_t t = sp.t0 + sp.nfull * 256;
             while (t < sp.hi) {
                 const uint32_t cnt = (uint32_t)min((uint64_t)64, sp.hi - t);
-                tile_narrow(A, w, t, cnt);
+                tile_narrow<UNIQ>(A, w, t, cnt);
                 t += cnt;
                 drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);
             }
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     if (UNIQ) store4(A.uniq_out + w0, i0, nvalid, block_scan4(ud, wave_tot));
 }
 
-uint32_t scan_lds_bytes(uint32_t n_words) { return (kMaxWin + kWaves * kQCap + n_words) * 4u; }
+uint32_t scan_lds_bytes(uint32_t n_words) { return (kMaxWin + kWaves * (kQCap + kPCap) + n_words) * 4u; }
 
 #define FAST_TRY(expr)                                                                      \
     do {                                                                                    \
@@ -633,7 +633,8 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     const uint32_t n_win = (g.n_segs + kWin - 1) / kWin;
     if (n_win > kMaxWin) return true;
     if (g.n_segs > (1u << 21)) return true;  // a queued run is (start id << 11) | (len - 1)
-    const uint32_t n_words = ((g.n_segs + 31) / 32 + 4 + 3) & ~3u;  // one word of slack for the two-word claim
+    const uint32_t n_words = ((g.n_segs + 31) / 32 + 3) & ~3u;
+    if (n_words > (1u << 15)) return true;  // a parked claim is (word << 17) | (half << 16) | 16 bits
     if (scan_lds_bytes(n_words) + 64 > kLdsLimit) return true;  // the "seen" bitset must fit one CU's LDS
     hipDeviceProp_t prop;
     int dev = 0;
