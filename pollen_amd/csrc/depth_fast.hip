@@ -56,7 +56,7 @@ constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr int kAccThreads = 1024;
 
 // diagnostic ablations (FLATGFA_DEBUG_SKIP, results are then wrong by construction)
-constexpr uint32_t kDbgNoStore = 1, kDbgNoBitset = 4, kDbgNoTiles = 8;
+constexpr uint32_t kDbgNoStore = 1, kDbgNoBitset = 4, kDbgNoTiles = 8, kDbgHotLoads = 16;
 // the ablation checks exist only in the DBG instantiation of the kernel
 #define FGFA_SKIP(bit) (DBG && (A.dbg & (bit)))
 
@@ -90,18 +90,32 @@ __device__ __forceinline__ void overflow_record(const ScanArgs &A, uint32_t id, 
     if (kind != 0u) overflow_apply(A.ovf_u, A.ovf_flag, id, len);
 }
 
+// Per-wave state: the run queue (LDS, kQCap entries of (start id << 11) | (len - 1)), how many
+// entries it holds, the id of the step before the next one, and the start id of the run that
+// step belongs to; and the queue of partially new claims (see emit_chunk).  `fill`, `pfill`,
+// `prev`, `rs` and `vm` are wave-uniform.
+struct Wave {
+    uint32_t *q, *pq;
+    uint32_t fill, pfill, prev, rs;
+    uint32_t vm[2];  // memory instructions issued since the loads into landing set 0 / 1 (see wait_block)
+    int lane;
+};
+
 // Store a record at slot `pos` of this workgroup's sub-bucket of window (id >> 12).  Branch
 // free: lanes with nothing to store (or no room) write to the sink window.  Returns whether
 // the record still has to take the overflow route.
 template <bool DBG>
-__device__ __forceinline__ bool put(const ScanArgs &A, uint32_t *mine, bool e, uint32_t pos, uint32_t id,
+__device__ __forceinline__ bool put(const ScanArgs &A, Wave &w, uint32_t *mine, bool e, uint32_t pos, uint32_t id,
                                     uint32_t lenm1, uint32_t kind) {
     const bool ok = e && pos < A.cap;
     // the bucket array holds fewer than 2^30 records, so a 32-bit byte offset from a uniform base suffices
     const uint32_t boff = (ok ? (id >> kWinBits) * A.stride + pos : A.sink) << 2;
-    if (!FGFA_SKIP(kDbgNoStore))
+    if (!FGFA_SKIP(kDbgNoStore)) {
         *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(mine) + boff) =
             (id & (kWin - 1)) | (lenm1 << kWinBits) | (kind << 24);
+        w.vm[0] += 1;  // exactly one store instruction, executed by the whole wave
+        w.vm[1] += 1;
+    }
     return e && !ok;
 }
 
@@ -117,28 +131,18 @@ __device__ __forceinline__ uint32_t lane_rank(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Per-wave state: the run queue (LDS, kQCap entries of (start id << 11) | (len - 1)), how many
-// entries it holds, the id of the step before the next one, and the start id of the run that
-// step belongs to; and the queue of partially new claims (see emit_chunk).  `fill`, `pfill`,
-// `prev` and `rs` are wave-uniform.
-struct Wave {
-    uint32_t *q, *pq;
-    uint32_t fill, pfill, prev, rs;
-    int lane;
-};
-
 __device__ __forceinline__ void enqueue(Wave &w, bool e, uint32_t rec) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(e);
     if (e) w.q[w.fill + lane_rank(m)] = rec;
     w.fill += (uint32_t)__builtin_popcountll(m);
 }
 
-constexpr uint32_t kQCap = 320;  // 63 left over + up to 256 from one tile
-constexpr uint32_t kPCap = 192;  // 63 left over + up to 2 x 64 from one chunk of claims
+constexpr uint32_t kQCap = 320;  // 63 left over + up to 256 from four steps of every lane
+constexpr uint32_t kPCap = 96;   // parked claims (two words each): 31 left over + up to 64 from one chunk
 
-__device__ __forceinline__ void push_partial(Wave &w, bool e, uint32_t ent) {
+__device__ __forceinline__ void push_partial(Wave &w, bool e, uint32_t word, uint32_t bits) {
     const unsigned long long m = __builtin_amdgcn_ballot_w64(e);
-    if (e) w.pq[w.pfill + lane_rank(m)] = ent;
+    if (e) reinterpret_cast<uint2 *>(w.pq)[w.pfill + lane_rank(m)] = make_uint2(word, bits);
     w.pfill += (uint32_t)__builtin_popcountll(m);
 }
 
@@ -147,9 +151,9 @@ __device__ __forceinline__ void push_partial(Wave &w, bool e, uint32_t ent) {
 // (runs are cut at multiples of 32, so a run lies inside one word): the bits that were still
 // clear are exactly the (path, segment) pairs this run is the first to touch.  If all of them
 // were clear the depth record doubles as the uniq record (kind 2), if none was there is nothing
-// to add.  The rare claim that is partly new is parked, as (word, half, 16 new bits), on a second
-// queue; that queue is turned into uniq records 64 entries at a time, so its bit-stretch loop
-// runs with all lanes busy instead of once per chunk for a lane or two.
+// to add.  The rare claim that is partly new is parked, as (word index, new bits), on a second
+// queue; that queue is turned into uniq records 32..64 entries at a time, so its bit-stretch
+// loop runs with most lanes busy instead of once per chunk for a lane or two.
 template <bool UNIQ, bool DBG>
 __device__ __forceinline__ void emit_chunk(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
                                            bool valid, uint32_t rec) {
@@ -160,106 +164,205 @@ __device__ __forceinline__ void emit_chunk(const ScanArgs &A, Wave &w, uint32_t 
         const uint32_t old = mask ? atomicOr(&seen[id >> 5], mask) : 0u;
         const uint32_t nb = mask & ~old;
         kind = (nb == mask) ? 2u : 0u;
-        const uint32_t part = (nb == mask) ? 0u : nb;
-        const uint32_t word = (id >> 5) << 17;
-        push_partial(w, (part & 0xFFFFu) != 0u, word | (part & 0xFFFFu));
-        push_partial(w, (part >> 16) != 0u, word | 0x10000u | (part >> 16));
+        push_partial(w, (nb != mask) & (nb != 0u), id >> 5, nb);
     }
     const uint32_t pos = valid ? atomicAdd(&bcur[win], 1u) : 0u;
-    const bool o0 = put<DBG>(A, mine, valid, pos, id, lenm1, kind);
+    const bool o0 = put<DBG>(A, w, mine, valid, pos, id, lenm1, kind);
     if (__builtin_amdgcn_ballot_w64(o0) && o0) overflow_record(A, id, lenm1 + 1, kind);  // rare: the sub-bucket is full
 }
 
-// Turn whole chunks of 64 parked claims (all of them when `all`) into uniq records: one per
-// stretch of new bits.
+// Turn parked claims into uniq records, one per stretch of new bits: the newest 64 while at
+// least 32 are parked (all of them when `all`).
 template <bool DBG>
 __device__ __forceinline__ void drain_partial(const ScanArgs &A, Wave &w, uint32_t *bcur, uint32_t *mine, bool all) {
-    while (w.pfill >= 64u || (all && w.pfill)) {
+    while (w.pfill >= 32u || (all && w.pfill)) {
         const uint32_t n = min(w.pfill, 64u);
+        w.pfill -= n;
         const bool valid = (uint32_t)w.lane < n;
-        const uint32_t ent = valid ? w.pq[w.lane] : 0u;
-        const uint32_t rest = w.pfill - n;
-        for (uint32_t i = w.lane; i < rest; i += 64) {  // ds ops of one wave execute in order
-            const uint32_t t = w.pq[n + i];
-            w.pq[i] = t;
-        }
-        w.pfill = rest;
-        const uint32_t base = ((ent >> 17) << 5) | ((ent >> 12) & 16u);  // first segment of the half word
+        const uint2 ent = valid ? reinterpret_cast<const uint2 *>(w.pq)[w.pfill + w.lane] : make_uint2(0u, 0u);
+        const uint32_t base = ent.x << 5;
         const uint32_t win = base >> kWinBits;
-        uint32_t m = ent & 0xFFFFu;
+        uint32_t m = ent.y;  // never all ones: that claim would have been entirely new
         while (__builtin_amdgcn_ballot_w64(m != 0u)) {
             const bool e = m != 0u;
             const uint32_t tz = e ? (uint32_t)__builtin_ctz(m) : 0u;
-            const uint32_t run = (uint32_t)__builtin_ctz(~(m >> tz));  // m has 16 bits: ~(m >> tz) is never 0
+            const uint32_t run = (uint32_t)__builtin_ctz(~(m >> tz));
             m &= ~(((1u << run) - 1u) << tz);
             const uint32_t p = e ? atomicAdd(&bcur[win], 1u) : 0u;
-            const bool o1 = put<DBG>(A, mine, e, p, base + tz, run - 1u, 1u);
+            const bool o1 = put<DBG>(A, w, mine, e, p, base + tz, run - 1u, 1u);
             if (__builtin_amdgcn_ballot_w64(o1) && o1) overflow_record(A, base + tz, run, 1u);
         }
     }
 }
 
-// Emit whole chunks of 64 queued runs (all of them when `all`), keeping the rest at the front.
+// Emit the newest 64 queued runs while at least 64 are queued (all of them when `all`).
 template <bool UNIQ, bool DBG>
 __device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine, bool all) {
     while (w.fill >= 64u || (all && w.fill)) {
         const uint32_t n = min(w.fill, 64u);
+        w.fill -= n;
         const bool valid = (uint32_t)w.lane < n;
-        const uint32_t rec = valid ? w.q[w.lane] : 0u;
+        const uint32_t rec = valid ? w.q[w.fill + w.lane] : 0u;
         emit_chunk<UNIQ, DBG>(A, w, seen, bcur, mine, valid, rec);
-        const uint32_t rest = w.fill - n;
-        for (uint32_t i = w.lane; i < rest; i += 64) {  // ds ops of one wave execute in order
-            const uint32_t t = w.q[n + i];
-            w.q[i] = t;
-        }
-        w.fill = rest;
         if (UNIQ) drain_partial<DBG>(A, w, bcur, mine, false);
     }
     if (UNIQ && all) drain_partial<DBG>(A, w, bcur, mine, true);
 }
 
-// 256 steps, four consecutive ones per lane (lane i holds steps 4i..4i+3 of the tile).
+// LDS byte address of a pointer into the workgroup's shared memory
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t lds_addr(uint32_t *p) { return (uint32_t)(uintptr_t)(lds_u32 *)p; }
+
+// Pass B of block16 for eight consecutive steps of every lane, hand-scheduled: for step j, the
+// lanes where a run starts (mask Mj) append (cur << 11) | (id before step j - cur) at their queue
+// cursor `p` and make step j's id their `cur`.  Written as asm so that each step is one scalar
+// instruction (exec = lanes that start a run) and five vector ones, with no branches; exec is
+// restored before the statement ends.  PM is the id before step 0.
+#define FGFA_PASSB_STEP(T, PMJ, XJ, MJ)                \
+    "s_and_b64 exec, %[sv], %[" MJ "]\n\t"             \
+    "v_sub_u32 %[" T "], %[" PMJ "], %[cur]\n\t"       \
+    "v_lshl_or_b32 %[" T "], %[cur], 11, %[" T "]\n\t" \
+    "ds_write_b32 %[p], %[" T "]\n\t"                  \
+    "v_add_u32 %[p], 4, %[p]\n\t"                      \
+    "v_mov_b32 %[cur], %[" XJ "]\n\t"
+#define FGFA_PASSB8(CUR, P, PM, X0, X1, X2, X3, X4, X5, X6, X7, M0, M1, M2, M3, M4, M5, M6, M7)                      \
+    do {                                                                                                             \
+        unsigned long long sv_;                                                                                      \
+        uint32_t t0_, t1_;                                                                                           \
+        asm volatile("s_mov_b64 %[sv], exec\n\t" FGFA_PASSB_STEP("t0", "pm", "x0", "m0")                             \
+                         FGFA_PASSB_STEP("t1", "x0", "x1", "m1") FGFA_PASSB_STEP("t0", "x1", "x2", "m2")             \
+                             FGFA_PASSB_STEP("t1", "x2", "x3", "m3") FGFA_PASSB_STEP("t0", "x3", "x4", "m4")         \
+                                 FGFA_PASSB_STEP("t1", "x4", "x5", "m5") FGFA_PASSB_STEP("t0", "x5", "x6", "m6")     \
+                                     FGFA_PASSB_STEP("t1", "x6", "x7", "m7") "s_mov_b64 exec, %[sv]"                 \
+                     : [cur] "+v"(CUR), [p] "+v"(P), [sv] "=&s"(sv_), [t0] "=&v"(t0_), [t1] "=&v"(t1_)               \
+                     : [pm] "v"(PM), [x0] "v"(X0), [x1] "v"(X1), [x2] "v"(X2), [x3] "v"(X3), [x4] "v"(X4),           \
+                       [x5] "v"(X5), [x6] "v"(X6), [x7] "v"(X7), [m0] "s"(M0), [m1] "s"(M1), [m2] "s"(M2),           \
+                       [m3] "s"(M3), [m4] "s"(M4), [m5] "s"(M5), [m6] "s"(M6), [m7] "s"(M7)                          \
+                     : "memory", "scc");                                                                             \
+    } while (0)
+
+// inclusive prefix sum across the wave
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0u, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, true);
+    return x;
+}
+
+// One block: 1024 consecutive steps of a wave's span, sixteen per lane (lane l holds steps
+// 16l..16l+15, i.e. its own 64 bytes), so that fifteen of every sixteen run boundaries are found
+// with in-lane compares.  Only the first `nl` lanes hold steps (nl < 64 for the last, partial
+// block of a span).
+//
+// A run ends wherever the next one starts, and that is where its (start, length) is queued.
+// Pass A marks the starts and counts them per lane; a wave prefix sum gives every lane its own
+// stretch of the run queue.  Pass B then walks the sixteen steps again and each lane appends
+// its runs to its stretch: no ballot or lane ranking per step.  The run that is in progress when
+// a lane's first step arrives started in a lane below; its start id is fetched afterwards (one
+// ballot + ds_bpermute per block) and patched into the lane's first queue entry.
+// When the block has more starts than the queue has room for (dense: few steps continue a run),
+// the steps are queued four at a time with the queue emitted in between.
 template <bool UNIQ, bool DBG>
-__device__ __forceinline__ void tile_full(const ScanArgs &A, Wave &w, uint4 v) {
-    uint32_t a0 = v.x >> 1, a1 = v.y >> 1, a2 = v.z >> 1, a3 = v.w >> 1;
-    if (max(max(a0, a1), max(a2, a3)) >= A.n_segs) {
-        a0 = clamp_id(A, a0);
-        a1 = clamp_id(A, a1);
-        a2 = clamp_id(A, a2);
-        a3 = clamp_id(A, a3);
+__device__ __forceinline__ void block16(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
+                                        uint32_t (&a)[16], uint32_t nl, bool fresh) {
+    const bool active = (uint32_t)w.lane < nl;
+    uint32_t mx = a[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) mx = max(mx, a[k]);
+    if (mx >= A.n_segs) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = clamp_id(A, a[k]);
     }
-    uint32_t prev = __builtin_amdgcn_update_dpp(0u, a3, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    if (fresh) {  // first steps of a span: the first one continues a (so far empty) run that starts at it
+        w.rs = __builtin_amdgcn_readfirstlane(a[0]);
+        w.prev = w.rs - 1u;
+    }
+    uint32_t prev = __builtin_amdgcn_update_dpp(0u, a[15], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     if (w.lane == 0) prev = w.prev;
-    const bool s0 = (a0 != prev + 1) | ((a0 & kCutMask<UNIQ>) == 0);
-    const bool s1 = (a1 != a0 + 1) | ((a1 & kCutMask<UNIQ>) == 0);
-    const bool s2 = (a2 != a1 + 1) | ((a2 & kCutMask<UNIQ>) == 0);
-    const bool s3 = (a3 != a2 + 1) | ((a3 & kCutMask<UNIQ>) == 0);
-    // start id of the run in progress when this lane's first step arrives
-    const bool any = s0 | s1 | s2 | s3;
-    const uint32_t last_start = s3 ? a3 : (s2 ? a2 : (s1 ? a1 : a0));
-    const unsigned long long below = __builtin_amdgcn_ballot_w64(any) & ((1ull << w.lane) - 1ull);
+    // pass A (lanes beyond `nl` compute garbage flags; they are kept out of `cnt` and of pass B)
+    bool st[16];
+    st[0] = ((a[0] != prev + 1) | ((a[0] & kCutMask<UNIQ>) == 0)) & !(fresh & (w.lane == 0));
+#pragma unroll
+    for (int k = 1; k < 16; ++k) st[k] = (a[k] != a[k - 1] + 1) | ((a[k] & kCutMask<UNIQ>) == 0);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cnt += st[k] ? 1u : 0u;
+    cnt = active ? cnt : 0u;
+    const uint32_t incl = wave_scan_incl(cnt);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    const unsigned long long below = __builtin_amdgcn_ballot_w64(cnt != 0u) & ((1ull << w.lane) - 1ull);
     const int src = below ? 63 - __builtin_clzll(below) : w.lane;
-    const uint32_t from_below = __shfl(last_start, src, 64);
-    const uint32_t rs = below ? from_below : w.rs;
-    // a run ends wherever the next one starts: queue (start, length) of the run that just ended
-    const uint32_t len0 = prev - rs + 1;
-    const uint32_t rsA = s0 ? a0 : rs;
-    const uint32_t rsB = s1 ? a1 : rsA;
-    const uint32_t rsC = s2 ? a2 : rsB;
-    const uint32_t rsD = s3 ? a3 : rsC;
-    enqueue(w, s0 && len0 != 0, (rs << kRunBits) | (len0 - 1));
-    enqueue(w, s1, (rsA << kRunBits) | (a0 - rsA));
-    enqueue(w, s2, (rsB << kRunBits) | (a1 - rsB));
-    enqueue(w, s3, (rsC << kRunBits) | (a2 - rsC));
-    w.prev = __builtin_amdgcn_readlane(a3, 63);
-    w.rs = __builtin_amdgcn_readlane(rsD, 63);
+    uint32_t cur;
+    if (w.fill + total <= kQCap) {
+        // pass B, lane-local: `cur` is the start of the run in progress, 0 standing in for the
+        // one that entered the lane (then the entry holds just the run's last id until patched)
+        uint32_t *const p0 = w.q + w.fill + (incl - cnt);
+        cur = 0u;
+        if (active) {
+            unsigned long long m[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) m[k] = __builtin_amdgcn_ballot_w64(st[k]);
+            uint32_t p = lds_addr(p0);
+            FGFA_PASSB8(cur, p, prev, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
+            FGFA_PASSB8(cur, p, a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15]);
+        }
+        // start id of the run in progress when this lane's first step arrived: the last start below
+        const uint32_t from_below = __shfl(cur, src, 64);
+        const uint32_t rs = below ? from_below : w.rs;
+        if (cnt) {
+            const uint32_t last = *p0;
+            *p0 = (rs << kRunBits) | (last - rs);
+        } else {
+            cur = rs;
+        }
+        w.fill += total;
+        drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) st[k] &= active;
+        uint32_t last_start = a[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) last_start = st[k] ? a[k] : last_start;
+        const uint32_t from_below = __shfl(last_start, src, 64);
+        const uint32_t rs = below ? from_below : w.rs;
+        cur = rs;
+#pragma unroll 1
+        for (int g = 0; g < 4; ++g) {
+            uint32_t pm, x0, x1, x2, x3;
+            bool s0, s1, s2, s3;
+            switch (g) {  // wave-uniform: one copy of the queueing and emitting code for all four groups
+                case 0: pm = prev, x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3], s0 = st[0], s1 = st[1], s2 = st[2], s3 = st[3]; break;
+                case 1: pm = a[3], x0 = a[4], x1 = a[5], x2 = a[6], x3 = a[7], s0 = st[4], s1 = st[5], s2 = st[6], s3 = st[7]; break;
+                case 2: pm = a[7], x0 = a[8], x1 = a[9], x2 = a[10], x3 = a[11], s0 = st[8], s1 = st[9], s2 = st[10], s3 = st[11]; break;
+                default: pm = a[11], x0 = a[12], x1 = a[13], x2 = a[14], x3 = a[15], s0 = st[12], s1 = st[13], s2 = st[14], s3 = st[15]; break;
+            }
+            enqueue(w, s0, (cur << kRunBits) | (pm - cur));
+            cur = s0 ? x0 : cur;
+            enqueue(w, s1, (cur << kRunBits) | (x0 - cur));
+            cur = s1 ? x1 : cur;
+            enqueue(w, s2, (cur << kRunBits) | (x1 - cur));
+            cur = s2 ? x2 : cur;
+            enqueue(w, s3, (cur << kRunBits) | (x2 - cur));
+            cur = s3 ? x3 : cur;
+            drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);
+        }
+    }
+    w.prev = __builtin_amdgcn_readlane(a[15], nl - 1);
+    w.rs = __builtin_amdgcn_readlane(cur, nl - 1);
 }
 
 // Up to 64 consecutive steps, one per lane (heads, tails and short spans).
 template <bool UNIQ>
-__device__ __forceinline__ void tile_narrow(const ScanArgs &A, Wave &w, uint64_t t, uint32_t count) {
+__device__ __forceinline__ void tile_narrow(const ScanArgs &A, Wave &w, uint64_t t, uint32_t count, bool fresh) {
     const bool valid = (uint32_t)w.lane < count;
     const uint32_t id = valid ? clamp_id(A, A.steps[t + w.lane] >> 1) : 0u;
+    if (fresh) {  // as in block16
+        w.rs = __builtin_amdgcn_readfirstlane(id);
+        w.prev = w.rs - 1u;
+    }
     uint32_t prev = __builtin_amdgcn_update_dpp(0u, id, 0x138, 0xf, 0xf, false);
     if (w.lane == 0) prev = w.prev;
     const bool s = valid && ((id != prev + 1) | ((id & kCutMask<UNIQ>) == 0));
@@ -274,90 +377,129 @@ __device__ __forceinline__ void tile_narrow(const ScanArgs &A, Wave &w, uint64_t
     if (m) w.rs = __shfl(id, 63 - __builtin_clzll(m), 64);
 }
 
-// One wave's share of one path: steps [lo, hi), of which [t0, t0 + 256 * nfull) are whole,
-// 16-byte-aligned tiles read through `src`.
+// One wave's share of one work item: steps [lo, hi).  [lo, t0) is the few steps before the first
+// 64-byte boundary (wave 0 only), then `nblk` blocks of 1024 steps read through `src`, the last
+// of which may hold only `nl_last` lanes' worth, then whatever is left for narrow tiles.
 struct Span {
-    uint64_t lo, hi, t0, nfull;
-    const uint4 *src;
-    uint32_t slot;  // where to leave the bitset when this is a piece of a split path
+    uint64_t lo, hi, t0;
+    uint32_t nblk, nl_last;
+    const uint4 *src;  // this lane's 64 bytes of block 0
+    uint32_t slot;     // where to leave the bitset when this is a piece of a split path
 };
+
+constexpr uint32_t kBlockSteps = 1024;
+constexpr uint32_t kMinPartialLanes = 22;  // below this a partial block costs more than narrow tiles
 
 __device__ __forceinline__ Span make_span(const ScanArgs &A, uint32_t job, int wave, int lane) {
     Span s;
-    s.lo = s.hi = s.t0 = s.nfull = 0;
+    s.lo = s.hi = s.t0 = 0;
+    s.nblk = 0;
+    s.nl_last = 64;
     s.src = nullptr;
     s.slot = kNoSlot;
     if (job < A.n_items) {
         const uint4 it = A.items[job];
         const uint64_t b = it.x, e = it.y, n = e - b;
         s.slot = it.z;
-        // contiguous span per wave, a whole number of tiles
-        const uint64_t per = ((n + kWaves - 1) / kWaves + 255) / 256 * 256;
-        s.lo = min(b + per * wave, e);
-        s.hi = min(s.lo + per, e);
-        s.t0 = min(s.lo + ((4 - (s.lo & 3)) & 3), s.hi);
-        s.nfull = (s.hi - s.t0) / 256;
-        s.src = reinterpret_cast<const uint4 *>(A.steps + s.t0) + lane;
+        // contiguous span per wave: a whole number of 16-step lane chunks, cut at 64-byte boundaries
+        const uint64_t a0 = (b + 15) & ~15ull;
+        const uint64_t per = ((n + kWaves - 1) / kWaves + 15) & ~15ull;
+        s.lo = wave ? min(a0 + per * wave, e) : b;
+        s.hi = min(a0 + per * (wave + 1), e);
+        s.t0 = min((s.lo + 15) & ~15ull, s.hi);
+        const uint64_t chunks = (s.hi - s.t0) / 16;
+        s.nblk = (uint32_t)(chunks / 64);
+        const uint32_t left = (uint32_t)(chunks % 64);
+        if (left >= kMinPartialLanes) {
+            s.nblk += 1;
+            s.nl_last = left;
+        }
+        // kDbgHotLoads (diagnostic): every span reads the same cache-resident megabyte
+        s.src = reinterpret_cast<const uint4 *>(A.steps + ((A.dbg & kDbgHotLoads) ? (s.t0 & 0x3FFF0u) : s.t0)) + lane * 4;
     }
     return s;
 }
 
-// Streaming loads of steps.  Each handle is read exactly once (nontemporal: keep it out of the
-// way of the bucket lines the L2 is write-combining).  Four tiles per wave are kept in flight
+// Streaming loads of steps.  Two blocks per wave (8 KiB; 128 KiB per CU) are kept in flight
 // across loop iterations.  hipcc cannot express that: it drains vmcnt to 0 at the top of the
 // loop, and an inline-asm load into a compiler-allocated register is unsafe because the compiler
 // may copy the register (to rotate it through the loop) while the load is still in flight.  So
-// the landing registers are four fixed quads, v[112:127], which the compiler is told are
-// clobbered and never otherwise allocates (the kernel needs < 100 VGPRs; 128 is the budget of a
-// 1024-thread workgroup).  tools/check_pinned_vgprs.py checks the generated ISA for exactly that
-// (run by `make check` and by the CPU test suite).
-// A tile is taken out of its quad by v_movs issued after a counted s_waitcnt: on gfx950 vmcnt
-// counts loads and stores in issue order, so "at most N outstanding" with N <= the number of
-// tile loads issued after the one we need is always sufficient; record stores issued in between
-// only make the wait stricter.
-#define FGFA_LOAD_Q(Q, A, B, C, D, p) \
-    asm volatile("global_load_dwordx4 " Q ", %0, off nt" ::"v"(p) : "memory", A, B, C, D)
-#define FGFA_TAKE_Q(A, B, C, D, cur)                                                                  \
-    asm volatile("v_mov_b32 %0, " A "\n\tv_mov_b32 %1, " B "\n\tv_mov_b32 %2, " C "\n\tv_mov_b32 %3, " D \
-                 : "=v"(cur.x), "=v"(cur.y), "=v"(cur.z), "=v"(cur.w)::"memory")
-template <int SLOT>
-__device__ __forceinline__ void load_tile_async(const uint4 *p) {
-    if (SLOT == 0) FGFA_LOAD_Q("v[112:115]", "v112", "v113", "v114", "v115", p);
-    if (SLOT == 1) FGFA_LOAD_Q("v[116:119]", "v116", "v117", "v118", "v119", p);
-    if (SLOT == 2) FGFA_LOAD_Q("v[120:123]", "v120", "v121", "v122", "v123", p);
-    if (SLOT == 3) FGFA_LOAD_Q("v[124:127]", "v124", "v125", "v126", "v127", p);
+// the landing registers are two fixed sets of sixteen, v[96:111] and v[112:127], which the
+// compiler is told are clobbered and never otherwise allocates (the kernel needs < 96 VGPRs; 128
+// is the budget of a 1024-thread workgroup).  tools/check_pinned_vgprs.py checks the generated
+// ISA for exactly that (`make check`, and the CPU test suite).
+// A block is taken out of its set, already shifted down to segment ids, by v_lshrrevs issued
+// after a counted s_waitcnt (wait_block).  On gfx950 vmcnt counts loads and stores alike and they
+// return in issue order (hipcc itself relies on that: it waits vmcnt(2) for a load followed by
+// two stores), so the wait counts the record stores issued since, too -- otherwise every block
+// would wait for the stores of the block before it to be acknowledged.
+// The four loads of a lane cover its own 64 bytes; the wave's four instructions together cover
+// 4 KiB, every 64-byte sector exactly once per instruction (measured at the same 5.9 TB/s as
+// fully coalesced loads, tools/loadpat.hip).  No nontemporal hint here: the sectors must survive
+// in cache from the first of the four instructions to the last.
+#define FGFA_CLOB_A "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111"
+#define FGFA_CLOB_B "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+template <int SET>
+__device__ __forceinline__ void load_block_async(Wave &w, const uint4 *p) {
+    w.vm[SET] = 0;
+    w.vm[1 - SET] += 4;
+    if (SET == 0)
+        asm volatile("global_load_dwordx4 v[96:99], %0, off\n\t"
+                     "global_load_dwordx4 v[100:103], %0, off offset:16\n\t"
+                     "global_load_dwordx4 v[104:107], %0, off offset:32\n\t"
+                     "global_load_dwordx4 v[108:111], %0, off offset:48" ::"v"(p) : "memory", FGFA_CLOB_A);
+    else
+        asm volatile("global_load_dwordx4 v[112:115], %0, off\n\t"
+                     "global_load_dwordx4 v[116:119], %0, off offset:16\n\t"
+                     "global_load_dwordx4 v[120:123], %0, off offset:32\n\t"
+                     "global_load_dwordx4 v[124:127], %0, off offset:48" ::"v"(p) : "memory", FGFA_CLOB_B);
 }
-// Waits until at most `younger` (capped at 3) of this wave's memory operations are outstanding.
-__device__ __forceinline__ void wait_tiles(uint64_t younger) {
-    if (younger >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (younger == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+// Waits until the loads into landing set SET have returned.  `w.vm[SET]` counts the memory
+// instructions this wave is known to have issued since (the other set's loads and the record
+// stores); they return in issue order, so the loads are back once at most that many operations
+// are outstanding.  Rounded down to one of a few immediates; anything issued but not counted
+// (rare paths) only makes the wait stricter.
+template <int SET>
+__device__ __forceinline__ void wait_block(const Wave &w) {
+    const uint32_t n = w.vm[SET];
+    if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
-template <int SLOT>
-__device__ __forceinline__ uint4 take_tile() {
-    uint4 cur;
-    if (SLOT == 0) FGFA_TAKE_Q("v112", "v113", "v114", "v115", cur);
-    if (SLOT == 1) FGFA_TAKE_Q("v116", "v117", "v118", "v119", cur);
-    if (SLOT == 2) FGFA_TAKE_Q("v120", "v121", "v122", "v123", cur);
-    if (SLOT == 3) FGFA_TAKE_Q("v124", "v125", "v126", "v127", cur);
-    return cur;
+#define FGFA_TAKE16(R0, R1, R2, R3, R4, R5, R6, R7, R8, R9, R10, R11, R12, R13, R14, R15)                              \
+    asm volatile("v_lshrrev_b32 %0, 1, " R0 "\n\tv_lshrrev_b32 %1, 1, " R1 "\n\tv_lshrrev_b32 %2, 1, " R2                \
+                 "\n\tv_lshrrev_b32 %3, 1, " R3 "\n\tv_lshrrev_b32 %4, 1, " R4 "\n\tv_lshrrev_b32 %5, 1, " R5            \
+                 "\n\tv_lshrrev_b32 %6, 1, " R6 "\n\tv_lshrrev_b32 %7, 1, " R7 "\n\tv_lshrrev_b32 %8, 1, " R8            \
+                 "\n\tv_lshrrev_b32 %9, 1, " R9 "\n\tv_lshrrev_b32 %10, 1, " R10 "\n\tv_lshrrev_b32 %11, 1, " R11        \
+                 "\n\tv_lshrrev_b32 %12, 1, " R12 "\n\tv_lshrrev_b32 %13, 1, " R13 "\n\tv_lshrrev_b32 %14, 1, " R14      \
+                 "\n\tv_lshrrev_b32 %15, 1, " R15                                                                       \
+                 : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]), "=v"(a[4]), "=v"(a[5]), "=v"(a[6]), "=v"(a[7]),       \
+                   "=v"(a[8]), "=v"(a[9]), "=v"(a[10]), "=v"(a[11]), "=v"(a[12]), "=v"(a[13]), "=v"(a[14]), "=v"(a[15])  \
+                 :                                                                                                      \
+                 : "memory")
+template <int SET>
+__device__ __forceinline__ void take_block(uint32_t (&a)[16]) {
+    if (SET == 0) FGFA_TAKE16("v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111");
+    else FGFA_TAKE16("v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
 }
 
 template <bool UNIQ, bool DBG>
 __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     extern __shared__ uint32_t lds[];
-    // layout: [bcur: kMaxWin][run queues: kWaves * kQCap][partial-claim queues: kWaves * kPCap][seen: n_words]
+    // layout: [bcur: kMaxWin][run queues: kWaves * kQCap][parked-claim queues: kWaves * 2 * kPCap][seen: n_words]
     uint32_t *bcur = lds;
-    uint32_t *seen = lds + kMaxWin + kWaves * (kQCap + kPCap);
+    uint32_t *seen = lds + kMaxWin + kWaves * (kQCap + 2 * kPCap);
     __shared__ uint32_t next_job;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the span math on the scalar unit
     uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;  // this workgroup's sub-bucket of window 0
     Wave w;
     w.q = lds + kMaxWin + wave * kQCap;
-    w.pq = lds + kMaxWin + kWaves * kQCap + wave * kPCap;
+    w.pq = lds + kMaxWin + kWaves * kQCap + wave * (2 * kPCap);
     w.fill = w.pfill = 0;
+    w.vm[0] = w.vm[1] = 0;
     w.lane = lane;
     for (uint32_t i = threadIdx.x; i < kMaxWin; i += kThreads) bcur[i] = 0u;
     if (UNIQ)
@@ -367,56 +509,58 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     uint32_t job = __builtin_amdgcn_readfirstlane(next_job);
     __syncthreads();
 
-    // The first tiles of a path are requested while the previous path is being wrapped up.
+    // The first blocks of an item are requested while the previous item is being wrapped up.
     Span sp = make_span(A, job, wave, lane);
-    uint32_t first_raw = 0;
-#define FGFA_PRELOAD()                                              \
-    do {                                                            \
-        if (sp.lo < sp.hi) first_raw = A.steps[sp.lo];              \
-        if (sp.nfull > 0) load_tile_async<0>(sp.src);               \
-        if (sp.nfull > 1) load_tile_async<1>(sp.src + 64);          \
-        if (sp.nfull > 2) load_tile_async<2>(sp.src + 128);         \
-        if (sp.nfull > 3) load_tile_async<3>(sp.src + 192);         \
+    // lanes beyond a partial block's last one re-read lane 0's chunk: same instruction stream for all
+#define FGFA_BLOCK_PTR(j) \
+    (sp.src + (size_t)(j) * 256 - (((j) + 1 == sp.nblk && (uint32_t)lane >= sp.nl_last) ? lane * 4 : 0))
+#define FGFA_PRELOAD()                                                  \
+    do {                                                                \
+        if (sp.nblk > 0) load_block_async<0>(w, FGFA_BLOCK_PTR(0u));    \
+        if (sp.nblk > 1) load_block_async<1>(w, FGFA_BLOCK_PTR(1u));    \
     } while (0)
-    // one tile: wait for its data, re-issue its register for the tile four ahead, process it
-#define FGFA_TILE(K)                                                                      \
-    if (i + (K) < sp.nfull) {                                                             \
-        wait_tiles(sp.nfull - 1 - (i + (K)));                                             \
-        const uint4 cur = take_tile<K>();                                                 \
-        if (i + (K) + 4 < sp.nfull) load_tile_async<K>(sp.src + (i + (K) + 4) * 64);      \
-        if (!FGFA_SKIP(kDbgNoTiles)) {                                                    \
-            tile_full<UNIQ, DBG>(A, w, cur);                                              \
-            drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);                              \
-        } else if (cur.x == 0x7FFFFFFFu) {                                                \
-            *A.status = 2u;                                                               \
-        }                                                                                 \
+    // one block: wait for its data, re-issue its register set for the block two ahead, process it
+#define FGFA_BLOCK(SET, J)                                                                    \
+    if ((J) < sp.nblk) {                                                                      \
+        wait_block<SET>(w);                                                                   \
+        uint32_t a[16];                                                                       \
+        take_block<SET>(a);                                                                   \
+        if ((J) + 2 < sp.nblk) load_block_async<SET>(w, FGFA_BLOCK_PTR((J) + 2));             \
+        if (!FGFA_SKIP(kDbgNoTiles)) {                                                        \
+            block16<UNIQ, DBG>(A, w, seen, bcur, mine, a, (J) + 1 == sp.nblk ? sp.nl_last : 64u, (J) == 0); \
+        } else if (a[0] == 0x3FFFFFFFu) {                                                     \
+            *A.status = 2u;                                                                   \
+        }                                                                                     \
     }
     FGFA_PRELOAD();
 
     while (job < A.n_items) {
         if (threadIdx.x == 0) next_job = atomicAdd(A.work_counter, 1u);  // consumed after the barrier below
         if (sp.lo < sp.hi) {
-            const uint32_t first = clamp_id(A, first_raw >> 1);
-            w.prev = first - 1;  // the first step then continues a (so far empty) run that starts at it
-            w.rs = first;
-            if (sp.t0 > sp.lo) tile_narrow<UNIQ>(A, w, sp.lo, (uint32_t)(sp.t0 - sp.lo));
-            // four tiles (4 KiB per wave, 64 KiB per CU) stay in flight
 #pragma unroll 1
-            for (uint64_t i = 0; i < sp.nfull; i += 4) {
-                FGFA_TILE(0)
-                FGFA_TILE(1)
-                FGFA_TILE(2)
-                FGFA_TILE(3)
+            for (uint32_t i = 0; i < sp.nblk; i += 2) {
+                FGFA_BLOCK(0, i)
+                FGFA_BLOCK(1, i + 1)
             }
-            uint64_t t = sp.t0 + sp.nfull * 256;
+            // what the blocks did not cover goes through narrow tiles, continuing the same walk
+            uint64_t t = sp.t0 + (uint64_t)(sp.nblk - (sp.nl_last < 64u)) * kBlockSteps + (sp.nl_last < 64u ? sp.nl_last * 16u : 0u);
+            bool fresh = sp.nblk == 0;
             while (t < sp.hi) {
                 const uint32_t cnt = (uint32_t)min((uint64_t)64, sp.hi - t);
-                tile_narrow<UNIQ>(A, w, t, cnt);
+                tile_narrow<UNIQ>(A, w, t, cnt, fresh);
+                fresh = false;
                 t += cnt;
                 drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);
             }
             // close the run still open at the end of the span
-            enqueue(w, lane == 0, (w.rs << kRunBits) | (w.prev - w.rs));
+            if (sp.t0 < sp.hi) enqueue(w, lane == 0, (w.rs << kRunBits) | (w.prev - w.rs));
+            // The few steps before the first 64-byte boundary are walked last and on their own
+            // (one more record per item): walking them first would make this wave wait for its
+            // freshly requested blocks together with these few steps.
+            if (sp.t0 > sp.lo) {
+                tile_narrow<UNIQ>(A, w, sp.lo, (uint32_t)(sp.t0 - sp.lo), true);
+                enqueue(w, lane == 0, (w.rs << kRunBits) | (w.prev - w.rs));
+            }
             drain<UNIQ, DBG>(A, w, seen, bcur, mine, true);
         }
         __syncthreads();  // every wave is done with this path's bitset; next_job is visible
@@ -428,7 +572,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             uint4 *sv = reinterpret_cast<uint4 *>(seen);
             if (done_slot != kNoSlot) {
                 // a piece of a split path: other pieces may have claimed the same segments, so
-                // the bitset is kept for k_merge to find the duplicates
+                // the bitset is kept for k_accum to find the duplicates
                 uint4 *dst = reinterpret_cast<uint4 *>(A.piece_bits + (size_t)done_slot * A.n_words);
                 for (uint32_t i = threadIdx.x; i < A.n_words / 4; i += kThreads) dst[i] = sv[i];
             }
@@ -437,9 +581,8 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         }
     }
 #undef FGFA_PRELOAD
-#undef FGFA_TILE
-#undef FGFA_LOAD_Q
-#undef FGFA_TAKE_Q
+#undef FGFA_BLOCK
+#undef FGFA_BLOCK_PTR
     // publish how many records this workgroup left in each window's sub-bucket
     __syncthreads();
     for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads)
@@ -613,7 +756,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     if (UNIQ) store4(A.uniq_out + w0, i0, nvalid, block_scan4(ud, wave_tot));
 }
 
-uint32_t scan_lds_bytes(uint32_t n_words) { return (kMaxWin + kWaves * (kQCap + kPCap) + n_words) * 4u; }
+uint32_t scan_lds_bytes(uint32_t n_words) { return (kMaxWin + kWaves * (kQCap + 2 * kPCap) + n_words) * 4u; }
 
 #define FAST_TRY(expr)                                                                      \
     do {                                                                                    \
@@ -634,7 +777,6 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     if (n_win > kMaxWin) return true;
     if (g.n_segs > (1u << 21)) return true;  // a queued run is (start id << 11) | (len - 1)
     const uint32_t n_words = ((g.n_segs + 31) / 32 + 3) & ~3u;
-    if (n_words > (1u << 15)) return true;  // a parked claim is (word << 17) | (half << 16) | 16 bits
     if (scan_lds_bytes(n_words) + 64 > kLdsLimit) return true;  // the "seen" bitset must fit one CU's LDS
     hipDeviceProp_t prop;
     int dev = 0;

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Build-time check for depth_fast.hip's pinned landing registers.
 
-k_scan keeps four 16-byte step units in flight in the fixed VGPR quads v[112:127]
-(see the comment above load_unit_async in pollen_amd/csrc/depth_fast.hip).  That is only sound if
+k_scan keeps two 1024-step blocks in flight in the fixed VGPR sets v[96:111] and v[112:127]
+(see the comment above load_block_async in pollen_amd/csrc/depth_fast.hip).  That is only sound if
 nothing else in the kernel touches those registers.  This script compiles the file to gfx950
 assembly and checks, for every k_scan instantiation and every function it can call:
 
-  * the only instructions that mention v112..v127 are `global_load_dwordx4 v[Q:Q+3], ..., off nt`
-    (as the destination) and `v_mov_b32 vN, v1xx` (as the source);
+  * the only instructions that mention v96..v127 are `global_load_dwordx4 v[Q:Q+3], ..., off`
+    (as the destination) and `v_lshrrev_b32 vN, 1, vQ` (as the source);
   * the kernel's VGPR budget stays at or under 128 (a 1024-thread workgroup needs 4 waves/SIMD).
 
 Usage: check_pinned_vgprs.py [path/to/depth_fast.hip]      exit status 0 = ok
@@ -22,10 +22,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "..", "pollen_amd", "csrc", "depth_fast.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-PINNED = set(range(112, 128))
+PINNED = set(range(96, 128))
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
-OK_LOAD = re.compile(r"^global_load_dwordx4 v\[(112|116|120|124):(115|119|123|127)\], v\[\d+:\d+\], off nt$")
-OK_TAKE = re.compile(r"^v_mov_b32(_e32)? v(\d+), v(\d+)$")
+OK_LOAD = re.compile(r"^global_load_dwordx4 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], off( offset:(16|32|48))?$")
+OK_TAKE = re.compile(r"^v_lshrrev_b32(_e32)? v(\d+), 1, v(\d+)$")
 
 
 def regs_of(text):
@@ -60,7 +60,9 @@ def main():
         touched = regs_of(s) & PINNED
         if not touched:
             continue
-        if OK_LOAD.match(s):
+        m = OK_LOAD.match(s)
+        if m and int(m.group(1)) in PINNED and int(m.group(1)) % 4 == 0 and int(m.group(2)) == int(m.group(1)) + 3 \
+                and int(m.group(3)) not in PINNED and int(m.group(4)) not in PINNED:
             n_load += 1
             continue
         m = OK_TAKE.match(s)
@@ -76,7 +78,7 @@ def main():
     if bad:
         print("pinned-VGPR check FAILED:\n  " + "\n  ".join(bad[:20]))
         return 1
-    print(f"pinned-VGPR check ok: {n_load} loads, {n_take} takes, nothing else touches v112..v127; "
+    print(f"pinned-VGPR check ok: {n_load} loads, {n_take} takes, nothing else touches v96..v127; "
           f"k_scan budgets {sorted(set(v for k, v in budgets.items() if 'k_scan' in k))}")
     return 0
 
