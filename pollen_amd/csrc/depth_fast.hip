@@ -54,6 +54,7 @@ constexpr uint32_t kMaxWin = 256;  // LDS cursor table entries (the bitset limit
 constexpr uint32_t kLdsLimit = 160 * 1024;
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr int kAccThreads = 1024;
+constexpr uint32_t kMaxSlots = 1024;  // sub-buckets per window (= workgroups of k_scan) k_accum can stage
 
 // diagnostic ablations (FLATGFA_DEBUG_SKIP, results are then wrong by construction)
 constexpr uint32_t kDbgNoStore = 1, kDbgNoBitset = 4, kDbgNoTiles = 8, kDbgHotLoads = 16;
@@ -108,11 +109,15 @@ template <bool DBG>
 __device__ __forceinline__ bool put(const ScanArgs &A, Wave &w, uint32_t *mine, bool e, uint32_t pos, uint32_t id,
                                     uint32_t lenm1, uint32_t kind) {
     const bool ok = e && pos < A.cap;
-    // the bucket array holds fewer than 2^30 records, so a 32-bit byte offset from a uniform base suffices
-    const uint32_t boff = (ok ? (id >> kWinBits) * A.stride + pos : A.sink) << 2;
+    // The bucket array holds fewer than 2^30 records, so a 32-bit byte offset from a uniform base
+    // suffices.  window * stride + pos as one full-rate 24-bit multiply-add (the plan keeps the
+    // stride below 2^24; hipcc would otherwise pick the quarter-rate 64-bit mad).
+    uint32_t slot;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(slot) : "v"(id >> kWinBits), "s"(A.stride), "v"(pos));
+    const uint32_t boff = (ok ? slot : A.sink) << 2;
     if (!FGFA_SKIP(kDbgNoStore)) {
         *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(mine) + boff) =
-            (id & (kWin - 1)) | (lenm1 << kWinBits) | (kind << 24);
+            (id & (kWin - 1)) | (lenm1 << kWinBits) | ((kind + 1u) << 24);  // bit 24: counts for depth, bit 25: for uniq
         w.vm[0] += 1;  // exactly one store instruction, executed by the whole wave
         w.vm[1] += 1;
     }
@@ -158,15 +163,17 @@ template <bool UNIQ, bool DBG>
 __device__ __forceinline__ void emit_chunk(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
                                            bool valid, uint32_t rec) {
     const uint32_t id = rec >> kRunBits, lenm1 = rec & (kRunSpan - 1), win = id >> kWinBits;
-    uint32_t kind = 0;
+    uint32_t kind = 0, pos;
     if (UNIQ && !FGFA_SKIP(kDbgNoBitset)) {
         const uint32_t mask = valid ? (0xFFFFFFFFu >> (31u - lenm1)) << (id & 31u) : 0u;
         const uint32_t old = mask ? atomicOr(&seen[id >> 5], mask) : 0u;
+        pos = valid ? atomicAdd(&bcur[win], 1u) : 0u;  // both LDS round trips in flight together
         const uint32_t nb = mask & ~old;
         kind = (nb == mask) ? 2u : 0u;
         push_partial(w, (nb != mask) & (nb != 0u), id >> 5, nb);
+    } else {
+        pos = valid ? atomicAdd(&bcur[win], 1u) : 0u;
     }
-    const uint32_t pos = valid ? atomicAdd(&bcur[win], 1u) : 0u;
     const bool o0 = put<DBG>(A, w, mine, valid, pos, id, lenm1, kind);
     if (__builtin_amdgcn_ballot_w64(o0) && o0) overflow_record(A, id, lenm1 + 1, kind);  // rare: the sub-bucket is full
 }
@@ -607,62 +614,73 @@ struct AccArgs {
     uint32_t *uniq_out;
 };
 
+// One record = +1 at its first segment and -1 just past its last one, in a difference array over
+// the window.  With unique depth the two difference arrays share one array of 64-bit cells, depth
+// in the low word and uniq in the high word, so a record is two LDS atomics whatever it counts
+// for: the packed cells add up as 64-bit integers (depth + uniq * 2^32, both signed), prefix-sum
+// as such, and are taken apart only at the end.
 template <bool UNIQ>
-__device__ __forceinline__ void apply_record(int *dd, int *ud, uint32_t rec) {
-    const uint32_t rel = rec & (kWin - 1), len = ((rec >> kWinBits) & (kWin - 1)) + 1;
-    const uint32_t kind = (rec >> 24) & 3u;  // 0 depth, 1 uniq, 2 both
-    if (!UNIQ || kind != 1u) {
+__device__ __forceinline__ void apply_record(long long *acc, uint32_t rec) {
+    const uint32_t rel = rec & (kWin - 1), end = rel + ((rec >> kWinBits) & (kWin - 1)) + 1;  // end <= 4096; cell 4096 is a sink
+    if (UNIQ) {
+        const unsigned long long v = (unsigned long long)((rec >> 24) & 1u) | ((unsigned long long)((rec >> 25) & 1u) << 32);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[rel]), v);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&acc[end]), 0ull - v);
+    } else {
+        int *dd = reinterpret_cast<int *>(acc);
         atomicAdd(&dd[rel], 1);
-        atomicAdd(&dd[rel + len], -1);  // rel + len <= 4096; slot 4096 is a sink
-    }
-    if (UNIQ && kind != 0u) {
-        atomicAdd(&ud[rel], 1);
-        atomicAdd(&ud[rel + len], -1);
+        atomicAdd(&dd[end], -1);
     }
 }
 
-// inclusive prefix sum of 4096 ints held 4 per thread by 1024 threads; returns this thread's
+// inclusive prefix sum of 4096 values held 4 per thread by 1024 threads; returns this thread's
 // four prefix values.
-__device__ __forceinline__ int4 block_scan4(const int *arr, int *wave_tot) {
+template <typename T>
+__device__ __forceinline__ void block_scan4(const T *arr, T *wave_tot, T (&v)[4]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int4 v = *reinterpret_cast<const int4 *>(arr + 4 * tid);
-    v.y += v.x;
-    v.z += v.y;
-    v.w += v.z;
-    int incl = v.w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = arr[4 * tid + k];
+    v[1] += v[0];
+    v[2] += v[1];
+    v[3] += v[2];
+    T incl = v[3];
     for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
+        const T t = __shfl_up(incl, off, 64);
         if (lane >= off) incl += t;
     }
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
-    int add = incl - v.w;
+    T add = incl - v[3];
     for (int k = 0; k < wave; ++k) add += wave_tot[k];
     __syncthreads();
-    v.x += add;
-    v.y += add;
-    v.z += add;
-    v.w += add;
-    return v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += add;
 }
 
-__device__ __forceinline__ void store4(uint32_t *out, uint32_t i0, uint32_t nvalid, int4 v) {
+__device__ __forceinline__ void store4(uint32_t *out, uint32_t i0, uint32_t nvalid, const uint32_t (&a)[4]) {
     if (i0 + 3 < nvalid) {
-        *reinterpret_cast<uint4 *>(out + i0) = make_uint4((uint32_t)v.x, (uint32_t)v.y, (uint32_t)v.z, (uint32_t)v.w);
+        *reinterpret_cast<uint4 *>(out + i0) = make_uint4(a[0], a[1], a[2], a[3]);
     } else {
-        const int a[4] = {v.x, v.y, v.z, v.w};
         for (uint32_t k = 0; k < 4; ++k)
-            if (i0 + k < nvalid) out[i0 + k] = (uint32_t)a[k];
+            if (i0 + k < nvalid) out[i0 + k] = a[k];
     }
 }
 
 template <bool UNIQ>
 __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
-    __shared__ __attribute__((aligned(16))) int dd[kWin + 64];
-    __shared__ __attribute__((aligned(16))) int ud[UNIQ ? kWin + 64 : 64];
-    __shared__ int wave_tot[kAccThreads / 64];
+    // difference array over the window: packed 64-bit cells with unique depth, plain ints without
+    __shared__ __attribute__((aligned(16))) long long cells[UNIQ ? kWin + 64 : (kWin + 64) / 2];
+    __shared__ long long wave_tot[kAccThreads / 64];
+    __shared__ uint32_t scnt[kMaxSlots];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t win = blockIdx.x, w0 = win * kWin;
+    // this window's record counts, one per sub-bucket: staged in LDS, and zeroed in place so that
+    // the scratch is clean for the next call
+    for (uint32_t sl = tid; sl < A.n_slots; sl += kAccThreads) {
+        uint32_t *c = A.counts + (size_t)win * A.n_slots + sl;
+        scnt[sl] = min(*c, A.cap);
+        *c = 0u;
+    }
     const uint32_t nvalid = min(kWin, A.n_segs - w0);
     const bool ovf = A.ovf_flag[win] != 0;
     for (uint32_t i = tid; i < kWin + 64; i += kAccThreads) {
@@ -675,8 +693,8 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
                 A.ovf_u[w0 + i] = 0;
             }
         }
-        dd[i] = d0;
-        if (UNIQ) ud[i] = u0;
+        if (UNIQ) cells[i] = (long long)d0 + ((long long)u0 << 32);
+        else reinterpret_cast<int *>(cells)[i] = d0;
     }
     __syncthreads();
     if (ovf && tid == 0) A.ovf_flag[win] = 0u;
@@ -705,55 +723,80 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
                             const uint32_t y = dup >> tz;
                             const uint32_t run = (y == 0xFFFFFFFFu) ? 32u : (uint32_t)__builtin_ctz(~y);
                             dup &= ~(((run == 32u) ? 0xFFFFFFFFu : ((1u << run) - 1u)) << tz);
-                            atomicAdd(&ud[(word << 5) + tz], -1);
-                            atomicAdd(&ud[(word << 5) + tz + run], 1);
+                            atomicAdd(reinterpret_cast<unsigned long long *>(&cells[(word << 5) + tz]), 0ull - (1ull << 32));
+                            atomicAdd(reinterpret_cast<unsigned long long *>(&cells[(word << 5) + tz + run]), 1ull << 32);
                         }
                     }
                 }
             }
         }
     }
-    // Drain the window's sub-buckets: each wave takes four of them per round so that four
-    // independent 16-byte loads per lane are in flight.
+    // Drain the window's sub-buckets.  Their record counts were staged in LDS above; each wave
+    // takes sixteen sub-buckets per round and requests the first 64 x 16 bytes of every one before
+    // it applies any, so a round pays the memory latency once.
     constexpr uint32_t kAccWaves = kAccThreads / 64;
-    const uint32_t *cnt_base = A.counts + (size_t)win * A.n_slots;
-    for (uint32_t s0 = wave; s0 < A.n_slots; s0 += 4 * kAccWaves) {
-        uint32_t cnt[4];
-        const uint32_t *bk[4];
+    constexpr int kPerRound = 16;
+    const uint32_t uw = __builtin_amdgcn_readfirstlane(wave);  // wave-uniform: sub-bucket addressing stays scalar
+    const uint32_t *wbase = A.buckets + (size_t)win * A.n_slots * A.cap;
+    for (uint32_t s0 = uw; s0 < A.n_slots; s0 += kPerRound * kAccWaves) {
+        uint4 r[kPerRound];
+        uint32_t cnt[kPerRound];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kPerRound; ++k) {
             const uint32_t s = s0 + k * kAccWaves;
-            cnt[k] = s < A.n_slots ? min(cnt_base[s], A.cap) : 0u;
-            bk[k] = A.buckets + ((size_t)win * A.n_slots + (s < A.n_slots ? s : 0u)) * A.cap;
-        }
-        const uint32_t max4 = max(max(cnt[0], cnt[1]), max(cnt[2], cnt[3])) >> 2;
-        for (uint32_t i = lane; i < max4; i += 64) {
-            uint4 r[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (i < (cnt[k] >> 2)) r[k] = reinterpret_cast<const uint4 *>(bk[k])[i];
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (i < (cnt[k] >> 2)) {
-                    apply_record<UNIQ>(dd, ud, r[k].x);
-                    apply_record<UNIQ>(dd, ud, r[k].y);
-                    apply_record<UNIQ>(dd, ud, r[k].z);
-                    apply_record<UNIQ>(dd, ud, r[k].w);
-                }
+            const uint32_t sc = s < A.n_slots ? s : 0u;
+            cnt[k] = s < A.n_slots ? scnt[sc] : 0u;
+            // unconditional (slot 0 always exists): a predicated load would be waited for on the spot
+            r[k] = reinterpret_cast<const uint4 *>(wbase + sc * A.cap)[(uint32_t)lane < (cnt[k] >> 2) ? lane : 0];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t rest = (cnt[k] & ~3u) + lane;
-            if (rest < cnt[k]) apply_record<UNIQ>(dd, ud, bk[k][rest]);
+        for (int k = 0; k < kPerRound; ++k) {
+            if ((uint32_t)lane < (cnt[k] >> 2)) {
+                apply_record<UNIQ>(cells, r[k].x);
+                apply_record<UNIQ>(cells, r[k].y);
+                apply_record<UNIQ>(cells, r[k].z);
+                apply_record<UNIQ>(cells, r[k].w);
+            }
+        }
+        // what does not fit the first pass (skewed sub-buckets), and the last 1..3 records
+#pragma unroll 1
+        for (int k = 0; k < kPerRound; ++k) {
+            const uint32_t s = s0 + k * kAccWaves;
+            if (s >= A.n_slots) break;
+            const uint32_t c = scnt[s];
+            const uint32_t *bk = wbase + s * A.cap;
+            for (uint32_t i = 64 + lane; i < (c >> 2); i += 64) {
+                const uint4 v = reinterpret_cast<const uint4 *>(bk)[i];
+                apply_record<UNIQ>(cells, v.x);
+                apply_record<UNIQ>(cells, v.y);
+                apply_record<UNIQ>(cells, v.z);
+                apply_record<UNIQ>(cells, v.w);
+            }
+            const uint32_t rest = (c & ~3u) + lane;
+            if (rest < c) apply_record<UNIQ>(cells, bk[rest]);
         }
     }
     __syncthreads();
-    // the scratch is clean for the next call
-    for (uint32_t s = tid; s < A.n_slots; s += kAccThreads) A.counts[(size_t)win * A.n_slots + s] = 0u;
     if (win == 0 && tid == 0) *A.work_counter = 0u;
     const uint32_t i0 = 4 * tid;
-    store4(A.depth_out + w0, i0, nvalid, block_scan4(dd, wave_tot));
-    if (UNIQ) store4(A.uniq_out + w0, i0, nvalid, block_scan4(ud, wave_tot));
+    uint32_t d[4], u[4];
+    if (UNIQ) {
+        long long v[4];
+        block_scan4(cells, wave_tot, v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            d[k] = (uint32_t)v[k];
+            u[k] = (uint32_t)((v[k] - (long long)(int)d[k]) >> 32);  // depth may carry a sign into the high word
+        }
+        store4(A.depth_out + w0, i0, nvalid, d);
+        store4(A.uniq_out + w0, i0, nvalid, u);
+    } else {
+        int v[4];
+        block_scan4(reinterpret_cast<const int *>(cells), reinterpret_cast<int *>(wave_tot), v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = (uint32_t)v[k];
+        store4(A.depth_out + w0, i0, nvalid, d);
+    }
 }
 
 uint32_t scan_lds_bytes(uint32_t n_words) { return (kMaxWin + kWaves * (kQCap + 2 * kPCap) + n_words) * 4u; }
@@ -784,6 +827,7 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     FAST_TRY(hipGetDeviceProperties(&prop, dev));
     fp->n_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     fp->n_slots = fp->n_cus;
+    if (fp->n_slots > kMaxSlots) return true;
     fp->n_win = n_win;
     fp->n_words = n_words;
     fp->lds_bytes_uniq = scan_lds_bytes(n_words);
@@ -798,6 +842,8 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     const uint64_t max_cap = ((1ull << 30) - 1) / ((uint64_t)(n_win + 1) * fp->n_slots);
     cap = std::min(cap, max_cap);
     if (const char *forced = getenv("FLATGFA_BUCKET_CAP")) cap = strtoull(forced, nullptr, 10);  // tests: force overflow
+    // put() addresses a slot as window * (n_slots * cap) + pos with a 24-bit multiply
+    cap = std::min<uint64_t>(cap, ((1ull << 24) - 1) / fp->n_slots);
     cap = std::min<uint64_t>(std::max<uint64_t>(cap & ~3ull, 4), max_cap & ~3ull);
     if (cap < 4) return true;
     fp->cap = (uint32_t)cap;
