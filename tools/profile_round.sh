@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/profiles; mkdir -p $OUT; cd $R
 CMD="bench.py --steps 20 --warmup 3"
 # 1. the bench line itself (all workloads; cfgL is the headline)
-for w in cfgL cfgL-uniform cfgL-short cfgS; do
+for w in cfgL cfgL-uniform cfgL-short cfgL-fewlong cfgS; do
   python3 bench.py --steps 20 --warmup 3 --workload $w 2>/dev/null | tail -1 > $OUT/${TAG}_bench_$w.json
 done
 # 2. kernel trace + stats of the same command (csv)
@@ -20,13 +20,35 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   rocprofv3 --kernel-trace --pmc $set -d $OUT/_pmc_$tag -o p -- python3 $CMD --no-cpu-baseline --no-verify > $OUT/_pmc_$tag.log 2>&1
 done
 python3 - <<PY > $OUT/${TAG}_pmc_summary.txt
-import sqlite3,glob
+import sqlite3,glob,re
+def short(k):
+    m=re.search(r"(k_\w+<[^>]*>)",k)
+    return m.group(1) if m else k[:40]
 print("# rocprofv3 --pmc, averages per dispatch over the bench run (python3 $CMD); FETCH_SIZE/WRITE_SIZE in KB")
 print("# (gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -- MI355X_MICROARCH.md; double it)")
 for d in sorted(glob.glob("$OUT/_pmc_*/**/*.db", recursive=True)):
     db=sqlite3.connect(d)
     for k,c,v,n in db.execute("select kernel_name,counter_name,avg(value),count(*) from counters_collection group by kernel_name,counter_name order by kernel_name,counter_name"):
         if 'fgfa_dev' in k:
-            print("%-22s %-22s %18.1f  dispatches=%d" % (k.split("(")[0].split("::")[-1], c, v, n))
+            print("%-22s %-22s %18.1f  dispatches=%d" % (short(k), c, v, n))
+PY
+# 4. per-kernel HBM traffic (what bench.py quotes as roofline.traffic)
+python3 - <<PY > $OUT/latest_traffic.json
+import sqlite3,glob,json,re
+vals={}
+for c in ("FETCH_SIZE","WRITE_SIZE"):
+    for d in glob.glob("$OUT/_pmc_%s/**/*.db" % c, recursive=True):
+        db=sqlite3.connect(d)
+        for k,v in db.execute("select kernel_name,avg(value) from counters_collection where counter_name=? group by kernel_name",(c,)):
+            if 'fgfa_dev' not in k: continue
+            m=re.search(r"(k_\w+<[^>]*>)",k)
+            name=m.group(1) if m else k[:40]
+            name=name.replace("<true, false>","<uniq>").replace("<true, true>","<uniq>").replace("<false, false>","<depth>").replace("<true>","<uniq>").replace("<false>","<depth>")
+            vals.setdefault(name,{})[c]=v
+out={"source":"profiles/${TAG}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; KB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 note)","workload":"cfgL","kernels":{}}
+for n,v in vals.items():
+    f=v.get("FETCH_SIZE",0)*1024*2; w=v.get("WRITE_SIZE",0)*1024
+    out["kernels"][n]={"fetch_bytes":f,"write_bytes":w,"hbm_bytes":f+w}
+print(json.dumps(out,indent=1))
 PY
 rm -rf $OUT/_trace $OUT/_pmc_* ; ls -la $OUT
