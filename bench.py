@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--workload", default="cfgL", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements (depth-only, path depth, end-to-end, copy bandwidth)")
     args = ap.parse_args()
 
     import torch
@@ -153,6 +155,68 @@ def main():
                     "all_kernels_ms_per_step": round(device_ms_per_step, 5),
                     "kernels_avg_ms": {k: round(v, 5) for k, v in kern_avg_ms.items()}}
 
+    # ---- secondary measurements, rank 0 at N=1 only, outside the timed region ----
+    extras = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = {}
+
+        def timed(fn, reps=5):
+            fn()
+            torch.cuda.synchronize(device)
+            ts = []
+            for _ in range(reps):
+                c0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize(device)
+                ts.append(time.perf_counter() - c0)
+            return float(np.median(ts)) * 1e3
+
+        # a2: depth only; a3: path depth of all paths (seg_depth + the per-path sums)
+        d_only = torch.zeros(S, dtype=torch.int32, device=device)
+        extras["seg_depth_only_ms"] = round(timed(lambda: plan.seg_depth(d_only, None)), 5)
+        ids = torch.arange(P, dtype=torch.int32, device=device)
+        len_out = torch.zeros(P, dtype=torch.int64, device=device)
+        wsum_out = torch.zeros(P, dtype=torch.int64, device=device)
+
+        def path_depth_all():
+            plan.seg_depth(d_only, None)
+            plan.path_sums(ids, d_only, len_out, wsum_out)
+        extras["path_depth_all_paths_ms"] = round(timed(path_depth_all), 5)
+        plan.status()
+        # device-to-device copy bandwidth of this box (read + write bytes), for the roofline's second denominator
+        a = torch.empty(1 << 28, dtype=torch.int32, device=device)
+        b = torch.empty_like(a)
+        copy_ms = timed(lambda: b.copy_(a), reps=10)
+        extras["d2d_copy_gbs"] = round(2 * a.numel() * 4 / (copy_ms * 1e-3) / 1e9, 1)
+        del a, b
+        if roofline:
+            roofline["frac_of_measured_copy"] = round(roofline["achieved"] / extras["d2d_copy_gbs"], 5)
+        # end to end through the host API on a fresh handle: .flatgfa mmap -> H2D -> kernels -> D2H -> TSV text
+        import tempfile
+        tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+        fpath = os.path.join(tmpdir, f"bench_{os.getpid()}.flatgfa")
+        try:
+            g.write_flatgfa(fpath)
+            c0 = time.perf_counter()
+            g2 = pa.load(fpath)
+            c1 = time.perf_counter()
+            g2.to_device(local_rank)
+            c2 = time.perf_counter()
+            g2.seg_depth_with_uniq()
+            c3 = time.perf_counter()
+            text = g2.depth_table()
+            c4 = time.perf_counter()
+            extras["end_to_end"] = {
+                "what": ".flatgfa mmap -> H2D -> seg_depth_with_uniq (kernels + D2H + widen to u64) -> depth table text",
+                "load_ms": round((c1 - c0) * 1e3, 3), "h2d_and_plan_ms": round((c2 - c1) * 1e3, 3),
+                "first_query_ms": round((c3 - c2) * 1e3, 3), "table_ms": round((c4 - c3) * 1e3, 3),
+                "table_bytes": len(text), "total_ms": round((c4 - c0) * 1e3, 3),
+                "steps_per_s": round(N / (c4 - c0), 1)}
+            g2.close()
+        finally:
+            if os.path.exists(fpath):
+                os.unlink(fpath)
+
     # ---- CPU baseline: the oracle, one core, same arrays (rank 0, N=1 only) ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -170,6 +234,18 @@ def main():
                "sample": f"full {args.workload} graph ({N} steps), seg_depth_with_uniq, median of {len(times)} runs "
                          f"after 1 warm-up, oracle/depth_oracle.c gcc -O3, host has {os.cpu_count()} logical cores",
                "seconds_median": round(med, 4)}
+        # BASELINE.md section 3 also asks for a path-parallel run on all host cores (not the
+        # reference's algorithm -- its loop is single-threaded -- so it is reported beside, not as, the baseline)
+        nthr = max(1, min(os.cpu_count() or 1, 32))  # more threads only add reduction work
+        if nthr > 1 and extras is not None:
+            fo.seg_depth_with_uniq_mt(pools, nthr)
+            mts = []
+            for _ in range(3):
+                c0 = time.perf_counter()
+                fo.seg_depth_with_uniq_mt(pools, nthr)
+                mts.append(time.perf_counter() - c0)
+            extras["cpu_all_cores"] = {"value": round(N / float(np.median(mts)), 1), "unit": "path-steps/s",
+                                       "cores": nthr, "kind": "port, path-parallel (pthreads)"}
 
     if rank == 0:
         value = world * N * args.steps / elapsed
@@ -186,6 +262,8 @@ def main():
             "bit_exact_vs_oracle": verified,
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if extras:
+            line["extras"] = extras
         if cpu:
             line["speedup_vs_cpu_1core"] = round(value / cpu["value"], 2)
         print(json.dumps(line), flush=True)

@@ -24,6 +24,8 @@
  *   Handle  (flatgfa/src/flatgfa.rs:186-209): u32, segment = h>>1, orient = h&1
  * Outputs mirror Vec<usize> (u64) and Vec<f64>.
  */
+#define _POSIX_C_SOURCE 200809L /* pthread barriers (all-cores baseline only) */
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -85,6 +87,88 @@ int oracle_seg_depth_with_uniq(const uint8_t *paths, uint64_t n_paths,
     }
     free(seen);
     return 0;
+}
+
+/* The same loop, path-parallel on `n_threads` host threads (the "all host
+ * cores" baseline).  Not in the reference -- its loop is single-threaded -- and never the
+ * checker: every thread runs depth.rs:25-36 over the paths p = t, t + T, ... into private
+ * 32-bit vectors with its own `seen` bitset; after a barrier every thread adds up one slice of
+ * the segments over all the private vectors. */
+typedef struct mt_job {
+    const uint8_t *paths; uint64_t n_paths; const uint32_t *steps; uint64_t n_steps, n_segs;
+    uint32_t *depths, *uniq; uint64_t t, T; int rc;
+    struct mt_job *all; pthread_barrier_t *bar; uint64_t *out_d, *out_u;
+} mt_job;
+static void *mt_worker(void *arg) {
+    mt_job *j = (mt_job *)arg;
+    uint64_t words = (j->n_segs + 63) / 64;
+    uint64_t *seen = (uint64_t *)malloc((words ? words : 1) * sizeof(uint64_t));
+    if (!seen) j->rc = -2;
+    for (uint64_t p = j->t; !j->rc && p < j->n_paths; p += j->T) {
+        const uint8_t *path = j->paths + p * PATH_STRIDE;
+        uint64_t start = rd32(path + 8), end = rd32(path + 12);
+        if (start > end || end > j->n_steps) { j->rc = -1; break; }
+        memset(seen, 0, words * sizeof(uint64_t));
+        for (uint64_t i = start; i < end; ++i) {
+            uint32_t h;
+            memcpy(&h, (const uint8_t *)j->steps + i * 4, 4);
+            uint64_t seg_id = h >> 1;
+            if (seg_id >= j->n_segs) { j->rc = -1; break; }
+            j->depths[seg_id] += 1;
+            uint64_t bit = 1ull << (seg_id & 63);
+            if (!(seen[seg_id >> 6] & bit)) {
+                j->uniq[seg_id] += 1;
+                seen[seg_id >> 6] |= bit;
+            }
+        }
+    }
+    free(seen);
+    pthread_barrier_wait(j->bar);
+    uint64_t lo = j->n_segs * j->t / j->T, hi = j->n_segs * (j->t + 1) / j->T;
+    for (uint64_t s = lo; s < hi; ++s) {
+        uint64_t d = 0, u = 0;
+        for (uint64_t k = 0; k < j->T; ++k) { d += j->all[k].depths[s]; u += j->all[k].uniq[s]; }
+        j->out_d[s] = d;
+        j->out_u[s] = u;
+    }
+    return NULL;
+}
+int oracle_seg_depth_with_uniq_mt(const uint8_t *paths, uint64_t n_paths, const uint32_t *steps,
+                                  uint64_t n_steps, uint64_t n_segs, uint64_t *depths,
+                                  uint64_t *uniq_depths, uint32_t n_threads) {
+    if (n_threads == 0 || n_threads > 1024) return -3;
+    mt_job *jobs = (mt_job *)calloc(n_threads, sizeof(mt_job));
+    pthread_t *tid = (pthread_t *)calloc(n_threads, sizeof(pthread_t));
+    pthread_barrier_t bar;
+    if (!jobs || !tid) { free(jobs); free(tid); return -2; }
+    int rc = 0;
+    for (uint32_t t = 0; t < n_threads; ++t) {
+        mt_job *j = &jobs[t];
+        j->paths = paths; j->n_paths = n_paths; j->steps = steps; j->n_steps = n_steps; j->n_segs = n_segs;
+        j->t = t; j->T = n_threads; j->all = jobs; j->bar = &bar; j->out_d = depths; j->out_u = uniq_depths;
+        j->depths = (uint32_t *)calloc(n_segs ? n_segs : 1, 4);
+        j->uniq = (uint32_t *)calloc(n_segs ? n_segs : 1, 4);
+        if (!j->depths || !j->uniq) rc = -2;
+    }
+    if (!rc) {
+        pthread_barrier_init(&bar, NULL, n_threads);
+        uint32_t started = 0;
+        for (; started < n_threads; ++started)
+            if (pthread_create(&tid[started], NULL, mt_worker, &jobs[started])) break;
+        if (started < n_threads) {
+            /* cannot run short-handed (the barrier counts n_threads): give the missing ones a turn inline is
+             * not possible either, so report the failure after the started ones are released */
+            rc = -2;
+            for (uint32_t t = started; t < n_threads; ++t) pthread_create(&tid[t], NULL, mt_worker, &jobs[t]);
+        }
+        for (uint32_t t = 0; t < n_threads; ++t) pthread_join(tid[t], NULL);
+        pthread_barrier_destroy(&bar);
+        for (uint32_t t = 0; t < n_threads; ++t)
+            if (!rc && jobs[t].rc) rc = jobs[t].rc;
+    }
+    for (uint32_t t = 0; t < n_threads; ++t) { free(jobs[t].depths); free(jobs[t].uniq); }
+    free(jobs); free(tid);
+    return rc;
 }
 
 /* seg_depth, ops/depth.rs:45-56 */

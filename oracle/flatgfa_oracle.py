@@ -398,7 +398,7 @@ def build(force: bool = False) -> str:
             os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
         return so
     os.makedirs(out_dir, exist_ok=True)
-    subprocess.check_call(["gcc", "-O3", "-march=x86-64-v2", "-std=c11", "-fPIC", "-shared",
+    subprocess.check_call(["gcc", "-O3", "-march=x86-64-v2", "-std=c11", "-fPIC", "-shared", "-pthread",
                            "-Wall", "-Wextra", "-o", so] + srcs)
     return so
 
@@ -449,6 +449,21 @@ def seg_depth_with_uniq(p: Pools) -> Tuple[np.ndarray, np.ndarray]:
                                           _ptr(d), _ptr(u))
     if rc:
         raise ParseError(f"oracle_seg_depth_with_uniq rc={rc}")
+    return d, u
+
+
+def seg_depth_with_uniq_mt(p: Pools, n_threads: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Path-parallel variant for the all-host-cores baseline (never the checker)."""
+    paths, steps = _c(p.paths), _c(p.steps)
+    S = len(p.segs)
+    d = np.zeros(S, dtype=np.uint64)
+    u = np.zeros(S, dtype=np.uint64)
+    fn = lib().oracle_seg_depth_with_uniq_mt
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    rc = fn(_ptr(paths), len(paths), _ptr(steps), len(steps), S, _ptr(d), _ptr(u), int(n_threads))
+    if rc:
+        raise ParseError(f"oracle_seg_depth_with_uniq_mt rc={rc}")
     return d, u
 
 

@@ -111,12 +111,20 @@ __global__ __launch_bounds__(kUniqThreads) void k_depth_uniq_path(const uint32_t
 // measure_path (depth.rs:116-131): each block reduces one slice of one requested path.
 constexpr int kSumThreads = 256;
 
+// (seg_len, depth) side by side, so that a step costs one 8-byte gather instead of two 4-byte ones
+__global__ __launch_bounds__(256) void k_pack_len_depth(const uint32_t *__restrict__ seg_len,
+                                                        const uint32_t *__restrict__ depth, uint32_t n_segs,
+                                                        uint2 *__restrict__ tab) {
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_segs; s += gridDim.x * blockDim.x)
+        tab[s] = make_uint2(seg_len[s], depth[s]);
+}
+
 __global__ __launch_bounds__(kSumThreads) void k_path_sums(const uint32_t *__restrict__ steps,
                                                             const uint32_t *__restrict__ path_begin,
                                                             const uint32_t *__restrict__ path_end, uint32_t n_paths,
-                                                            uint32_t n_segs, const uint32_t *__restrict__ seg_len,
+                                                            uint32_t n_segs, const uint2 *__restrict__ tab,
                                                             const uint32_t *__restrict__ path_ids, uint32_t n_ids,
-                                                            uint32_t split, const uint32_t *__restrict__ depth,
+                                                            uint32_t split,
                                                             unsigned long long *__restrict__ length_out,
                                                             unsigned long long *__restrict__ weighted_out,
                                                             uint32_t *__restrict__ status) {
@@ -130,15 +138,15 @@ __global__ __launch_bounds__(kSumThreads) void k_path_sums(const uint32_t *__res
             const uint64_t b = path_begin[p], e = path_end[p];
             const uint64_t n = e - b;
             const uint64_t lo = b + n * part / split, hi = b + n * (part + 1) / split;
+            // consecutive lanes take consecutive steps: along a run their table entries share lines
+#pragma unroll 4
             for (uint64_t i = lo + threadIdx.x; i < hi; i += kSumThreads) {
                 const uint32_t seg = steps[i] >> 1;
-                if (seg < n_segs) {
-                    const unsigned long long l = seg_len[seg];
-                    len += l;
-                    wsum += (unsigned long long)depth[seg] * l;
-                } else {
-                    *status = 1u;
-                }
+                const bool ok = seg < n_segs;
+                const uint2 ld = tab[ok ? seg : 0u];
+                len += ok ? (unsigned long long)ld.x : 0ull;
+                wsum += ok ? (unsigned long long)ld.y * ld.x : 0ull;
+                if (!ok) *status = 1u;
             }
         } else if (threadIdx.x == 0 && part == 0) {
             *status = 1u;
@@ -183,6 +191,7 @@ struct flatgfa_dev_plan {
     uint32_t n_windows = 1;
     FastPlan fast;  // the bucketed two-kernel path, used whenever the graph is eligible
     uint32_t *overlap_bits = nullptr;  // per-path oriented-handle bitsets (built on first overlap query)
+    uint2 *len_depth = nullptr;        // (seg_len, depth) table of the last path_sums call (built on first use)
 };
 
 extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int n_cus, uint32_t **bits_cache,
@@ -250,6 +259,7 @@ extern "C" void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *pl) {
     if (!pl) return;
     fast_plan_destroy(&pl->fast);
     if (pl->overlap_bits) (void)hipFree(pl->overlap_bits);
+    if (pl->len_depth) (void)hipFree(pl->len_depth);
     if (pl->items) (void)hipFree(pl->items);
     if (pl->status) (void)hipFree(pl->status);
     delete pl;
@@ -303,10 +313,16 @@ extern "C" int flatgfa_dev_path_sums(flatgfa_dev_plan_t *pl, const uint32_t *pat
     uint32_t split = std::max<uint32_t>(1u, std::min<uint32_t>(64u, (uint32_t)(pl->n_cus * 16) / n_ids));
     uint64_t jobs = (uint64_t)n_ids * split;
     uint32_t grid = (uint32_t)std::min<uint64_t>(jobs, (uint64_t)pl->n_cus * 32u);
+    if (!pl->len_depth) HIP_TRY(hipMalloc(&pl->len_depth, (size_t)std::max<uint32_t>(g.n_segs, 1u) * sizeof(uint2)), return FLATGFA_ERR_HIP);
+    {
+        ProfScope ps("k_pack_len_depth", stream);
+        const uint32_t pgrid = std::max<uint32_t>(1u, std::min<uint32_t>((g.n_segs + 255) / 256, (uint32_t)pl->n_cus * 8u));
+        hipLaunchKernelGGL(k_pack_len_depth, dim3(pgrid), dim3(256), 0, stream, g.seg_len, depth, g.n_segs, pl->len_depth);
+    }
     {
         ProfScope ps("k_path_sums", stream);
         hipLaunchKernelGGL(k_path_sums, dim3(grid), dim3(kSumThreads), 0, stream, g.steps, g.path_begin, g.path_end,
-                           g.n_paths, g.n_segs, g.seg_len, path_ids, n_ids, split, depth,
+                           g.n_paths, g.n_segs, pl->len_depth, path_ids, n_ids, split,
                            (unsigned long long *)length_out, (unsigned long long *)weighted_out, pl->status);
     }
     HIP_TRY(hipGetLastError(), return FLATGFA_ERR_HIP);

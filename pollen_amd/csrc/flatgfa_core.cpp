@@ -516,16 +516,33 @@ std::string format_float(double x, int digits) {
     return std::string(buf, (size_t)n);
 }
 
+// decimal digits of x at p, returns the end
+static inline char *write_u64(char *p, uint64_t x) {
+    char tmp[20];
+    int n = 0;
+    do {
+        tmp[n++] = (char)('0' + x % 10);
+        x /= 10;
+    } while (x);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+
 void emit_seg_depth(const View &v, const uint64_t *depth, const uint64_t *uniq, std::string *out) {
     out->append("#node.id\tdepth\tdepth.uniq\n");
-    out->reserve(out->size() + v.segs.len * 16);
-    char line[96];
+    // one line is at most 10 + 20 + 20 digits, two tabs and a newline
+    const size_t head = out->size();
+    out->resize(head + v.segs.len * 53);
+    char *p = &(*out)[head];
     for (size_t i = 0; i < v.segs.len; ++i) {
-        uint32_t name = (uint32_t)v.segs[i].name;  // `seg.name as u32`, depth.rs:71
-        int n = snprintf(line, sizeof line, "%u\t%llu\t%llu\n", name, (unsigned long long)depth[i],
-                         (unsigned long long)uniq[i]);
-        out->append(line, (size_t)n);
+        p = write_u64(p, (uint32_t)v.segs[i].name);  // `seg.name as u32`, depth.rs:71
+        *p++ = '\t';
+        p = write_u64(p, depth[i]);
+        *p++ = '\t';
+        p = write_u64(p, uniq[i]);
+        *p++ = '\n';
     }
+    out->resize((size_t)(p - out->data()));
 }
 
 void emit_path_depth(const View &v, const uint32_t *path_ids, size_t n, const uint64_t *lengths,
