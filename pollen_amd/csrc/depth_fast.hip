@@ -57,7 +57,7 @@ constexpr int kAccThreads = 1024;
 constexpr uint32_t kMaxSlots = 1024;  // sub-buckets per window (= workgroups of k_scan) k_accum can stage
 
 // diagnostic ablations (FLATGFA_DEBUG_SKIP, results are then wrong by construction)
-constexpr uint32_t kDbgNoStore = 1, kDbgNoBitset = 4, kDbgNoTiles = 8, kDbgHotLoads = 16;
+constexpr uint32_t kDbgNoStore = 1, kDbgNoBitset = 4, kDbgNoTiles = 8, kDbgHotLoads = 16, kDbgTime = 32;
 // the ablation checks exist only in the DBG instantiation of the kernel
 #define FGFA_SKIP(bit) (DBG && (A.dbg & (bit)))
 
@@ -99,6 +99,7 @@ struct Wave {
     uint32_t *q, *pq;
     uint32_t fill, pfill, prev, rs;
     uint32_t vm[2];  // memory instructions issued since the loads into landing set 0 / 1 (see wait_block)
+    unsigned long long tacc[6], tlast;  // kDbgTime (diagnostic): cycles per phase of this wave
     int lane;
 };
 
@@ -130,6 +131,16 @@ __device__ __forceinline__ uint32_t clamp_id(const ScanArgs &A, uint32_t id) {
         return 0u;
     }
     return id;
+}
+
+// kDbgTime: charge the cycles since the last mark to phase `ph`
+template <bool DBG>
+__device__ __forceinline__ void tmark(const ScanArgs &A, Wave &w, int ph) {
+    if (DBG && (A.dbg & kDbgTime)) {
+        const unsigned long long t = __builtin_readcyclecounter();
+        w.tacc[ph] += t - w.tlast;
+        w.tlast = t;
+    }
 }
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long m) {
@@ -220,6 +231,32 @@ __device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ uint32_t lds_addr(uint32_t *p) { return (uint32_t)(uintptr_t)(lds_u32 *)p; }
 
+// Pass A of block16 for eight consecutive steps of every lane, hand-scheduled: Mj (a lane mask in
+// an SGPR pair) = "step j starts a run" = its id is not the id before it plus one, or it sits on
+// a cut boundary; CNT += Mj per lane.  Five vector and one scalar instruction per step, where the
+// compiler's rendering of the same C++ costs eight and three (it rebuilds every mask from a 0/1
+// register).  PM is the id before step 0.
+#define FGFA_PASSA_STEP(PMJ, XJ, MJ)                         \
+    "v_add_u32 %[t], 1, %[" PMJ "]\n\t"                      \
+    "v_cmp_ne_u32 %[" MJ "], %[" XJ "], %[t]\n\t"            \
+    "v_and_b32 %[t], %[cut], %[" XJ "]\n\t"                  \
+    "v_cmp_eq_u32 vcc, 0, %[t]\n\t"                          \
+    "s_or_b64 %[" MJ "], %[" MJ "], vcc\n\t"                 \
+    "v_addc_co_u32_e64 %[cnt], vcc, 0, %[cnt], %[" MJ "]\n\t"
+#define FGFA_PASSA8(CUT, CNT, PM, X0, X1, X2, X3, X4, X5, X6, X7, M0, M1, M2, M3, M4, M5, M6, M7)                    \
+    do {                                                                                                             \
+        uint32_t t_;                                                                                                 \
+        asm volatile(FGFA_PASSA_STEP("pm", "x0", "m0") FGFA_PASSA_STEP("x0", "x1", "m1")                             \
+                         FGFA_PASSA_STEP("x1", "x2", "m2") FGFA_PASSA_STEP("x2", "x3", "m3")                         \
+                             FGFA_PASSA_STEP("x3", "x4", "m4") FGFA_PASSA_STEP("x4", "x5", "m5")                     \
+                                 FGFA_PASSA_STEP("x5", "x6", "m6") FGFA_PASSA_STEP("x6", "x7", "m7")                 \
+                     : [cnt] "+v"(CNT), [t] "=&v"(t_), [m0] "=&s"(M0), [m1] "=&s"(M1), [m2] "=&s"(M2),               \
+                       [m3] "=&s"(M3), [m4] "=&s"(M4), [m5] "=&s"(M5), [m6] "=&s"(M6), [m7] "=&s"(M7)                \
+                     : [pm] "v"(PM), [x0] "v"(X0), [x1] "v"(X1), [x2] "v"(X2), [x3] "v"(X3), [x4] "v"(X4),           \
+                       [x5] "v"(X5), [x6] "v"(X6), [x7] "v"(X7), [cut] "i"(CUT)                                      \
+                     : "vcc", "scc");                                                                                \
+    } while (0)
+
 // Pass B of block16 for eight consecutive steps of every lane, hand-scheduled: for step j, the
 // lanes where a run starts (mask Mj) append (cur << 11) | (id before step j - cur) at their queue
 // cursor `p` and make step j's id their `cur`.  Written as asm so that each step is one scalar
@@ -290,28 +327,27 @@ __device__ __forceinline__ void block16(const ScanArgs &A, Wave &w, uint32_t *se
     uint32_t prev = __builtin_amdgcn_update_dpp(0u, a[15], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     if (w.lane == 0) prev = w.prev;
     // pass A (lanes beyond `nl` compute garbage flags; they are kept out of `cnt` and of pass B)
-    bool st[16];
-    st[0] = ((a[0] != prev + 1) | ((a[0] & kCutMask<UNIQ>) == 0)) & !(fresh & (w.lane == 0));
-#pragma unroll
-    for (int k = 1; k < 16; ++k) st[k] = (a[k] != a[k - 1] + 1) | ((a[k] & kCutMask<UNIQ>) == 0);
+    unsigned long long m[16];
     uint32_t cnt = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) cnt += st[k] ? 1u : 0u;
+    FGFA_PASSA8(kCutMask<UNIQ>, cnt, prev, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
+    FGFA_PASSA8(kCutMask<UNIQ>, cnt, a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15]);
+    if (fresh && (m[0] & 1ull)) {  // nothing has ended at the very first step of a span, cut boundary or not
+        m[0] &= ~1ull;
+        cnt -= (w.lane == 0) ? 1u : 0u;
+    }
     cnt = active ? cnt : 0u;
     const uint32_t incl = wave_scan_incl(cnt);
     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
     const unsigned long long below = __builtin_amdgcn_ballot_w64(cnt != 0u) & ((1ull << w.lane) - 1ull);
     const int src = below ? 63 - __builtin_clzll(below) : w.lane;
     uint32_t cur;
+
     if (w.fill + total <= kQCap) {
         // pass B, lane-local: `cur` is the start of the run in progress, 0 standing in for the
         // one that entered the lane (then the entry holds just the run's last id until patched)
         uint32_t *const p0 = w.q + w.fill + (incl - cnt);
         cur = 0u;
         if (active) {
-            unsigned long long m[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) m[k] = __builtin_amdgcn_ballot_w64(st[k]);
             uint32_t p = lds_addr(p0);
             FGFA_PASSB8(cur, p, prev, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
             FGFA_PASSB8(cur, p, a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15]);
@@ -326,10 +362,16 @@ __device__ __forceinline__ void block16(const ScanArgs &A, Wave &w, uint32_t *se
             cur = rs;
         }
         w.fill += total;
+        tmark<DBG>(A, w, 2);
         drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);
+        tmark<DBG>(A, w, 3);
     } else {
+        bool st[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) st[k] &= active;
+        for (int k = 0; k < 16; ++k) {
+            asm volatile("" : "+s"(m[k]));  // keeps this path's work from being hoisted above the branch
+            st[k] = __builtin_amdgcn_inverse_ballot_w64(m[k]) & active;
+        }
         uint32_t last_start = a[0];
 #pragma unroll
         for (int k = 1; k < 16; ++k) last_start = st[k] ? a[k] : last_start;
@@ -395,17 +437,24 @@ struct Span {
 };
 
 constexpr uint32_t kBlockSteps = 1024;
-constexpr uint32_t kMinPartialLanes = 22;  // below this a partial block costs more than narrow tiles
+constexpr uint32_t kMinPartialLanes = 1;  // whatever is left in whole 16-step chunks goes through one more, partial block: narrow tiles are not prefetched and each costs a full memory latency
 
-__device__ __forceinline__ Span make_span(const ScanArgs &A, uint32_t job, int wave, int lane) {
+// Which item a workgroup takes in its r-th turn.  Items are sorted longest first and dealt out
+// in snake order (0..G-1, then G-1..0, ...), which balances a sorted list well and needs no
+// queue: a returning global atomic per item sat on the critical path of every path (the wave
+// that issued it waited microseconds for it, and the other fifteen for that wave at the barrier).
+__device__ __forceinline__ uint32_t item_of(uint32_t round, uint32_t wg, uint32_t n_wg) {
+    return round * n_wg + ((round & 1u) ? n_wg - 1u - wg : wg);
+}
+
+__device__ __forceinline__ Span make_span(const ScanArgs &A, bool have, uint4 it, int wave, int lane) {
     Span s;
     s.lo = s.hi = s.t0 = 0;
     s.nblk = 0;
     s.nl_last = 64;
     s.src = nullptr;
     s.slot = kNoSlot;
-    if (job < A.n_items) {
-        const uint4 it = A.items[job];
+    if (have) {
         const uint64_t b = it.x, e = it.y, n = e - b;
         s.slot = it.z;
         // contiguous span per wave: a whole number of 16-step lane chunks, cut at 64-byte boundaries
@@ -498,7 +547,6 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     // layout: [bcur: kMaxWin][run queues: kWaves * kQCap][parked-claim queues: kWaves * 2 * kPCap][seen: n_words]
     uint32_t *bcur = lds;
     uint32_t *seen = lds + kMaxWin + kWaves * (kQCap + 2 * kPCap);
-    __shared__ uint32_t next_job;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the span math on the scalar unit
     uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;  // this workgroup's sub-bucket of window 0
@@ -507,17 +555,19 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     w.pq = lds + kMaxWin + kWaves * kQCap + wave * (2 * kPCap);
     w.fill = w.pfill = 0;
     w.vm[0] = w.vm[1] = 0;
+    for (int k = 0; k < 6; ++k) w.tacc[k] = 0;
+    w.tlast = (DBG && (A.dbg & kDbgTime)) ? __builtin_readcyclecounter() : 0ull;
     w.lane = lane;
     for (uint32_t i = threadIdx.x; i < kMaxWin; i += kThreads) bcur[i] = 0u;
     if (UNIQ)
         for (uint32_t i = threadIdx.x; i < A.n_words; i += kThreads) seen[i] = 0u;
-    if (threadIdx.x == 0) next_job = atomicAdd(A.work_counter, 1u);
-    __syncthreads();
-    uint32_t job = __builtin_amdgcn_readfirstlane(next_job);
     __syncthreads();
 
-    // The first blocks of an item are requested while the previous item is being wrapped up.
-    Span sp = make_span(A, job, wave, lane);
+    // The first blocks of an item are requested while the previous item is being wrapped up, and
+    // its descriptor while the previous item is being walked.
+    uint32_t round = 0;
+    uint32_t job = item_of(0, blockIdx.x, gridDim.x);
+    Span sp = make_span(A, job < A.n_items, job < A.n_items ? A.items[job] : make_uint4(0u, 0u, 0u, 0u), wave, lane);
     // lanes beyond a partial block's last one re-read lane 0's chunk: same instruction stream for all
 #define FGFA_BLOCK_PTR(j) \
     (sp.src + (size_t)(j) * 256 - (((j) + 1 == sp.nblk && (uint32_t)lane >= sp.nl_last) ? lane * 4 : 0))
@@ -529,7 +579,9 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     // one block: wait for its data, re-issue its register set for the block two ahead, process it
 #define FGFA_BLOCK(SET, J)                                                                    \
     if ((J) < sp.nblk) {                                                                      \
+        tmark<DBG>(A, w, 4);                                                                  \
         wait_block<SET>(w);                                                                   \
+        tmark<DBG>(A, w, 0);                                                                  \
         uint32_t a[16];                                                                       \
         take_block<SET>(a);                                                                   \
         if ((J) + 2 < sp.nblk) load_block_async<SET>(w, FGFA_BLOCK_PTR((J) + 2));             \
@@ -542,7 +594,8 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     FGFA_PRELOAD();
 
     while (job < A.n_items) {
-        if (threadIdx.x == 0) next_job = atomicAdd(A.work_counter, 1u);  // consumed after the barrier below
+        const uint32_t next_job = item_of(++round, blockIdx.x, gridDim.x);
+        const uint4 next_item = next_job < A.n_items ? A.items[next_job] : make_uint4(0u, 0u, 0u, 0u);  // needed after the barrier below
         if (sp.lo < sp.hi) {
 #pragma unroll 1
             for (uint32_t i = 0; i < sp.nblk; i += 2) {
@@ -570,10 +623,12 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             }
             drain<UNIQ, DBG>(A, w, seen, bcur, mine, true);
         }
-        __syncthreads();  // every wave is done with this path's bitset; next_job is visible
+        tmark<DBG>(A, w, 4);
+        __syncthreads();  // every wave is done with this path's bitset
+        tmark<DBG>(A, w, 1);
         const uint32_t done_slot = sp.slot;
-        job = __builtin_amdgcn_readfirstlane(next_job);
-        sp = make_span(A, job, wave, lane);
+        job = next_job;
+        sp = make_span(A, job < A.n_items, next_item, wave, lane);
         FGFA_PRELOAD();
         if (UNIQ) {
             uint4 *sv = reinterpret_cast<uint4 *>(seen);
@@ -586,6 +641,12 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             for (uint32_t i = threadIdx.x; i < A.n_words / 4; i += kThreads) sv[i] = make_uint4(0u, 0u, 0u, 0u);
             __syncthreads();  // the bitset is clean before the next path claims bits
         }
+        tmark<DBG>(A, w, 5);
+    }
+    if (DBG && (A.dbg & kDbgTime) && lane == 0) {
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(A.status + 8);
+        for (int k = 0; k < 6; ++k) atomicAdd(&acc[k], w.tacc[k]);
+        atomicAdd(&acc[6 + wave], w.tacc[1]);  // barrier wait by wave index
     }
 #undef FGFA_PRELOAD
 #undef FGFA_BLOCK
@@ -940,6 +1001,18 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
     if (hipGetLastError() != hipSuccess) {
         set_error("fast_seg_depth: kernel launch failed");
         return FLATGFA_ERR_HIP;
+    }
+    if (fp.dbg & kDbgTime) {  // diagnostic: where the waves of k_scan spend their cycles
+        unsigned long long acc[6 + kWaves] = {};
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(acc, status + 8, sizeof acc, hipMemcpyDeviceToHost);
+        (void)hipMemset(status + 8, 0, sizeof acc);
+        const double waves = (double)grid * kWaves;
+        fprintf(stderr, "k_scan cycles per wave (s_memtime ticks): wait_block %.0f  barrier_wait %.0f  passA+B %.0f  drain %.0f  other %.0f  next_item+wipe %.0f\n",
+                acc[0] / waves, acc[1] / waves, acc[2] / waves, acc[3] / waves, acc[4] / waves, acc[5] / waves);
+        fprintf(stderr, "  barrier wait by wave index:");
+        for (int k = 0; k < kWaves; ++k) fprintf(stderr, " %.0f", (double)acc[6 + k] / grid);
+        fprintf(stderr, "\n");
     }
     return FLATGFA_OK;
 }

@@ -1,7 +1,9 @@
 // Microbenchmark: how fast can a persistent 1024-thread workgroup per CU stream 400 MB with
 //   (a) coalesced 16-byte loads (lane l reads unit k*64 + l of its wave's 4 KB block), vs
 //   (b) "lane owns 64 bytes": lane l reads units 4l..4l+3 with four back-to-back 16-byte loads,
-//   (c) "lane owns 32 bytes": lane l reads units 2l, 2l+1 (two blocks of 2 KB per 4 KB).
+//   (c) "lane owns 32 bytes": lane l reads units 2l, 2l+1 (two blocks of 2 KB per 4 KB),
+//   (d) "quad reads 64 bytes": instruction k, lane l reads unit 16(l/4) + 4k + l%4, so that a
+//       4x4 transpose inside each lane quad turns the block into layout (b).
 // Build: hipcc --offload-arch=gfx950 -O3 tools/loadpat.hip -o /tmp/loadpat
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -38,6 +40,10 @@ __global__ __launch_bounds__(1024) void k_pat(const u32x4 *__restrict__ src, uin
             p += lane * 4;
             if (NT) { v0 = __builtin_nontemporal_load(p); v1 = __builtin_nontemporal_load(p + 1); v2 = __builtin_nontemporal_load(p + 2); v3 = __builtin_nontemporal_load(p + 3); }
             else { v0 = p[0]; v1 = p[1]; v2 = p[2]; v3 = p[3]; }
+        } else if (MODE == 3) {
+            p += (lane >> 2) * 16 + (lane & 3);
+            if (NT) { v0 = __builtin_nontemporal_load(p); v1 = __builtin_nontemporal_load(p + 4); v2 = __builtin_nontemporal_load(p + 8); v3 = __builtin_nontemporal_load(p + 12); }
+            else { v0 = p[0]; v1 = p[4]; v2 = p[8]; v3 = p[12]; }
         } else {
             p += lane * 2;
             if (NT) { v0 = __builtin_nontemporal_load(p); v1 = __builtin_nontemporal_load(p + 1); v2 = __builtin_nontemporal_load(p + 128); v3 = __builtin_nontemporal_load(p + 129); }
@@ -81,5 +87,7 @@ int main() {
     run<1, true>("lane owns 64 B nt", src, nb, out, cus);
     run<2, false>("lane owns 32 B", src, nb, out, cus);
     run<2, true>("lane owns 32 B nt", src, nb, out, cus);
+    run<3, false>("quad reads 64 B", src, nb, out, cus);
+    run<3, true>("quad reads 64 B nt", src, nb, out, cus);
     return 0;
 }
