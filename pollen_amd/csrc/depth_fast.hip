@@ -99,7 +99,7 @@ struct Wave {
     uint32_t *q, *pq;
     uint32_t fill, pfill, prev, rs;
     uint32_t vm[2];  // memory instructions issued since the loads into landing set 0 / 1 (see wait_block)
-    unsigned long long tacc[6], tlast;  // kDbgTime (diagnostic): cycles per phase of this wave
+    unsigned long long tacc[8], tlast;  // kDbgTime (diagnostic): cycles per phase of this wave
     int lane;
 };
 
@@ -311,8 +311,9 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
 // the steps are queued four at a time with the queue emitted in between.
 template <bool UNIQ, bool DBG>
 __device__ __forceinline__ void block16(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
-                                        uint32_t (&a)[16], uint32_t nl, bool fresh) {
+                                        uint32_t (&a)[16], uint32_t nl) {
     const bool active = (uint32_t)w.lane < nl;
+    const bool last_lane = (uint32_t)w.lane + 1u == nl;
     uint32_t mx = a[0];
 #pragma unroll
     for (int k = 1; k < 16; ++k) mx = max(mx, a[k]);
@@ -320,47 +321,42 @@ __device__ __forceinline__ void block16(const ScanArgs &A, Wave &w, uint32_t *se
 #pragma unroll
         for (int k = 0; k < 16; ++k) a[k] = clamp_id(A, a[k]);
     }
-    if (fresh) {  // first steps of a span: the first one continues a (so far empty) run that starts at it
-        w.rs = __builtin_amdgcn_readfirstlane(a[0]);
-        w.prev = w.rs - 1u;
-    }
-    uint32_t prev = __builtin_amdgcn_update_dpp(0u, a[15], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    if (w.lane == 0) prev = w.prev;
+    // a block is walked on its own: its first step opens a run, its last step closes one
+    const uint32_t first = __builtin_amdgcn_readfirstlane(a[0]);
+    const uint32_t prev = __builtin_amdgcn_update_dpp(0u, a[15], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     // pass A (lanes beyond `nl` compute garbage flags; they are kept out of `cnt` and of pass B)
     unsigned long long m[16];
     uint32_t cnt = 0;
     FGFA_PASSA8(kCutMask<UNIQ>, cnt, prev, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
     FGFA_PASSA8(kCutMask<UNIQ>, cnt, a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15]);
-    if (fresh && (m[0] & 1ull)) {  // nothing has ended at the very first step of a span, cut boundary or not
-        m[0] &= ~1ull;
-        cnt -= (w.lane == 0) ? 1u : 0u;
-    }
+    cnt -= (w.lane == 0) ? (uint32_t)(m[0] & 1ull) : 0u;  // nothing ends at the block's first step
+    m[0] &= ~1ull;
     cnt = active ? cnt : 0u;
-    const uint32_t incl = wave_scan_incl(cnt);
+    const uint32_t slots = cnt + (last_lane ? 1u : 0u);  // the last lane also queues the run that is open at the end
+    const uint32_t incl = wave_scan_incl(slots);
     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
     const unsigned long long below = __builtin_amdgcn_ballot_w64(cnt != 0u) & ((1ull << w.lane) - 1ull);
     const int src = below ? 63 - __builtin_clzll(below) : w.lane;
-    uint32_t cur;
-
     if (w.fill + total <= kQCap) {
         // pass B, lane-local: `cur` is the start of the run in progress, 0 standing in for the
         // one that entered the lane (then the entry holds just the run's last id until patched)
-        uint32_t *const p0 = w.q + w.fill + (incl - cnt);
-        cur = 0u;
+        uint32_t *const p0 = w.q + w.fill + (incl - slots);
+        uint32_t cur = 0u;
+        uint32_t p = lds_addr(p0);
         if (active) {
-            uint32_t p = lds_addr(p0);
             FGFA_PASSB8(cur, p, prev, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
             FGFA_PASSB8(cur, p, a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15]);
         }
         // start id of the run in progress when this lane's first step arrived: the last start below
         const uint32_t from_below = __shfl(cur, src, 64);
-        const uint32_t rs = below ? from_below : w.rs;
+        const uint32_t rs = below ? from_below : first;
         if (cnt) {
             const uint32_t last = *p0;
             *p0 = (rs << kRunBits) | (last - rs);
         } else {
             cur = rs;
         }
+        if (last_lane) *reinterpret_cast<lds_u32 *>((uintptr_t)p) = (cur << kRunBits) | (a[15] - cur);
         w.fill += total;
         tmark<DBG>(A, w, 2);
         drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);
@@ -376,8 +372,8 @@ __device__ __forceinline__ void block16(const ScanArgs &A, Wave &w, uint32_t *se
 #pragma unroll
         for (int k = 1; k < 16; ++k) last_start = st[k] ? a[k] : last_start;
         const uint32_t from_below = __shfl(last_start, src, 64);
-        const uint32_t rs = below ? from_below : w.rs;
-        cur = rs;
+        const uint32_t rs = below ? from_below : first;
+        uint32_t cur = rs;
 #pragma unroll 1
         for (int g = 0; g < 4; ++g) {
             uint32_t pm, x0, x1, x2, x3;
@@ -398,9 +394,8 @@ __device__ __forceinline__ void block16(const ScanArgs &A, Wave &w, uint32_t *se
             cur = s3 ? x3 : cur;
             drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);
         }
+        enqueue(w, last_lane, (cur << kRunBits) | (a[15] - cur));
     }
-    w.prev = __builtin_amdgcn_readlane(a[15], nl - 1);
-    w.rs = __builtin_amdgcn_readlane(cur, nl - 1);
 }
 
 // Up to 64 consecutive steps, one per lane (heads, tails and short spans).
@@ -426,54 +421,49 @@ __device__ __forceinline__ void tile_narrow(const ScanArgs &A, Wave &w, uint64_t
     if (m) w.rs = __shfl(id, 63 - __builtin_clzll(m), 64);
 }
 
-// One wave's share of one work item: steps [lo, hi).  [lo, t0) is the few steps before the first
-// 64-byte boundary (wave 0 only), then `nblk` blocks of 1024 steps read through `src`, the last
-// of which may hold only `nl_last` lanes' worth, then whatever is left for narrow tiles.
-struct Span {
-    uint64_t lo, hi, t0;
+// How one work item (a path, or a piece of a long one) is cut up: the few steps [b, t0) before
+// the first 64-byte boundary, then `nblk` blocks of 1024 steps starting at t0, the last of which
+// may hold only `nl_last` lanes' worth of 16-step chunks, then fewer than 16 steps [tail, e).
+// Blocks are not assigned to waves in advance: a wave takes the next free one from an LDS counter
+// whenever one of its landing sets is free (its first two are its own index and that plus 16).
+// The SIMDs favour their older waves, so with equal fixed shares the youngest four waves finished
+// a path up to 25% after the oldest four, which then idled at the barrier.
+struct Item {
+    uint64_t b, e, t0, tail;
     uint32_t nblk, nl_last;
     const uint4 *src;  // this lane's 64 bytes of block 0
     uint32_t slot;     // where to leave the bitset when this is a piece of a split path
 };
 
-constexpr uint32_t kBlockSteps = 1024;
-constexpr uint32_t kMinPartialLanes = 1;  // whatever is left in whole 16-step chunks goes through one more, partial block: narrow tiles are not prefetched and each costs a full memory latency
 
 // Which item a workgroup takes in its r-th turn.  Items are sorted longest first and dealt out
 // in snake order (0..G-1, then G-1..0, ...), which balances a sorted list well and needs no
-// queue: a returning global atomic per item sat on the critical path of every path (the wave
-// that issued it waited microseconds for it, and the other fifteen for that wave at the barrier).
+// queue: a returning global atomic per item sat on the critical path of every path.
 __device__ __forceinline__ uint32_t item_of(uint32_t round, uint32_t wg, uint32_t n_wg) {
     return round * n_wg + ((round & 1u) ? n_wg - 1u - wg : wg);
 }
 
-__device__ __forceinline__ Span make_span(const ScanArgs &A, bool have, uint4 it, int wave, int lane) {
-    Span s;
-    s.lo = s.hi = s.t0 = 0;
-    s.nblk = 0;
-    s.nl_last = 64;
-    s.src = nullptr;
-    s.slot = kNoSlot;
+__device__ __forceinline__ Item make_item(const ScanArgs &A, bool have, uint4 d, int lane) {
+    Item it;
+    it.b = it.e = it.t0 = it.tail = 0;
+    it.nblk = 0;
+    it.nl_last = 64;
+    it.src = nullptr;
+    it.slot = kNoSlot;
     if (have) {
-        const uint64_t b = it.x, e = it.y, n = e - b;
-        s.slot = it.z;
-        // contiguous span per wave: a whole number of 16-step lane chunks, cut at 64-byte boundaries
-        const uint64_t a0 = (b + 15) & ~15ull;
-        const uint64_t per = ((n + kWaves - 1) / kWaves + 15) & ~15ull;
-        s.lo = wave ? min(a0 + per * wave, e) : b;
-        s.hi = min(a0 + per * (wave + 1), e);
-        s.t0 = min((s.lo + 15) & ~15ull, s.hi);
-        const uint64_t chunks = (s.hi - s.t0) / 16;
-        s.nblk = (uint32_t)(chunks / 64);
-        const uint32_t left = (uint32_t)(chunks % 64);
-        if (left >= kMinPartialLanes) {
-            s.nblk += 1;
-            s.nl_last = left;
-        }
-        // kDbgHotLoads (diagnostic): every span reads the same cache-resident megabyte
-        s.src = reinterpret_cast<const uint4 *>(A.steps + ((A.dbg & kDbgHotLoads) ? (s.t0 & 0x3FFF0u) : s.t0)) + lane * 4;
+        it.b = d.x;
+        it.e = d.y;
+        it.slot = d.z;
+        const uint64_t up = (it.b + 15) & ~(uint64_t)15;
+        it.t0 = up < it.e ? up : it.e;
+        const uint64_t chunks = (it.e - it.t0) / 16;
+        it.tail = it.t0 + chunks * 16;
+        it.nblk = (uint32_t)((chunks + 63) / 64);
+        it.nl_last = (chunks % 64) ? (uint32_t)(chunks % 64) : 64u;
+        // kDbgHotLoads (diagnostic): every item reads the same cache-resident megabyte
+        it.src = reinterpret_cast<const uint4 *>(A.steps + ((A.dbg & kDbgHotLoads) ? (it.t0 & 0x3FFF0u) : it.t0)) + lane * 4;
     }
-    return s;
+    return it;
 }
 
 // Streaming loads of steps.  Two blocks per wave (8 KiB; 128 KiB per CU) are kept in flight
@@ -547,6 +537,8 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     // layout: [bcur: kMaxWin][run queues: kWaves * kQCap][parked-claim queues: kWaves * 2 * kPCap][seen: n_words]
     uint32_t *bcur = lds;
     uint32_t *seen = lds + kMaxWin + kWaves * (kQCap + 2 * kPCap);
+    __shared__ uint32_t next_blk_cell;
+    uint32_t *next_blk = &next_blk_cell;  // the next block of the current item nobody has taken yet
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the span math on the scalar unit
     uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;  // this workgroup's sub-bucket of window 0
@@ -555,38 +547,46 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     w.pq = lds + kMaxWin + kWaves * kQCap + wave * (2 * kPCap);
     w.fill = w.pfill = 0;
     w.vm[0] = w.vm[1] = 0;
-    for (int k = 0; k < 6; ++k) w.tacc[k] = 0;
+    for (int k = 0; k < 8; ++k) w.tacc[k] = 0;
     w.tlast = (DBG && (A.dbg & kDbgTime)) ? __builtin_readcyclecounter() : 0ull;
     w.lane = lane;
     for (uint32_t i = threadIdx.x; i < kMaxWin; i += kThreads) bcur[i] = 0u;
     if (UNIQ)
         for (uint32_t i = threadIdx.x; i < A.n_words; i += kThreads) seen[i] = 0u;
+    if (threadIdx.x == 0) *next_blk = 2u * kWaves;
     __syncthreads();
 
     // The first blocks of an item are requested while the previous item is being wrapped up, and
     // its descriptor while the previous item is being walked.
     uint32_t round = 0;
     uint32_t job = item_of(0, blockIdx.x, gridDim.x);
-    Span sp = make_span(A, job < A.n_items, job < A.n_items ? A.items[job] : make_uint4(0u, 0u, 0u, 0u), wave, lane);
+    Item it = make_item(A, job < A.n_items, job < A.n_items ? A.items[job] : make_uint4(0u, 0u, 0u, 0u), lane);
+    uint32_t blk[2];  // the block each landing set holds (or will hold next)
     // lanes beyond a partial block's last one re-read lane 0's chunk: same instruction stream for all
 #define FGFA_BLOCK_PTR(j) \
-    (sp.src + (size_t)(j) * 256 - (((j) + 1 == sp.nblk && (uint32_t)lane >= sp.nl_last) ? lane * 4 : 0))
-#define FGFA_PRELOAD()                                                  \
-    do {                                                                \
-        if (sp.nblk > 0) load_block_async<0>(w, FGFA_BLOCK_PTR(0u));    \
-        if (sp.nblk > 1) load_block_async<1>(w, FGFA_BLOCK_PTR(1u));    \
+    (it.src + (size_t)(j) * 256 - (((j) + 1 == it.nblk && (uint32_t)lane >= it.nl_last) ? lane * 4 : 0))
+#define FGFA_PRELOAD()                                                      \
+    do {                                                                    \
+        blk[0] = (uint32_t)wave;                                            \
+        blk[1] = (uint32_t)wave + kWaves;                                   \
+        if (blk[0] < it.nblk) load_block_async<0>(w, FGFA_BLOCK_PTR(blk[0])); \
+        if (blk[1] < it.nblk) load_block_async<1>(w, FGFA_BLOCK_PTR(blk[1])); \
     } while (0)
-    // one block: wait for its data, re-issue its register set for the block two ahead, process it
-#define FGFA_BLOCK(SET, J)                                                                    \
-    if ((J) < sp.nblk) {                                                                      \
+    // one block: wait for its data, take the next free block for its register set, process it
+#define FGFA_BLOCK(SET)                                                                       \
+    if (blk[SET] < it.nblk) {                                                                 \
         tmark<DBG>(A, w, 4);                                                                  \
         wait_block<SET>(w);                                                                   \
         tmark<DBG>(A, w, 0);                                                                  \
         uint32_t a[16];                                                                       \
         take_block<SET>(a);                                                                   \
-        if ((J) + 2 < sp.nblk) load_block_async<SET>(w, FGFA_BLOCK_PTR((J) + 2));             \
+        const uint32_t mine_now = blk[SET];                                                   \
+        uint32_t got = 0;                                                                     \
+        if (lane == 0) got = atomicAdd(next_blk, 1u);                                         \
+        blk[SET] = __builtin_amdgcn_readfirstlane(got);                                       \
+        if (blk[SET] < it.nblk) load_block_async<SET>(w, FGFA_BLOCK_PTR(blk[SET]));           \
         if (!FGFA_SKIP(kDbgNoTiles)) {                                                        \
-            block16<UNIQ, DBG>(A, w, seen, bcur, mine, a, (J) + 1 == sp.nblk ? sp.nl_last : 64u, (J) == 0); \
+            block16<UNIQ, DBG>(A, w, seen, bcur, mine, a, mine_now + 1 == it.nblk ? it.nl_last : 64u); \
         } else if (a[0] == 0x3FFFFFFFu) {                                                     \
             *A.status = 2u;                                                                   \
         }                                                                                     \
@@ -596,40 +596,30 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     while (job < A.n_items) {
         const uint32_t next_job = item_of(++round, blockIdx.x, gridDim.x);
         const uint4 next_item = next_job < A.n_items ? A.items[next_job] : make_uint4(0u, 0u, 0u, 0u);  // needed after the barrier below
-        if (sp.lo < sp.hi) {
-#pragma unroll 1
-            for (uint32_t i = 0; i < sp.nblk; i += 2) {
-                FGFA_BLOCK(0, i)
-                FGFA_BLOCK(1, i + 1)
-            }
-            // what the blocks did not cover goes through narrow tiles, continuing the same walk
-            uint64_t t = sp.t0 + (uint64_t)(sp.nblk - (sp.nl_last < 64u)) * kBlockSteps + (sp.nl_last < 64u ? sp.nl_last * 16u : 0u);
-            bool fresh = sp.nblk == 0;
-            while (t < sp.hi) {
-                const uint32_t cnt = (uint32_t)min((uint64_t)64, sp.hi - t);
-                tile_narrow<UNIQ>(A, w, t, cnt, fresh);
-                fresh = false;
-                t += cnt;
-                drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);
-            }
-            // close the run still open at the end of the span
-            if (sp.t0 < sp.hi) enqueue(w, lane == 0, (w.rs << kRunBits) | (w.prev - w.rs));
-            // The few steps before the first 64-byte boundary are walked last and on their own
-            // (one more record per item): walking them first would make this wave wait for its
-            // freshly requested blocks together with these few steps.
-            if (sp.t0 > sp.lo) {
-                tile_narrow<UNIQ>(A, w, sp.lo, (uint32_t)(sp.t0 - sp.lo), true);
-                enqueue(w, lane == 0, (w.rs << kRunBits) | (w.prev - w.rs));
-            }
-            drain<UNIQ, DBG>(A, w, seen, bcur, mine, true);
+        // the few steps outside the blocks are walked on their own, by the first and the last wave
+        if (wave == 0 && it.t0 > it.b) {
+            tile_narrow<UNIQ>(A, w, it.b, (uint32_t)(it.t0 - it.b), true);
+            enqueue(w, lane == 0, (w.rs << kRunBits) | (w.prev - w.rs));
         }
+        if (wave == kWaves - 1 && it.e > it.tail) {
+            tile_narrow<UNIQ>(A, w, it.tail, (uint32_t)(it.e - it.tail), true);
+            enqueue(w, lane == 0, (w.rs << kRunBits) | (w.prev - w.rs));
+        }
+#pragma unroll 1
+        while (blk[0] < it.nblk || blk[1] < it.nblk) {
+            FGFA_BLOCK(0)
+            FGFA_BLOCK(1)
+        }
+        drain<UNIQ, DBG>(A, w, seen, bcur, mine, true);
         tmark<DBG>(A, w, 4);
         __syncthreads();  // every wave is done with this path's bitset
         tmark<DBG>(A, w, 1);
-        const uint32_t done_slot = sp.slot;
+        const uint32_t done_slot = it.slot;
         job = next_job;
-        sp = make_span(A, job < A.n_items, next_item, wave, lane);
+        it = make_item(A, job < A.n_items, next_item, lane);
         FGFA_PRELOAD();
+        tmark<DBG>(A, w, 6);
+        if (threadIdx.x == 0) *next_blk = 2u * kWaves;  // nobody takes a block before the barrier below
         if (UNIQ) {
             uint4 *sv = reinterpret_cast<uint4 *>(seen);
             if (done_slot != kNoSlot) {
@@ -639,14 +629,15 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
                 for (uint32_t i = threadIdx.x; i < A.n_words / 4; i += kThreads) dst[i] = sv[i];
             }
             for (uint32_t i = threadIdx.x; i < A.n_words / 4; i += kThreads) sv[i] = make_uint4(0u, 0u, 0u, 0u);
-            __syncthreads();  // the bitset is clean before the next path claims bits
         }
+        tmark<DBG>(A, w, 7);
+        __syncthreads();  // the bitset is clean, and the block counter set, before the next path starts
         tmark<DBG>(A, w, 5);
     }
     if (DBG && (A.dbg & kDbgTime) && lane == 0) {
         unsigned long long *acc = reinterpret_cast<unsigned long long *>(A.status + 8);
-        for (int k = 0; k < 6; ++k) atomicAdd(&acc[k], w.tacc[k]);
-        atomicAdd(&acc[6 + wave], w.tacc[1]);  // barrier wait by wave index
+        for (int k = 0; k < 8; ++k) atomicAdd(&acc[k], w.tacc[k]);
+        atomicAdd(&acc[8 + wave], w.tacc[1]);  // barrier wait by wave index
     }
 #undef FGFA_PRELOAD
 #undef FGFA_BLOCK
@@ -1003,15 +994,16 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
         return FLATGFA_ERR_HIP;
     }
     if (fp.dbg & kDbgTime) {  // diagnostic: where the waves of k_scan spend their cycles
-        unsigned long long acc[6 + kWaves] = {};
+        unsigned long long acc[8 + kWaves] = {};
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(acc, status + 8, sizeof acc, hipMemcpyDeviceToHost);
         (void)hipMemset(status + 8, 0, sizeof acc);
         const double waves = (double)grid * kWaves;
         fprintf(stderr, "k_scan cycles per wave (s_memtime ticks): wait_block %.0f  barrier_wait %.0f  passA+B %.0f  drain %.0f  other %.0f  next_item+wipe %.0f\n",
                 acc[0] / waves, acc[1] / waves, acc[2] / waves, acc[3] / waves, acc[4] / waves, acc[5] / waves);
+        fprintf(stderr, "  of next_item+wipe: make_item+preload %.0f  wipe %.0f (the rest is the second barrier)\n", acc[6] / waves, acc[7] / waves);
         fprintf(stderr, "  barrier wait by wave index:");
-        for (int k = 0; k < kWaves; ++k) fprintf(stderr, " %.0f", (double)acc[6 + k] / grid);
+        for (int k = 0; k < kWaves; ++k) fprintf(stderr, " %.0f", (double)acc[8 + k] / grid);
         fprintf(stderr, "\n");
     }
     return FLATGFA_OK;
