@@ -213,9 +213,49 @@ __device__ __forceinline__ void drain_partial(const ScanArgs &A, Wave &w, uint32
     }
 }
 
+// Two full chunks at once, two runs per lane: the same as emit_chunk twice, but with all four LDS
+// round trips (two claims, two cursors) in flight together, so that a wave waits once instead of
+// twice for every 128 runs.
+template <bool UNIQ, bool DBG>
+__device__ __forceinline__ void emit_pair(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
+                                          uint32_t rec0, uint32_t rec1) {
+    const uint32_t id0 = rec0 >> kRunBits, l0 = rec0 & (kRunSpan - 1), win0 = id0 >> kWinBits;
+    const uint32_t id1 = rec1 >> kRunBits, l1 = rec1 & (kRunSpan - 1), win1 = id1 >> kWinBits;
+    uint32_t kind0 = 0, kind1 = 0, pos0, pos1;
+    if (UNIQ && !FGFA_SKIP(kDbgNoBitset)) {
+        const uint32_t mask0 = (0xFFFFFFFFu >> (31u - l0)) << (id0 & 31u);
+        const uint32_t mask1 = (0xFFFFFFFFu >> (31u - l1)) << (id1 & 31u);
+        const uint32_t old0 = atomicOr(&seen[id0 >> 5], mask0);  // LDS operations of one wave execute in order,
+        const uint32_t old1 = atomicOr(&seen[id1 >> 5], mask1);  // so a lane's second claim sees its first
+        pos0 = atomicAdd(&bcur[win0], 1u);
+        pos1 = atomicAdd(&bcur[win1], 1u);
+        const uint32_t nb0 = mask0 & ~old0, nb1 = mask1 & ~old1;
+        kind0 = (nb0 == mask0) ? 2u : 0u;
+        kind1 = (nb1 == mask1) ? 2u : 0u;
+        push_partial(w, (nb0 != mask0) & (nb0 != 0u), id0 >> 5, nb0);
+        drain_partial<DBG>(A, w, bcur, mine, false);  // keeps the parked-claim queue within its 96 entries
+        push_partial(w, (nb1 != mask1) & (nb1 != 0u), id1 >> 5, nb1);
+    } else {
+        pos0 = atomicAdd(&bcur[win0], 1u);
+        pos1 = atomicAdd(&bcur[win1], 1u);
+    }
+    const bool o0 = put<DBG>(A, w, mine, true, pos0, id0, l0, kind0);
+    const bool o1 = put<DBG>(A, w, mine, true, pos1, id1, l1, kind1);
+    if (__builtin_amdgcn_ballot_w64(o0 | o1)) {  // rare: a sub-bucket is full
+        if (o0) overflow_record(A, id0, l0 + 1, kind0);
+        if (o1) overflow_record(A, id1, l1 + 1, kind1);
+    }
+}
+
 // Emit the newest 64 queued runs while at least 64 are queued (all of them when `all`).
 template <bool UNIQ, bool DBG>
 __device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine, bool all) {
+    while (w.fill >= 128u) {
+        w.fill -= 128u;
+        const uint32_t rec0 = w.q[w.fill + w.lane], rec1 = w.q[w.fill + 64u + w.lane];
+        emit_pair<UNIQ, DBG>(A, w, seen, bcur, mine, rec0, rec1);
+        if (UNIQ) drain_partial<DBG>(A, w, bcur, mine, false);
+    }
     while (w.fill >= 64u || (all && w.fill)) {
         const uint32_t n = min(w.fill, 64u);
         w.fill -= n;
