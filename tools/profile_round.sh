@@ -11,13 +11,13 @@ for w in cfgL cfgL-uniform cfgL-short cfgL-fewlong cfgS; do
   python3 bench.py --steps 20 --warmup 3 --workload $w 2>/dev/null | tail -1 > $OUT/${TAG}_bench_$w.json
 done
 # 2. kernel trace + stats of the same command (csv)
-rm -rf $OUT/_trace; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_trace -o t -- python3 $CMD --no-cpu-baseline > $OUT/_trace.log 2>&1
+rm -rf $OUT/_trace; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_trace -o t -- python3 $CMD --no-cpu-baseline --no-extras > $OUT/_trace.log 2>&1
 f=$(find $OUT/_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_rocprofv3_kernel_stats.csv
 # 3. PMC passes (separate runs; --kernel-trace only, as gpurun requires)
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE"; do
   tag=$(echo $set | cut -d' ' -f1)
   rm -rf $OUT/_pmc_$tag
-  rocprofv3 --kernel-trace --pmc $set -d $OUT/_pmc_$tag -o p -- python3 $CMD --no-cpu-baseline --no-verify > $OUT/_pmc_$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set -d $OUT/_pmc_$tag -o p -- python3 $CMD --no-cpu-baseline --no-verify --no-extras > $OUT/_pmc_$tag.log 2>&1
 done
 python3 - <<PY > $OUT/${TAG}_pmc_summary.txt
 import sqlite3,glob,re
