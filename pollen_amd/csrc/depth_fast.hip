@@ -53,6 +53,10 @@ constexpr uint32_t kWinWords = kWin / 32;
 constexpr uint32_t kMaxWin = 256;  // LDS cursor table entries (the bitset limit keeps n_win below this)
 constexpr uint32_t kLdsLimit = 160 * 1024;
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+// The short-path kernel (k_scan_short): every wave walks whole short paths on its own.
+constexpr uint32_t kShortMax = 2048;      // steps; longer paths go through k_scan
+constexpr uint32_t kDummyBase = 1u << 20;  // ids from here up stand in for steps outside the path (never emitted)
+constexpr uint32_t kTabEntries = 512;      // per-wave hash set of (bitset word index + 1, bits) pairs
 constexpr int kAccThreads = 1024;
 constexpr uint32_t kMaxSlots = 1024;  // sub-buckets per window (= workgroups of k_scan) k_accum can stage
 
@@ -63,7 +67,10 @@ constexpr uint32_t kDbgNoStore = 1, kDbgNoBitset = 4, kDbgNoTiles = 8, kDbgHotLo
 
 struct ScanArgs {
     const uint32_t *steps;
-    const uint4 *items;  // work queue, longest first: {begin, end, piece slot or kNoSlot, unused}
+    uint4 *items;        // work items, longest first: {begin, end, piece slot or kNoSlot, path}; room behind the
+                         // first n_items for the short paths k_scan_short hands back (counted in *work_counter)
+    const uint4 *short_items;  // paths of at most kShortMax steps, longest first
+    uint32_t n_short;
     uint32_t *piece_bits;  // [n_piece_slots][n_words]: "seen" bitsets of the pieces of split paths
     uint32_t n_items, n_segs, n_win, n_words, n_slots;
     uint32_t *work_counter;
@@ -170,14 +177,38 @@ __device__ __forceinline__ void push_partial(Wave &w, bool e, uint32_t word, uin
 // to add.  The rare claim that is partly new is parked, as (word index, new bits), on a second
 // queue; that queue is turned into uniq records 32..64 entries at a time, so its bit-stretch
 // loop runs with most lanes busy instead of once per chunk for a lane or two.
-template <bool UNIQ, bool DBG>
+// The short-path kernel's claim: the path's "seen" words live in a small per-wave hash set (open
+// addressing, keyed by word index + 1) instead of a bitset over all segments.  A path is only
+// walked this way when it has at most kQCap runs, so the set never holds more than kQCap of
+// its kTabEntries entries.
+__device__ __forceinline__ uint32_t claim_hashed(uint32_t *tab, bool valid, uint32_t word, uint32_t mask) {
+    uint32_t h = (word * 0x9E3779B1u) >> 23;  // 9 bits
+    bool todo = valid;
+    uint32_t old = 0;
+    while (__builtin_amdgcn_ballot_w64(todo)) {
+        if (todo) {
+            uint32_t *e = tab + 2u * h;
+            const uint32_t k = atomicCAS(e, 0u, word + 1u);
+            if (k == 0u || k == word + 1u) {
+                old = atomicOr(e + 1, mask);
+                todo = false;
+            } else {
+                h = (h + 1u) & (kTabEntries - 1u);
+            }
+        }
+    }
+    return old;
+}
+
+template <bool UNIQ, bool DBG, bool SHORT = false>
 __device__ __forceinline__ void emit_chunk(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
                                            bool valid, uint32_t rec) {
     const uint32_t id = rec >> kRunBits, lenm1 = rec & (kRunSpan - 1), win = id >> kWinBits;
+    if (SHORT) valid = valid && id < kDummyBase;  // runs of placeholder ids are dropped here
     uint32_t kind = 0, pos;
     if (UNIQ && !FGFA_SKIP(kDbgNoBitset)) {
         const uint32_t mask = valid ? (0xFFFFFFFFu >> (31u - lenm1)) << (id & 31u) : 0u;
-        const uint32_t old = mask ? atomicOr(&seen[id >> 5], mask) : 0u;
+        const uint32_t old = SHORT ? claim_hashed(seen, valid, id >> 5, mask) : (mask ? atomicOr(&seen[id >> 5], mask) : 0u);
         pos = valid ? atomicAdd(&bcur[win], 1u) : 0u;  // both LDS round trips in flight together
         const uint32_t nb = mask & ~old;
         kind = (nb == mask) ? 2u : 0u;
@@ -248,9 +279,9 @@ __device__ __forceinline__ void emit_pair(const ScanArgs &A, Wave &w, uint32_t *
 }
 
 // Emit the newest 64 queued runs while at least 64 are queued (all of them when `all`).
-template <bool UNIQ, bool DBG>
+template <bool UNIQ, bool DBG, bool SHORT = false>
 __device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine, bool all) {
-    while (w.fill >= 128u) {
+    while (!SHORT && w.fill >= 128u) {
         w.fill -= 128u;
         const uint32_t rec0 = w.q[w.fill + w.lane], rec1 = w.q[w.fill + 64u + w.lane];
         emit_pair<UNIQ, DBG>(A, w, seen, bcur, mine, rec0, rec1);
@@ -261,7 +292,7 @@ __device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen
         w.fill -= n;
         const bool valid = (uint32_t)w.lane < n;
         const uint32_t rec = valid ? w.q[w.fill + w.lane] : 0u;
-        emit_chunk<UNIQ, DBG>(A, w, seen, bcur, mine, valid, rec);
+        emit_chunk<UNIQ, DBG, SHORT>(A, w, seen, bcur, mine, valid, rec);
         if (UNIQ) drain_partial<DBG>(A, w, bcur, mine, false);
     }
     if (UNIQ && all) drain_partial<DBG>(A, w, bcur, mine, true);
@@ -349,17 +380,31 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
 // ballot + ds_bpermute per block) and patched into the lane's first queue entry.
 // When the block has more starts than the queue has room for (dense: few steps continue a run),
 // the steps are queued four at a time with the queue emitted in between.
-template <bool UNIQ, bool DBG>
-__device__ __forceinline__ void block16(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
-                                        uint32_t (&a)[16], uint32_t nl) {
+// In the short-path kernel (SHORT) a block may reach beyond its path at either end (it starts and
+// ends on 64-byte boundaries): steps at block-relative positions outside [rel_lo, rel_hi) get
+// consecutive placeholder ids, whose runs are dropped when emitted.  There the block's runs are
+// only queued, never emitted; the return value says whether they fitted the queue.
+template <bool UNIQ, bool DBG, bool SHORT = false>
+__device__ __forceinline__ bool block16(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
+                                        uint32_t (&a)[16], uint32_t nl, uint32_t rel_lo = 0, uint32_t rel_hi = 1024,
+                                        uint32_t blk_pos = 0) {
     const bool active = (uint32_t)w.lane < nl;
     const bool last_lane = (uint32_t)w.lane + 1u == nl;
-    uint32_t mx = a[0];
+    if (SHORT && (rel_lo > 0u || rel_hi < 16u * nl)) {
 #pragma unroll
-    for (int k = 1; k < 16; ++k) mx = max(mx, a[k]);
-    if (mx >= A.n_segs) {
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t rel = 16u * (uint32_t)w.lane + (uint32_t)k;
+            const bool inside = rel >= rel_lo && rel < rel_hi;
+            a[k] = inside ? clamp_id(A, a[k]) : kDummyBase + ((blk_pos + rel) & 0xFFFFu);
+        }
+    } else {
+        uint32_t mx = a[0];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) a[k] = clamp_id(A, a[k]);
+        for (int k = 1; k < 16; ++k) mx = max(mx, a[k]);
+        if (mx >= A.n_segs) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k] = clamp_id(A, a[k]);
+        }
     }
     // a block is walked on its own: its first step opens a run, its last step closes one
     const uint32_t first = __builtin_amdgcn_readfirstlane(a[0]);
@@ -398,10 +443,12 @@ __device__ __forceinline__ void block16(const ScanArgs &A, Wave &w, uint32_t *se
         }
         if (last_lane) *reinterpret_cast<lds_u32 *>((uintptr_t)p) = (cur << kRunBits) | (a[15] - cur);
         w.fill += total;
+        if (SHORT) return true;
         tmark<DBG>(A, w, 2);
         drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);
         tmark<DBG>(A, w, 3);
     } else {
+        if (SHORT) return false;
         bool st[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -436,6 +483,7 @@ __device__ __forceinline__ void block16(const ScanArgs &A, Wave &w, uint32_t *se
         }
         enqueue(w, last_lane, (cur << kRunBits) | (a[15] - cur));
     }
+    return true;
 }
 
 // Up to 64 consecutive steps, one per lane (heads, tails and short spans).
@@ -590,17 +638,19 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     for (int k = 0; k < 8; ++k) w.tacc[k] = 0;
     w.tlast = (DBG && (A.dbg & kDbgTime)) ? __builtin_readcyclecounter() : 0ull;
     w.lane = lane;
-    for (uint32_t i = threadIdx.x; i < kMaxWin; i += kThreads) bcur[i] = 0u;
+    // the cursors continue where k_scan_short (if it ran) left this workgroup's sub-buckets
+    for (uint32_t i = threadIdx.x; i < kMaxWin; i += kThreads) bcur[i] = i < A.n_win ? A.counts[(size_t)i * A.n_slots + blockIdx.x] : 0u;
     if (UNIQ)
         for (uint32_t i = threadIdx.x; i < A.n_words; i += kThreads) seen[i] = 0u;
     if (threadIdx.x == 0) *next_blk = 2u * kWaves;
     __syncthreads();
+    const uint32_t n_items = A.n_items + (A.n_short ? *A.work_counter : 0u);  // plus what k_scan_short handed back
 
     // The first blocks of an item are requested while the previous item is being wrapped up, and
     // its descriptor while the previous item is being walked.
     uint32_t round = 0;
     uint32_t job = item_of(0, blockIdx.x, gridDim.x);
-    Item it = make_item(A, job < A.n_items, job < A.n_items ? A.items[job] : make_uint4(0u, 0u, 0u, 0u), lane);
+    Item it = make_item(A, job < n_items, job < n_items ? A.items[job] : make_uint4(0u, 0u, 0u, 0u), lane);
     uint32_t blk[2];  // the block each landing set holds (or will hold next)
     // lanes beyond a partial block's last one re-read lane 0's chunk: same instruction stream for all
 #define FGFA_BLOCK_PTR(j) \
@@ -633,9 +683,9 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     }
     FGFA_PRELOAD();
 
-    while (job < A.n_items) {
+    while (job < n_items) {
         const uint32_t next_job = item_of(++round, blockIdx.x, gridDim.x);
-        const uint4 next_item = next_job < A.n_items ? A.items[next_job] : make_uint4(0u, 0u, 0u, 0u);  // needed after the barrier below
+        const uint4 next_item = next_job < n_items ? A.items[next_job] : make_uint4(0u, 0u, 0u, 0u);  // needed after the barrier below
         // the few steps outside the blocks are walked on their own, by the first and the last wave
         if (wave == 0 && it.t0 > it.b) {
             tile_narrow<UNIQ>(A, w, it.b, (uint32_t)(it.t0 - it.b), true);
@@ -656,7 +706,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         tmark<DBG>(A, w, 1);
         const uint32_t done_slot = it.slot;
         job = next_job;
-        it = make_item(A, job < A.n_items, next_item, lane);
+        it = make_item(A, job < n_items, next_item, lane);
         FGFA_PRELOAD();
         tmark<DBG>(A, w, 6);
         if (threadIdx.x == 0) *next_blk = 2u * kWaves;  // nobody takes a block before the barrier below
@@ -683,6 +733,135 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
 #undef FGFA_BLOCK
 #undef FGFA_BLOCK_PTR
     // publish how many records this workgroup left in each window's sub-bucket
+    __syncthreads();
+    for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads)
+        A.counts[(size_t)wdw * A.n_slots + blockIdx.x] = bcur[wdw];
+}
+
+// ------------------------------------------------------- pass 1, short paths ---
+//
+// k_scan gives a whole workgroup to one path at a time, because the path's "seen" bitset fills the
+// CU's LDS; a path of a thousand steps then costs two barriers, a 125 KB wipe and an exposed
+// memory latency for one block of work.  Here every wave walks its own short paths: blocks as in
+// k_scan (block16), but the runs of a path are only queued; when the path is complete they are
+// emitted against a per-wave hash set of bitset words.  A path with more runs than the queue
+// holds is handed back to k_scan (appended to its item list), which runs afterwards.
+
+struct ShortBlk {
+    uint32_t b, e;     // the path's steps
+    uint32_t pos;      // first step of the block (a multiple of 16)
+    uint32_t nl;       // lanes holding steps
+    bool last, valid;  // last block of its path; there is a block at all
+};
+
+// The blocks of this wave's paths, in order.  The next path's descriptor is always requested one
+// path ahead of its use.
+struct ShortStream {
+    uint32_t gi, stride, b, e, pos, end, nb, ne;
+};
+__device__ __forceinline__ void stream_fetch(const ScanArgs &A, ShortStream &g) {  // descriptor of path gi + stride
+    const uint32_t nx = g.gi + g.stride;
+    const uint4 d = nx < A.n_short && nx >= g.gi ? A.short_items[nx] : make_uint4(0u, 0u, 0u, 0u);
+    g.nb = d.x;
+    g.ne = d.y;
+}
+__device__ __forceinline__ ShortBlk stream_next(const ScanArgs &A, ShortStream &g) {
+    ShortBlk k;
+    k.valid = g.gi < A.n_short;
+    k.b = g.b;
+    k.e = g.e;
+    k.pos = g.pos;
+    const uint32_t left = k.valid ? (g.end - g.pos) / 16u : 0u;
+    k.nl = min(left, 64u);
+    k.last = left <= 64u;
+    g.pos += 1024u;
+    if (k.valid && k.last) {
+        g.gi = (g.gi + g.stride >= g.gi) ? g.gi + g.stride : 0xFFFFFFFFu;
+        g.b = g.nb;
+        g.e = g.ne;
+        g.pos = g.b & ~15u;
+        g.end = (g.e + 15u) & ~15u;
+        stream_fetch(A, g);
+    }
+    return k;
+}
+
+template <bool UNIQ>
+__global__ __launch_bounds__(kThreads) void k_scan_short(const ScanArgs A) {
+    extern __shared__ uint32_t lds[];
+    // layout: [bcur: kMaxWin][run queues: kWaves * kQCap][parked-claim queues: kWaves * 2 * kPCap][hash sets: kWaves * 2 * kTabEntries]
+    uint32_t *bcur = lds;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *tab = lds + kMaxWin + kWaves * (kQCap + 2 * kPCap) + wave * (2 * kTabEntries);
+    uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;
+    Wave w;
+    w.q = lds + kMaxWin + wave * kQCap;
+    w.pq = lds + kMaxWin + kWaves * kQCap + wave * (2 * kPCap);
+    w.fill = w.pfill = 0;
+    w.vm[0] = w.vm[1] = 0;
+    w.tlast = 0;
+    w.lane = lane;
+    for (uint32_t i = threadIdx.x; i < kMaxWin; i += kThreads) bcur[i] = i < A.n_win ? A.counts[(size_t)i * A.n_slots + blockIdx.x] : 0u;
+    if (UNIQ)
+        for (uint32_t i = lane; i < kTabEntries / 2; i += 64) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+
+    ShortStream g;
+    g.stride = gridDim.x * kWaves;
+    g.gi = blockIdx.x * kWaves + wave;
+    {
+        const uint4 d = g.gi < A.n_short ? A.short_items[g.gi] : make_uint4(0u, 0u, 0u, 0u);
+        g.b = d.x;
+        g.e = d.y;
+        g.pos = g.b & ~15u;
+        g.end = (g.e + 15u) & ~15u;
+        stream_fetch(A, g);
+    }
+    ShortBlk slot[2];
+    bool handed_back = false;  // the current path did not fit the run queue
+    const uint4 *steps4 = reinterpret_cast<const uint4 *>(A.steps);
+    // lanes beyond the last one holding steps re-read lane 0's chunk
+#define FGFA_SPTR(K) (steps4 + (size_t)(K).pos / 4 + ((uint32_t)lane < (K).nl ? lane * 4 : 0))
+    slot[0] = stream_next(A, g);
+    if (slot[0].valid) load_block_async<0>(w, FGFA_SPTR(slot[0]));
+    slot[1] = stream_next(A, g);
+    if (slot[1].valid) load_block_async<1>(w, FGFA_SPTR(slot[1]));
+#define FGFA_SBLOCK(SET)                                                                                \
+    if (slot[SET].valid) {                                                                              \
+        wait_block<SET>(w);                                                                             \
+        uint32_t a[16];                                                                                 \
+        take_block<SET>(a);                                                                             \
+        const ShortBlk cur = slot[SET];                                                                 \
+        slot[SET] = stream_next(A, g);                                                                  \
+        if (slot[SET].valid) load_block_async<SET>(w, FGFA_SPTR(slot[SET]));                            \
+        if (!handed_back) {                                                                             \
+            const uint32_t lo = cur.b > cur.pos ? cur.b - cur.pos : 0u;                                 \
+            const uint32_t hi = cur.e - cur.pos < 1024u ? cur.e - cur.pos : 1024u;                      \
+            if (!block16<UNIQ, false, true>(A, w, tab, bcur, mine, a, cur.nl, lo, hi, cur.pos)) {       \
+                handed_back = true;                                                                     \
+                w.fill = 0;                                                                             \
+            }                                                                                           \
+        }                                                                                               \
+        if (cur.last) {                                                                                 \
+            if (handed_back) {                                                                          \
+                if (lane == 0) A.items[A.n_items + atomicAdd(A.work_counter, 1u)] = make_uint4(cur.b, cur.e, kNoSlot, 0u); \
+                handed_back = false;                                                                    \
+            } else {                                                                                    \
+                drain<UNIQ, false, true>(A, w, tab, bcur, mine, true);                                  \
+                if (UNIQ)                                                                               \
+                    for (uint32_t i = lane; i < kTabEntries / 2; i += 64)                               \
+                        reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0u, 0u, 0u, 0u);                 \
+            }                                                                                           \
+        }                                                                                               \
+    }
+#pragma unroll 1
+    while (slot[0].valid || slot[1].valid) {
+        FGFA_SBLOCK(0)
+        FGFA_SBLOCK(1)
+    }
+#undef FGFA_SBLOCK
+#undef FGFA_SPTR
     __syncthreads();
     for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads)
         A.counts[(size_t)wdw * A.n_slots + blockIdx.x] = bcur[wdw];
@@ -945,13 +1124,19 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     uint64_t piece = std::max<uint64_t>(65536, (g.n_steps + 2ull * fp->n_cus - 1) / (2ull * fp->n_cus));
     if (const char *forced = getenv("FLATGFA_PIECE_STEPS")) piece = std::max<uint64_t>(256, strtoull(forced, nullptr, 10));
     piece = (piece + 255) & ~255ull;
-    std::vector<uint4> items;
+    // Paths of at most `short_max` steps are walked by single waves (k_scan_short), unless their
+    // last block would reach beyond the step array.
+    uint64_t short_max = fp->dbg ? 0 : kShortMax;  // the ablation switches are k_scan's
+    if (const char *forced = getenv("FLATGFA_SHORT_MAX")) short_max = std::min<uint64_t>(kShortMax, strtoull(forced, nullptr, 10));
+    std::vector<uint4> items, short_items;
     std::vector<uint2> split;
     uint32_t n_piece_slots = 0;
     for (uint32_t p = 0; p < g.n_paths; ++p) {
         const uint64_t b = hb[p], e = he[p], n = e - b;
         if (n == 0) continue;
-        if (n <= piece) {
+        if (n <= short_max && ((e + 15) & ~15ull) <= g.n_steps) {
+            short_items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
+        } else if (n <= piece) {
             items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
         } else {
             const uint32_t k = (uint32_t)((n + piece - 1) / piece);
@@ -963,10 +1148,13 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
             n_piece_slots += k;
         }
     }
-    std::stable_sort(items.begin(), items.end(), [](const uint4 &a, const uint4 &b) { return a.y - a.x > b.y - b.x; });
+    const auto longer = [](const uint4 &a, const uint4 &b) { return a.y - a.x > b.y - b.x; };
+    std::stable_sort(items.begin(), items.end(), longer);
+    std::stable_sort(short_items.begin(), short_items.end(), longer);
     fp->n_items = (uint32_t)items.size();
+    fp->n_short = (uint32_t)short_items.size();
     fp->n_split = (uint32_t)split.size();
-    if (items.empty()) return true;
+    if (items.empty() && short_items.empty()) return true;
     FAST_TRY(hipMalloc(&fp->counts, slots * 4));
     FAST_TRY(hipMemset(fp->counts, 0, slots * 4));
     FAST_TRY(hipMalloc(&fp->buckets, (slots + fp->n_slots) * cap * 4));
@@ -976,8 +1164,15 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     FAST_TRY(hipMemset(fp->ovf_u, 0, ((size_t)g.n_segs + 1) * 4));
     FAST_TRY(hipMalloc(&fp->ovf_flag, (size_t)n_win * 4));
     FAST_TRY(hipMemset(fp->ovf_flag, 0, (size_t)n_win * 4));
-    FAST_TRY(hipMalloc(&fp->items, items.size() * sizeof(uint4)));
-    FAST_TRY(hipMemcpy(fp->items, items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    FAST_TRY(hipMalloc(&fp->items, (items.size() + short_items.size() + 1) * sizeof(uint4)));
+    if (!items.empty()) FAST_TRY(hipMemcpy(fp->items, items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    if (!short_items.empty()) {
+        FAST_TRY(hipMalloc(&fp->short_items, short_items.size() * sizeof(uint4)));
+        FAST_TRY(hipMemcpy(fp->short_items, short_items.data(), short_items.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    }
+    fp->lds_bytes_short = (kMaxWin + kWaves * (kQCap + 2 * kPCap + 2 * kTabEntries)) * 4u;
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan_short<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_short));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan_short<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_short));
     if (n_piece_slots) {
         FAST_TRY(hipMalloc(&fp->piece_bits, (size_t)n_piece_slots * n_words * 4));
         FAST_TRY(hipMalloc(&fp->split, split.size() * sizeof(uint2)));
@@ -994,7 +1189,7 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
 
 void fast_plan_destroy(FastPlan *fp) {
     for (void *p : {(void *)fp->counts, (void *)fp->buckets, (void *)fp->ovf_d, (void *)fp->ovf_u, (void *)fp->ovf_flag,
-                    (void *)fp->items, (void *)fp->piece_bits, (void *)fp->split, (void *)fp->work_counter})
+                    (void *)fp->items, (void *)fp->short_items, (void *)fp->piece_bits, (void *)fp->split, (void *)fp->work_counter})
         if (p) (void)hipFree(p);
     *fp = FastPlan();
 }
@@ -1002,13 +1197,21 @@ void fast_plan_destroy(FastPlan *fp) {
 int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
                    uint32_t *status, hipStream_t stream) {
     const uint32_t stride = fp.n_slots * fp.cap;
-    ScanArgs sa{g.steps, reinterpret_cast<const uint4 *>(fp.items), fp.piece_bits, fp.n_items, g.n_segs, fp.n_win,
+    ScanArgs sa{g.steps, reinterpret_cast<uint4 *>(fp.items), reinterpret_cast<const uint4 *>(fp.short_items), fp.n_short,
+                fp.piece_bits, fp.n_items, g.n_segs, fp.n_win,
                 uniq_out ? fp.n_words : 0u, fp.n_slots, fp.work_counter, fp.counts, fp.buckets, fp.cap, stride,
                 fp.n_win * stride, fp.ovf_d, fp.ovf_u, fp.ovf_flag, status, fp.dbg};
     AccArgs aa{g.n_segs, fp.n_win, fp.n_slots, fp.cap, fp.piece_bits, reinterpret_cast<const uint2 *>(fp.split),
                uniq_out ? fp.n_split : 0u, fp.n_words, fp.counts, fp.buckets, fp.ovf_d, fp.ovf_u, fp.ovf_flag,
                fp.work_counter, depth_out, uniq_out};
-    const uint32_t grid = std::min<uint32_t>(fp.n_items, fp.n_slots);  // one persistent workgroup per CU
+    // one persistent workgroup per CU; k_scan may be handed short paths back, so it gets a full grid when there are any
+    const uint32_t grid = fp.n_short ? fp.n_slots : std::min<uint32_t>(fp.n_items, fp.n_slots);
+    if (fp.n_short) {
+        const uint32_t sgrid = std::min<uint32_t>((fp.n_short + kWaves - 1) / kWaves, fp.n_slots);
+        ProfScope ps(uniq_out ? "k_scan_short<uniq>" : "k_scan_short<depth>", stream);
+        if (uniq_out) hipLaunchKernelGGL(k_scan_short<true>, dim3(sgrid), dim3(kThreads), fp.lds_bytes_short, stream, sa);
+        else hipLaunchKernelGGL(k_scan_short<false>, dim3(sgrid), dim3(kThreads), fp.lds_bytes_short, stream, sa);
+    }
     if (uniq_out) {
         {
             ProfScope ps("k_scan<uniq>", stream);

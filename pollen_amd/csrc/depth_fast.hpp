@@ -22,12 +22,16 @@ struct FastPlan {
     int *ovf_d = nullptr;          // int[n_segs + 1], zero between calls
     int *ovf_u = nullptr;
     uint32_t *ovf_flag = nullptr;  // u32[n_win]
-    void *items = nullptr;         // uint4[n_items] work queue: whole paths and pieces of long paths
+    void *items = nullptr;         // uint4[n_items + n_short] whole paths and pieces of long paths, longest first,
+                                   // with room for the short paths k_scan_short hands back
     uint32_t n_items = 0;
+    void *short_items = nullptr;   // uint4[n_short] paths every wave walks on its own (k_scan_short)
+    uint32_t n_short = 0;
+    uint32_t lds_bytes_short = 0;
     uint32_t *piece_bits = nullptr;  // bitsets left behind by the pieces of split paths
     void *split = nullptr;         // uint2[n_split] {first piece slot, pieces} per split path
     uint32_t n_split = 0;
-    uint32_t *work_counter = nullptr;
+    uint32_t *work_counter = nullptr;  // how many short paths were handed back in this call (pass 2 resets)
 };
 
 // Decides eligibility (the per-path bitset must fit one CU's 160 KiB LDS, steps must be

@@ -18,14 +18,19 @@ pytestmark = pytest.mark.gpu
 FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
-@pytest.fixture(params=["auto", "atomic", "tinycap", "pieces"])
+@pytest.fixture(params=["auto", "atomic", "tinycap", "pieces", "noshort"])
 def device_path(request, monkeypatch):
-    """Runs a test once per device path: the bucketed two-kernel path (default), the simple
-    global-atomic kernels, and the bucketed path with 8-record buckets so that nearly every
-    record takes the overflow route.  The variables are read when a graph becomes resident."""
+    """Runs a test once per device path: the bucketed path (default: short paths walked by single
+    waves, k_scan_short; the rest by whole workgroups, k_scan), the simple global-atomic kernels,
+    the bucketed path with 8-record buckets so that nearly every record takes the overflow route,
+    long paths cut into 512-step pieces, and k_scan alone (no short-path kernel).  The variables
+    are read when a graph becomes resident."""
     monkeypatch.delenv("FLATGFA_DEPTH_PATH", raising=False)
     monkeypatch.delenv("FLATGFA_BUCKET_CAP", raising=False)
     monkeypatch.delenv("FLATGFA_PIECE_STEPS", raising=False)
+    monkeypatch.delenv("FLATGFA_SHORT_MAX", raising=False)
+    if request.param == "noshort":
+        monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
     if request.param == "pieces":   # every path longer than 512 steps is scanned as several pieces + k_merge
         monkeypatch.setenv("FLATGFA_PIECE_STEPS", "512")
     if request.param == "atomic":
@@ -138,6 +143,10 @@ SHAPES = [
     (11, 2_500_000, 6, 30_000, "uniform"),   # three windows
     (12, 50_000, 3, 700_001, "pangenome"),   # few long paths: split into pieces by default
     (13, 3_000, 2, 400_000, "uniform"),      # pieces of one path revisit the same segments heavily
+    (14, 200_000, 5000, 1000, "pangenome"),  # short paths, one block each (k_scan_short)
+    (15, 50_000, 300, 2048, "uniform"),      # short paths with too many runs: handed back to k_scan
+    (16, 70_000, 900, 1500, "pangenome"),    # two blocks per short path
+    (17, 999, 4000, 17, "pangenome"),        # paths shorter than a lane chunk, every alignment
 ]
 
 
