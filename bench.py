@@ -35,6 +35,7 @@ WORKLOADS = {
     "cfgL-uniform": (1_000_000, 1000, 100_000, "uniform"),
     "cfgL-short": (1_000_000, 100_000, 1000, "pangenome"),
     "cfgL-fewlong": (1_000_000, 100, 1_000_000, "pangenome"),
+    "cfgL-4Mseg": (4_000_000, 1000, 100_000, "pangenome"),   # beyond the LDS bitset: the atomic kernels
     "cfgS": (10_000, 100, 10_000, "pangenome"),
 }
 

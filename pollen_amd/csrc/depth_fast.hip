@@ -1,28 +1,31 @@
-// The bucketed node-depth path for gfx950: two kernels, no global atomics on the data path.
+// The bucketed node-depth path for gfx950 (seg_depth_with_uniq / seg_depth, ops/depth.rs:15-56):
+// three kernels, no global atomics on the data path.  DESIGN.md section 3 is the long version.
 //
-//   k_scan   (pass 1)  persistent workgroups (one per CU), each pulling whole paths from a
-//            queue.  Every wave streams a contiguous span of the path's steps with 16-byte
-//            loads (4 handles per lane, 4 tiles in flight), detects maximal +1 runs of segment
-//            ids, and turns each run into ONE range record (start id, length) instead of
-//            `length` histogram updates.  For unique depth the path's "seen" bitset of
-//            ops/depth.rs:23-34 lives in LDS (1 bit per segment); when the path ends, the
-//            set-bit runs of the bitset become range records of a second kind and the bitset
-//            is left zeroed.  A record goes straight to the bucket of its 4096-segment window:
-//            buckets are split into one private sub-bucket per workgroup, so the append cursor
-//            is an LDS counter and no global atomic is needed; each workgroup's writes stay on
-//            its own XCD's L2 until the line is full.
-//   k_accum  (pass 2)  one workgroup per window: applies the window's records as +1/-1 pairs
-//            to two LDS difference arrays, prefix-sums them, and writes depth/uniq with
-//            coalesced 16-byte stores.  It also zeroes the counts it consumed, so the scratch
-//            is clean for the next call without any memset.
+//   k_scan        (pass 1)  one persistent workgroup per CU walks one path (or one piece of a
+//                 long path) at a time.  The path's steps are cut into blocks of 1024; a wave takes
+//                 a block, every lane owns sixteen consecutive steps (its own 64 bytes), finds
+//                 the maximal +1 runs of segment ids among them, and queues each run as ONE range
+//                 record (start id, length) instead of `length` histogram updates.  For unique
+//                 depth the path's "seen" bitset of depth.rs:23-34 lives in LDS (1 bit per
+//                 segment): a queued run claims its bits with one returning LDS OR (runs are cut
+//                 at multiples of 32), and the bits that were clear are what the path touches for
+//                 the first time.  A record goes to the bucket of its 4096-segment window; buckets
+//                 are split into one private sub-bucket per workgroup, so the append cursor is an
+//                 LDS counter and a workgroup's partial lines stay in its own XCD's L2.
+//   k_scan_short  (pass 1 for paths of at most 2048 steps)  every wave walks whole paths on its
+//                 own -- no barrier, no 125 KB bitset: the same blocks, but a path's runs are
+//                 queued first and then claimed in a per-wave hash set of bitset words.
+//   k_accum       (pass 2)  one workgroup per window: applies the window's records as +1/-1 pairs
+//                 to an LDS difference array (depth and uniq packed in 64-bit cells), prefix-sums
+//                 it and writes depth/uniq with 16-byte stores.  It also zeroes the counts it
+//                 consumed, so the scratch is clean for the next call without any memset.
 //
 // Exactness: every step lies in exactly one run, so it contributes +1 to exactly one depth
-// record; every (path, segment) pair that occurs sets exactly one bit, which lies in exactly
-// one uniq record.  Sums of +1s are order-independent, hence the results equal
-// ops/depth.rs:15-39 bit for bit under any scheduling.  Runs are cut at ids that are multiples
-// of 2048, so a record never crosses a window.  Sub-buckets have a fixed capacity; a record
-// that does not fit is applied to a global difference array with atomics instead (slow, still
-// exact) and k_accum folds that array in.
+// record; every (path, segment) pair that occurs sets exactly one bit, claimed by exactly one
+// lane, covered by exactly one uniq record.  Sums of +1s are order-independent, hence the results
+// equal depth.rs bit for bit under any scheduling.  A record never crosses a window.  Sub-buckets
+// have a fixed capacity; a record that does not fit is applied to a global difference array with
+// atomics instead (slow, still exact) and k_accum folds that array in.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
