@@ -60,6 +60,9 @@ constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr uint32_t kShortMax = 2048;      // steps; longer paths go through k_scan
 constexpr uint32_t kDummyBase = 1u << 20;  // ids from here up stand in for steps outside the path (never emitted)
 constexpr uint32_t kTabEntries = 512;      // per-wave hash set of (bitset word index + 1, bits) pairs
+// Segment-range passes for graphs whose bitset does not fit LDS (see fast_plan_create).
+constexpr uint32_t kRangeSegs = 253u * 4096u;  // < kDummyBase; its bitset (129.5 KB) fits beside the queues
+constexpr uint32_t kMaxPasses = 6;
 constexpr int kAccThreads = 1024;
 constexpr uint32_t kMaxSlots = 1024;  // sub-buckets per window (= workgroups of k_scan) k_accum can stage
 
@@ -76,6 +79,9 @@ struct ScanArgs {
     uint32_t n_short;
     uint32_t *piece_bits;  // [n_piece_slots][n_words]: "seen" bitsets of the pieces of split paths
     uint32_t n_items, n_segs, n_win, n_words, n_slots;
+    // Segment-range passes (graphs whose bitset does not fit LDS): this launch covers segments
+    // [seg_lo, seg_lo + seg_n) only, renumbered from 0; n_segs stays the graph's segment count.
+    uint32_t ranged, seg_lo, seg_n;
     uint32_t *work_counter;
     uint32_t *counts;   // [n_win][n_slots]
     uint32_t *buckets;  // [n_win + 1][n_slots][cap]; window n_win is a write sink
@@ -153,6 +159,18 @@ __device__ __forceinline__ void tmark(const ScanArgs &A, Wave &w, int ph) {
     }
 }
 
+// Ranged launches: a segment id becomes its offset in the launch's range, or -- outside the range --
+// a placeholder that continues from the placeholder of the step before (so that a stretch of
+// outside steps is one run), which is dropped when emitted.  `pos` is the step's index.
+__device__ __forceinline__ uint32_t map_id(const ScanArgs &A, uint32_t id, uint32_t pos) {
+    if (id >= A.n_segs) {
+        *A.status = 1u;
+        id = A.seg_lo;
+    }
+    const uint32_t rel = id - A.seg_lo;
+    return rel < A.seg_n ? rel : kDummyBase + (pos & 0xFFFFu);
+}
+
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
@@ -207,7 +225,7 @@ template <bool UNIQ, bool DBG, bool SHORT = false>
 __device__ __forceinline__ void emit_chunk(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
                                            bool valid, uint32_t rec) {
     const uint32_t id = rec >> kRunBits, lenm1 = rec & (kRunSpan - 1), win = id >> kWinBits;
-    if (SHORT) valid = valid && id < kDummyBase;  // runs of placeholder ids are dropped here
+    if (SHORT || A.ranged) valid = valid && id < kDummyBase;  // runs of placeholder ids are dropped here
     uint32_t kind = 0, pos;
     if (UNIQ && !FGFA_SKIP(kDbgNoBitset)) {
         const uint32_t mask = valid ? (0xFFFFFFFFu >> (31u - lenm1)) << (id & 31u) : 0u;
@@ -284,7 +302,7 @@ __device__ __forceinline__ void emit_pair(const ScanArgs &A, Wave &w, uint32_t *
 // Emit the newest 64 queued runs while at least 64 are queued (all of them when `all`).
 template <bool UNIQ, bool DBG, bool SHORT = false>
 __device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine, bool all) {
-    while (!SHORT && w.fill >= 128u) {
+    while (!SHORT && !A.ranged && w.fill >= 128u) {
         w.fill -= 128u;
         const uint32_t rec0 = w.q[w.fill + w.lane], rec1 = w.q[w.fill + 64u + w.lane];
         emit_pair<UNIQ, DBG>(A, w, seen, bcur, mine, rec0, rec1);
@@ -398,8 +416,11 @@ __device__ __forceinline__ bool block16(const ScanArgs &A, Wave &w, uint32_t *se
         for (int k = 0; k < 16; ++k) {
             const uint32_t rel = 16u * (uint32_t)w.lane + (uint32_t)k;
             const bool inside = rel >= rel_lo && rel < rel_hi;
-            a[k] = inside ? clamp_id(A, a[k]) : kDummyBase + ((blk_pos + rel) & 0xFFFFu);
+            a[k] = !inside ? kDummyBase + ((blk_pos + rel) & 0xFFFFu) : A.ranged ? map_id(A, a[k], blk_pos + rel) : clamp_id(A, a[k]);
         }
+    } else if (A.ranged) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[k] = map_id(A, a[k], blk_pos + 16u * (uint32_t)w.lane + (uint32_t)k);
     } else {
         uint32_t mx = a[0];
 #pragma unroll
@@ -493,7 +514,8 @@ __device__ __forceinline__ bool block16(const ScanArgs &A, Wave &w, uint32_t *se
 template <bool UNIQ>
 __device__ __forceinline__ void tile_narrow(const ScanArgs &A, Wave &w, uint64_t t, uint32_t count, bool fresh) {
     const bool valid = (uint32_t)w.lane < count;
-    const uint32_t id = valid ? clamp_id(A, A.steps[t + w.lane] >> 1) : 0u;
+    const uint32_t raw = valid ? A.steps[t + w.lane] >> 1 : 0u;
+    const uint32_t id = !valid ? 0u : A.ranged ? map_id(A, raw, (uint32_t)t + (uint32_t)w.lane) : clamp_id(A, raw);
     if (fresh) {  // as in block16
         w.rs = __builtin_amdgcn_readfirstlane(id);
         w.prev = w.rs - 1u;
@@ -679,7 +701,8 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         blk[SET] = __builtin_amdgcn_readfirstlane(got);                                       \
         if (blk[SET] < it.nblk) load_block_async<SET>(w, FGFA_BLOCK_PTR(blk[SET]));           \
         if (!FGFA_SKIP(kDbgNoTiles)) {                                                        \
-            block16<UNIQ, DBG>(A, w, seen, bcur, mine, a, mine_now + 1 == it.nblk ? it.nl_last : 64u); \
+            block16<UNIQ, DBG>(A, w, seen, bcur, mine, a, mine_now + 1 == it.nblk ? it.nl_last : 64u, 0u, 1024u, \
+                               (uint32_t)it.t0 + mine_now * 1024u);                           \
         } else if (a[0] == 0x3FFFFFFFu) {                                                     \
             *A.status = 2u;                                                                   \
         }                                                                                     \
@@ -1090,11 +1113,21 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     *fp = FastPlan();
     if (g.n_segs == 0 || g.n_paths == 0 || g.n_steps == 0) return true;
     if ((reinterpret_cast<uintptr_t>(g.steps) & 15u) != 0) return true;  // 16-byte step loads
-    const uint32_t n_win = (g.n_segs + kWin - 1) / kWin;
-    if (n_win > kMaxWin) return true;
-    if (g.n_segs > (1u << 21)) return true;  // a queued run is (start id << 11) | (len - 1)
-    const uint32_t n_words = ((g.n_segs + 31) / 32 + 3) & ~3u;
-    if (scan_lds_bytes(n_words) + 64 > kLdsLimit) return true;  // the "seen" bitset must fit one CU's LDS
+    // The per-path "seen" bitset must fit one CU's LDS next to the queues.  A graph with more
+    // segments is done in up to kMaxPasses passes, each over one range of kRangeSegs segments
+    // (every pass reads all steps; beyond that the simple atomic kernels are no slower).
+    uint32_t seg_range = g.n_segs, n_pass = 1;
+    if (scan_lds_bytes(((g.n_segs + 31) / 32 + 3) & ~3u) + 64 > kLdsLimit || (g.n_segs + kWin - 1) / kWin > kMaxWin) {
+        seg_range = kRangeSegs;
+        n_pass = (g.n_segs + kRangeSegs - 1) / kRangeSegs;
+        if (n_pass > kMaxPasses) return true;
+        if (const char *off = getenv("FLATGFA_MAX_PASSES")) {
+            if (n_pass > strtoul(off, nullptr, 10)) return true;
+        }
+    }
+    const uint32_t n_win = (seg_range + kWin - 1) / kWin;
+    const uint32_t n_words = ((seg_range + 31) / 32 + 3) & ~3u;
+    if (n_win > kMaxWin || scan_lds_bytes(n_words) + 64 > kLdsLimit) return true;
     hipDeviceProp_t prop;
     int dev = 0;
     FAST_TRY(hipGetDevice(&dev));
@@ -1103,6 +1136,8 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     fp->n_slots = fp->n_cus;
     if (fp->n_slots > kMaxSlots) return true;
     fp->n_win = n_win;
+    fp->n_pass = n_pass;
+    fp->seg_range = seg_range;
     fp->n_words = n_words;
     fp->lds_bytes_uniq = scan_lds_bytes(n_words);
     fp->lds_bytes_depth = scan_lds_bytes(0);
@@ -1200,39 +1235,65 @@ void fast_plan_destroy(FastPlan *fp) {
 int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
                    uint32_t *status, hipStream_t stream) {
     const uint32_t stride = fp.n_slots * fp.cap;
-    ScanArgs sa{g.steps, reinterpret_cast<uint4 *>(fp.items), reinterpret_cast<const uint4 *>(fp.short_items), fp.n_short,
-                fp.piece_bits, fp.n_items, g.n_segs, fp.n_win,
-                uniq_out ? fp.n_words : 0u, fp.n_slots, fp.work_counter, fp.counts, fp.buckets, fp.cap, stride,
-                fp.n_win * stride, fp.ovf_d, fp.ovf_u, fp.ovf_flag, status, fp.dbg};
-    AccArgs aa{g.n_segs, fp.n_win, fp.n_slots, fp.cap, fp.piece_bits, reinterpret_cast<const uint2 *>(fp.split),
-               uniq_out ? fp.n_split : 0u, fp.n_words, fp.counts, fp.buckets, fp.ovf_d, fp.ovf_u, fp.ovf_flag,
-               fp.work_counter, depth_out, uniq_out};
     // one persistent workgroup per CU; k_scan may be handed short paths back, so it gets a full grid when there are any
     const uint32_t grid = fp.n_short ? fp.n_slots : std::min<uint32_t>(fp.n_items, fp.n_slots);
-    if (fp.n_short) {
-        const uint32_t sgrid = std::min<uint32_t>((fp.n_short + kWaves - 1) / kWaves, fp.n_slots);
-        ProfScope ps(uniq_out ? "k_scan_short<uniq>" : "k_scan_short<depth>", stream);
-        if (uniq_out) hipLaunchKernelGGL(k_scan_short<true>, dim3(sgrid), dim3(kThreads), fp.lds_bytes_short, stream, sa);
-        else hipLaunchKernelGGL(k_scan_short<false>, dim3(sgrid), dim3(kThreads), fp.lds_bytes_short, stream, sa);
-    }
-    if (uniq_out) {
-        {
-            ProfScope ps("k_scan<uniq>", stream);
-            if (fp.dbg) hipLaunchKernelGGL((k_scan<true, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_uniq, stream, sa);
-            else hipLaunchKernelGGL((k_scan<true, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_uniq, stream, sa);
+    for (uint32_t pass = 0; pass < fp.n_pass; ++pass) {
+        const uint32_t seg_lo = pass * fp.seg_range, seg_n = std::min(fp.seg_range, g.n_segs - seg_lo);
+        const uint32_t n_win = (seg_n + kWin - 1) / kWin, n_words = ((seg_n + 31) / 32 + 3) & ~3u;
+        ScanArgs sa;
+        sa.steps = g.steps;
+        sa.items = reinterpret_cast<uint4 *>(fp.items);
+        sa.short_items = reinterpret_cast<const uint4 *>(fp.short_items);
+        sa.n_short = fp.n_short;
+        sa.piece_bits = fp.piece_bits;
+        sa.n_items = fp.n_items;
+        sa.n_segs = g.n_segs;
+        sa.n_win = n_win;
+        sa.n_words = uniq_out ? n_words : 0u;
+        sa.n_slots = fp.n_slots;
+        sa.ranged = fp.n_pass > 1 ? 1u : 0u;
+        sa.seg_lo = seg_lo;
+        sa.seg_n = seg_n;
+        sa.work_counter = fp.work_counter;
+        sa.counts = fp.counts;
+        sa.buckets = fp.buckets;
+        sa.cap = fp.cap;
+        sa.stride = stride;
+        sa.sink = fp.n_win * stride;
+        sa.ovf_d = fp.ovf_d;
+        sa.ovf_u = fp.ovf_u;
+        sa.ovf_flag = fp.ovf_flag;
+        sa.status = status;
+        sa.dbg = fp.dbg;
+        AccArgs aa{seg_n, n_win, fp.n_slots, fp.cap, fp.piece_bits, reinterpret_cast<const uint2 *>(fp.split),
+                   uniq_out ? fp.n_split : 0u, n_words, fp.counts, fp.buckets, fp.ovf_d, fp.ovf_u, fp.ovf_flag,
+                   fp.work_counter, depth_out + seg_lo, uniq_out ? uniq_out + seg_lo : nullptr};
+        const uint32_t lds_uniq = scan_lds_bytes(n_words);
+        if (fp.n_short) {
+            const uint32_t sgrid = std::min<uint32_t>((fp.n_short + kWaves - 1) / kWaves, fp.n_slots);
+            ProfScope ps(uniq_out ? "k_scan_short<uniq>" : "k_scan_short<depth>", stream);
+            if (uniq_out) hipLaunchKernelGGL(k_scan_short<true>, dim3(sgrid), dim3(kThreads), fp.lds_bytes_short, stream, sa);
+            else hipLaunchKernelGGL(k_scan_short<false>, dim3(sgrid), dim3(kThreads), fp.lds_bytes_short, stream, sa);
         }
-        {
-            ProfScope ps("k_accum<uniq>", stream);
-            hipLaunchKernelGGL(k_accum<true>, dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
-        }
-    } else {
-        {
-            ProfScope ps("k_scan<depth>", stream);
-            hipLaunchKernelGGL((k_scan<false, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_depth, stream, sa);
-        }
-        {
-            ProfScope ps("k_accum<depth>", stream);
-            hipLaunchKernelGGL(k_accum<false>, dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
+        if (uniq_out) {
+            {
+                ProfScope ps("k_scan<uniq>", stream);
+                if (fp.dbg) hipLaunchKernelGGL((k_scan<true, true>), dim3(grid), dim3(kThreads), lds_uniq, stream, sa);
+                else hipLaunchKernelGGL((k_scan<true, false>), dim3(grid), dim3(kThreads), lds_uniq, stream, sa);
+            }
+            {
+                ProfScope ps("k_accum<uniq>", stream);
+                hipLaunchKernelGGL(k_accum<true>, dim3(n_win), dim3(kAccThreads), 0, stream, aa);
+            }
+        } else {
+            {
+                ProfScope ps("k_scan<depth>", stream);
+                hipLaunchKernelGGL((k_scan<false, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_depth, stream, sa);
+            }
+            {
+                ProfScope ps("k_accum<depth>", stream);
+                hipLaunchKernelGGL(k_accum<false>, dim3(n_win), dim3(kAccThreads), 0, stream, aa);
+            }
         }
     }
     if (hipGetLastError() != hipSuccess) {

@@ -12,7 +12,9 @@ struct FastPlan {
     bool eligible = false;
     uint32_t n_cus = 256;
     uint32_t n_slots = 0;      // sub-buckets per window = persistent workgroups of pass 1
-    uint32_t n_win = 0;        // 4096-segment accumulation windows
+    uint32_t n_win = 0;        // 4096-segment accumulation windows (of one segment-range pass)
+    uint32_t n_pass = 1;       // segment-range passes: 1 when the whole bitset fits LDS
+    uint32_t seg_range = 0;    // segments per pass
     uint32_t n_words = 0;      // 32-bit words of the per-path "seen" bitset (padded)
     uint32_t cap = 0;          // records per (window, sub-bucket)
     uint32_t lds_bytes_uniq = 0, lds_bytes_depth = 0;
