@@ -727,13 +727,15 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             FGFA_BLOCK(1)
         }
         drain<UNIQ, DBG>(A, w, seen, bcur, mine, true);
-        tmark<DBG>(A, w, 4);
-        __syncthreads();  // every wave is done with this path's bitset
-        tmark<DBG>(A, w, 1);
+        // This wave is done with the item: it requests its first two blocks of the next one right
+        // away, so that the waves' preloads do not all queue up behind the barrier.
         const uint32_t done_slot = it.slot;
         job = next_job;
         it = make_item(A, job < n_items, next_item, lane);
         FGFA_PRELOAD();
+        tmark<DBG>(A, w, 4);
+        __syncthreads();  // every wave is done with this path's bitset
+        tmark<DBG>(A, w, 1);
         tmark<DBG>(A, w, 6);
         if (threadIdx.x == 0) *next_blk = 2u * kWaves;  // nobody takes a block before the barrier below
         if (UNIQ) {
