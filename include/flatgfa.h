@@ -171,7 +171,9 @@ typedef struct flatgfa_dev_graph_t {
  * is created.  `host_path_begin/host_path_end` are host copies of the span arrays (P entries each);
  * pass NULL to have them copied back from the device.  Returns NULL on failure
  * (flatgfa_last_error()); spans that are reversed or exceed n_steps are rejected here, where the
- * reference would panic on the slice index (pool.rs:341-347). */
+ * reference would panic on the slice index (pool.rs:341-347).  The plan is laid out for the path
+ * spans it was created with: the span arrays must not change while it lives (the step values
+ * may; every call checks them against n_segs).  Calls on one plan must not overlap in time. */
 typedef struct flatgfa_dev_plan flatgfa_dev_plan_t;
 flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t *g, const uint32_t *host_path_begin,
                                             const uint32_t *host_path_end);

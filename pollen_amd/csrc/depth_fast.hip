@@ -538,7 +538,7 @@ __device__ __forceinline__ void tile_narrow(const ScanArgs &A, Wave &w, uint64_t
 // the first 64-byte boundary, then `nblk` blocks of 1024 steps starting at t0, the last of which
 // may hold only `nl_last` lanes' worth of 16-step chunks, then fewer than 16 steps [tail, e).
 // Blocks are not assigned to waves in advance: a wave takes the next free one from an LDS counter
-// whenever one of its landing sets is free (its first two are its own index and that plus 16).
+// whenever one of its landing sets is free (its first three are its own index plus 0, 16 and 32).
 // The SIMDs favour their older waves, so with equal fixed shares the youngest four waves finished
 // a path up to 25% after the oldest four, which then idled at the barrier.
 struct Item {
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     for (uint32_t i = threadIdx.x; i < kMaxWin; i += kThreads) bcur[i] = i < A.n_win ? A.counts[(size_t)i * A.n_slots + blockIdx.x] : 0u;
     if (UNIQ)
         for (uint32_t i = threadIdx.x; i < A.n_words; i += kThreads) seen[i] = 0u;
-    if (threadIdx.x == 0) *next_blk = 2u * kWaves;
+    if (threadIdx.x == 0) *next_blk = 3u * kWaves;
     __syncthreads();
     const uint32_t n_items = A.n_items + (A.n_short ? *A.work_counter : 0u);  // plus what k_scan_short handed back
 
@@ -677,6 +677,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     uint32_t job = item_of(0, blockIdx.x, gridDim.x);
     Item it = make_item(A, job < n_items, job < n_items ? A.items[job] : make_uint4(0u, 0u, 0u, 0u), lane);
     uint32_t blk[2];  // the block each landing set holds (or will hold next)
+    uint32_t resv;    // the block this wave takes after those
     // lanes beyond a partial block's last one re-read lane 0's chunk: same instruction stream for all
 #define FGFA_BLOCK_PTR(j) \
     (it.src + (size_t)(j) * 256 - (((j) + 1 == it.nblk && (uint32_t)lane >= it.nl_last) ? lane * 4 : 0))
@@ -684,6 +685,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     do {                                                                    \
         blk[0] = (uint32_t)wave;                                            \
         blk[1] = (uint32_t)wave + kWaves;                                   \
+        resv = (uint32_t)wave + 2u * kWaves;                                \
         if (blk[0] < it.nblk) load_block_async<0>(w, FGFA_BLOCK_PTR(blk[0])); \
         if (blk[1] < it.nblk) load_block_async<1>(w, FGFA_BLOCK_PTR(blk[1])); \
     } while (0)
@@ -696,16 +698,17 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         uint32_t a[16];                                                                       \
         take_block<SET>(a);                                                                   \
         const uint32_t mine_now = blk[SET];                                                   \
+        blk[SET] = resv;  /* taken one block ago, so that the LDS round trip is off this path */ \
+        if (blk[SET] < it.nblk) load_block_async<SET>(w, FGFA_BLOCK_PTR(blk[SET]));           \
         uint32_t got = 0;                                                                     \
         if (lane == 0) got = atomicAdd(next_blk, 1u);                                         \
-        blk[SET] = __builtin_amdgcn_readfirstlane(got);                                       \
-        if (blk[SET] < it.nblk) load_block_async<SET>(w, FGFA_BLOCK_PTR(blk[SET]));           \
         if (!FGFA_SKIP(kDbgNoTiles)) {                                                        \
             block16<UNIQ, DBG>(A, w, seen, bcur, mine, a, mine_now + 1 == it.nblk ? it.nl_last : 64u, 0u, 1024u, \
                                (uint32_t)it.t0 + mine_now * 1024u);                           \
         } else if (a[0] == 0x3FFFFFFFu) {                                                     \
             *A.status = 2u;                                                                   \
         }                                                                                     \
+        resv = __builtin_amdgcn_readfirstlane(got);                                           \
     }
     FGFA_PRELOAD();
 
@@ -737,7 +740,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         __syncthreads();  // every wave is done with this path's bitset
         tmark<DBG>(A, w, 1);
         tmark<DBG>(A, w, 6);
-        if (threadIdx.x == 0) *next_blk = 2u * kWaves;  // nobody takes a block before the barrier below
+        if (threadIdx.x == 0) *next_blk = 3u * kWaves;  // nobody takes a block before the barrier below
         if (UNIQ) {
             uint4 *sv = reinterpret_cast<uint4 *>(seen);
             if (done_slot != kNoSlot) {
