@@ -5,8 +5,10 @@ synthetic graph (BASELINE.json metric; configs[2] at N=1).
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfgL|cfgL-uniform|cfgL-short|cfgS]
 
 One "step" = one pass of the hot path (seg_depth_with_uniq, ops/depth.rs:15-39) over the
-rank's resident graph image: zero the outputs, run the HIP kernels, and -- for N > 1 -- one
-RCCL sum all-reduce of the fused [depth | uniq] vector.  Inputs are in HBM before the timed
+rank's resident graph image: run the HIP kernels, and -- for N > 1 -- one RCCL sum all-reduce of
+the fused [depth | uniq] vector.  Steps alternate between two result buffers, so the all-reduce
+of one step overlaps the kernels of the next (pollen_amd/sharded.py); the timed region ends
+when every kernel and every collective of its K steps has finished.  Inputs are in HBM before the timed
 region starts.  For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
 holds its own 1000 paths x 100k steps over the same 1M segments (weak scaling: the path set
 grows with the GPU count, which is when sharding is warranted); value = all ranks' steps /
@@ -74,11 +76,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    # Test hooks (single-GPU box): FLATGFA_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # FLATGFA_BENCH_BACKEND=gloo replaces RCCL, so that the multi-rank control flow can be run there.
+    if os.environ.get("FLATGFA_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("FLATGFA_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     S, P, L, model = WORKLOADS[args.workload]
     N = P * L
@@ -90,6 +100,7 @@ def main():
     op = ShardedDepth(S, plan.seg_depth, device=device, with_uniq=True)
 
     def sync_all():
+        op.finish()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
@@ -266,7 +277,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: seg_depth_with_uniq on synth(seed=1+rank, S={S}, P={P}, L={L}, "
                                    f"model={model}) per GPU", "segments": S, "paths_per_gpu": P,
-                       "steps_per_gpu": N, "sharding": "by path, one sum all-reduce of [depth|uniq]" if world > 1
+                       "steps_per_gpu": N, "sharding": "by path, one sum all-reduce of [depth|uniq] per step, overlapping the next step's kernels" if world > 1
                        else "none"},
             "bit_exact_vs_oracle": verified,
             "roofline": roofline, "cpu_baseline": cpu,

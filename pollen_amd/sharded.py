@@ -58,9 +58,16 @@ def local_slice(steps: np.ndarray, path_begin: np.ndarray, path_end: np.ndarray,
 
 
 class ShardedDepth:
-    """seg_depth_with_uniq over a path-sharded graph: local HIP partials + one sum all-reduce."""
+    """seg_depth_with_uniq over a path-sharded graph: local HIP partials + one sum all-reduce.
 
-    def __init__(self, n_segs: int, local_fn: Callable, device, with_uniq: bool = True, group=None):
+    Steps are pipelined over `depth_of_pipeline` result buffers: `run()` enqueues the local kernels
+    of a step into the next buffer and starts its all-reduce asynchronously (RCCL runs it on its
+    own stream, after the kernels), so the collective of step i overlaps the kernels of step
+    i + 1.  `finish()` waits for everything in flight; `depth` / `uniq` / `buf` refer to the most
+    recent step and are complete after `finish()`."""
+
+    def __init__(self, n_segs: int, local_fn: Callable, device, with_uniq: bool = True, group=None,
+                 depth_of_pipeline: int = 2):
         import torch
         self.torch = torch
         self.n_segs = int(n_segs)
@@ -68,8 +75,15 @@ class ShardedDepth:
         self.with_uniq = with_uniq
         self.group = group
         k = 2 if with_uniq else 1
-        # one fused buffer so that a single collective carries both vectors
-        self.buf = torch.zeros(k * self.n_segs, dtype=torch.int32, device=device)
+        # one fused buffer per step in flight, so that a single collective carries both vectors
+        self.bufs = [torch.zeros(k * self.n_segs, dtype=torch.int32, device=device)
+                     for _ in range(max(1, int(depth_of_pipeline)))]
+        self.works = [None] * len(self.bufs)
+        self.cur = 0
+
+    @property
+    def buf(self):
+        return self.bufs[self.cur]
 
     @property
     def depth(self):
@@ -80,8 +94,21 @@ class ShardedDepth:
         return self.buf[self.n_segs:] if self.with_uniq else None
 
     def run(self) -> None:
-        """One step: local partials into the fused buffer, then the all-reduce (if world > 1)."""
+        """One step: local partials into the next buffer, then its all-reduce (if world > 1)."""
         import torch.distributed as dist
-        self.local_fn(self.depth, self.uniq)
+        j = (self.cur + 1) % len(self.bufs)
+        if self.works[j] is not None:  # the collective that last used this buffer
+            self.works[j].wait()
+            self.works[j] = None
+        b = self.bufs[j]
+        self.local_fn(b[: self.n_segs], b[self.n_segs:] if self.with_uniq else None)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group)
+            self.works[j] = dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.cur = j
+
+    def finish(self) -> None:
+        """Wait (the current stream, for RCCL) for every collective still in flight."""
+        for k, w in enumerate(self.works):
+            if w is not None:
+                w.wait()
+                self.works[k] = None

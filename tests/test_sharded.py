@@ -78,6 +78,8 @@ def _worker(rank, world, port, seed, S, P, L, model, q):
         op = ShardedDepth(S, local_fn, device="cpu", with_uniq=True)
         op.run()
         op.run()  # a second step must not accumulate
+        op.run()  # a third one reuses the first buffer, whose collective must have finished
+        op.finish()
         want_d, want_u = fo.seg_depth_with_uniq(pools)
         ok = (op.depth.numpy().view(np.uint32) == want_d).all() and (op.uniq.numpy().view(np.uint32) == want_u).all()
         q.put((rank, bool(ok)))
