@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Randomised differential check of the HIP depth path against the C oracle (run on a GPU box):
+random segment counts, path counts and lengths (mixes of short, medium and long paths in one
+graph, arbitrary span alignments), both step models, all device configurations.
+Usage: python tools/fuzz_gpu.py [n_cases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import pollen_amd as pa  # noqa: E402
+from oracle import flatgfa_oracle as fo  # noqa: E402
+
+ENVS = [{}, {"FLATGFA_SHORT_MAX": "0"}, {"FLATGFA_BUCKET_CAP": "8"}, {"FLATGFA_PIECE_STEPS": "512"},
+        {"FLATGFA_SHORT_MAX": "300"}, {"FLATGFA_DEPTH_PATH": "atomic"}]
+
+
+def random_graph(rng):
+    S = int(rng.choice([1, 7, 33, 1000, 5000, 70_000, 300_000, 1_100_000, 2_200_000]))
+    kinds = rng.integers(0, 4)
+    lens = []
+    n_paths = int(rng.integers(1, 400))
+    for _ in range(n_paths):
+        k = rng.integers(0, 10)
+        if k < 5:
+            lens.append(int(rng.integers(1, 2100)))        # short
+        elif k < 8:
+            lens.append(int(rng.integers(2000, 40_000)))   # medium
+        else:
+            lens.append(int(rng.integers(40_000, 400_000)))  # long
+        if sum(lens) > 3_000_000:
+            break
+    P = len(lens)
+    N = sum(lens)
+    model = kinds % 2
+    steps = np.empty(N, dtype=np.uint32)
+    pos = 0
+    for L in lens:
+        if model == 0:  # locally monotone with jumps (wraps around S)
+            u = rng.integers(0, 100, size=L)
+            j = rng.integers(0, 1 << 30, size=L)
+            inc = np.where(u < 90, 1, np.where(u < 95, 2 + (j & 7), np.where(u < 99, -(1 + (j & 3)), 0))).astype(np.int64)
+            jump = u >= 99
+            jump[0] = True
+            base = np.where(jump, j % S, 0).astype(np.int64)
+            inc[jump] = 0
+            c = np.cumsum(inc)
+            last = np.maximum.accumulate(np.where(jump, np.arange(L), 0))
+            ids = (base[last] + c - c[last]) % S
+        else:
+            ids = rng.integers(0, S, size=L)
+        steps[pos:pos + L] = (ids.astype(np.uint32) << 1) | rng.integers(0, 2, size=L).astype(np.uint32)
+        pos += L
+    # spans: contiguous, plus sometimes gaps (unused steps between paths)
+    begins = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint32)
+    ends = (begins + np.array(lens, dtype=np.uint32)).astype(np.uint32)
+    return S, P, steps, begins, ends
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    from pollen_amd import device as dev
+    import torch
+    bad = 0
+    for case in range(n_cases):
+        S, P, steps, pb, pe = random_graph(rng)
+        seg_len = rng.integers(1, 40, size=S).astype(np.uint32)
+        # oracle on raw arrays
+        paths = np.zeros(P, dtype=fo.PATH_DT)
+        paths["steps_start"], paths["steps_end"] = pb, pe
+        segs = np.zeros(S, dtype=fo.SEG_DT)
+        pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
+        pools.paths, pools.steps, pools.segs = paths, steps, segs
+        want_d, want_u = fo.seg_depth_with_uniq(pools)
+        env = ENVS[case % len(ENVS)]
+        for k in ("FLATGFA_SHORT_MAX", "FLATGFA_BUCKET_CAP", "FLATGFA_PIECE_STEPS", "FLATGFA_DEPTH_PATH"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        graph = dev.DeviceGraph(steps, pb, pe, S, seg_len, device="cuda:0")
+        plan = dev.DepthPlan(graph)
+        d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        d2 = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        for _ in range(2):  # twice: the scratch must be clean again
+            plan.seg_depth(d, u)
+            plan.seg_depth(d2, None)
+        plan.status()
+        gd, gu, gd2 = (t.cpu().numpy().view(np.uint32) for t in (d, u, d2))
+        ok = (gd == want_d).all() and (gu == want_u).all() and (gd2 == want_d).all()
+        print(f"case {case}: S={S} P={P} N={len(steps)} env={env} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+        if not ok:
+            bad += 1
+            print("   depth bad:", int((gd != want_d).sum()), "uniq bad:", int((gu != want_u).sum()), "depth-only bad:", int((gd2 != want_d).sum()))
+        plan.close()
+    print("mismatching cases:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
