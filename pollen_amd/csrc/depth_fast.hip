@@ -96,15 +96,17 @@ struct ScanArgs {
 };
 
 // A record whose sub-bucket is full: apply it to the global difference array instead.
-__device__ __noinline__ void overflow_apply(int *arr, uint32_t *flag, uint32_t id, uint32_t len) {
+// `n` = segments of this launch: the -1 is dropped where k_accum would not read (and clear) it --
+// past the window, and past the last segment (where a later segment-range pass would find it).
+__device__ __noinline__ void overflow_apply(int *arr, uint32_t *flag, uint32_t id, uint32_t len, uint32_t n) {
     flag[id >> kWinBits] = 1u;
     atomicAdd(&arr[id], 1);
-    if ((id & (kWin - 1)) + len < kWin) atomicAdd(&arr[id + len], -1);
+    if ((id & (kWin - 1)) + len < kWin && id + len < n) atomicAdd(&arr[id + len], -1);
 }
 // kind: 0 = depth, 1 = uniq, 2 = both
 __device__ __forceinline__ void overflow_record(const ScanArgs &A, uint32_t id, uint32_t len, uint32_t kind) {
-    if (kind != 1u) overflow_apply(A.ovf_d, A.ovf_flag, id, len);  // by value: A stays in SGPRs
-    if (kind != 0u) overflow_apply(A.ovf_u, A.ovf_flag, id, len);
+    if (kind != 1u) overflow_apply(A.ovf_d, A.ovf_flag, id, len, A.seg_n);  // by value: A stays in SGPRs
+    if (kind != 0u) overflow_apply(A.ovf_u, A.ovf_flag, id, len, A.seg_n);
 }
 
 // Per-wave state: the run queue (LDS, kQCap entries of (start id << 11) | (len - 1)), how many

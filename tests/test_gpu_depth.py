@@ -226,6 +226,41 @@ def test_repeat_calls_are_idempotent(device_path):
     assert (g.seg_depth() == a[0]).all()
 
 
+@pytest.mark.parametrize("n_segs", [70_000, 1_100_000, 2_200_000])
+def test_runs_that_end_at_the_last_segment(n_segs, device_path):
+    """Runs ending exactly at the last segment (of the graph, hence of the last segment-range
+    pass), called repeatedly: nothing a call leaves behind in the scratch may leak into the next
+    one (found by tools/fuzz_gpu.py: the overflow route's -1 past the last segment did)."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    rng = np.random.default_rng(5)
+    S = n_segs
+    lens = [5000, 30_000, 700, 90_000, 1500, 12_000]
+    ids = []
+    for L in lens:  # walks that wrap around S, so that many runs end at S - 1 and start at 0
+        start = S - int(rng.integers(1, L))
+        ids.append((start + np.arange(L)) % S)
+    steps = (np.concatenate(ids).astype(np.uint32) << 1)
+    pe = np.cumsum(lens).astype(np.uint32)
+    pb = (pe - np.array(lens, dtype=np.uint32)).astype(np.uint32)
+    paths = np.zeros(len(lens), dtype=fo.PATH_DT)
+    paths["steps_start"], paths["steps_end"] = pb, pe
+    pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
+    pools.paths, pools.steps, pools.segs = paths, steps, np.zeros(S, dtype=fo.SEG_DT)
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    plan = DepthPlan(DeviceGraph(steps, pb, pe, S))
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    for _ in range(3):
+        plan.seg_depth(d, u)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == want_d).all()
+        assert (u.cpu().numpy().view(np.uint32) == want_u).all()
+        plan.seg_depth(d, None)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == want_d).all()
+
+
 def test_linearity_over_path_subsets():
     # depth and uniq are sums of per-path contributions: computing two disjoint path groups
     # separately and adding must equal the whole (this is what multi-GPU sharding relies on).
