@@ -52,10 +52,24 @@ def random_graph(rng):
             ids = rng.integers(0, S, size=L)
         steps[pos:pos + L] = (ids.astype(np.uint32) << 1) | rng.integers(0, 2, size=L).astype(np.uint32)
         pos += L
-    # spans: contiguous, plus sometimes gaps (unused steps between paths)
-    begins = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint32)
-    ends = (begins + np.array(lens, dtype=np.uint32)).astype(np.uint32)
-    return S, P, steps, begins, ends
+    # spans: contiguous, or with gaps of unused steps that hold garbage handles (the type allows
+    # arbitrary spans; nothing outside a span may be looked at), plus a few duplicated spans
+    begins = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+    if kinds >= 2:
+        gaps = rng.integers(0, 41, size=P)
+        shift = np.cumsum(gaps)
+        out = np.full(N + int(shift[-1]) + int(rng.integers(0, 20)), 0xFFFFFFFF, dtype=np.uint32)
+        for p in range(P):
+            out[begins[p] + shift[p]: begins[p] + shift[p] + lens[p]] = steps[begins[p]: begins[p] + lens[p]]
+        steps = out
+        begins = begins + shift
+    ends = begins + np.array(lens, dtype=np.int64)
+    if P > 2 and kinds == 3:  # the same span twice: two paths over the same steps
+        k = int(rng.integers(0, P))
+        begins = np.append(begins, begins[k])
+        ends = np.append(ends, ends[k])
+        P += 1
+    return S, P, steps, begins.astype(np.uint32), ends.astype(np.uint32)
 
 
 def main():
@@ -72,6 +86,7 @@ def main():
         paths = np.zeros(P, dtype=fo.PATH_DT)
         paths["steps_start"], paths["steps_end"] = pb, pe
         segs = np.zeros(S, dtype=fo.SEG_DT)
+        segs["seq_end"] = seg_len  # only the length matters to path depth
         pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
         pools.paths, pools.steps, pools.segs = paths, steps, segs
         want_d, want_u = fo.seg_depth_with_uniq(pools)
@@ -87,9 +102,19 @@ def main():
         for _ in range(2):  # twice: the scratch must be clean again
             plan.seg_depth(d, u)
             plan.seg_depth(d2, None)
+        # path depth of a strided subset of the paths: integer sums on the device, one f64 division here
+        ids = np.arange(P - 1, -1, -3, dtype=np.uint32)
+        t_ids = torch.from_numpy(ids.view(np.int32)).to("cuda:0")
+        ln = torch.zeros(len(ids), dtype=torch.int64, device="cuda:0")
+        ws = torch.zeros(len(ids), dtype=torch.int64, device="cuda:0")
+        plan.path_sums(t_ids, d2, ln, ws)
         plan.status()
+        want_ln, want_mean = fo.path_depth(pools, ids)
+        got_ln = ln.cpu().numpy().view(np.uint64)
+        got_mean = ws.cpu().numpy().view(np.uint64).astype(np.float64) / got_ln.astype(np.float64)
         gd, gu, gd2 = (t.cpu().numpy().view(np.uint32) for t in (d, u, d2))
-        ok = (gd == want_d).all() and (gu == want_u).all() and (gd2 == want_d).all()
+        ok = (gd == want_d).all() and (gu == want_u).all() and (gd2 == want_d).all() \
+            and (got_ln == want_ln).all() and got_mean.tobytes() == want_mean.tobytes()
         print(f"case {case}: S={S} P={P} N={len(steps)} env={env} -> {'ok' if ok else 'MISMATCH'}", flush=True)
         if not ok:
             bad += 1
