@@ -138,16 +138,38 @@ __global__ __launch_bounds__(kSumThreads) void k_path_sums(const uint32_t *__res
             const uint64_t b = path_begin[p], e = path_end[p];
             const uint64_t n = e - b;
             const uint64_t lo = b + n * part / split, hi = b + n * (part + 1) / split;
-            // consecutive lanes take consecutive steps: along a run their table entries share lines
-#pragma unroll 4
-            for (uint64_t i = lo + threadIdx.x; i < hi; i += kSumThreads) {
+            // Consecutive lanes take consecutive steps: along a run their table entries share lines.
+            // Eight steps per thread are requested before any is used, then their eight table
+            // entries: the loop is bound by memory latency, not by bandwidth.
+            constexpr int kBatch = 8;
+            bool bad = false;
+            uint64_t i = lo + threadIdx.x;
+            for (; i + (uint64_t)(kBatch - 1) * kSumThreads < hi; i += (uint64_t)kBatch * kSumThreads) {
+                uint32_t seg[kBatch];
+                uint2 ld[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) seg[k] = steps[i + (uint64_t)k * kSumThreads] >> 1;
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    bad |= seg[k] >= n_segs;
+                    ld[k] = tab[seg[k] < n_segs ? seg[k] : 0u];
+                }
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    const bool ok = seg[k] < n_segs;
+                    len += ok ? (unsigned long long)ld[k].x : 0ull;
+                    wsum += ok ? (unsigned long long)ld[k].y * ld[k].x : 0ull;
+                }
+            }
+            for (; i < hi; i += kSumThreads) {
                 const uint32_t seg = steps[i] >> 1;
                 const bool ok = seg < n_segs;
                 const uint2 ld = tab[ok ? seg : 0u];
+                bad |= !ok;
                 len += ok ? (unsigned long long)ld.x : 0ull;
                 wsum += ok ? (unsigned long long)ld.y * ld.x : 0ull;
-                if (!ok) *status = 1u;
             }
+            if (bad) *status = 1u;
         } else if (threadIdx.x == 0 && part == 0) {
             *status = 1u;
         }
