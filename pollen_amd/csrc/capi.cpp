@@ -6,7 +6,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <atomic>
+#include <chrono>
 #include <mutex>
+#include <thread>
+#include <vector>
 
 #include "../../include/flatgfa.h"
 #include "device_common.hpp"
@@ -200,6 +204,56 @@ int flatgfa_format_float(double x, int digits, char *out, int cap) {
 
 // ---- device residency ----
 
+// Host -> device copy of a large pageable (or file-mapped) region.  A plain hipMemcpy stages it
+// through the runtime's own pinned buffer on one thread (10-24 GB/s here, less when the source
+// is a mapped file that still has to be faulted in); four threads copying 8 MB chunks into their
+// own pinned buffers and queueing async copies reach the PCIe rate (~49 GB/s measured,
+// tools/h2d_test.hip; a freshly mapped file adds ~17 ms of first-touch page faults per 400 MB,
+// which pread() into the pinned buffers does not beat).  Small regions take the plain route.
+static hipError_t upload(void *dst, const void *src, size_t bytes, hipStream_t stream) {
+    constexpr size_t kChunk = 8u << 20;
+    constexpr int kThreads = 4;
+    if (bytes < 4 * kChunk) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    int device = 0;
+    hipError_t rc = hipGetDevice(&device);
+    if (rc != hipSuccess) return rc;
+    char *stage[2 * kThreads] = {};
+    hipEvent_t ev[2 * kThreads] = {};
+    for (int i = 0; i < 2 * kThreads && rc == hipSuccess; ++i) {
+        rc = hipHostMalloc((void **)&stage[i], kChunk, hipHostMallocDefault);
+        if (rc == hipSuccess) rc = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+    }
+    std::atomic<int> failed{(int)rc};
+    if (rc == hipSuccess) {
+        const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
+        std::vector<std::thread> workers;
+        for (int t = 0; t < kThreads; ++t)
+            workers.emplace_back([&, t]() {
+                if (hipSetDevice(device) != hipSuccess) { failed = (int)hipErrorInvalidDevice; return; }
+                int round = 0;
+                for (size_t c = (size_t)t; c < n_chunks && !failed; c += kThreads, ++round) {
+                    const int b = 2 * t + (round & 1);
+                    hipError_t e = round >= 2 ? hipEventSynchronize(ev[b]) : hipSuccess;  // the buffer's previous copy is done
+                    const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+                    if (e == hipSuccess) {
+                        memcpy(stage[b], (const char *)src + off, len);
+                        e = hipMemcpyAsync((char *)dst + off, stage[b], len, hipMemcpyHostToDevice, stream);
+                    }
+                    if (e == hipSuccess) e = hipEventRecord(ev[b], stream);
+                    if (e != hipSuccess) failed = (int)e;
+                }
+            });
+        for (auto &w : workers) w.join();
+        const hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess && !failed) failed = (int)e;
+    }
+    for (int i = 0; i < 2 * kThreads; ++i) {
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+        if (stage[i]) (void)hipHostFree(stage[i]);
+    }
+    return (hipError_t)failed.load();
+}
+
 static int ensure_device(CStore *cs, int device) {
     std::lock_guard<std::mutex> lk(cs->dev_mu);
     if (cs->on_device) {
@@ -219,9 +273,17 @@ static int ensure_device(CStore *cs, int device) {
         set_error("graph too large for 32-bit ids");
         return FLATGFA_ERR_TOO_LARGE;
     }
+    const bool timing = getenv("FLATGFA_TIMING") != nullptr;  // diagnostic: where making a graph resident spends its time
+    auto tick = [t = std::chrono::steady_clock::now(), timing](const char *what) mutable {
+        if (!timing) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "to_device: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    };
     CAPI_HIP(hipSetDevice(device));
     cs->device = device;
     CAPI_HIP(hipStreamCreateWithFlags(&cs->stream, hipStreamNonBlocking));
+    tick("device + stream");
     const size_t N = v.steps.len, P = v.paths.len, S = v.segs.len;
     // AoS (packed, align-1) -> SoA.  Byte copies only: the file regions may be unaligned.
     cs->h_path_begin.resize(P);
@@ -232,10 +294,12 @@ static int ensure_device(CStore *cs, int device) {
     }
     std::vector<uint32_t> seg_len(S);
     for (size_t i = 0; i < S; ++i) seg_len[i] = v.segs[i].seq.len();
+    tick("span arrays on the host");
     if (N) {
         CAPI_HIP(hipMalloc(&cs->d_steps, N * 4));
-        CAPI_HIP(hipMemcpy(cs->d_steps, v.steps.data, N * 4, hipMemcpyHostToDevice));
+        CAPI_HIP(upload(cs->d_steps, v.steps.data, N * 4, cs->stream));
     }
+    tick("steps: hipMalloc + upload");
     if (P) {
         CAPI_HIP(hipMalloc(&cs->d_path_begin, P * 4));
         CAPI_HIP(hipMalloc(&cs->d_path_end, P * 4));
@@ -249,7 +313,9 @@ static int ensure_device(CStore *cs, int device) {
         CAPI_HIP(hipMalloc(&cs->d_uniq, S * 4));
     }
     flatgfa_dev_graph_t g{cs->d_steps, (uint64_t)N, cs->d_path_begin, cs->d_path_end, (uint32_t)P, (uint32_t)S, cs->d_seg_len};
+    tick("paths, segments, outputs");
     cs->plan = flatgfa_dev_plan_create(&g, cs->h_path_begin.data(), cs->h_path_end.data());
+    tick("plan (scratch + item lists)");
     if (!cs->plan) return FLATGFA_ERR_BOUNDS;
     cs->on_device = true;
     return FLATGFA_OK;
