@@ -37,7 +37,8 @@ WORKLOADS = {
     "cfgL-uniform": (1_000_000, 1000, 100_000, "uniform"),
     "cfgL-short": (1_000_000, 100_000, 1000, "pangenome"),
     "cfgL-fewlong": (1_000_000, 100, 1_000_000, "pangenome"),
-    "cfgL-4Mseg": (4_000_000, 1000, 100_000, "pangenome"),   # beyond the LDS bitset: the atomic kernels
+    "cfgL-medium": (1_000_000, 10_000, 10_000, "pangenome"),  # paths of ten blocks each
+    "cfgL-4Mseg": (4_000_000, 1000, 100_000, "pangenome"),   # beyond one LDS bitset: four segment-range passes
     "cfgS": (10_000, 100, 10_000, "pangenome"),
 }
 

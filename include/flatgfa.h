@@ -172,8 +172,10 @@ typedef struct flatgfa_dev_graph_t {
  * pass NULL to have them copied back from the device.  Returns NULL on failure
  * (flatgfa_last_error()); spans that are reversed or exceed n_steps are rejected here, where the
  * reference would panic on the slice index (pool.rs:341-347).  The plan is laid out for the path
- * spans it was created with: the span arrays must not change while it lives (the step values
- * may; every call checks them against n_segs).  Calls on one plan must not overlap in time. */
+ * spans and the step values it was created with (how many runs each path has decides which
+ * kernel walks it): neither may change while it lives.  Every call still checks the step values
+ * against n_segs, and reports an error rather than a wrong answer if they no longer fit the plan.
+ * Calls on one plan must not overlap in time. */
 typedef struct flatgfa_dev_plan flatgfa_dev_plan_t;
 flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t *g, const uint32_t *host_path_begin,
                                             const uint32_t *host_path_end);

@@ -59,7 +59,11 @@ constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 // The short-path kernel (k_scan_short): every wave walks whole short paths on its own.
 constexpr uint32_t kShortMax = 2048;      // steps; longer paths go through k_scan
 constexpr uint32_t kDummyBase = 1u << 20;  // ids from here up stand in for steps outside the path (never emitted)
-constexpr uint32_t kTabEntries = 512;      // per-wave hash set of (bitset word index + 1, bits) pairs
+constexpr int kShortHash = 9;               // per-wave hash set of 512 (bitset word index + 1, bits) pairs
+// The medium-path kernel: eight waves per workgroup, each with a hash set of 2048 entries, for paths
+// whose run count (known to the plan) fits it.
+constexpr int kMediumHash = 11, kMediumWaves = 8;
+constexpr uint32_t kMediumRuns = 1500;
 // Segment-range passes for graphs whose bitset does not fit LDS (see fast_plan_create).
 constexpr uint32_t kRangeSegs = 253u * 4096u;  // < kDummyBase; its bitset (129.5 KB) fits beside the queues
 constexpr uint32_t kMaxPasses = 6;
@@ -203,12 +207,17 @@ __device__ __forceinline__ void push_partial(Wave &w, bool e, uint32_t word, uin
 // The short-path kernel's claim: the path's "seen" words live in a small per-wave hash set (open
 // addressing, keyed by word index + 1) instead of a bitset over all segments.  A path is only
 // walked this way when it has at most kQCap runs, so the set never holds more than kQCap of
-// its kTabEntries entries.
-__device__ __forceinline__ uint32_t claim_hashed(uint32_t *tab, bool valid, uint32_t word, uint32_t mask) {
-    uint32_t h = (word * 0x9E3779B1u) >> 23;  // 9 bits
+// its 512 entries.
+template <int BITS>
+__device__ __forceinline__ uint32_t claim_hashed(const ScanArgs &A, uint32_t *tab, bool valid, uint32_t word, uint32_t mask) {
+    uint32_t h = (word * 0x9E3779B1u) >> (32 - BITS);
     bool todo = valid;
-    uint32_t old = 0;
+    uint32_t old = 0, probes = 0;
     while (__builtin_amdgcn_ballot_w64(todo)) {
+        if (++probes > (1u << BITS)) {  // cannot happen while the plan matches the steps: the set would be full
+            *A.status = 1u;
+            break;
+        }
         if (todo) {
             uint32_t *e = tab + 2u * h;
             const uint32_t k = atomicCAS(e, 0u, word + 1u);
@@ -216,22 +225,22 @@ __device__ __forceinline__ uint32_t claim_hashed(uint32_t *tab, bool valid, uint
                 old = atomicOr(e + 1, mask);
                 todo = false;
             } else {
-                h = (h + 1u) & (kTabEntries - 1u);
+                h = (h + 1u) & ((1u << BITS) - 1u);
             }
         }
     }
     return old;
 }
 
-template <bool UNIQ, bool DBG, bool SHORT = false>
+template <bool UNIQ, bool DBG, int HASH = 0>
 __device__ __forceinline__ void emit_chunk(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
                                            bool valid, uint32_t rec) {
     const uint32_t id = rec >> kRunBits, lenm1 = rec & (kRunSpan - 1), win = id >> kWinBits;
-    if (SHORT || A.ranged) valid = valid && id < kDummyBase;  // runs of placeholder ids are dropped here
+    if (HASH || A.ranged) valid = valid && id < kDummyBase;  // runs of placeholder ids are dropped here
     uint32_t kind = 0, pos;
     if (UNIQ && !FGFA_SKIP(kDbgNoBitset)) {
         const uint32_t mask = valid ? (0xFFFFFFFFu >> (31u - lenm1)) << (id & 31u) : 0u;
-        const uint32_t old = SHORT ? claim_hashed(seen, valid, id >> 5, mask) : (mask ? atomicOr(&seen[id >> 5], mask) : 0u);
+        const uint32_t old = HASH ? claim_hashed<HASH ? HASH : 1>(A, seen, valid, id >> 5, mask) : (mask ? atomicOr(&seen[id >> 5], mask) : 0u);
         pos = valid ? atomicAdd(&bcur[win], 1u) : 0u;  // both LDS round trips in flight together
         const uint32_t nb = mask & ~old;
         kind = (nb == mask) ? 2u : 0u;
@@ -302,9 +311,9 @@ __device__ __forceinline__ void emit_pair(const ScanArgs &A, Wave &w, uint32_t *
 }
 
 // Emit the newest 64 queued runs while at least 64 are queued (all of them when `all`).
-template <bool UNIQ, bool DBG, bool SHORT = false>
+template <bool UNIQ, bool DBG, int HASH = 0>
 __device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine, bool all) {
-    while (!SHORT && !A.ranged && w.fill >= 128u) {
+    while (!HASH && !A.ranged && w.fill >= 128u) {
         w.fill -= 128u;
         const uint32_t rec0 = w.q[w.fill + w.lane], rec1 = w.q[w.fill + 64u + w.lane];
         emit_pair<UNIQ, DBG>(A, w, seen, bcur, mine, rec0, rec1);
@@ -315,7 +324,7 @@ __device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen
         w.fill -= n;
         const bool valid = (uint32_t)w.lane < n;
         const uint32_t rec = valid ? w.q[w.fill + w.lane] : 0u;
-        emit_chunk<UNIQ, DBG, SHORT>(A, w, seen, bcur, mine, valid, rec);
+        emit_chunk<UNIQ, DBG, HASH>(A, w, seen, bcur, mine, valid, rec);
         if (UNIQ) drain_partial<DBG>(A, w, bcur, mine, false);
     }
     if (UNIQ && all) drain_partial<DBG>(A, w, bcur, mine, true);
@@ -403,17 +412,18 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
 // ballot + ds_bpermute per block) and patched into the lane's first queue entry.
 // When the block has more starts than the queue has room for (dense: few steps continue a run),
 // the steps are queued four at a time with the queue emitted in between.
-// In the short-path kernel (SHORT) a block may reach beyond its path at either end (it starts and
-// ends on 64-byte boundaries): steps at block-relative positions outside [rel_lo, rel_hi) get
-// consecutive placeholder ids, whose runs are dropped when emitted.  There the block's runs are
-// only queued, never emitted; the return value says whether they fitted the queue.
-template <bool UNIQ, bool DBG, bool SHORT = false>
+// In the wave-per-path kernels (HASH = log2 of the hash set's entries) a block may reach beyond its
+// path at either end (it starts and ends on 64-byte boundaries): steps at block-relative positions
+// outside [rel_lo, rel_hi) get consecutive placeholder ids, whose runs are dropped when emitted.
+// With QONLY the block's runs are only queued, never emitted; the return value says whether they
+// fitted the queue.
+template <bool UNIQ, bool DBG, int HASH = 0, bool QONLY = (HASH != 0)>
 __device__ __forceinline__ bool block16(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
                                         uint32_t (&a)[16], uint32_t nl, uint32_t rel_lo = 0, uint32_t rel_hi = 1024,
                                         uint32_t blk_pos = 0) {
     const bool active = (uint32_t)w.lane < nl;
     const bool last_lane = (uint32_t)w.lane + 1u == nl;
-    if (SHORT && (rel_lo > 0u || rel_hi < 16u * nl)) {
+    if (HASH && (rel_lo > 0u || rel_hi < 16u * nl)) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const uint32_t rel = 16u * (uint32_t)w.lane + (uint32_t)k;
@@ -469,12 +479,12 @@ __device__ __forceinline__ bool block16(const ScanArgs &A, Wave &w, uint32_t *se
         }
         if (last_lane) *reinterpret_cast<lds_u32 *>((uintptr_t)p) = (cur << kRunBits) | (a[15] - cur);
         w.fill += total;
-        if (SHORT) return true;
+        if (QONLY) return true;
         tmark<DBG>(A, w, 2);
-        drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);
+        drain<UNIQ, DBG, HASH>(A, w, seen, bcur, mine, false);
         tmark<DBG>(A, w, 3);
     } else {
-        if (SHORT) return false;
+        if (QONLY) return false;
         bool st[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -505,7 +515,7 @@ __device__ __forceinline__ bool block16(const ScanArgs &A, Wave &w, uint32_t *se
             cur = s2 ? x2 : cur;
             enqueue(w, s3, (cur << kRunBits) | (x2 - cur));
             cur = s3 ? x3 : cur;
-            drain<UNIQ, DBG>(A, w, seen, bcur, mine, false);
+            drain<UNIQ, DBG, HASH>(A, w, seen, bcur, mine, false);
         }
         enqueue(w, last_lane, (cur << kRunBits) | (a[15] - cur));
     }
@@ -819,30 +829,35 @@ __device__ __forceinline__ ShortBlk stream_next(const ScanArgs &A, ShortStream &
     return k;
 }
 
-template <bool UNIQ>
-__global__ __launch_bounds__(kThreads) void k_scan_short(const ScanArgs A) {
+// WAVES waves per workgroup, each with a hash set of 2^HASH entries.  QONLY: a path's runs are
+// queued first and emitted when it is complete (short paths; those that do not fit are handed
+// back); otherwise they are emitted as they come (medium paths, whose run count the plan knows).
+template <bool UNIQ, int WAVES, int HASH, bool QONLY>
+__global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
+    constexpr uint32_t kTab = 1u << HASH;
+    constexpr int kThr = WAVES * 64;
     extern __shared__ uint32_t lds[];
-    // layout: [bcur: kMaxWin][run queues: kWaves * kQCap][parked-claim queues: kWaves * 2 * kPCap][hash sets: kWaves * 2 * kTabEntries]
+    // layout: [bcur: kMaxWin][run queues: WAVES * kQCap][parked-claim queues: WAVES * 2 * kPCap][hash sets: WAVES * 2 * kTab]
     uint32_t *bcur = lds;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t *tab = lds + kMaxWin + kWaves * (kQCap + 2 * kPCap) + wave * (2 * kTabEntries);
+    uint32_t *tab = lds + kMaxWin + WAVES * (kQCap + 2 * kPCap) + wave * (2 * kTab);
     uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;
     Wave w;
     w.q = lds + kMaxWin + wave * kQCap;
-    w.pq = lds + kMaxWin + kWaves * kQCap + wave * (2 * kPCap);
+    w.pq = lds + kMaxWin + WAVES * kQCap + wave * (2 * kPCap);
     w.fill = w.pfill = 0;
     w.vm[0] = w.vm[1] = 0;
     w.tlast = 0;
     w.lane = lane;
-    for (uint32_t i = threadIdx.x; i < kMaxWin; i += kThreads) bcur[i] = i < A.n_win ? A.counts[(size_t)i * A.n_slots + blockIdx.x] : 0u;
+    for (uint32_t i = threadIdx.x; i < kMaxWin; i += kThr) bcur[i] = i < A.n_win ? A.counts[(size_t)i * A.n_slots + blockIdx.x] : 0u;
     if (UNIQ)
-        for (uint32_t i = lane; i < kTabEntries / 2; i += 64) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t i = lane; i < kTab / 2; i += 64) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
 
     ShortStream g;
-    g.stride = gridDim.x * kWaves;
-    g.gi = blockIdx.x * kWaves + wave;
+    g.stride = gridDim.x * WAVES;
+    g.gi = blockIdx.x * WAVES + wave;
     {
         const uint4 d = g.gi < A.n_short ? A.short_items[g.gi] : make_uint4(0u, 0u, 0u, 0u);
         g.b = d.x;
@@ -871,7 +886,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_short(const ScanArgs A) {
         if (!handed_back) {                                                                             \
             const uint32_t lo = cur.b > cur.pos ? cur.b - cur.pos : 0u;                                 \
             const uint32_t hi = cur.e - cur.pos < 1024u ? cur.e - cur.pos : 1024u;                      \
-            if (!block16<UNIQ, false, true>(A, w, tab, bcur, mine, a, cur.nl, lo, hi, cur.pos)) {       \
+            if (!block16<UNIQ, false, HASH, QONLY>(A, w, tab, bcur, mine, a, cur.nl, lo, hi, cur.pos)) { \
                 handed_back = true;                                                                     \
                 w.fill = 0;                                                                             \
             }                                                                                           \
@@ -881,9 +896,9 @@ __global__ __launch_bounds__(kThreads) void k_scan_short(const ScanArgs A) {
                 if (lane == 0) A.items[A.n_items + atomicAdd(A.work_counter, 1u)] = make_uint4(cur.b, cur.e, kNoSlot, 0u); \
                 handed_back = false;                                                                    \
             } else {                                                                                    \
-                drain<UNIQ, false, true>(A, w, tab, bcur, mine, true);                                  \
+                drain<UNIQ, false, HASH>(A, w, tab, bcur, mine, true);                                  \
                 if (UNIQ)                                                                               \
-                    for (uint32_t i = lane; i < kTabEntries / 2; i += 64)                               \
+                    for (uint32_t i = lane; i < kTab / 2; i += 64)                                      \
                         reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0u, 0u, 0u, 0u);                 \
             }                                                                                           \
         }                                                                                               \
@@ -896,9 +911,14 @@ __global__ __launch_bounds__(kThreads) void k_scan_short(const ScanArgs A) {
 #undef FGFA_SBLOCK
 #undef FGFA_SPTR
     __syncthreads();
-    for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads)
+    for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThr)
         A.counts[(size_t)wdw * A.n_slots + blockIdx.x] = bcur[wdw];
 }
+
+template <bool UNIQ>
+constexpr auto k_walk_short = k_scan_short<UNIQ, kWaves, kShortHash, true>;
+template <bool UNIQ>
+constexpr auto k_walk_medium = k_scan_short<UNIQ, kMediumWaves, kMediumHash, false>;
 
 // ------------------------------------------------------------------ pass 2 ---
 
@@ -1103,6 +1123,30 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     }
 }
 
+// Plan time: how many runs (as k_scan cuts them: +1 continuations, cut at multiples of 32) each
+// path has.  One workgroup per path at a time.
+__global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__ steps, const uint32_t *__restrict__ pb,
+                                                     const uint32_t *__restrict__ pe, uint32_t n_paths,
+                                                     uint32_t *__restrict__ runs) {
+    __shared__ uint32_t total;
+    for (uint32_t p = blockIdx.x; p < n_paths; p += gridDim.x) {
+        if (threadIdx.x == 0) total = 0;
+        __syncthreads();
+        const uint64_t b = pb[p], e = pe[p];
+        uint32_t mine = 0;
+        for (uint64_t i = b + threadIdx.x; i < e; i += 256) {
+            const uint32_t id = steps[i] >> 1;
+            const bool start = i == b || id != (steps[i - 1] >> 1) + 1u || (id & 31u) == 0u;
+            mine += start ? 1u : 0u;
+        }
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&total, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) runs[p] = total;
+        __syncthreads();
+    }
+}
+
 uint32_t scan_lds_bytes(uint32_t n_words) { return (kMaxWin + kWaves * (kQCap + 2 * kPCap) + n_words) * 4u; }
 
 #define FAST_TRY(expr)                                                                      \
@@ -1173,14 +1217,34 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     // last block would reach beyond the step array.
     uint64_t short_max = fp->dbg ? 0 : kShortMax;  // the ablation switches are k_scan's
     if (const char *forced = getenv("FLATGFA_SHORT_MAX")) short_max = std::min<uint64_t>(kShortMax, strtoull(forced, nullptr, 10));
-    std::vector<uint4> items, short_items;
+    // Longer paths with at most kMediumRuns runs are walked by single waves too, eight per CU, each
+    // with a bigger hash set (k_scan_short's medium variant); that needs the run counts.
+    std::vector<uint32_t> runs;
+    if (short_max) {
+        bool any = false;
+        for (uint32_t p = 0; p < g.n_paths && !any; ++p) any = (uint64_t)he[p] - hb[p] > short_max;
+        if (any) {
+            uint32_t *d_runs = nullptr;
+            FAST_TRY(hipMalloc(&d_runs, (size_t)g.n_paths * 4));
+            hipLaunchKernelGGL(k_count_runs, dim3(std::min<uint32_t>(g.n_paths, fp->n_cus * 8u)), dim3(256), 0, nullptr, g.steps,
+                               g.path_begin, g.path_end, g.n_paths, d_runs);
+            runs.resize(g.n_paths);
+            const hipError_t e = hipMemcpy(runs.data(), d_runs, (size_t)g.n_paths * 4, hipMemcpyDeviceToHost);
+            (void)hipFree(d_runs);
+            FAST_TRY(e);
+        }
+    }
+    std::vector<uint4> items, short_items, medium_items;
     std::vector<uint2> split;
     uint32_t n_piece_slots = 0;
     for (uint32_t p = 0; p < g.n_paths; ++p) {
         const uint64_t b = hb[p], e = he[p], n = e - b;
         if (n == 0) continue;
-        if (n <= short_max && ((e + 15) & ~15ull) <= g.n_steps) {
+        const bool in_reach = ((e + 15) & ~15ull) <= g.n_steps;  // the last block must not read past the step array
+        if (n <= short_max && in_reach) {
             short_items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
+        } else if (short_max && in_reach && !runs.empty() && runs[p] <= kMediumRuns) {
+            medium_items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
         } else if (n <= piece) {
             items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
         } else {
@@ -1196,10 +1260,12 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     const auto longer = [](const uint4 &a, const uint4 &b) { return a.y - a.x > b.y - b.x; };
     std::stable_sort(items.begin(), items.end(), longer);
     std::stable_sort(short_items.begin(), short_items.end(), longer);
+    std::stable_sort(medium_items.begin(), medium_items.end(), longer);
     fp->n_items = (uint32_t)items.size();
     fp->n_short = (uint32_t)short_items.size();
+    fp->n_medium = (uint32_t)medium_items.size();
     fp->n_split = (uint32_t)split.size();
-    if (items.empty() && short_items.empty()) return true;
+    if (items.empty() && short_items.empty() && medium_items.empty()) return true;
     FAST_TRY(hipMalloc(&fp->counts, slots * 4));
     FAST_TRY(hipMemset(fp->counts, 0, slots * 4));
     FAST_TRY(hipMalloc(&fp->buckets, (slots + fp->n_slots) * cap * 4));
@@ -1215,9 +1281,16 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
         FAST_TRY(hipMalloc(&fp->short_items, short_items.size() * sizeof(uint4)));
         FAST_TRY(hipMemcpy(fp->short_items, short_items.data(), short_items.size() * sizeof(uint4), hipMemcpyHostToDevice));
     }
-    fp->lds_bytes_short = (kMaxWin + kWaves * (kQCap + 2 * kPCap + 2 * kTabEntries)) * 4u;
-    FAST_TRY(hipFuncSetAttribute((const void *)k_scan_short<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_short));
-    FAST_TRY(hipFuncSetAttribute((const void *)k_scan_short<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_short));
+    if (!medium_items.empty()) {
+        FAST_TRY(hipMalloc(&fp->medium_items, medium_items.size() * sizeof(uint4)));
+        FAST_TRY(hipMemcpy(fp->medium_items, medium_items.data(), medium_items.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    }
+    fp->lds_bytes_short = (kMaxWin + kWaves * (kQCap + 2 * kPCap + (2u << kShortHash))) * 4u;
+    fp->lds_bytes_medium = (kMaxWin + kMediumWaves * (kQCap + 2 * kPCap + (2u << kMediumHash))) * 4u;
+    FAST_TRY(hipFuncSetAttribute((const void *)k_walk_short<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_short));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_walk_short<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_short));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_walk_medium<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_medium));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_walk_medium<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_medium));
     if (n_piece_slots) {
         FAST_TRY(hipMalloc(&fp->piece_bits, (size_t)n_piece_slots * n_words * 4));
         FAST_TRY(hipMalloc(&fp->split, split.size() * sizeof(uint2)));
@@ -1234,7 +1307,7 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
 
 void fast_plan_destroy(FastPlan *fp) {
     for (void *p : {(void *)fp->counts, (void *)fp->buckets, (void *)fp->ovf_d, (void *)fp->ovf_u, (void *)fp->ovf_flag,
-                    (void *)fp->items, (void *)fp->short_items, (void *)fp->piece_bits, (void *)fp->split, (void *)fp->work_counter})
+                    (void *)fp->items, (void *)fp->short_items, (void *)fp->medium_items, (void *)fp->piece_bits, (void *)fp->split, (void *)fp->work_counter})
         if (p) (void)hipFree(p);
     *fp = FastPlan();
 }
@@ -1279,11 +1352,20 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
         if (fp.n_short) {
             const uint32_t sgrid = std::min<uint32_t>((fp.n_short + kWaves - 1) / kWaves, fp.n_slots);
             ProfScope ps(uniq_out ? "k_scan_short<uniq>" : "k_scan_short<depth>", stream);
-            if (uniq_out) hipLaunchKernelGGL(k_scan_short<true>, dim3(sgrid), dim3(kThreads), fp.lds_bytes_short, stream, sa);
-            else hipLaunchKernelGGL(k_scan_short<false>, dim3(sgrid), dim3(kThreads), fp.lds_bytes_short, stream, sa);
+            if (uniq_out) hipLaunchKernelGGL(k_walk_short<true>, dim3(sgrid), dim3(kThreads), fp.lds_bytes_short, stream, sa);
+            else hipLaunchKernelGGL(k_walk_short<false>, dim3(sgrid), dim3(kThreads), fp.lds_bytes_short, stream, sa);
+        }
+        if (fp.n_medium) {
+            ScanArgs sm = sa;
+            sm.short_items = reinterpret_cast<const uint4 *>(fp.medium_items);
+            sm.n_short = fp.n_medium;
+            const uint32_t mgrid = std::min<uint32_t>((fp.n_medium + kMediumWaves - 1) / kMediumWaves, fp.n_slots);
+            ProfScope ps(uniq_out ? "k_scan_medium<uniq>" : "k_scan_medium<depth>", stream);
+            if (uniq_out) hipLaunchKernelGGL(k_walk_medium<true>, dim3(mgrid), dim3(kMediumWaves * 64), fp.lds_bytes_medium, stream, sm);
+            else hipLaunchKernelGGL(k_walk_medium<false>, dim3(mgrid), dim3(kMediumWaves * 64), fp.lds_bytes_medium, stream, sm);
         }
         if (uniq_out) {
-            {
+            if (grid) {
                 ProfScope ps("k_scan<uniq>", stream);
                 if (fp.dbg) hipLaunchKernelGGL((k_scan<true, true>), dim3(grid), dim3(kThreads), lds_uniq, stream, sa);
                 else hipLaunchKernelGGL((k_scan<true, false>), dim3(grid), dim3(kThreads), lds_uniq, stream, sa);
@@ -1293,7 +1375,7 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
                 hipLaunchKernelGGL(k_accum<true>, dim3(n_win), dim3(kAccThreads), 0, stream, aa);
             }
         } else {
-            {
+            if (grid) {
                 ProfScope ps("k_scan<depth>", stream);
                 hipLaunchKernelGGL((k_scan<false, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_depth, stream, sa);
             }

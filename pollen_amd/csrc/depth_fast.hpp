@@ -30,6 +30,9 @@ struct FastPlan {
     void *short_items = nullptr;   // uint4[n_short] paths every wave walks on its own (k_scan_short)
     uint32_t n_short = 0;
     uint32_t lds_bytes_short = 0;
+    void *medium_items = nullptr;  // uint4[n_medium] longer paths with few enough runs for a 4096-entry hash set
+    uint32_t n_medium = 0;
+    uint32_t lds_bytes_medium = 0;
     uint32_t *piece_bits = nullptr;  // bitsets left behind by the pieces of split paths
     void *split = nullptr;         // uint2[n_split] {first piece slot, pieces} per split path
     uint32_t n_split = 0;

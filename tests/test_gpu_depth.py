@@ -149,6 +149,9 @@ SHAPES = [
     (17, 999, 4000, 17, "pangenome"),        # paths shorter than a lane chunk, every alignment
     (18, 1_500_000, 3000, 700, "pangenome"),   # two segment-range passes over short paths
     (19, 1_200_000, 5, 300_000, "uniform"),    # two segment-range passes over long paths cut into pieces
+    (20, 400_000, 600, 9000, "pangenome"),     # medium paths: single waves with the larger hash set
+    (21, 1_300_000, 90, 15_000, "pangenome"),  # medium paths in two segment-range passes
+    (22, 90_000, 40, 6000, "uniform"),         # too many runs for the medium kernel: k_scan
 ]
 
 
