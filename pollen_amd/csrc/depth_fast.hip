@@ -1217,23 +1217,21 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     // last block would reach beyond the step array.
     uint64_t short_max = fp->dbg ? 0 : kShortMax;  // the ablation switches are k_scan's
     if (const char *forced = getenv("FLATGFA_SHORT_MAX")) short_max = std::min<uint64_t>(kShortMax, strtoull(forced, nullptr, 10));
-    // Longer paths with at most kMediumRuns runs are walked by single waves too, eight per CU, each
-    // with a bigger hash set (k_scan_short's medium variant); that needs the run counts.
+    // Which kernel walks a path depends on how many runs it has: short paths must fit the run queue,
+    // paths with at most kMediumRuns runs are walked by single waves too, eight per CU, each with a
+    // bigger hash set (k_scan_short's medium variant).  The counts come from a one-off kernel.
     std::vector<uint32_t> runs;
     if (short_max) {
-        bool any = false;
-        for (uint32_t p = 0; p < g.n_paths && !any; ++p) any = (uint64_t)he[p] - hb[p] > short_max;
-        if (any) {
-            uint32_t *d_runs = nullptr;
-            FAST_TRY(hipMalloc(&d_runs, (size_t)g.n_paths * 4));
-            hipLaunchKernelGGL(k_count_runs, dim3(std::min<uint32_t>(g.n_paths, fp->n_cus * 8u)), dim3(256), 0, nullptr, g.steps,
-                               g.path_begin, g.path_end, g.n_paths, d_runs);
-            runs.resize(g.n_paths);
-            const hipError_t e = hipMemcpy(runs.data(), d_runs, (size_t)g.n_paths * 4, hipMemcpyDeviceToHost);
-            (void)hipFree(d_runs);
-            FAST_TRY(e);
-        }
+        uint32_t *d_runs = nullptr;
+        FAST_TRY(hipMalloc(&d_runs, (size_t)g.n_paths * 4));
+        hipLaunchKernelGGL(k_count_runs, dim3(std::min<uint32_t>(g.n_paths, fp->n_cus * 8u)), dim3(256), 0, nullptr, g.steps,
+                           g.path_begin, g.path_end, g.n_paths, d_runs);
+        runs.resize(g.n_paths);
+        const hipError_t e = hipMemcpy(runs.data(), d_runs, (size_t)g.n_paths * 4, hipMemcpyDeviceToHost);
+        (void)hipFree(d_runs);
+        FAST_TRY(e);
     }
+    const bool short_any = getenv("FLATGFA_SHORT_ANY") != nullptr;  // tests: let k_scan_short find out and hand back
     std::vector<uint4> items, short_items, medium_items;
     std::vector<uint2> split;
     uint32_t n_piece_slots = 0;
@@ -1241,9 +1239,10 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
         const uint64_t b = hb[p], e = he[p], n = e - b;
         if (n == 0) continue;
         const bool in_reach = ((e + 15) & ~15ull) <= g.n_steps;  // the last block must not read past the step array
-        if (n <= short_max && in_reach) {
+        // a short path's runs (plus a few block-closing and placeholder ones) must fit the run queue
+        if (n <= short_max && in_reach && (runs[p] + 16 <= kQCap || short_any)) {
             short_items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
-        } else if (short_max && in_reach && !runs.empty() && runs[p] <= kMediumRuns) {
+        } else if (short_max && in_reach && runs[p] <= kMediumRuns) {
             medium_items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
         } else if (n <= piece) {
             items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
