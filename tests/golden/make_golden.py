@@ -38,6 +38,14 @@ from slow_odgi import overlap as so_overlap  # noqa: E402
 from oracle import synth  # noqa: E402
 
 CFG_S = dict(seed=1, S=10_000, P=100, L=10_000, model="pangenome")
+# Further synthetic graphs, chosen so that each of the device kernels that walk paths is pinned to
+# slow_odgi by at least one golden table: paths of 10 k steps (cfg-S: the medium-path kernel),
+# short paths (k_scan_short), long paths (k_scan), and uniform-random ids (no runs to speak of).
+SYNTH_MORE = {
+    "synth_short": dict(seed=7, S=8_000, P=600, L=800, model="pangenome"),
+    "synth_long": dict(seed=9, S=12_000, P=8, L=70_000, model="pangenome"),
+    "synth_uniform": dict(seed=11, S=6_000, P=40, L=3_000, model="uniform"),
+}
 
 
 def run(fn, *args) -> bytes:
@@ -92,6 +100,14 @@ def main():
     open(os.path.join(HERE, "synth_cfgS.depth.tsv"), "wb").write(out)
     manifest["synth_cfgS.depth.tsv"] = sha(out)
     print("synth_cfgS: ok")
+    for name, cfg in SYNTH_MORE.items():
+        pools = synth.pools(**cfg)
+        text = synth.gfa_text(pools)
+        manifest[name + ".steps.u32le"] = sha(pools.steps.tobytes())
+        out = run(so_depth.depth, parse(text), None)
+        open(os.path.join(HERE, name + ".depth.tsv"), "wb").write(out)
+        manifest[name + ".depth.tsv"] = sha(out)
+        print(f"{name}: ok")
 
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

@@ -207,6 +207,16 @@ def test_cfgS_matches_slow_odgi_golden():
     check_graph(g, pools_of(g))
 
 
+@pytest.mark.parametrize("name,cfg", [
+    ("synth_short", (7, 8_000, 600, 800, "pangenome")),    # k_scan_short
+    ("synth_long", (9, 12_000, 8, 70_000, "pangenome")),   # k_scan
+    ("synth_uniform", (11, 6_000, 40, 3_000, "uniform")),  # hardly any runs
+])
+def test_more_synthetic_graphs_match_slow_odgi_goldens(name, cfg, device_path):
+    g = pa.synth(*cfg, True)
+    assert g.depth_table() == read(os.path.join(GOLDEN, name + ".depth.tsv"))
+
+
 @pytest.mark.parametrize("model", ["pangenome", "uniform"])
 def test_cfgL_full_size(model):
     # BASELINE.json configs[2]: 1M segments / 100M steps.  Checked against the oracle (a few

@@ -99,6 +99,23 @@ def test_cfgS_synthetic_matches_slow_odgi_golden():
     assert table == read(os.path.join(GOLDEN, "synth_cfgS.depth.tsv"))
 
 
+SYNTH_MORE = {  # tests/golden/make_golden.py
+    "synth_short": dict(seed=7, S=8_000, P=600, L=800, model="pangenome"),
+    "synth_long": dict(seed=9, S=12_000, P=8, L=70_000, model="pangenome"),
+    "synth_uniform": dict(seed=11, S=6_000, P=40, L=3_000, model="uniform"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SYNTH_MORE))
+def test_more_synthetic_graphs_match_slow_odgi_goldens(name):
+    manifest = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))
+    pools = synth.pools(**SYNTH_MORE[name])
+    assert hashlib.sha256(pools.steps.tobytes()).hexdigest() == manifest[name + ".steps.u32le"]
+    table = fo.fgfa_depth(pools, True)
+    assert hashlib.sha256(table).hexdigest() == manifest[name + ".depth.tsv"]
+    assert table == read(os.path.join(GOLDEN, name + ".depth.tsv"))
+
+
 def test_out_of_range_is_an_error():
     pools = fo.parse_gfa(b"S\t1\tA\nP\tp\t1+\t*\n")
     pools.steps[0] = 5 << 1
