@@ -233,6 +233,13 @@ def main():
                 "first_query_ms": round((c3 - c2) * 1e3, 3), "table_ms": round((c4 - c3) * 1e3, 3),
                 "table_bytes": len(text), "total_ms": round((c4 - c0) * 1e3, 3),
                 "steps_per_s": round(N / (c4 - c0), 1)}
+            # BASELINE.json configs[4]: which paths share an oriented handle with which (all pairs)
+            g2.path_overlaps([0])  # builds the per-path handle bitsets (once per resident graph)
+            c5 = time.perf_counter()
+            touch = g2.path_overlaps(list(range(P)))
+            c6 = time.perf_counter()
+            extras["overlap_all_pairs"] = {"pairs": int(P) * int(P), "touching": int(touch.sum()),
+                                           "ms": round((c6 - c5) * 1e3, 3), "note": "host API call incl. D2H of the P x P byte matrix"}
             g2.close()
         finally:
             if os.path.exists(fpath):
