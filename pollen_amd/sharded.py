@@ -112,3 +112,25 @@ class ShardedDepth:
             if w is not None:
                 w.wait()
                 self.works[k] = None
+
+
+def gather_path_depth(local_lengths, local_weighted, group=None) -> Tuple[np.ndarray, np.ndarray]:
+    """path_depth over a path-sharded graph: every rank measures ITS paths
+    against the all-reduced node depth (DepthPlan.path_sums over its local path ids gives the two
+    integer sums of measure_path, ops/depth.rs:116-131), and since ranks own contiguous groups of
+    whole paths the per-path results are disjoint: an all-gather in rank order concatenates them,
+    no reduction.  Takes this rank's `lengths` and `weighted` sums (int64 tensors of u64 bits, or
+    numpy arrays); returns (lengths u64[P], means f64[P]) for all paths in path order, the one f64
+    division per path done exactly as depth.rs:129 does it."""
+    import torch
+    import torch.distributed as dist
+    ln = np.ascontiguousarray(local_lengths.cpu().numpy() if hasattr(local_lengths, "cpu") else local_lengths).view(np.uint64)
+    ws = np.ascontiguousarray(local_weighted.cpu().numpy() if hasattr(local_weighted, "cpu") else local_weighted).view(np.uint64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        parts = [None] * dist.get_world_size(group)
+        dist.all_gather_object(parts, (ln, ws), group=group)  # P integers per rank: tiny, host-side
+        ln = np.concatenate([p[0] for p in parts]) if parts else ln
+        ws = np.concatenate([p[1] for p in parts]) if parts else ws
+    with np.errstate(divide="ignore", invalid="ignore"):
+        mean = ws.astype(np.float64) / ln.astype(np.float64)  # 0/0 -> NaN, as the reference prints it
+    return ln, mean

@@ -82,6 +82,16 @@ def _worker(rank, world, port, seed, S, P, L, model, q):
         op.finish()
         want_d, want_u = fo.seg_depth_with_uniq(pools)
         ok = (op.depth.numpy().view(np.uint32) == want_d).all() and (op.uniq.numpy().view(np.uint32) == want_u).all()
+        # path depth: every rank measures its own paths against the reduced depth; results are concatenated
+        from pollen_amd.sharded import gather_path_depth
+        depth = op.depth.numpy().view(np.uint32).astype(np.uint64)
+        seg_len = (pools.segs["seq_end"] - pools.segs["seq_start"]).astype(np.uint64)
+        ids_all = pools.steps >> 1
+        ln = np.array([seg_len[ids_all[pb[p]:pe[p]]].sum() for p in range(lo, hi)], dtype=np.uint64)
+        ws = np.array([(depth[ids_all[pb[p]:pe[p]]] * seg_len[ids_all[pb[p]:pe[p]]]).sum() for p in range(lo, hi)], dtype=np.uint64)
+        got_ln, got_mean = gather_path_depth(ln, ws)
+        want_ln, want_mean = fo.path_depth(pools)
+        ok = ok and (got_ln == want_ln).all() and got_mean.tobytes() == want_mean.tobytes()
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
