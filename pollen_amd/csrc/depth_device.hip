@@ -214,6 +214,10 @@ struct flatgfa_dev_plan {
     FastPlan fast;  // the bucketed two-kernel path, used whenever the graph is eligible
     uint32_t *overlap_bits = nullptr;  // per-path oriented-handle bitsets (built on first overlap query)
     uint2 *len_depth = nullptr;        // (seg_len, depth) table of the last path_sums call (built on first use)
+    // the outputs of the last node-depth call through the bucketed path: flatgfa_dev_status
+    // completes that call if its records did not fit the sub-buckets
+    uint32_t *last_depth = nullptr, *last_uniq = nullptr;
+    bool last_fast = false;
 };
 
 extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int n_cus, uint32_t **bits_cache,
@@ -287,12 +291,9 @@ extern "C" void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *pl) {
     delete pl;
 }
 
-extern "C" int flatgfa_dev_seg_depth(flatgfa_dev_plan_t *pl, uint32_t *depth_out, uint32_t *uniq_out, void *stream_) {
-    if (!pl || (!depth_out && pl->g.n_segs)) { set_error("dev_seg_depth: NULL argument"); return FLATGFA_ERR_ARG; }
-    hipStream_t stream = (hipStream_t)stream_;
+// The simple global-atomic kernels: the general fallback, and the correctness anchor of the tests.
+static int atomic_seg_depth(flatgfa_dev_plan_t *pl, uint32_t *depth_out, uint32_t *uniq_out, hipStream_t stream) {
     const flatgfa_dev_graph_t &g = pl->g;
-    if (g.n_segs == 0) return FLATGFA_OK;
-    if (pl->fast.eligible) return fast_seg_depth(pl->fast, g, depth_out, uniq_out, pl->status, stream);
     {
         ProfScope ps("memset_outputs", stream);
         HIP_TRY(hipMemsetAsync(depth_out, 0, (size_t)g.n_segs * 4, stream), return FLATGFA_ERR_HIP);
@@ -314,6 +315,18 @@ extern "C" int flatgfa_dev_seg_depth(flatgfa_dev_plan_t *pl, uint32_t *depth_out
     }
     HIP_TRY(hipGetLastError(), return FLATGFA_ERR_HIP);
     return FLATGFA_OK;
+}
+
+extern "C" int flatgfa_dev_seg_depth(flatgfa_dev_plan_t *pl, uint32_t *depth_out, uint32_t *uniq_out, void *stream_) {
+    if (!pl || (!depth_out && pl->g.n_segs)) { set_error("dev_seg_depth: NULL argument"); return FLATGFA_ERR_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    const flatgfa_dev_graph_t &g = pl->g;
+    if (g.n_segs == 0) return FLATGFA_OK;
+    pl->last_fast = pl->fast.eligible;
+    pl->last_depth = depth_out;
+    pl->last_uniq = uniq_out;
+    if (pl->fast.eligible) return fast_seg_depth(pl->fast, g, depth_out, uniq_out, pl->status, stream);
+    return atomic_seg_depth(pl, depth_out, uniq_out, stream);
 }
 
 extern "C" int flatgfa_dev_path_sums(flatgfa_dev_plan_t *pl, const uint32_t *path_ids, uint32_t n_ids,
@@ -358,18 +371,38 @@ extern "C" int flatgfa_dev_path_overlaps(flatgfa_dev_plan_t *pl, const uint32_t 
                                           (hipStream_t)stream_);
 }
 
+// Status word bits set by the kernels: 1 = an id was out of range, 2 = a diagnostic mode's
+// sentinel, 4 = a record did not fit its sub-bucket (depth_fast.hip).
 extern "C" int flatgfa_dev_status(flatgfa_dev_plan_t *pl, void *stream_) {
     if (!pl) return FLATGFA_ERR_ARG;
     hipStream_t stream = (hipStream_t)stream_;
-    uint32_t st = 0;
-    HIP_TRY(hipMemcpyAsync(&st, pl->status, 4, hipMemcpyDeviceToHost, stream), return FLATGFA_ERR_HIP);
-    HIP_TRY(hipStreamSynchronize(stream), return FLATGFA_ERR_HIP);
-    if (st) {
+    for (int attempt = 0;; ++attempt) {
+        uint32_t st = 0;
+        HIP_TRY(hipMemcpyAsync(&st, pl->status, 4, hipMemcpyDeviceToHost, stream), return FLATGFA_ERR_HIP);
+        HIP_TRY(hipStreamSynchronize(stream), return FLATGFA_ERR_HIP);
+        if (!st) return FLATGFA_OK;
         HIP_TRY(hipMemsetAsync(pl->status, 0, 4, stream), return FLATGFA_ERR_HIP);
-        set_error("a step refers to a segment id (or a query to a path id) that is out of range");
-        return FLATGFA_ERR_BOUNDS;
+        if (st & 1u) {
+            set_error("a step refers to a segment id (or a query to a path id) that is out of range");
+            return FLATGFA_ERR_BOUNDS;
+        }
+        if (!(st & 4u)) return FLATGFA_OK;
+        // The last node-depth call ran out of sub-bucket room, so its outputs are incomplete: run
+        // it again with four times the room, or -- when the plan cannot grow -- through the
+        // atomic kernels.  The scratch cleans itself in pass 2, whatever was dropped.
+        if (!pl->last_fast || !pl->last_depth || attempt > 8) {
+            set_error("node depth: scratch overflow could not be resolved");
+            return FLATGFA_ERR_HIP;
+        }
+        int rc;
+        if (fast_plan_grow(&pl->fast)) {
+            rc = fast_seg_depth(pl->fast, pl->g, pl->last_depth, pl->last_uniq, pl->status, stream);
+        } else {
+            pl->last_fast = false;
+            rc = atomic_seg_depth(pl, pl->last_depth, pl->last_uniq, stream);
+        }
+        if (rc) return rc;
     }
-    return FLATGFA_OK;
 }
 
 extern "C" void flatgfa_dev_profile_enable(int on) {

@@ -1,4 +1,4 @@
-// The bucketed two-kernel node-depth path (depth_fast.hip); see DESIGN.md "Kernels".
+// The bucketed node-depth path (depth_fast.hip); see DESIGN.md "Kernels".
 #pragma once
 #include <hip/hip_runtime_api.h>
 
@@ -10,41 +10,45 @@ namespace fgfa_dev {
 
 struct FastPlan {
     bool eligible = false;
+    bool cap_forced = false;   // FLATGFA_BUCKET_CAP (tests): the capacity must not grow
     uint32_t n_cus = 256;
     uint32_t n_slots = 0;      // sub-buckets per window = persistent workgroups of pass 1
-    uint32_t n_win = 0;        // 4096-segment accumulation windows (of one segment-range pass)
-    uint32_t n_pass = 1;       // segment-range passes: 1 when the whole bitset fits LDS
-    uint32_t seg_range = 0;    // segments per pass
-    uint32_t n_words = 0;      // 32-bit words of the per-path "seen" bitset (padded)
+    uint32_t n_win = 0;        // accumulation windows
+    uint32_t wb = 12;          // log2 of the window size (4096 segments, 8192 beyond 4 M segments)
+    uint32_t nwp = 0;          // n_win rounded up to a multiple of 64
     uint32_t cap = 0;          // records per (window, sub-bucket)
-    uint32_t lds_bytes_uniq = 0, lds_bytes_depth = 0;
+    uint32_t lds_bytes_scan = 0;
     uint32_t dbg = 0;          // FLATGFA_DEBUG_SKIP ablation mask (diagnostics only)
-    uint32_t *counts = nullptr;    // u32[n_win * n_slots], zero between calls (pass 2 resets)
-    uint32_t *buckets = nullptr;   // u32[n_win * n_slots * cap]
-    int *ovf_d = nullptr;          // int[n_segs + 1], zero between calls
-    int *ovf_u = nullptr;
-    uint32_t *ovf_flag = nullptr;  // u32[n_win]
-    void *items = nullptr;         // uint4[n_items + n_short] whole paths and pieces of long paths, longest first,
+    uint32_t *counts = nullptr;    // u32[n_win * n_slots] cursors, zero between calls (pass 2 resets)
+    uint32_t *counts0 = nullptr;   // u32[n_win * n_slots] the cursors k_scan started from
+    uint32_t *buckets = nullptr;   // u32[(n_win + 1) * n_slots * cap]
+    void *dir = nullptr;           // uint2[n_win * dstride] {cursor before, after} each item, per window
+    uint32_t *islot = nullptr;     // u32[dstride] the sub-bucket that holds item j's records
+    uint32_t dstride = 0;          // n_items + max_back + 1
+    uint32_t *elist = nullptr;     // k_scan's items in pass 2's order (grouped by path, split among its waves)
+    uint32_t *wave_off = nullptr;  // u32[17] the stretch of elist each wave of pass 2 walks
+    void *items = nullptr;         // uint4[n_items + max_back] whole paths and pieces of long paths, longest first,
                                    // with room for the short paths k_scan_short hands back
     uint32_t n_items = 0;
+    uint32_t max_back = 0;
     void *short_items = nullptr;   // uint4[n_short] paths every wave walks on its own (k_scan_short)
     uint32_t n_short = 0;
     uint32_t lds_bytes_short = 0;
-    void *medium_items = nullptr;  // uint4[n_medium] longer paths with few enough runs for a 4096-entry hash set
+    void *medium_items = nullptr;  // uint4[n_medium] longer paths with few enough runs for a 2048-entry hash set
     uint32_t n_medium = 0;
     uint32_t lds_bytes_medium = 0;
-    uint32_t *piece_bits = nullptr;  // bitsets left behind by the pieces of split paths
-    void *split = nullptr;         // uint2[n_split] {first piece slot, pieces} per split path
-    uint32_t n_split = 0;
-    uint32_t *work_counter = nullptr;  // how many short paths were handed back in this call (pass 2 resets)
+    uint32_t *work_counter = nullptr;  // how many short paths were handed back in this call
 };
 
-// Decides eligibility (the per-path bitset must fit one CU's 160 KiB LDS, steps must be
-// 16-byte aligned) and allocates the scratch.  Returns false only on a HIP error.
+// Decides eligibility (at most 2048 windows, 16-byte aligned steps, a directory that stays small
+// next to the steps) and allocates the scratch.  Returns false only on a HIP error.
 bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *host_path_begin, const uint32_t *host_path_end,
                       FastPlan *fp);
 void fast_plan_destroy(FastPlan *fp);
-// Enqueues the two kernels.  uniq_out may be NULL (seg_depth).
+// After a call whose records did not fit their sub-buckets (status bit 4): quadruple the capacity.
+// Returns false -- and marks the plan ineligible -- when that is not possible.
+bool fast_plan_grow(FastPlan *fp);
+// Enqueues the kernels.  uniq_out may be NULL (seg_depth).
 int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
                    uint32_t *status, hipStream_t stream);
 
