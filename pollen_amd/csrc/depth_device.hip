@@ -325,7 +325,9 @@ extern "C" int flatgfa_dev_seg_depth(flatgfa_dev_plan_t *pl, uint32_t *depth_out
     pl->last_fast = pl->fast.eligible;
     pl->last_depth = depth_out;
     pl->last_uniq = uniq_out;
-    if (pl->fast.eligible) return fast_seg_depth(pl->fast, g, depth_out, uniq_out, pl->status, stream);
+    if (pl->fast.eligible) {
+        return fast_seg_depth(pl->fast, g, depth_out, uniq_out, pl->status, stream);
+    }
     return atomic_seg_depth(pl, depth_out, uniq_out, stream);
 }
 

@@ -78,7 +78,6 @@ constexpr uint32_t kMaxHandBack = 4096;    // short paths k_scan_short may hand 
 constexpr uint32_t kMaxWin = 2048;        // windows per launch (LDS cursor table)
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;  // queue entry that starts no run (terminates the one before it)
 constexpr uint32_t kQ2 = 64 + 1024 + 8;   // queue entries per wave: what is left over + one all-starts block
-constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 // diagnostic ablations (FLATGFA_DEBUG_SKIP, results are then wrong by construction)
 constexpr uint32_t kDbgNoStore = 1, kDbgNoTiles = 8, kDbgHotLoads = 16, kDbgTime = 32;
@@ -1043,89 +1042,75 @@ struct AccArgs {
     uint32_t max_back;
     uint32_t *depth_out;
     uint32_t *uniq_out;
+    uint32_t *status;
 };
 
-// One record = +1 at its first segment and -1 just past its last one, in a difference array over
-// the window.  With unique depth the two difference arrays share one array of 64-bit cells, depth
-// in the low word and uniq in the high word, so a record is two LDS atomics whatever it counts
-// for: the packed cells add up as 64-bit integers (depth + uniq * 2^32), prefix-sum as such, and
-// are taken apart only at the end.
+// Pass 2 keeps two difference arrays over the window in LDS: D for depth and R for revisits (steps
+// on a segment their path had already touched).  A record is +1 at its first segment and -1 just
+// past its last one in D; the stretches of its segments that were already claimed get the same
+// pair in R.  uniq = depth - revisits.  First visits are the common case and cost nothing extra.
+// A record of k_scan_short says what it counts for (bit 24: depth, bit 25: uniq).
 template <bool UNIQ, int WB>
-__device__ __forceinline__ void apply_record(unsigned long long *acc, uint32_t rec) {
+__device__ __forceinline__ void apply_record(int *D, int *R, uint32_t rec) {
     constexpr uint32_t kW = 1u << WB;
     const uint32_t rel = rec & (kW - 1), end = rel + ((rec >> WB) & 2047u) + 1;  // end <= window size; that cell is a sink
     if (UNIQ) {
-        const unsigned long long v = (unsigned long long)((rec >> 24) & 1u) | ((unsigned long long)((rec >> 25) & 1u) << 32);
-        atomicAdd(&acc[rel], v);
-        atomicAdd(&acc[end], 0ull - v);
+        const int d = (int)((rec >> 24) & 1u), rv = d - (int)((rec >> 25) & 1u);
+        if (d) {
+            atomicAdd(&D[rel], 1);
+            atomicAdd(&D[end], -1);
+        }
+        if (rv) {
+            atomicAdd(&R[rel], rv);
+            atomicAdd(&R[end], -rv);
+        }
     } else {
-        int *dd = reinterpret_cast<int *>(acc);
-        atomicAdd(&dd[rel], 1);
-        atomicAdd(&dd[end], -1);
+        atomicAdd(&D[rel], 1);
+        atomicAdd(&D[end], -1);
     }
 }
 
 // A record of k_scan (it counts for depth; what it counts for uniq is decided here): claim its
-// segments in the bitset of its path's group, word by word.  The bits that were clear are first
-// visits.  Stretches of first visits are added to the uniq half of the cells; in the common case
-// -- the whole run is new -- that is the same +1/-1 pair as for depth, so the record still costs
-// two LDS atomics.
+// segments in the bitset of its path's group, word by word, with returning ORs.  The bits that
+// were already set are revisits.  rec == 0: nothing to do for this lane.
 template <int WB>
-__device__ __forceinline__ void claim_apply(unsigned long long *cells, uint32_t *bits, bool valid, uint32_t rec) {
+__device__ __forceinline__ void claim_apply(int *D, int *R, uint32_t *bits, uint32_t rec) {
     constexpr uint32_t kW = 1u << WB;
-    constexpr unsigned long long kU = 1ull << 32;
-    const uint32_t rel = rec & (kW - 1), end = rel + ((rec >> WB) & 1023u);  // last segment of the run
-    uint32_t pos = rel, ustart = kNone;  // ustart: where the open stretch of first visits began
+    const bool valid = rec != 0u;
+    const uint32_t rel = rec & (kW - 1), e = rel + ((rec >> WB) & 1023u);  // last segment of the run
+    if (valid) {
+        atomicAdd(&D[rel], 1);
+        atomicAdd(&D[e + 1u], -1);
+    }
+    uint32_t p = rel;
     bool more = valid;
     while (__builtin_amdgcn_ballot_w64(more)) {
+        uint32_t rv = 0, base = 0;
         if (more) {
-            const uint32_t lo = pos & 31u, width = min(end + 1u - pos, 32u - lo);
+            const uint32_t lo = p & 31u, wl = min(e, p | 31u), width = wl - p + 1u;
             const uint32_t mask = (0xFFFFFFFFu >> (32u - width)) << lo;
-            const uint32_t nb = mask & ~atomicOr(&bits[pos >> 5], mask);
-            if (nb == mask) {
-                if (ustart == kNone) ustart = pos;
-            } else {
-                if (ustart != kNone) {
-                    atomicAdd(&cells[ustart], kU);
-                    atomicAdd(&cells[pos], 0ull - kU);
-                    ustart = kNone;
-                }
-                uint32_t m = nb;  // never all ones here
-                const uint32_t w0 = pos & ~31u;
-                while (m) {
-                    const uint32_t tz = (uint32_t)__builtin_ctz(m);
-                    const uint32_t run = (uint32_t)__builtin_ctz(~(m >> tz));
-                    m &= ~(((1u << run) - 1u) << tz);
-                    atomicAdd(&cells[w0 + tz], kU);
-                    atomicAdd(&cells[w0 + tz + run], 0ull - kU);
-                }
-            }
-            pos += width;
-            more = pos <= end;
+            rv = mask & atomicOr(&bits[p >> 5], mask);
+            base = p & ~31u;
+            p = wl + 1u;
+            more = p <= e;
         }
-    }
-    if (valid) {
-        if (ustart == rel) {  // every word was entirely new
-            atomicAdd(&cells[rel], 1ull + kU);
-            atomicAdd(&cells[end + 1u], 0ull - (1ull + kU));
-        } else {
-            atomicAdd(&cells[rel], 1ull);
-            atomicAdd(&cells[end + 1u], ~0ull);
-            if (ustart != kNone) {
-                atomicAdd(&cells[ustart], kU);
-                atomicAdd(&cells[end + 1u], 0ull - kU);
+        while (__builtin_amdgcn_ballot_w64(rv != 0u)) {  // one stretch of revisited segments per round
+            if (rv) {
+                const uint32_t low = rv & (0u - rv), sum = rv + low;  // adding the lowest set bit carries through its stretch
+                const uint32_t from = (uint32_t)__builtin_ctz(low), to = sum ? (uint32_t)__builtin_ctz(sum) : 32u;
+                rv &= sum;
+                atomicAdd(&R[base + from], 1);
+                atomicAdd(&R[base + to], -1);
             }
         }
     }
 }
 
-// inclusive prefix sum of N*1024 values held N per thread by 1024 threads; returns this thread's
-// N prefix values.
+// inclusive prefix sum of N*1024 values held N per thread by 1024 threads (v[] holds this thread's
+// values on entry, their prefix sums on return).
 template <typename T, int N>
-__device__ __forceinline__ void block_scan(const T *arr, T *wave_tot, T (&v)[N]) {
+__device__ __forceinline__ void block_scan(T *wave_tot, T (&v)[N]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = arr[N * tid + k];
 #pragma unroll
     for (int k = 1; k < N; ++k) v[k] += v[k - 1];
     T incl = v[N - 1];
@@ -1159,7 +1144,7 @@ __device__ __forceinline__ void store_n(uint32_t *out, uint32_t i0, uint32_t nva
 // they count for).  Each wave takes sixteen sub-buckets per round and requests the first 64 x 16
 // bytes of every one before it applies any, so a round pays the memory latency once.
 template <bool UNIQ, int WB>
-__device__ __forceinline__ void apply_flat(const AccArgs &A, unsigned long long *cells, const uint32_t *scnt, const uint32_t *wbase) {
+__device__ __forceinline__ void apply_flat(const AccArgs &A, int *D, int *R, const uint32_t *scnt, const uint32_t *wbase) {
     constexpr int kPerRound = 16;
     const int lane = threadIdx.x & 63;
     const uint32_t uw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: sub-bucket addressing stays scalar
@@ -1177,10 +1162,10 @@ __device__ __forceinline__ void apply_flat(const AccArgs &A, unsigned long long 
 #pragma unroll
         for (int k = 0; k < kPerRound; ++k) {
             if ((uint32_t)lane < (cnt[k] >> 2)) {
-                apply_record<UNIQ, WB>(cells, r[k].x);
-                apply_record<UNIQ, WB>(cells, r[k].y);
-                apply_record<UNIQ, WB>(cells, r[k].z);
-                apply_record<UNIQ, WB>(cells, r[k].w);
+                apply_record<UNIQ, WB>(D, R, r[k].x);
+                apply_record<UNIQ, WB>(D, R, r[k].y);
+                apply_record<UNIQ, WB>(D, R, r[k].z);
+                apply_record<UNIQ, WB>(D, R, r[k].w);
             }
         }
         // what does not fit the first pass (skewed sub-buckets), and the last 1..3 records
@@ -1192,24 +1177,35 @@ __device__ __forceinline__ void apply_flat(const AccArgs &A, unsigned long long 
             const uint32_t *bk = wbase + (size_t)s * A.cap;
             for (uint32_t i = 64 + lane; i < (c >> 2); i += 64) {
                 const uint4 v = reinterpret_cast<const uint4 *>(bk)[i];
-                apply_record<UNIQ, WB>(cells, v.x);
-                apply_record<UNIQ, WB>(cells, v.y);
-                apply_record<UNIQ, WB>(cells, v.z);
-                apply_record<UNIQ, WB>(cells, v.w);
+                apply_record<UNIQ, WB>(D, R, v.x);
+                apply_record<UNIQ, WB>(D, R, v.y);
+                apply_record<UNIQ, WB>(D, R, v.z);
+                apply_record<UNIQ, WB>(D, R, v.w);
             }
             const uint32_t rest = (c & ~3u) + lane;
-            if (rest < c) apply_record<UNIQ, WB>(cells, bk[rest]);
+            if (rest < c) apply_record<UNIQ, WB>(D, R, bk[rest]);
         }
     }
+}
+
+// inclusive prefix maximum across the wave
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0u, x, 0x111 /* row_shr:1 */, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0u, x, 0x112 /* row_shr:2 */, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0u, x, 0x114 /* row_shr:4 */, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0u, x, 0x118 /* row_shr:8 */, 0xf, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0u, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, true));
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0u, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, true));
+    return x;
 }
 
 // Walk this wave's stretch of k_scan's items (plus its share of the handed-back ones).  Their
 // directory entries are fetched 64 at a time, one per lane; the records of consecutive items are
 // then walked as one stream, 64 records per step whatever the items' sizes, every lane knowing
 // which item (hence which path's bitset) its record belongs to.  A wave keeps kSlots bitsets: a
-// step never spans more paths than that.
+// step never spans more paths than that.  Three steps' records are requested ahead of their use.
 template <int WB>
-__device__ __forceinline__ void apply_groups(const AccArgs &A, unsigned long long *cells, uint32_t *mybits, const uint32_t *wbase, uint32_t win) {
+__device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, uint32_t *mybits, uint32_t *mark, const uint32_t *wbase, uint32_t win) {
     constexpr uint32_t kNW = (1u << WB) / 32u;             // words per bitset
     constexpr uint32_t kSlots = WB == 12 ? 8u : 4u;
     const int lane = threadIdx.x & 63;
@@ -1219,7 +1215,7 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, unsigned long lon
     const uint32_t nst = e1 - e0;
     const uint32_t nE = nst + (nback > wave ? (nback - wave + kAccWaves - 1u) / kAccWaves : 0u);
     uint32_t gbase = 0, carryG = 0;  // path ordinals are 1-based: 0 = none yet
-    uint32_t hbase = 0, lastH = 0;   // ordinals of the paths that have records in this window
+    uint32_t hbase = 0, hdone = 0;   // ordinals (mod 256 where compared) of the paths that have records in this window
     for (uint32_t mb = 0; mb < nE; mb += 64u) {
         const uint32_t cntE = min(64u, nE - mb);
         const uint32_t x = mb + (uint32_t)lane;
@@ -1231,7 +1227,6 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, unsigned long lon
         const uint32_t sl = have ? A.islot[j] : 0u;
         const uint32_t b = min(be.x, A.cap), en = max(b, min(be.y, A.cap));
         const uint32_t n = en - b;
-        const uint32_t off = sl * A.cap + b;
         const uint32_t incl = wave_scan_incl(n), P = incl - n;
         const uint32_t T = __builtin_amdgcn_readlane(incl, 63);
         const uint32_t G = gbase + wave_scan_incl(first);  // which path the item belongs to
@@ -1246,39 +1241,65 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, unsigned long lon
         const uint32_t H = hbase + wave_scan_incl((n != 0u && gprev != G) ? 1u : 0u);
         hbase = __builtin_amdgcn_readlane(H, 63);
         if (ne) carryG = __builtin_amdgcn_readlane(G, 63 - __builtin_clzll(ne));
-        uint32_t cs = 0, nn = 0, lastE = 0;
-        while (cs < T) {
-            uint32_t ce = min(cs + 64u, T);
+        // the item's first record (an element offset from the window's bucket base, < 2^24) and H mod 256
+        const uint32_t offH = (sl * A.cap + b) | (H << 24);
+        uint32_t cs = 0, lastE = 0;
+        struct Chunk {
+            uint32_t rec, slot;  // per lane: the record (0 = none) and its path's bitset (a word offset)
+            uint32_t nv, hl;     // uniform: records in this step, ordinal of the last one's path
+        };
+        // The next step of the stream: up to 64 records from position cs on.  Every item that
+        // starts inside [cs, cs + 64) leaves its index at its start position; a running maximum
+        // then tells every position which item it lies in.
+        auto prep = [&]() -> Chunk {
+            Chunk c{0u, 0u, 0u, 0u};
+            if (cs >= T) return c;
             const uint32_t q = cs + (uint32_t)lane;
-            uint32_t sel = lastE, entered = 0;
-            while (nn < cntE) {
-                if (__builtin_amdgcn_readlane(n, nn) == 0u) {
-                    ++nn;
-                    continue;
-                }
-                const uint32_t Pn = __builtin_amdgcn_readlane(P, nn);
-                if (Pn >= ce) break;
-                const uint32_t h = __builtin_amdgcn_readlane(H, nn);
-                if (h != lastH) {  // a new path starts: give it a clean bitset
-                    if (entered == kSlots - 1u) {
-                        ce = Pn;
-                        break;
-                    }
-                    uint32_t *bs = mybits + (h & (kSlots - 1u)) * kNW;
-                    for (uint32_t i = lane; i < kNW / 2u; i += 64) reinterpret_cast<uint2 *>(bs)[i] = make_uint2(0u, 0u);
-                    lastH = h;
-                    ++entered;
-                }
-                sel = q >= Pn ? nn : sel;
-                lastE = nn;
-                ++nn;
+            const uint32_t relp = P - cs;
+            mark[lane] = 0u;
+            if (n != 0u && relp < 64u) mark[relp] = (uint32_t)lane + 1u;
+            // Lanes talk to each other through `mark`: without this the compiler forwards the zero a
+            // lane has just stored to its own load (it reasons about one thread at a time).
+            asm volatile("" ::: "memory");
+            const uint32_t sel = max(wave_scan_max(mark[lane]), lastE + 1u) - 1u;
+            const uint32_t oh = __shfl(offH, (int)sel, 64), Ps = __shfl(P, (int)sel, 64);
+            const uint32_t h = oh >> 24;
+            const uint32_t hf = __builtin_amdgcn_readfirstlane(h);
+            const bool valid = q < T && ((h - hf) & 0xFFu) < kSlots;
+            c.nv = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid));  // a prefix of the lanes
+            c.rec = valid ? wbase[(oh & 0xFFFFFFu) + (q - Ps)] : 0u;
+            c.slot = (h & (kSlots - 1u)) * kNW;
+            c.hl = __builtin_amdgcn_readlane(h, c.nv - 1u);
+            lastE = __builtin_amdgcn_readlane(sel, c.nv - 1u);
+            cs += c.nv;
+            return c;
+        };
+        auto process = [&](const Chunk &c) {
+            // the paths met for the first time in this step get clean bitsets
+            const uint32_t fresh = (c.hl - hdone) & 0xFFu;
+            for (uint32_t k = 1; k <= fresh; ++k) {
+                uint32_t *bs = mybits + ((hdone + k) & (kSlots - 1u)) * kNW;
+                for (uint32_t i = lane; i < kNW / 2u; i += 64) reinterpret_cast<uint2 *>(bs)[i] = make_uint2(0u, 0u);
             }
-            const bool valid = q < ce;
-            const int ss = valid ? (int)sel : 0;
-            const uint32_t off_s = __shfl(off, ss, 64), P_s = __shfl(P, ss, 64), h_s = __shfl(H, ss, 64);
-            const uint32_t rec = valid ? wbase[off_s + (q - P_s)] : 0u;
-            claim_apply<WB>(cells, mybits + (h_s & (kSlots - 1u)) * kNW, valid, rec);
-            cs = ce;
+            hdone = c.hl;
+            claim_apply<WB>(D, R, mybits + c.slot, c.rec);
+        };
+        Chunk ch[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ch[k] = prep();
+        bool done = false;
+        while (!done) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (!done) {
+                    if (ch[k].nv == 0u) {
+                        done = true;
+                    } else {
+                        process(ch[k]);
+                        ch[k] = prep();
+                    }
+                }
+            }
         }
     }
 }
@@ -1288,11 +1309,13 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     constexpr uint32_t kW = 1u << WB;
     constexpr int kPer = kW / kAccThreads;  // cells per thread: 4 or 8
     constexpr uint32_t kSlots = WB == 12 ? 8u : 4u;
-    // difference array over the window: packed 64-bit cells with unique depth, plain ints without
-    __shared__ __attribute__((aligned(16))) unsigned long long cells[UNIQ ? kW + 64 : (kW + 64) / 2];
+    // difference arrays over the window: depth, and (with unique depth) revisits
+    __shared__ __attribute__((aligned(16))) int cells[(UNIQ ? 2 : 1) * (kW + 64)];
     __shared__ unsigned long long wave_tot[kAccWaves];
     __shared__ uint32_t scnt[kMaxSlots];
     __shared__ __attribute__((aligned(16))) uint32_t bits[UNIQ ? kAccWaves * kSlots * (kW / 32) : 4];
+    __shared__ uint32_t marks[UNIQ ? kAccWaves * 64 : 4];
+    int *D = cells, *R = cells + (UNIQ ? kW + 64 : 0);
     const int tid = threadIdx.x, wave = tid >> 6;
     const uint32_t win = blockIdx.x, w0 = win * kW;
     // this window's record counts, one per sub-bucket: staged in LDS, and zeroed in place so that
@@ -1307,31 +1330,33 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
         scnt[sl] = min(v, A.cap);
     }
     const uint32_t nvalid = min(kW, A.n_segs - w0);
-    for (uint32_t i = tid; i < kW + 64; i += kAccThreads) {
-        if (UNIQ) cells[i] = 0ull;
-        else reinterpret_cast<int *>(cells)[i] = 0;
-    }
+    for (uint32_t i = tid; i < (UNIQ ? 2u : 1u) * (kW + 64); i += kAccThreads) cells[i] = 0;
     __syncthreads();
     const uint32_t *wbase = A.buckets + (size_t)win * A.n_slots * A.cap;
-    if (flat) apply_flat<UNIQ, WB>(A, cells, scnt, wbase);
-    if (UNIQ) apply_groups<WB>(A, cells, bits + wave * (kSlots * (kW / 32)), wbase, win);
+    if (flat) apply_flat<UNIQ, WB>(A, D, R, scnt, wbase);
+    if (UNIQ) apply_groups<WB>(A, D, R, bits + wave * (kSlots * (kW / 32)), marks + wave * 64, wbase, win);
     __syncthreads();
     const uint32_t i0 = kPer * tid;
     uint32_t d[kPer], u[kPer];
     if (UNIQ) {
+        // one scan for both: depth in the low word, revisits in the high word of a 64-bit value
+        // (every prefix has both counts non-negative, so the words do not disturb each other)
         unsigned long long v[kPer];
-        block_scan<unsigned long long, kPer>(cells, wave_tot, v);
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) v[k] = (unsigned long long)(long long)D[i0 + k] + ((unsigned long long)(long long)R[i0 + k] << 32);
+        block_scan<unsigned long long, kPer>(wave_tot, v);
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
-            // every prefix is depth + uniq * 2^32 with both counts non-negative: no borrow to undo
             d[k] = (uint32_t)v[k];
-            u[k] = (uint32_t)(v[k] >> 32);
+            u[k] = d[k] - (uint32_t)(v[k] >> 32);
         }
         store_n<kPer>(A.depth_out + w0, i0, nvalid, d);
         store_n<kPer>(A.uniq_out + w0, i0, nvalid, u);
     } else {
         int v[kPer];
-        block_scan<int, kPer>(reinterpret_cast<const int *>(cells), reinterpret_cast<int *>(wave_tot), v);
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) v[k] = D[i0 + k];
+        block_scan<int, kPer>(reinterpret_cast<int *>(wave_tot), v);
 #pragma unroll
         for (int k = 0; k < kPer; ++k) d[k] = (uint32_t)v[k];
         store_n<kPer>(A.depth_out + w0, i0, nvalid, d);
@@ -1631,7 +1656,7 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
     sa.dbg = fp.dbg;
     AccArgs aa{g.n_segs, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.counts0, has_pre ? 1u : 0u, fp.buckets,
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
-               fp.work_counter, fp.max_back, depth_out, uniq_out};
+               fp.work_counter, fp.max_back, depth_out, uniq_out, status};
     if (fp.n_short) {
         if (hipMemsetAsync(fp.work_counter, 0, 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
         const uint32_t sgrid = std::min<uint32_t>((fp.n_short + kWaves - 1) / kWaves, fp.n_slots);
