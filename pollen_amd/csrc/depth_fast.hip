@@ -80,7 +80,7 @@ constexpr uint32_t kInvalid = 0xFFFFFFFFu;  // queue entry that starts no run (t
 constexpr uint32_t kQ2 = 64 + 1024 + 8;   // queue entries per wave: what is left over + one all-starts block
 
 // diagnostic ablations (FLATGFA_DEBUG_SKIP, results are then wrong by construction)
-constexpr uint32_t kDbgNoStore = 1, kDbgNoTiles = 8, kDbgHotLoads = 16, kDbgTime = 32;
+constexpr uint32_t kDbgNoStore = 1, kDbgNoTiles = 8, kDbgHotLoads = 16, kDbgTime = 32, kDbgNoClaim = 64, kDbgNoRevisit = 128, kDbgNoDepth = 256;
 // the ablation checks exist only in the DBG instantiation of the kernel
 #define FGFA_SKIP(bit) (DBG && (A.dbg & (bit)))
 
@@ -144,6 +144,7 @@ __device__ __forceinline__ bool put(const ScanArgs &A, W &w, uint32_t *mine, boo
         *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(mine) + boff) = rec;
         w.vm[0] += 1;  // exactly one store instruction, executed by the whole wave
         w.vm[1] += 1;
+        w.vm[2] += 1;
     }
     return e && !ok;
 }
@@ -172,21 +173,27 @@ __device__ __forceinline__ void flag_if_any(const ScanArgs &A, bool b, uint32_t 
 // fully coalesced loads, tools/loadpat.hip).  No nontemporal hint here: the sectors must survive
 // in cache from the first of the four instructions to the last.
 #define FGFA_CLOB_A "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111"
+#define FGFA_CLOB_C "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95"
 #define FGFA_CLOB_B "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
 template <int SET, typename W>
 __device__ __forceinline__ void load_block_async(W &w, const uint4 *p) {
-    w.vm[SET] = 0;
-    w.vm[1 - SET] += 4;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w.vm[k] = k == SET ? 0u : w.vm[k] + 4u;
     if (SET == 0)
         asm volatile("global_load_dwordx4 v[96:99], %0, off\n\t"
                      "global_load_dwordx4 v[100:103], %0, off offset:16\n\t"
                      "global_load_dwordx4 v[104:107], %0, off offset:32\n\t"
                      "global_load_dwordx4 v[108:111], %0, off offset:48" ::"v"(p) : "memory", FGFA_CLOB_A);
-    else
+    else if (SET == 1)
         asm volatile("global_load_dwordx4 v[112:115], %0, off\n\t"
                      "global_load_dwordx4 v[116:119], %0, off offset:16\n\t"
                      "global_load_dwordx4 v[120:123], %0, off offset:32\n\t"
                      "global_load_dwordx4 v[124:127], %0, off offset:48" ::"v"(p) : "memory", FGFA_CLOB_B);
+    else
+        asm volatile("global_load_dwordx4 v[80:83], %0, off\n\t"
+                     "global_load_dwordx4 v[84:87], %0, off offset:16\n\t"
+                     "global_load_dwordx4 v[88:91], %0, off offset:32\n\t"
+                     "global_load_dwordx4 v[92:95], %0, off offset:48" ::"v"(p) : "memory", FGFA_CLOB_C);
 }
 // Waits until the loads into landing set SET have returned.  `w.vm[SET]` counts the memory
 // instructions this wave is known to have issued since (the other set's loads and the record
@@ -216,6 +223,7 @@ __device__ __forceinline__ void wait_block(const W &w) {
 template <int SET>
 __device__ __forceinline__ void take_block(uint32_t (&a)[16]) {
     if (SET == 0) FGFA_TAKE16("v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111");
+    else if (SET == 2) FGFA_TAKE16("v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
     else FGFA_TAKE16("v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
 }
 
@@ -232,7 +240,7 @@ __device__ __forceinline__ void take_block(uint32_t (&a)[16]) {
 struct Wave {
     uint32_t *q, *pq;
     uint32_t fill, pfill;
-    uint32_t vm[2];  // memory instructions issued since the loads into landing set 0 / 1 (see wait_block)
+    uint32_t vm[3];  // memory instructions issued since the loads into landing set 0 / 1 / 2 (see wait_block)
     int lane;
 };
 
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
     w.q = lds + kShortMaxWin + wave * kQCap;
     w.pq = lds + kShortMaxWin + WAVES * kQCap + wave * (2 * kPCap);
     w.fill = w.pfill = 0;
-    w.vm[0] = w.vm[1] = 0;
+    w.vm[0] = w.vm[1] = w.vm[2] = 0;
     w.lane = lane;
     for (uint32_t i = threadIdx.x; i < kShortMaxWin; i += kThr) bcur[i] = i < A.n_win ? A.counts[(size_t)i * A.n_slots + blockIdx.x] : 0u;
     if (UNIQ)
@@ -663,7 +671,7 @@ constexpr auto k_walk_medium = k_scan_short<UNIQ, kMediumWaves, kMediumHash, fal
 struct RWave {
     uint2 *q;
     uint32_t fill;
-    uint32_t vm[2];
+    uint32_t vm[3];
     int lane;
     bool epoch_ok;  // the item before the current one is complete: this wave may append records
     unsigned long long tacc[8], tlast;  // kDbgTime (diagnostic): cycles per phase of this wave
@@ -749,7 +757,22 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
     const uint32_t win = id >> wb, rel = id & wmask;
     const bool cross = valid && rel + lenm1 > wmask;
     const uint32_t l1 = cross ? wmask - rel : lenm1;
-    const uint32_t pos = valid ? atomicAdd(&bcur[win], 1u) : 0u;
+    // Consecutive entries mostly go to the same window (a stretch of the path between two jumps):
+    // the first lane of every stretch of equal windows takes the stretch's slots with ONE cursor
+    // update and hands the base to the others -- a handful of LDS atomics per chunk instead of 64
+    // that serialize on the same address, and neighbouring lanes store to neighbouring slots.
+    // Stretches are found within each half of the wave, so that the lane masks are 32 bits wide.
+    const uint32_t key = valid ? win : 0xFFFFFFFFu;
+    const uint32_t kprev = __builtin_amdgcn_update_dpp(0u, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const uint32_t l5 = (uint32_t)w.lane & 31u;
+    const unsigned long long hm = __builtin_amdgcn_ballot_w64(l5 == 0u || key != kprev);
+    const uint32_t h32 = w.lane < 32 ? (uint32_t)hm : (uint32_t)(hm >> 32);
+    const uint32_t back = (uint32_t)__builtin_clz(h32 << (31u - l5));  // lanes back to the stretch's first one
+    const uint32_t up = (h32 >> l5) >> 1;                                // first lanes above this one
+    const uint32_t cnt = min(up ? (uint32_t)__builtin_ctz(up) + 1u : 32u, 32u - l5);
+    uint32_t base0 = 0u;
+    if (valid && back == 0u) base0 = atomicAdd(&bcur[win], cnt);
+    const uint32_t pos = __shfl(base0, w.lane - (int)back, 64) + back;
     bool ovf = put<DBG>(A, w, mine, valid, pos, win, rel | (l1 << wb) | (1u << 24));
     if (__builtin_amdgcn_ballot_w64(cross)) {
         const uint32_t pos2 = cross ? atomicAdd(&bcur[win + 1u], 1u) : 0u;
@@ -899,7 +922,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     RWave w;
     w.q = reinterpret_cast<uint2 *>(lds + 2u * A.nwp + kCtlWords) + (uint32_t)wave * kQ2;
     w.fill = 0;
-    w.vm[0] = w.vm[1] = 0;
+    w.vm[0] = w.vm[1] = w.vm[2] = 0;
     w.lane = lane;
     w.epoch_ok = true;
     for (int k = 0; k < 8; ++k) w.tacc[k] = 0;
@@ -911,7 +934,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         snap[i] = c;
         if (A.has_pre && i < A.n_win) A.counts0[(size_t)i * A.n_slots + blockIdx.x] = c;
     }
-    if (threadIdx.x < kCtlWords) ctl[threadIdx.x] = threadIdx.x < 2 ? 3u * kWaves : 0u;
+    if (threadIdx.x < kCtlWords) ctl[threadIdx.x] = threadIdx.x < 2 ? 4u * kWaves : 0u;
     // block-relative positions of this lane's sixteen steps; opaque, so that they stay in registers
     uint32_t pj[16];
 #pragma unroll
@@ -928,7 +951,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     uint32_t rr = 0;  // this workgroup's items so far
     uint32_t job = item_of(0, blockIdx.x, gridDim.x);
     Item it = make_item(A, job < n_items, job < n_items ? A.items[job] : make_uint4(0u, 0u, 0u, 0u), lane);
-    uint32_t blk[2];  // the block each landing set holds (or will hold next)
+    uint32_t blk[3];  // the block each landing set holds (or will hold next)
     uint32_t resv;    // the block this wave takes after those
     // lanes beyond a partial block's last one re-read lane 0's chunk: same instruction stream for all
 #define FGFA_BLOCK_PTR(j) \
@@ -937,9 +960,11 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     do {                                                                    \
         blk[0] = (uint32_t)wave;                                            \
         blk[1] = (uint32_t)wave + kWaves;                                   \
-        resv = (uint32_t)wave + 2u * kWaves;                                \
+        blk[2] = (uint32_t)wave + 2u * kWaves;                              \
+        resv = (uint32_t)wave + 3u * kWaves;                                \
         if (blk[0] < it.nblk) load_block_async<0>(w, FGFA_BLOCK_PTR(blk[0])); \
         if (blk[1] < it.nblk) load_block_async<1>(w, FGFA_BLOCK_PTR(blk[1])); \
+        if (blk[2] < it.nblk) load_block_async<2>(w, FGFA_BLOCK_PTR(blk[2])); \
     } while (0)
     // one block: wait for its data, take the next free block for its register set, process it
 #define FGFA_BLOCK(SET)                                                                       \
@@ -970,9 +995,10 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         if (wave == 0 && it.t0 > it.b) tile_narrow_raw(A, w, it.b, (uint32_t)(it.t0 - it.b));
         if (wave == kWaves - 1 && it.e > it.tail) tile_narrow_raw(A, w, it.tail, (uint32_t)(it.e - it.tail));
 #pragma unroll 1
-        while (blk[0] < it.nblk || blk[1] < it.nblk) {
+        while (blk[0] < it.nblk || blk[1] < it.nblk || blk[2] < it.nblk) {
             FGFA_BLOCK(0)
             FGFA_BLOCK(1)
+            FGFA_BLOCK(2)
         }
         // Records of this item may only be appended once every wave has left the item before it
         // (its cursor snapshot is taken then); a wave that got ahead has been queueing until now.
@@ -1003,7 +1029,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             if (lane == 0) {
                 A.islot[done_job] = blockIdx.x;
                 ctl[kCtlArrive + (rr & 1u)] = 0u;
-                ctl[kCtlNext + (rr & 1u)] = 3u * kWaves;  // for the item after the next one
+                ctl[kCtlNext + (rr & 1u)] = 4u * kWaves;  // for the item after the next one
             }
             __hip_atomic_store(ctl + kCtlEpoch, rr + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -1043,6 +1069,7 @@ struct AccArgs {
     uint32_t *depth_out;
     uint32_t *uniq_out;
     uint32_t *status;
+    uint32_t dbg;  // FLATGFA_DEBUG_SKIP ablations (results are then wrong by construction)
 };
 
 // Pass 2 keeps two difference arrays over the window in LDS: D for depth and R for revisits (steps
@@ -1074,16 +1101,16 @@ __device__ __forceinline__ void apply_record(int *D, int *R, uint32_t rec) {
 // segments in the bitset of its path's group, word by word, with returning ORs.  The bits that
 // were already set are revisits.  rec == 0: nothing to do for this lane.
 template <int WB>
-__device__ __forceinline__ void claim_apply(int *D, int *R, uint32_t *bits, uint32_t rec) {
+__device__ __forceinline__ void claim_apply(int *D, int *R, uint32_t *bits, uint32_t rec, uint32_t dbg) {
     constexpr uint32_t kW = 1u << WB;
     const bool valid = rec != 0u;
     const uint32_t rel = rec & (kW - 1), e = rel + ((rec >> WB) & 1023u);  // last segment of the run
-    if (valid) {
+    if (valid && !(dbg & kDbgNoDepth)) {
         atomicAdd(&D[rel], 1);
         atomicAdd(&D[e + 1u], -1);
     }
     uint32_t p = rel;
-    bool more = valid;
+    bool more = valid && !(dbg & kDbgNoClaim);
     while (__builtin_amdgcn_ballot_w64(more)) {
         uint32_t rv = 0, base = 0;
         if (more) {
@@ -1093,6 +1120,7 @@ __device__ __forceinline__ void claim_apply(int *D, int *R, uint32_t *bits, uint
             base = p & ~31u;
             p = wl + 1u;
             more = p <= e;
+            if (dbg & kDbgNoRevisit) rv = 0;
         }
         while (__builtin_amdgcn_ballot_w64(rv != 0u)) {  // one stretch of revisited segments per round
             if (rv) {
@@ -1129,8 +1157,13 @@ __device__ __forceinline__ void block_scan(T *wave_tot, T (&v)[N]) {
 
 template <int N>
 __device__ __forceinline__ void store_n(uint32_t *out, uint32_t i0, uint32_t nvalid, const uint32_t (&a)[N]) {
+    if (N == 2) {
+        if (i0 + 1 < nvalid) *reinterpret_cast<uint2 *>(out + i0) = make_uint2(a[0], a[1]);
+        else if (i0 < nvalid) out[i0] = a[0];
+        return;
+    }
 #pragma unroll
-    for (int k0 = 0; k0 < N; k0 += 4) {
+    for (int k0 = 0; k0 + 3 < N; k0 += 4) {
         if (i0 + k0 + 3 < nvalid) {
             *reinterpret_cast<uint4 *>(out + i0 + k0) = make_uint4(a[k0], a[k0 + 1], a[k0 + 2], a[k0 + 3]);
         } else {
@@ -1188,6 +1221,26 @@ __device__ __forceinline__ void apply_flat(const AccArgs &A, int *D, int *R, con
     }
 }
 
+// Pass 2 requests the records of three steps ahead of their use.  As in k_scan, hipcc cannot keep
+// a load in flight across loop iterations (it copies the destination register, which waits for
+// the load), so the three landing registers are fixed -- v120, v121, v122, told to the compiler as
+// clobbered and checked by tools/check_pinned_vgprs.py -- and a record is taken out after a
+// counted wait: the two younger requests are the only other vector-memory operations in flight.
+template <int K>
+__device__ __forceinline__ void rec_request(const uint32_t *p) {
+    if (K == 0) asm volatile("global_load_dword v120, %0, off" ::"v"(p) : "memory", "v120");
+    else if (K == 1) asm volatile("global_load_dword v121, %0, off" ::"v"(p) : "memory", "v121");
+    else asm volatile("global_load_dword v122, %0, off" ::"v"(p) : "memory", "v122");
+}
+template <int K>
+__device__ __forceinline__ uint32_t rec_take() {
+    uint32_t r;
+    if (K == 0) asm volatile("s_waitcnt vmcnt(2)\n\tv_mov_b32 %0, v120" : "=v"(r)::"memory");
+    else if (K == 1) asm volatile("s_waitcnt vmcnt(2)\n\tv_mov_b32 %0, v121" : "=v"(r)::"memory");
+    else asm volatile("s_waitcnt vmcnt(2)\n\tv_mov_b32 %0, v122" : "=v"(r)::"memory");
+    return r;
+}
+
 // inclusive prefix maximum across the wave
 __device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
     x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0u, x, 0x111 /* row_shr:1 */, 0xf, 0xf, true));
@@ -1207,7 +1260,7 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
 template <int WB>
 __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, uint32_t *mybits, uint32_t *mark, const uint32_t *wbase, uint32_t win) {
     constexpr uint32_t kNW = (1u << WB) / 32u;             // words per bitset
-    constexpr uint32_t kSlots = WB == 12 ? 8u : 4u;
+    constexpr uint32_t kSlots = WB <= 12 ? 8u : 4u;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t e0 = __builtin_amdgcn_readfirstlane(A.wave_off[wave]), e1 = __builtin_amdgcn_readfirstlane(A.wave_off[wave + 1]);
@@ -1244,16 +1297,18 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
         // the item's first record (an element offset from the window's bucket base, < 2^24) and H mod 256
         const uint32_t offH = (sl * A.cap + b) | (H << 24);
         uint32_t cs = 0, lastE = 0;
+        uint32_t hseen = hdone;  // ordinal of the last record's path in the steps prepared so far
         struct Chunk {
-            uint32_t rec, slot;  // per lane: the record (0 = none) and its path's bitset (a word offset)
-            uint32_t nv, hl;     // uniform: records in this step, ordinal of the last one's path
+            const uint32_t *src;  // per lane: where its record is (the bucket base for lanes without one)
+            uint32_t slot;        // per lane: its path's bitset (a word offset), or kNoSlot for lanes without a record
+            uint32_t nv, hl;      // uniform: records in this step, ordinal of the last one's path
         };
         // The next step of the stream: up to 64 records from position cs on.  Every item that
         // starts inside [cs, cs + 64) leaves its index at its start position; a running maximum
-        // then tells every position which item it lies in.
+        // then tells every position which item it lies in.  When the stream is exhausted the
+        // step is empty (nv = 0) but is still formed, so that every step requests one load.
         auto prep = [&]() -> Chunk {
-            Chunk c{0u, 0u, 0u, 0u};
-            if (cs >= T) return c;
+            Chunk c;
             const uint32_t q = cs + (uint32_t)lane;
             const uint32_t relp = P - cs;
             mark[lane] = 0u;
@@ -1267,14 +1322,16 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
             const uint32_t hf = __builtin_amdgcn_readfirstlane(h);
             const bool valid = q < T && ((h - hf) & 0xFFu) < kSlots;
             c.nv = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid));  // a prefix of the lanes
-            c.rec = valid ? wbase[(oh & 0xFFFFFFu) + (q - Ps)] : 0u;
-            c.slot = (h & (kSlots - 1u)) * kNW;
-            c.hl = __builtin_amdgcn_readlane(h, c.nv - 1u);
-            lastE = __builtin_amdgcn_readlane(sel, c.nv - 1u);
+            c.src = wbase + (valid ? (oh & 0xFFFFFFu) + (q - Ps) : 0u);
+            c.slot = valid ? (h & (kSlots - 1u)) * kNW : kNoSlot;
+            const uint32_t last = c.nv ? c.nv - 1u : 0u;
+            c.hl = c.nv ? __builtin_amdgcn_readlane(h, last) : hseen;
+            lastE = c.nv ? __builtin_amdgcn_readlane(sel, last) : lastE;
+            hseen = c.hl;
             cs += c.nv;
             return c;
         };
-        auto process = [&](const Chunk &c) {
+        auto process = [&](const Chunk &c, uint32_t loaded) {
             // the paths met for the first time in this step get clean bitsets
             const uint32_t fresh = (c.hl - hdone) & 0xFFu;
             for (uint32_t k = 1; k <= fresh; ++k) {
@@ -1282,24 +1339,28 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
                 for (uint32_t i = lane; i < kNW / 2u; i += 64) reinterpret_cast<uint2 *>(bs)[i] = make_uint2(0u, 0u);
             }
             hdone = c.hl;
-            claim_apply<WB>(D, R, mybits + c.slot, c.rec);
+            const bool has = c.slot != kNoSlot;
+            claim_apply<WB>(D, R, mybits + (has ? c.slot : 0u), has ? loaded : 0u, A.dbg);
         };
-        Chunk ch[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) ch[k] = prep();
-        bool done = false;
-        while (!done) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                if (!done) {
-                    if (ch[k].nv == 0u) {
-                        done = true;
-                    } else {
-                        process(ch[k]);
-                        ch[k] = prep();
-                    }
-                }
-            }
+        Chunk c0 = prep();
+        rec_request<0>(c0.src);
+        Chunk c1 = prep();
+        rec_request<1>(c1.src);
+        Chunk c2 = prep();
+        rec_request<2>(c2.src);
+        while (true) {
+            if (c0.nv == 0u) break;
+            process(c0, rec_take<0>());
+            c0 = prep();
+            rec_request<0>(c0.src);
+            if (c1.nv == 0u) break;
+            process(c1, rec_take<1>());
+            c1 = prep();
+            rec_request<1>(c1.src);
+            if (c2.nv == 0u) break;
+            process(c2, rec_take<2>());
+            c2 = prep();
+            rec_request<2>(c2.src);
         }
     }
 }
@@ -1308,7 +1369,7 @@ template <bool UNIQ, int WB>
 __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     constexpr uint32_t kW = 1u << WB;
     constexpr int kPer = kW / kAccThreads;  // cells per thread: 4 or 8
-    constexpr uint32_t kSlots = WB == 12 ? 8u : 4u;
+    constexpr uint32_t kSlots = WB <= 12 ? 8u : 4u;
     // difference arrays over the window: depth, and (with unique depth) revisits
     __shared__ __attribute__((aligned(16))) int cells[(UNIQ ? 2 : 1) * (kW + 64)];
     __shared__ unsigned long long wave_tot[kAccWaves];
@@ -1406,7 +1467,7 @@ int alloc_buckets(FastPlan *fp, uint64_t want_cap) {
     const uint64_t max_cap = ((1ull << 30) - 1) / ((uint64_t)(fp->n_win + 1) * fp->n_slots);
     uint64_t cap = std::min(want_cap, max_cap);
     cap = std::min<uint64_t>(cap, ((1ull << 24) - 1) / fp->n_slots);  // window * (n_slots * cap) + pos is a 24-bit multiply
-    cap &= ~3ull;
+    cap &= cap >= 64 ? ~31ull : ~3ull;  // sub-buckets start on 128-byte lines: neighbours (other workgroups, other XCDs) never share one
     if (cap < 4) return 0;
     if (fp->buckets) {
         (void)hipFree(fp->buckets);
@@ -1430,7 +1491,8 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     if ((reinterpret_cast<uintptr_t>(g.steps) & 15u) != 0) return true;  // 16-byte step loads
     // Windows of 4096 segments up to 4 M segments, of 8192 beyond (pass 2 keeps a window's
     // difference array and per-path bitsets in LDS); beyond 16 M the atomic kernels take over.
-    const uint32_t wb = g.n_segs <= 1024u * 4096u ? 12u : 13u;
+    uint32_t wb = g.n_segs <= 1024u * 4096u ? 12u : 13u;
+    if (const char *f = getenv("FLATGFA_WB")) wb = (uint32_t)strtoul(f, nullptr, 10);
     const uint32_t n_win = (uint32_t)(((uint64_t)g.n_segs + (1u << wb) - 1) >> wb);
     if (n_win > kMaxWin) return true;
     if (const char *off = getenv("FLATGFA_MAX_WINDOWS")) {
@@ -1656,7 +1718,7 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
     sa.dbg = fp.dbg;
     AccArgs aa{g.n_segs, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.counts0, has_pre ? 1u : 0u, fp.buckets,
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
-               fp.work_counter, fp.max_back, depth_out, uniq_out, status};
+               fp.work_counter, fp.max_back, depth_out, uniq_out, status, fp.dbg};
     if (fp.n_short) {
         if (hipMemsetAsync(fp.work_counter, 0, 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
         const uint32_t sgrid = std::min<uint32_t>((fp.n_short + kWaves - 1) / kWaves, fp.n_slots);
@@ -1681,10 +1743,12 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
     {
         ProfScope ps(uniq_out ? "k_accum<uniq>" : "k_accum<depth>", stream);
         if (uniq_out) {
-            if (fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
+            if (fp.wb == 11) hipLaunchKernelGGL((k_accum<true, 11>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
+            else if (fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
             else hipLaunchKernelGGL((k_accum<true, 13>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
         } else {
-            if (fp.wb == 12) hipLaunchKernelGGL((k_accum<false, 12>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
+            if (fp.wb == 11) hipLaunchKernelGGL((k_accum<false, 11>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
+            else if (fp.wb == 12) hipLaunchKernelGGL((k_accum<false, 12>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
             else hipLaunchKernelGGL((k_accum<false, 13>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
         }
     }

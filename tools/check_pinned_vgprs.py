@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Build-time check for depth_fast.hip's pinned landing registers.
 
-k_scan keeps two 1024-step blocks in flight in the fixed VGPR sets v[96:111] and v[112:127]
+k_scan keeps two 1024-step blocks in flight in the fixed VGPR sets v[80:95], v[96:111] and v[112:127]
 (see the comment above load_block_async in pollen_amd/csrc/depth_fast.hip).  That is only sound if
 nothing else in the kernel touches those registers.  This script compiles the file to gfx950
 assembly and checks, for every k_scan instantiation and every function it can call:
 
-  * the only instructions that mention v96..v127 are `global_load_dwordx4 v[Q:Q+3], ..., off`
+  * the only instructions that mention v80..v127 are `global_load_dwordx4 v[Q:Q+3], ..., off`
     (as the destination) and `v_lshrrev_b32 vN, 1, vQ` (as the source);
   * the kernel's VGPR budget stays at or under 128 (a 1024-thread workgroup needs 4 waves/SIMD).
 
@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "..", "pollen_amd", "csrc", "depth_fast.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-PINNED = set(range(96, 128))
+PINNED = set(range(80, 128))
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 OK_LOAD = re.compile(r"^global_load_dwordx4 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], off( offset:(16|32|48))?$")
 OK_TAKE = re.compile(r"^v_lshrrev_b32(_e32)? v(\d+), 1, v(\d+)$")
@@ -45,6 +45,7 @@ def main():
                                SRC, "-o", asm], stderr=subprocess.DEVNULL)
         lines = open(asm).read().splitlines()
     bad, n_load, n_take, func = [], 0, 0, "?"
+    n_acc_load = n_acc_take = 0
     budgets = {}
     for ln in lines:
         s = ln.split(";")[0].strip()
@@ -56,6 +57,17 @@ def main():
             budgets[func] = int(m.group(1))
             continue
         if not s or s.startswith("."):
+            continue
+        if "k_accum" in func:  # pass 2: three pinned record registers (rec_request / rec_take)
+            if regs_of(s) & {120, 121, 122}:
+                if re.match(r"^global_load_dword v12[012], v\[\d+:\d+\], off$", s):
+                    n_acc_load += 1
+                elif re.match(r"^v_mov_b32(_e32)? v(\d+), v12[012]$", s) and int(re.match(r"^v_mov_b32(_e32)? v(\d+),", s).group(2)) < 120:
+                    n_acc_take += 1
+                else:
+                    bad.append(f"{func}: {s}")
+            continue
+        if "k_scan" not in func:  # only the kernels that use the landing sets (everything is inlined into them)
             continue
         touched = regs_of(s) & PINNED
         if not touched:
@@ -73,12 +85,15 @@ def main():
     for name, v in budgets.items():
         if "k_scan" in name and v > 128:
             bad.append(f"{name}: {v} VGPRs > 128")
+    if n_acc_load == 0 or n_acc_take == 0:
+        bad.append("no pinned record loads/takes found in k_accum -- did the kernel change?")
     if n_load == 0 or n_take == 0:
         bad.append("no pinned loads/takes found -- did the kernel change?")
     if bad:
         print("pinned-VGPR check FAILED:\n  " + "\n  ".join(bad[:20]))
         return 1
-    print(f"pinned-VGPR check ok: {n_load} loads, {n_take} takes, nothing else touches v96..v127; "
+    print(f"pinned-VGPR check ok: k_accum {n_acc_load} record loads, {n_acc_take} takes, nothing else touches v120..v122; "
+          f"k_scan {n_load} loads, {n_take} takes, nothing else touches v80..v127; "
           f"k_scan budgets {sorted(set(v for k, v in budgets.items() if 'k_scan' in k))}")
     return 0
 
