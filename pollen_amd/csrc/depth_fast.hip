@@ -80,7 +80,7 @@ constexpr uint32_t kInvalid = 0xFFFFFFFFu;  // queue entry that starts no run (t
 constexpr uint32_t kQ2 = 64 + 1024 + 8;   // queue entries per wave: what is left over + one all-starts block
 
 // diagnostic ablations (FLATGFA_DEBUG_SKIP, results are then wrong by construction)
-constexpr uint32_t kDbgNoStore = 1, kDbgNoTiles = 8, kDbgHotLoads = 16, kDbgTime = 32, kDbgNoClaim = 64, kDbgNoRevisit = 128, kDbgNoDepth = 256;
+constexpr uint32_t kDbgNoStore = 1, kDbgNoTiles = 8, kDbgHotLoads = 16, kDbgTime = 32, kDbgNoEmit = 2, kDbgNoPassB = 4, kDbgNoClaim = 64, kDbgNoRevisit = 128, kDbgNoDepth = 256, kDbgHotStores = 512;
 // the ablation checks exist only in the DBG instantiation of the kernel
 #define FGFA_SKIP(bit) (DBG && (A.dbg & (bit)))
 
@@ -139,9 +139,14 @@ __device__ __forceinline__ bool put(const ScanArgs &A, W &w, uint32_t *mine, boo
     // stride below 2^24; hipcc would otherwise pick the quarter-rate 64-bit mad).
     uint32_t slot;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(slot) : "v"(win), "s"(A.stride), "v"(pos));
-    const uint32_t boff = (ok ? slot : A.sink) << 2;
+    uint32_t boff = (ok ? slot : A.sink) << 2;
+    if (FGFA_SKIP(kDbgHotStores)) boff = (pos & 1023u) << 2;  // diagnostic: the same instructions, but the lines stay in L2
     if (!FGFA_SKIP(kDbgNoStore)) {
+#ifdef FGFA_NT_STORE
+        __builtin_nontemporal_store(rec, reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(mine) + boff));
+#else
         *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(mine) + boff) = rec;
+#endif
         w.vm[0] += 1;  // exactly one store instruction, executed by the whole wave
         w.vm[1] += 1;
         w.vm[2] += 1;
@@ -172,6 +177,9 @@ __device__ __forceinline__ void flag_if_any(const ScanArgs &A, bool b, uint32_t 
 // 4 KiB, every 64-byte sector exactly once per instruction (measured at the same 5.9 TB/s as
 // fully coalesced loads, tools/loadpat.hip).  No nontemporal hint here: the sectors must survive
 // in cache from the first of the four instructions to the last.
+#ifndef FGFA_LOAD_POLICY
+#define FGFA_LOAD_POLICY ""  /* cache-policy bits of the step loads (experiments: " nt", " sc1", ...) */
+#endif
 #define FGFA_CLOB_A "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111"
 #define FGFA_CLOB_C "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95"
 #define FGFA_CLOB_B "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
@@ -180,20 +188,20 @@ __device__ __forceinline__ void load_block_async(W &w, const uint4 *p) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) w.vm[k] = k == SET ? 0u : w.vm[k] + 4u;
     if (SET == 0)
-        asm volatile("global_load_dwordx4 v[96:99], %0, off\n\t"
-                     "global_load_dwordx4 v[100:103], %0, off offset:16\n\t"
-                     "global_load_dwordx4 v[104:107], %0, off offset:32\n\t"
-                     "global_load_dwordx4 v[108:111], %0, off offset:48" ::"v"(p) : "memory", FGFA_CLOB_A);
+        asm volatile("global_load_dwordx4 v[96:99], %0, off" FGFA_LOAD_POLICY "\n\t"
+                     "global_load_dwordx4 v[100:103], %0, off offset:16" FGFA_LOAD_POLICY "\n\t"
+                     "global_load_dwordx4 v[104:107], %0, off offset:32" FGFA_LOAD_POLICY "\n\t"
+                     "global_load_dwordx4 v[108:111], %0, off offset:48" FGFA_LOAD_POLICY "" ::"v"(p) : "memory", FGFA_CLOB_A);
     else if (SET == 1)
-        asm volatile("global_load_dwordx4 v[112:115], %0, off\n\t"
-                     "global_load_dwordx4 v[116:119], %0, off offset:16\n\t"
-                     "global_load_dwordx4 v[120:123], %0, off offset:32\n\t"
-                     "global_load_dwordx4 v[124:127], %0, off offset:48" ::"v"(p) : "memory", FGFA_CLOB_B);
+        asm volatile("global_load_dwordx4 v[112:115], %0, off" FGFA_LOAD_POLICY "\n\t"
+                     "global_load_dwordx4 v[116:119], %0, off offset:16" FGFA_LOAD_POLICY "\n\t"
+                     "global_load_dwordx4 v[120:123], %0, off offset:32" FGFA_LOAD_POLICY "\n\t"
+                     "global_load_dwordx4 v[124:127], %0, off offset:48" FGFA_LOAD_POLICY "" ::"v"(p) : "memory", FGFA_CLOB_B);
     else
-        asm volatile("global_load_dwordx4 v[80:83], %0, off\n\t"
-                     "global_load_dwordx4 v[84:87], %0, off offset:16\n\t"
-                     "global_load_dwordx4 v[88:91], %0, off offset:32\n\t"
-                     "global_load_dwordx4 v[92:95], %0, off offset:48" ::"v"(p) : "memory", FGFA_CLOB_C);
+        asm volatile("global_load_dwordx4 v[80:83], %0, off" FGFA_LOAD_POLICY "\n\t"
+                     "global_load_dwordx4 v[84:87], %0, off offset:16" FGFA_LOAD_POLICY "\n\t"
+                     "global_load_dwordx4 v[88:91], %0, off offset:32" FGFA_LOAD_POLICY "\n\t"
+                     "global_load_dwordx4 v[92:95], %0, off offset:48" FGFA_LOAD_POLICY "" ::"v"(p) : "memory", FGFA_CLOB_C);
 }
 // Waits until the loads into landing set SET have returned.  `w.vm[SET]` counts the memory
 // instructions this wave is known to have issued since (the other set's loads and the record
@@ -757,22 +765,7 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
     const uint32_t win = id >> wb, rel = id & wmask;
     const bool cross = valid && rel + lenm1 > wmask;
     const uint32_t l1 = cross ? wmask - rel : lenm1;
-    // Consecutive entries mostly go to the same window (a stretch of the path between two jumps):
-    // the first lane of every stretch of equal windows takes the stretch's slots with ONE cursor
-    // update and hands the base to the others -- a handful of LDS atomics per chunk instead of 64
-    // that serialize on the same address, and neighbouring lanes store to neighbouring slots.
-    // Stretches are found within each half of the wave, so that the lane masks are 32 bits wide.
-    const uint32_t key = valid ? win : 0xFFFFFFFFu;
-    const uint32_t kprev = __builtin_amdgcn_update_dpp(0u, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    const uint32_t l5 = (uint32_t)w.lane & 31u;
-    const unsigned long long hm = __builtin_amdgcn_ballot_w64(l5 == 0u || key != kprev);
-    const uint32_t h32 = w.lane < 32 ? (uint32_t)hm : (uint32_t)(hm >> 32);
-    const uint32_t back = (uint32_t)__builtin_clz(h32 << (31u - l5));  // lanes back to the stretch's first one
-    const uint32_t up = (h32 >> l5) >> 1;                                // first lanes above this one
-    const uint32_t cnt = min(up ? (uint32_t)__builtin_ctz(up) + 1u : 32u, 32u - l5);
-    uint32_t base0 = 0u;
-    if (valid && back == 0u) base0 = atomicAdd(&bcur[win], cnt);
-    const uint32_t pos = __shfl(base0, w.lane - (int)back, 64) + back;
+    const uint32_t pos = valid ? atomicAdd(&bcur[win], 1u) : 0u;
     bool ovf = put<DBG>(A, w, mine, valid, pos, win, rel | (l1 << wb) | (1u << 24));
     if (__builtin_amdgcn_ballot_w64(cross)) {
         const uint32_t pos2 = cross ? atomicAdd(&bcur[win + 1u], 1u) : 0u;
@@ -882,7 +875,9 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
     const uint32_t incl = wave_scan_incl(slots);
     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
     tmark<DBG>(A, w, 2);
-    if (w.fill >= 65u || w.fill + total + 2u > kQ2) {
+    if (FGFA_SKIP(kDbgNoEmit)) {
+        w.fill = 0;
+    } else if (w.fill >= 65u || w.fill + total + 2u > kQ2) {
         if (!w.epoch_ok) {
             if (epoch_now(ctl) >= rr) {
                 w.epoch_ok = true;
@@ -896,7 +891,7 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
         tmark<DBG>(A, w, 3);
     }
     uint32_t p = lds_addr(w.q + w.fill + (incl - slots));
-    if (active) {
+    if (active && !FGFA_SKIP(kDbgNoPassB)) {
         FGFA_PB8(p, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], pj[0], pj[1], pj[2], pj[3], pj[4], pj[5], pj[6], pj[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
         FGFA_PB8(p, a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], pj[8], pj[9], pj[10], pj[11], pj[12], pj[13], pj[14], pj[15], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15]);
     }
@@ -1097,41 +1092,123 @@ __device__ __forceinline__ void apply_record(int *D, int *R, uint32_t rec) {
     }
 }
 
-// A record of k_scan (it counts for depth; what it counts for uniq is decided here): claim its
-// segments in the bitset of its path's group, word by word, with returning ORs.  The bits that
-// were already set are revisits.  rec == 0: nothing to do for this lane.
+// Claiming a record of k_scan (it counts for depth; what it counts for uniq is decided here).
+// A record's segments are claimed in the bitset of its path's group word by word, with returning
+// ORs; the bits that were already set are revisits, which go to R one stretch at a time.  Most
+// records lie in one word and have at most one stretch of revisits, some span thirty words: a
+// loop over "the lanes that still have something to do" would run for the longest record of every
+// step with most lanes idle.  So a step claims only the first word of its records; what is left
+// of a record, and every word that has revisits, is parked on two small per-wave LDS lists and
+// worked off 64 at a time, all lanes busy.
+constexpr uint32_t kPend = 96;      // entries per list: fewer than kPendRun parked + up to 64 from one step
+constexpr uint32_t kPendRun = 32;   // a list is worked off while it holds at least this many
+struct Pending {
+    uint32_t *m;   // [kPend] rest of a record: first unclaimed segment | last segment << 13 | bitset slot << 26
+    uint2 *r;      // [kPend] {window-relative first segment of a bitset word, its revisited bits}
+    uint32_t mcnt, rcnt;
+    uint32_t moldest;  // ordinal (mod 256) of the path of the oldest entry on m
+    int lane;
+};
+
+// One word of the lanes' records [p, e]: returns the word's revisited bits, and advances p.
+__device__ __forceinline__ uint32_t claim_word(uint32_t *bits, bool act, uint32_t &p, uint32_t e, uint32_t &base) {
+    uint32_t rv = 0;
+    base = p & ~31u;
+    if (act) {
+        const uint32_t lo = p & 31u, wl = min(e, p | 31u), width = wl - p + 1u;
+        const uint32_t mask = (0xFFFFFFFFu >> (32u - width)) << lo;
+        rv = mask & atomicOr(&bits[p >> 5], mask);
+        p = wl + 1u;
+    }
+    return rv;
+}
+__device__ __forceinline__ void park_rest(Pending &q, bool e, uint32_t val) {
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(e);
+    if (e) q.m[q.mcnt + lane_rank(mk)] = val;
+    q.mcnt += (uint32_t)__builtin_popcountll(mk);
+}
+__device__ __forceinline__ void park_revisit(Pending &q, bool e, uint32_t base, uint32_t rv) {
+    const unsigned long long mk = __builtin_amdgcn_ballot_w64(e);
+    if (e) q.r[q.rcnt + lane_rank(mk)] = make_uint2(base, rv);
+    q.rcnt += (uint32_t)__builtin_popcountll(mk);
+}
+// the newest (up to) 64 parked records: one more word each
 template <int WB>
-__device__ __forceinline__ void claim_apply(int *D, int *R, uint32_t *bits, uint32_t rec, uint32_t dbg) {
-    constexpr uint32_t kW = 1u << WB;
+__device__ __forceinline__ void run_rest(Pending &q, uint32_t *mybits, uint32_t dbg) {
+    constexpr uint32_t kNW = (1u << WB) / 32u;
+    const uint32_t n = min(q.mcnt, 64u);
+    q.mcnt -= n;
+    const bool act = (uint32_t)q.lane < n;
+    const uint32_t v = act ? q.m[q.mcnt + q.lane] : 0u;
+    asm volatile("" ::: "memory");  // the slots read here are written again below, by other lanes
+    uint32_t p = v & 0x1FFFu, base;
+    const uint32_t e = (v >> 13) & 0x1FFFu;
+    uint32_t rv = claim_word(mybits + (v >> 26) * kNW, act, p, e, base);
+    if (dbg & kDbgNoRevisit) rv = 0;
+    park_rest(q, act && p <= e, (v & ~0x1FFFu) | p);
+    park_revisit(q, rv != 0u, base, rv);
+}
+// the newest (up to) 64 parked words: one stretch of revisited segments each
+__device__ __forceinline__ void run_revisits(Pending &q, int *R) {
+    const uint32_t n = min(q.rcnt, 64u);
+    q.rcnt -= n;
+    const bool act = (uint32_t)q.lane < n;
+    const uint2 v = act ? q.r[q.rcnt + q.lane] : make_uint2(0u, 0u);
+    asm volatile("" ::: "memory");
+    uint32_t rv = v.y;
+    if (rv) {
+        const uint32_t low = rv & (0u - rv), sum = rv + low;  // adding the lowest set bit carries through its stretch
+        const uint32_t from = (uint32_t)__builtin_ctz(low), to = sum ? (uint32_t)__builtin_ctz(sum) : 32u;
+        rv &= sum;
+        atomicAdd(&R[v.x + from], 1);
+        atomicAdd(&R[v.x + to], -1);
+    }
+    park_revisit(q, rv != 0u, v.x, rv);
+}
+template <int WB>
+__device__ __forceinline__ void run_pending(Pending &q, int *R, uint32_t *mybits, uint32_t dbg, uint32_t at_least) {
+    while (q.mcnt >= at_least || q.rcnt >= at_least) {
+        if (q.rcnt >= at_least) run_revisits(q, R);
+        else run_rest<WB>(q, mybits, dbg);
+        if (at_least == 1u && q.mcnt == 0u && q.rcnt == 0u) break;
+    }
+}
+
+// One step: 64 records (rec == 0: none for this lane), `slot` = the bitset slot of the lane's path.
+// In two halves, so that the caller can put independent work (forming the next step) between
+// the request of the first word's claim and the use of its answer.
+struct Claim {
+    uint32_t old, mask, p, e, base, slot;
+    bool act;
+};
+template <int WB>
+__device__ __forceinline__ Claim claim_begin(int *D, Pending &q, uint32_t *mybits, uint32_t slot, uint32_t hfirst, uint32_t rec, uint32_t dbg) {
+    constexpr uint32_t kW = 1u << WB, kNW = kW / 32u;
+    Claim c;
     const bool valid = rec != 0u;
-    const uint32_t rel = rec & (kW - 1), e = rel + ((rec >> WB) & 1023u);  // last segment of the run
+    const uint32_t rel = rec & (kW - 1);
+    c.e = rel + ((rec >> WB) & 1023u);  // last segment of the run
     if (valid && !(dbg & kDbgNoDepth)) {
         atomicAdd(&D[rel], 1);
-        atomicAdd(&D[e + 1u], -1);
+        atomicAdd(&D[c.e + 1u], -1);
     }
-    uint32_t p = rel;
-    bool more = valid && !(dbg & kDbgNoClaim);
-    while (__builtin_amdgcn_ballot_w64(more)) {
-        uint32_t rv = 0, base = 0;
-        if (more) {
-            const uint32_t lo = p & 31u, wl = min(e, p | 31u), width = wl - p + 1u;
-            const uint32_t mask = (0xFFFFFFFFu >> (32u - width)) << lo;
-            rv = mask & atomicOr(&bits[p >> 5], mask);
-            base = p & ~31u;
-            p = wl + 1u;
-            more = p <= e;
-            if (dbg & kDbgNoRevisit) rv = 0;
-        }
-        while (__builtin_amdgcn_ballot_w64(rv != 0u)) {  // one stretch of revisited segments per round
-            if (rv) {
-                const uint32_t low = rv & (0u - rv), sum = rv + low;  // adding the lowest set bit carries through its stretch
-                const uint32_t from = (uint32_t)__builtin_ctz(low), to = sum ? (uint32_t)__builtin_ctz(sum) : 32u;
-                rv &= sum;
-                atomicAdd(&R[base + from], 1);
-                atomicAdd(&R[base + to], -1);
-            }
-        }
-    }
+    c.act = valid && !(dbg & kDbgNoClaim);
+    c.slot = slot;
+    c.base = rel & ~31u;
+    const uint32_t lo = rel & 31u, wl = min(c.e, rel | 31u), width = wl - rel + 1u;
+    c.mask = (0xFFFFFFFFu >> (32u - width)) << lo;
+    c.p = wl + 1u;
+    c.old = c.act ? atomicOr(&mybits[slot * kNW + (rel >> 5)], c.mask) : 0u;
+    if (q.mcnt == 0u) q.moldest = hfirst;
+    return c;
+}
+template <int WB>
+__device__ __forceinline__ void claim_end(int *R, Pending &q, uint32_t *mybits, const Claim &c, uint32_t dbg) {
+    uint32_t rv = c.act ? (c.mask & c.old) : 0u;
+    if (dbg & kDbgNoRevisit) rv = 0;
+    park_rest(q, c.act && c.p <= c.e, c.p | (c.e << 13) | (c.slot << 26));
+    park_revisit(q, rv != 0u, c.base, rv);
+    run_pending<WB>(q, R, mybits, dbg, kPendRun);
 }
 
 // inclusive prefix sum of N*1024 values held N per thread by 1024 threads (v[] holds this thread's
@@ -1258,7 +1335,7 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
 // which item (hence which path's bitset) its record belongs to.  A wave keeps kSlots bitsets: a
 // step never spans more paths than that.  Three steps' records are requested ahead of their use.
 template <int WB>
-__device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, uint32_t *mybits, uint32_t *mark, const uint32_t *wbase, uint32_t win) {
+__device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, uint32_t *mybits, uint32_t *mark, uint32_t *pend, const uint32_t *wbase, uint32_t win) {
     constexpr uint32_t kNW = (1u << WB) / 32u;             // words per bitset
     constexpr uint32_t kSlots = WB <= 12 ? 8u : 4u;
     const int lane = threadIdx.x & 63;
@@ -1269,6 +1346,11 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
     const uint32_t nE = nst + (nback > wave ? (nback - wave + kAccWaves - 1u) / kAccWaves : 0u);
     uint32_t gbase = 0, carryG = 0;  // path ordinals are 1-based: 0 = none yet
     uint32_t hbase = 0, hdone = 0;   // ordinals (mod 256 where compared) of the paths that have records in this window
+    Pending pq;
+    pq.m = pend;
+    pq.r = reinterpret_cast<uint2 *>(pend + kPend);
+    pq.mcnt = pq.rcnt = pq.moldest = 0;
+    pq.lane = lane;
     for (uint32_t mb = 0; mb < nE; mb += 64u) {
         const uint32_t cntE = min(64u, nE - mb);
         const uint32_t x = mb + (uint32_t)lane;
@@ -1296,17 +1378,20 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
         if (ne) carryG = __builtin_amdgcn_readlane(G, 63 - __builtin_clzll(ne));
         // the item's first record (an element offset from the window's bucket base, < 2^24) and H mod 256
         const uint32_t offH = (sl * A.cap + b) | (H << 24);
-        uint32_t cs = 0, lastE = 0;
-        uint32_t hseen = hdone;  // ordinal of the last record's path in the steps prepared so far
+        uint32_t cs = 0, lastE = 0;  // position in the stream; the item the stream's last prepared record lies in
+        uint32_t hseen = hdone;      // ordinal of the last record's path in the steps prepared so far
         struct Chunk {
             const uint32_t *src;  // per lane: where its record is (the bucket base for lanes without one)
-            uint32_t slot;        // per lane: its path's bitset (a word offset), or kNoSlot for lanes without a record
-            uint32_t nv, hl;      // uniform: records in this step, ordinal of the last one's path
+            uint32_t slot;        // per lane: its path's bitset slot, or kNoSlot for lanes without a record
+            uint32_t nv, hl, hf;  // uniform: records in this step, ordinals of the last and the first one's path
         };
         // The next step of the stream: up to 64 records from position cs on.  Every item that
         // starts inside [cs, cs + 64) leaves its index at its start position; a running maximum
-        // then tells every position which item it lies in.  When the stream is exhausted the
-        // step is empty (nv = 0) but is still formed, so that every step requests one load.
+        // then tells every position which item it lies in (a scalar loop over the items is as fast
+        // when a step holds one or two items, and several times slower when it holds many).  A
+        // step stops short of the record that would bring a kSlots-th further path into it.  When
+        // the stream is exhausted the step is empty (nv = 0) but is still formed, so that every
+        // step requests one load.
         auto prep = [&]() -> Chunk {
             Chunk c;
             const uint32_t q = cs + (uint32_t)lane;
@@ -1319,11 +1404,11 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
             const uint32_t sel = max(wave_scan_max(mark[lane]), lastE + 1u) - 1u;
             const uint32_t oh = __shfl(offH, (int)sel, 64), Ps = __shfl(P, (int)sel, 64);
             const uint32_t h = oh >> 24;
-            const uint32_t hf = __builtin_amdgcn_readfirstlane(h);
-            const bool valid = q < T && ((h - hf) & 0xFFu) < kSlots;
+            c.hf = __builtin_amdgcn_readfirstlane(h);
+            const bool valid = q < T && ((h - c.hf) & 0xFFu) < kSlots;
             c.nv = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(valid));  // a prefix of the lanes
             c.src = wbase + (valid ? (oh & 0xFFFFFFu) + (q - Ps) : 0u);
-            c.slot = valid ? (h & (kSlots - 1u)) * kNW : kNoSlot;
+            c.slot = valid ? (h & (kSlots - 1u)) : kNoSlot;
             const uint32_t last = c.nv ? c.nv - 1u : 0u;
             c.hl = c.nv ? __builtin_amdgcn_readlane(h, last) : hseen;
             lastE = c.nv ? __builtin_amdgcn_readlane(sel, last) : lastE;
@@ -1331,16 +1416,24 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
             cs += c.nv;
             return c;
         };
-        auto process = [&](const Chunk &c, uint32_t loaded) {
-            // the paths met for the first time in this step get clean bitsets
+        auto begin = [&](const Chunk &c, uint32_t loaded) -> Claim {
+            // The paths met for the first time in this step get clean bitsets.  A slot is reused
+            // every kSlots paths: whatever is still parked for its previous owner goes first.
             const uint32_t fresh = (c.hl - hdone) & 0xFFu;
+            if (fresh && pq.mcnt && ((c.hl - pq.moldest) & 0xFFu) >= kSlots) {
+                while (pq.mcnt) {
+                    if (pq.rcnt >= kPendRun) run_revisits(pq, R);
+                    else run_rest<WB>(pq, mybits, A.dbg);
+                }
+                run_pending<WB>(pq, R, mybits, A.dbg, kPendRun);
+            }
             for (uint32_t k = 1; k <= fresh; ++k) {
                 uint32_t *bs = mybits + ((hdone + k) & (kSlots - 1u)) * kNW;
                 for (uint32_t i = lane; i < kNW / 2u; i += 64) reinterpret_cast<uint2 *>(bs)[i] = make_uint2(0u, 0u);
             }
             hdone = c.hl;
             const bool has = c.slot != kNoSlot;
-            claim_apply<WB>(D, R, mybits + (has ? c.slot : 0u), has ? loaded : 0u, A.dbg);
+            return claim_begin<WB>(D, pq, mybits, has ? c.slot : 0u, c.hf, has ? loaded : 0u, A.dbg);
         };
         Chunk c0 = prep();
         rec_request<0>(c0.src);
@@ -1348,21 +1441,24 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
         rec_request<1>(c1.src);
         Chunk c2 = prep();
         rec_request<2>(c2.src);
-        while (true) {
-            if (c0.nv == 0u) break;
-            process(c0, rec_take<0>());
-            c0 = prep();
-            rec_request<0>(c0.src);
-            if (c1.nv == 0u) break;
-            process(c1, rec_take<1>());
-            c1 = prep();
-            rec_request<1>(c1.src);
-            if (c2.nv == 0u) break;
-            process(c2, rec_take<2>());
-            c2 = prep();
-            rec_request<2>(c2.src);
-        }
+        // One step: take its records, request the claim of their first words, form the step three
+        // ahead and request its records while that claim is under way, then use the claim's answer.
+#define FGFA_ACC_STEP(K, CK)                                  \
+    if (CK.nv == 0u) break;                                   \
+    {                                                         \
+        const Claim cl = begin(CK, rec_take<K>());            \
+        CK = prep();                                          \
+        rec_request<K>(CK.src);                               \
+        claim_end<WB>(R, pq, mybits, cl, A.dbg);              \
     }
+        while (true) {
+            FGFA_ACC_STEP(0, c0)
+            FGFA_ACC_STEP(1, c1)
+            FGFA_ACC_STEP(2, c2)
+        }
+#undef FGFA_ACC_STEP
+    }
+    run_pending<WB>(pq, R, mybits, A.dbg, 1u);
 }
 
 template <bool UNIQ, int WB>
@@ -1376,6 +1472,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     __shared__ uint32_t scnt[kMaxSlots];
     __shared__ __attribute__((aligned(16))) uint32_t bits[UNIQ ? kAccWaves * kSlots * (kW / 32) : 4];
     __shared__ uint32_t marks[UNIQ ? kAccWaves * 64 : 4];
+    __shared__ __attribute__((aligned(8))) uint32_t pend[UNIQ ? kAccWaves * 3 * kPend : 4];
     int *D = cells, *R = cells + (UNIQ ? kW + 64 : 0);
     const int tid = threadIdx.x, wave = tid >> 6;
     const uint32_t win = blockIdx.x, w0 = win * kW;
@@ -1395,7 +1492,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     __syncthreads();
     const uint32_t *wbase = A.buckets + (size_t)win * A.n_slots * A.cap;
     if (flat) apply_flat<UNIQ, WB>(A, D, R, scnt, wbase);
-    if (UNIQ) apply_groups<WB>(A, D, R, bits + wave * (kSlots * (kW / 32)), marks + wave * 64, wbase, win);
+    if (UNIQ) apply_groups<WB>(A, D, R, bits + wave * (kSlots * (kW / 32)), marks + wave * 64, pend + wave * (3 * kPend), wbase, win);
     __syncthreads();
     const uint32_t i0 = kPer * tid;
     uint32_t d[kPer], u[kPer];
