@@ -1,26 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- path-steps/sec of node depth (+ unique depth) on the 1M-segment / 100M-step
-synthetic graph (BASELINE.json metric; configs[2] at N=1).
+synthetic graph (BASELINE.json metric; configs[2] at N=1, configs[3] at N>1).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfgL|cfgL-uniform|cfgL-short|cfgS]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfgL|...] [--scaling strong|weak]
+                  [--rotate K]
 
-One "step" = one pass of the hot path (seg_depth_with_uniq, ops/depth.rs:15-39) over the
-rank's resident graph image: run the HIP kernels, and -- for N > 1 -- one RCCL sum all-reduce of
-the fused [depth | uniq] vector.  Steps alternate between two result buffers, so the all-reduce
-of one step overlaps the kernels of the next (pollen_amd/sharded.py); the timed region ends
-when every kernel and every collective of its K steps has finished.  Inputs are in HBM before the timed
-region starts.  For N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
-holds its own 1000 paths x 100k steps over the same 1M segments (weak scaling: the path set
-grows with the GPU count, which is when sharding is warranted); value = all ranks' steps /
-max-over-ranks time.
+One "step" = one pass of the hot path (seg_depth_with_uniq, ops/depth.rs:15-39) over the rank's
+resident graph image: run the HIP kernels, and -- for N > 1 -- one RCCL sum all-reduce of the
+fused [depth | uniq] vector.  Steps alternate between two result buffers, so the all-reduce of
+one step overlaps the kernels of the next (pollen_amd/sharded.py); the timed region ends when
+every kernel and every collective of its K steps has finished.  Inputs are in HBM before the
+timed region starts.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel, from HIP events recorded
-around each kernel launch on the launch stream inside the timed region; `cpu_baseline` is the
-single-threaded C oracle (the reference's loop is single-threaded) timed on this host.
+N > 1 (launched by torch.distributed.run, one rank per GPU):
+  --scaling strong (default)  BASELINE.json configs[3]: the SAME graph, its paths cut into N
+                              contiguous groups of whole paths with equal step counts
+                              (shard_paths / local_slice); value = the graph's steps / time.
+  --scaling weak              every rank holds its own 1000 paths x 100k steps over the same
+                              segments (the path set grows with the GPU count, which is when
+                              sharding is warranted); value = all ranks' steps / time.
+Before anything is timed the REDUCED vector is checked against the oracle on every rank.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel: its own algorithmic bytes
+(k_scan reads every step once: 4N + 8P; k_accum writes the result vectors: 4Sk) over its average
+duration from HIP events recorded around each launch on the launch stream inside the timed
+region; `roofline.whole_call` is the whole call's algorithmic bytes (4N + 8P + 4Sk, SURVEY.md
+8(d)) over all its kernels.  `cpu_baseline` is the single-threaded C oracle (the reference's loop
+is single-threaded) timed on this host.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -38,7 +49,9 @@ WORKLOADS = {
     "cfgL-short": (1_000_000, 100_000, 1000, "pangenome"),
     "cfgL-fewlong": (1_000_000, 100, 1_000_000, "pangenome"),
     "cfgL-medium": (1_000_000, 10_000, 10_000, "pangenome"),  # paths of ten blocks each
-    "cfgL-4Mseg": (4_000_000, 1000, 100_000, "pangenome"),   # beyond one LDS bitset: four segment-range passes
+    "cfgL-32k": (1_000_000, 3125, 32_000, "pangenome"),       # mid-length paths
+    "cfgL-4Mseg": (4_000_000, 1000, 100_000, "pangenome"),
+    "cfgL-16Mseg": (16_000_000, 1000, 100_000, "pangenome"),
     "cfgS": (10_000, 100, 10_000, "pangenome"),
 }
 
@@ -48,16 +61,37 @@ def algorithmic_bytes(N, P, S, k):
     return 4 * N + 8 * P + 4 * S * k
 
 
+def kernel_bytes(name, N, P, S, k):
+    """Algorithmic bytes of one kernel of the call: the scan kernels share the step reads, pass 2
+    writes the result vectors."""
+    if name.startswith("k_accum"):
+        return 4 * S * k
+    return 4 * N + 8 * P
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=5).stdout.strip() or None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfgL", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: shard ONE graph by path (strong), or one graph per rank (weak)")
+    ap.add_argument("--rotate", type=int, default=3,
+                    help="N = 1 extras: also time the loop cycling this many resident graph images (seeds 1..K), "
+                         "so that no step finds its steps in the 256 MiB Infinity Cache; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the secondary measurements (depth-only, path depth, end-to-end, copy bandwidth)")
+                    help="skip the secondary measurements (depth-only, path depth, rotation, end-to-end, copy bandwidth)")
     args = ap.parse_args()
 
     import torch
@@ -65,7 +99,7 @@ def main():
 
     import pollen_amd as pa
     from pollen_amd import device as dev
-    from pollen_amd.sharded import ShardedDepth
+    from pollen_amd.sharded import ShardedDepth, local_slice, shard_paths
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -90,13 +124,24 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    coll_device = device if backend == "nccl" else torch.device("cpu")  # where tensors of a collective live
+    scaling = args.scaling if world > 1 else "weak"  # N = 1: the two coincide; "weak" is what round 1 reported
 
     S, P, L, model = WORKLOADS[args.workload]
     N = P * L
     # ---- build the rank's graph and make it resident (not timed) ----
-    g = pa.synth(1 + rank, S, P, L, model, False)
+    strong = world > 1 and scaling == "strong"
+    g = pa.synth(1 if strong else 1 + rank, S, P, L, model, False)
     steps, pb, pe, seg_len = g.soa()
-    graph = dev.DeviceGraph(steps, pb, pe, S, seg_len, device=str(device))
+    if strong:
+        lo, hi = shard_paths(pb, pe, world)[rank]
+        l_steps, l_pb, l_pe = local_slice(steps, pb, pe, lo, hi)
+    else:
+        lo, hi = 0, P
+        l_steps, l_pb, l_pe = steps, pb, pe
+    N_local, P_local = int((l_pe.astype(np.int64) - l_pb.astype(np.int64)).sum()), int(hi - lo)
+    N_job = N if strong else world * N  # steps one step of the whole job walks
+    graph = dev.DeviceGraph(l_steps, l_pb, l_pe, S, seg_len, device=str(device))
     plan = dev.DepthPlan(graph)
     op = ShardedDepth(S, plan.seg_depth, device=device, with_uniq=True)
 
@@ -112,41 +157,71 @@ def main():
     plan.status()
     sync_all()
 
-    # ---- verification of what is being timed (rank-local partials vs the oracle; N=1: the result) ----
+    # ---- verification of what is being timed: the REDUCED vector against the oracle, on every rank ----
     verified = None
-    if not args.no_verify and world == 1:
+    if not args.no_verify:
         from oracle import flatgfa_oracle as fo
         pools = fo.Pools(**{n: g.pool(n) for n in fo.POOL_ORDER})
         want_d, want_u = fo.seg_depth_with_uniq(pools)
-        got = op.buf.cpu().numpy().view(np.uint32)
-        verified = bool((got[:S] == want_d).all() and (got[S:] == want_u).all())
+        want = np.concatenate([want_d, want_u]).astype(np.int64)
+        if world > 1 and not strong:
+            # every rank has its own graph: the expected reduced vector is the sum of the ranks' oracle vectors
+            t = torch.from_numpy(want).to(coll_device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            want = t.cpu().numpy()
+        got = op.buf.cpu().numpy().view(np.uint32).astype(np.int64)
+        ok = bool((got == want).all())
+        if world > 1:
+            t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=coll_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = bool(int(t.item()))
+        verified = ok
         if not verified:
-            raise SystemExit("HIP result differs from the oracle: refusing to report a number")
+            bad = np.nonzero(got != want)[0]
+            raise SystemExit(f"rank {rank}: HIP result differs from the oracle in {len(bad)} of {len(want)} entries "
+                             f"(first at {bad[:4].tolist()}: got {got[bad[:4]].tolist()}, want {want[bad[:4]].tolist()}): "
+                             "refusing to report a number")
 
     # ---- timed region: exactly K steps ----
     # Kernel durations come from HIP events recorded around each launch, inside this region, on
-    # every EVENT_EVERY-th step: four event records per step cost ~8% of a 0.17 ms step, and the
+    # every EVENT_EVERY-th step: the event records cost a few percent of a 0.19 ms step, and the
     # value reported is the whole region's throughput.
     EVENT_EVERY = 4
-    dev.profile_enable(False)
-    dev.profile_read()
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        dev.profile_enable(i % EVENT_EVERY == 0)
-        op.run()
-    sync_all()
-    t1 = time.perf_counter()
-    dev.profile_enable(False)
-    kernels = dev.profile_read()
+
+    def timed_loop(run_step, n_steps, with_events):
+        dev.profile_enable(False)
+        dev.profile_read()
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            if with_events:
+                dev.profile_enable(i % EVENT_EVERY == 0)
+            run_step(i)
+        sync_all()
+        t1 = time.perf_counter()
+        dev.profile_enable(False)
+        return t1 - t0, dev.profile_read()
+
+    elapsed, kernels = timed_loop(lambda i: op.run(), args.steps, True)
     n_timed_steps = len(range(0, args.steps, EVENT_EVERY))
     plan.status()
-
-    elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # N > 1: the all-reduce alone (8 MB, latency-bound), for reading the scaling numbers
+    allreduce_ms = None
+    if world > 1:
+        sync_all()
+        c0 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(op.buf, op=dist.ReduceOp.SUM)
+        sync_all()
+        allreduce_ms = (time.perf_counter() - c0) / 10 * 1e3
+        # the buffer now holds garbage sums: one more real step leaves a valid result behind
+        op.run()
+        sync_all()
 
     # ---- per-kernel durations -> roofline for the dominant kernel ----
     per = {}
@@ -154,24 +229,31 @@ def main():
         per.setdefault(name, []).append(ms)
     kern_avg_ms = {k: float(np.mean(v)) for k, v in per.items()}
     dom = max(kern_avg_ms, key=lambda k: kern_avg_ms[k] * len(per[k])) if kern_avg_ms else None
-    B = algorithmic_bytes(N, P, S, 2)
+    B_call = algorithmic_bytes(N_local, P_local, S, 2)
     device_ms_per_step = sum(kern_avg_ms[k] * len(per[k]) for k in per) / max(n_timed_steps, 1)
     roofline = None
     if dom:
-        achieved = B / (kern_avg_ms[dom] * 1e-3) / 1e9
+        B_dom = kernel_bytes(dom, N_local, P_local, S, 2)
+        achieved = B_dom / (kern_avg_ms[dom] * 1e-3) / 1e9
         # HBM bytes per launch of the dominant kernel from the PMC counters: they need separate
-        # rocprofv3 --pmc passes (tools/profile_round.sh), so the committed summary is quoted here.
-        traffic = None
+        # rocprofv3 --pmc passes (tools/profile_round.sh), so the committed summary of the same
+        # workload is quoted, with where it came from; null when it is for another workload.
+        traffic, traffic_source = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "latest_traffic.json")))
-            if tj.get("workload") == args.workload and dom in tj["kernels"]:
+            if tj.get("workload") == args.workload and world == 1 and dom in tj["kernels"]:
                 traffic = tj["kernels"][dom]["hbm_bytes"]
+                traffic_source = {"file": "profiles/latest_traffic.json", "from": tj.get("source"), "commit": tj.get("commit")}
         except (OSError, ValueError, KeyError):
             pass
+        whole = B_call / (device_ms_per_step * 1e-3) / 1e9 if device_ms_per_step else None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "kernel_avg_ms": round(kern_avg_ms[dom], 5), "algorithmic_bytes": B,
-                    "all_kernels_ms_per_step": round(device_ms_per_step, 5),
+                    "traffic_source": traffic_source,
+                    "kernel_avg_ms": round(kern_avg_ms[dom], 5), "algorithmic_bytes": B_dom,
+                    "whole_call": {"algorithmic_bytes": B_call, "all_kernels_ms_per_step": round(device_ms_per_step, 5),
+                                   "achieved": round(whole, 2) if whole else None,
+                                   "frac": round(whole / HBM_PEAK_GBS, 5) if whole else None},
                     "kernels_avg_ms": {k: round(v, 5) for k, v in kern_avg_ms.items()},
                     "kernel_timing": f"HIP events around each launch on steps 0, {EVENT_EVERY}, {2 * EVENT_EVERY}, ... "
                                      f"of the timed region ({n_timed_steps} of {args.steps} steps)"}
@@ -204,6 +286,31 @@ def main():
             plan.path_sums(ids, d_only, len_out, wsum_out)
         extras["path_depth_all_paths_ms"] = round(timed(path_depth_all), 5)
         plan.status()
+        # The timed loop walks the same 400 MB image every step; MI355X has 256 MiB of Infinity
+        # Cache and FETCH_SIZE counts its hits as fetches.  Cycle K resident images (> 1 GB): if
+        # the cache helped, this is slower.
+        if args.rotate >= 2:
+            ops = [op]
+            keep = []
+            for seed in range(2, args.rotate + 1):
+                gk = pa.synth(seed, S, P, L, model, False)
+                sk, bk, ek, lk = gk.soa()
+                grk = dev.DeviceGraph(sk, bk, ek, S, lk, device=str(device))
+                plk = dev.DepthPlan(grk)
+                ops.append(ShardedDepth(S, plk.seg_depth, device=device, with_uniq=True))
+                keep.append((gk, grk, plk))
+            for o in ops:
+                o.run()
+            torch.cuda.synchronize(device)
+            rot_elapsed, _ = timed_loop(lambda i: ops[i % len(ops)].run(), args.steps, False)
+            same_elapsed, _ = timed_loop(lambda i: op.run(), args.steps, False)
+            for _, _, plk in keep:
+                plk.status()
+            extras["rotate"] = {"images": len(ops), "resident_step_bytes": len(ops) * 4 * N,
+                                "ms_per_step_rotating": round(rot_elapsed / args.steps * 1e3, 5),
+                                "ms_per_step_same_image": round(same_elapsed / args.steps * 1e3, 5),
+                                "note": "no per-kernel events in either loop"}
+            del ops, keep
         # device-to-device copy bandwidth of this box (read + write bytes), for the roofline's second denominator
         a = torch.empty(1 << 28, dtype=torch.int32, device=device)
         b = torch.empty_like(a)
@@ -233,6 +340,15 @@ def main():
                 "first_query_ms": round((c3 - c2) * 1e3, 3), "table_ms": round((c4 - c3) * 1e3, 3),
                 "table_bytes": len(text), "total_ms": round((c4 - c0) * 1e3, 3),
                 "steps_per_s": round(N / (c4 - c0), 1)}
+            # the same on the host alone: oracle compute + oracle emitter (one core, as the reference runs)
+            from oracle import flatgfa_oracle as fo
+            pools = fo.Pools(**{n: g.pool(n) for n in fo.POOL_ORDER})
+            fo.fgfa_depth(pools, True)
+            c5 = time.perf_counter()
+            cpu_text = fo.fgfa_depth(pools, True)
+            c6 = time.perf_counter()
+            extras["cpu_end_to_end"] = {"what": "oracle seg_depth_with_uniq + oracle SegDepth::emit, one core, arrays in memory",
+                                        "total_ms": round((c6 - c5) * 1e3, 3), "same_bytes": bool(cpu_text == text)}
             # BASELINE.json configs[4]: which paths share an oriented handle with which (all pairs)
             g2.path_overlaps([0])  # builds the per-path handle bitsets (once per resident graph)
             c5 = time.perf_counter()
@@ -276,20 +392,34 @@ def main():
                                        "cores": nthr, "kind": "port, path-parallel (pthreads)"}
 
     if rank == 0:
-        value = world * N * args.steps / elapsed
+        value = N_job * args.steps / elapsed
+        metric = f"path-steps/sec on `depth` ({S / 1e6:g}M seg / {N_job / 1e6:g}M step GFA)"
+        if verified:
+            metric += "; bit-exact vs flatgfa CPU"
+        if world == 1:
+            sharding = "none"
+        elif strong:
+            sharding = (f"one graph, paths cut into {world} contiguous groups of equal step counts; per step one sum "
+                        "all-reduce of [depth|uniq] (8 bytes per segment), overlapping the next step's kernels")
+        else:
+            sharding = ("one graph per rank over the same segments; per step one sum all-reduce of [depth|uniq], "
+                        "overlapping the next step's kernels")
         line = {
-            "metric": "path-steps/sec on `depth` (1M seg / 100M step GFA); bit-exact vs flatgfa CPU",
+            "metric": metric,
             "value": round(value, 1), "unit": "path-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: seg_depth_with_uniq on synth(seed=1+rank, S={S}, P={P}, L={L}, "
-                                   f"model={model}) per GPU", "segments": S, "paths_per_gpu": P,
-                       "steps_per_gpu": N, "sharding": "by path, one sum all-reduce of [depth|uniq] per step, overlapping the next step's kernels" if world > 1
-                       else "none"},
+            "config": {"workload": f"{args.workload}: seg_depth_with_uniq on synth(seed={'1' if strong or world == 1 else '1+rank'}, "
+                                   f"S={S}, P={P}, L={L}, model={model})" + (" per GPU" if world > 1 and not strong else ""),
+                       "segments": S, "paths_per_gpu": P_local if strong else P,
+                       "steps_per_gpu": N_local, "steps_per_job_step": N_job, "sharding": sharding},
             "bit_exact_vs_oracle": verified,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "commit": git_head(),
         }
+        if allreduce_ms is not None:
+            line["allreduce_ms"] = round(allreduce_ms, 5)
+            line["allreduce_bytes"] = 8 * S
         if extras:
             line["extras"] = extras
         if cpu:

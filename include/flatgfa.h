@@ -198,7 +198,11 @@ int flatgfa_dev_path_sums(flatgfa_dev_plan_t *plan, const uint32_t *path_ids, ui
 int flatgfa_dev_path_overlaps(flatgfa_dev_plan_t *plan, const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out,
                               void *stream);
 /* Synchronizes `stream`, then returns FLATGFA_OK, or FLATGFA_ERR_BOUNDS if any kernel since the
- * last call saw a segment id >= n_segs or a path id >= n_paths. */
+ * last call saw a segment id >= n_segs or a path id >= n_paths.  Plans size their scratch for the
+ * graph when they are created; should a node-depth call nevertheless have run out of scratch room
+ * (the step values changed behind the plan's back), this call runs it again on a larger plan
+ * before it returns, into the same output buffers -- which therefore must not have been
+ * modified in between. */
 int flatgfa_dev_status(flatgfa_dev_plan_t *plan, void *stream);
 
 /* Kernel-level timing for bench.py: when enabled, every kernel the library launches is bracketed

@@ -278,6 +278,28 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
     if (!(force && std::string(force) == "atomic")) {
         if (!fast_plan_create(pl->g, hb, he, &pl->fast)) { flatgfa_dev_plan_destroy(pl); return nullptr; }
     }
+    // Size the sub-buckets for this graph now, with one query into scratch outputs, so that no
+    // later call runs out of room (the record counts per sub-bucket depend on the steps only):
+    // a caller that consumes results on the stream -- an all-reduce right behind the kernels --
+    // never sees an incomplete vector.  (FLATGFA_BUCKET_CAP keeps its forced capacity: the
+    // tests want the overflow route.)
+    if (pl->fast.eligible && !pl->fast.cap_forced && g->n_segs) {
+        uint32_t *tmp = nullptr;
+        HIP_TRY(hipMalloc(&tmp, (size_t)g->n_segs * 8), { flatgfa_dev_plan_destroy(pl); return nullptr; });
+        for (int attempt = 0; attempt < 10 && pl->fast.eligible; ++attempt) {
+            uint32_t st = 0;
+            if (fast_seg_depth(pl->fast, pl->g, tmp, tmp + g->n_segs, pl->status, nullptr) != FLATGFA_OK ||
+                hipMemcpy(&st, pl->status, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                hipMemset(pl->status, 0, 4) != hipSuccess) {
+                (void)hipFree(tmp);
+                flatgfa_dev_plan_destroy(pl);
+                return nullptr;
+            }
+            if (!(st & 4u)) break;  // (an out-of-range id is reported by the query that meets it)
+            (void)fast_plan_grow(&pl->fast);
+        }
+        (void)hipFree(tmp);
+    }
     return pl;
 }
 

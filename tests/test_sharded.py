@@ -111,3 +111,26 @@ def test_gloo_world2_allreduce_matches_unsharded(shape):
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(2))
     assert got == [(0, True), (1, True)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_multirank_control_flow_on_one_gpu(scaling):
+    """bench.py's N > 1 path end to end on a one-GPU box: two ranks share cuda:0, gloo stands in for
+    RCCL.  The reduced vector is checked against the oracle inside bench.py (it refuses to print a
+    line otherwise), for both ways of sharding."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FLATGFA_BENCH_ONE_DEVICE="1", FLATGFA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "cfgS", "--scaling", scaling],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["bit_exact_vs_oracle"] is True
+    assert line["config"]["steps_per_job_step"] == (1_000_000 if scaling == "strong" else 2_000_000)
+    assert line["allreduce_ms"] > 0 and line["roofline"]["kernel"]
