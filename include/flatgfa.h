@@ -123,6 +123,10 @@ int flatgfa_depth_table(flatgfa_t gfa, char **text, size_t *len);
 /* The bytes `fgfa depth [-r NAME]...` prints: PathDepth::emit (ops/depth.rs:143-160;
  * cli/cmds.rs:256-284).  path_ids == NULL means all paths, in order. */
 int flatgfa_path_depth_table(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, char **text, size_t *len);
+/* PathDepth::as_bed (ops/depth.rs:173-183): the same paths as a BED store -- one entry
+ * {path name, 0, path length in base pairs} each, the depths dropped -- rendered as three-column
+ * BED text (`name\t0\tlength\n`).  path_ids == NULL means all paths, in order. */
+int flatgfa_path_depth_bed(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, char **text, size_t *len);
 /* odgi-style node depth restricted to a subset of paths (`odgi depth -d -s FILE`,
  * slow_odgi/slow_odgi/depth.py:12; tests/turnt.toml:31-44).  The reference's Rust `-d` ignores
  * `-r`; this closes that gap.  path_ids may repeat: each occurrence counts as its own path. */

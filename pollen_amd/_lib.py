@@ -54,6 +54,7 @@ SIGNATURES = {
     "flatgfa_path_depth": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_void_p]),
     "flatgfa_depth_table": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]),
     "flatgfa_path_depth_table": (c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_void_p), POINTER(c_size_t)]),
+    "flatgfa_path_depth_bed": (c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_void_p), POINTER(c_size_t)]),
     "flatgfa_format_float": (c_int, [c_double, c_int, c_char_p, c_int]),
     "flatgfa_seg_depth_subset": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_void_p]),
     "flatgfa_path_overlaps": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p]),

@@ -35,6 +35,7 @@ struct CStore {
     std::vector<uint32_t> h_path_begin, h_path_end;
     flatgfa_dev_plan_t *plan = nullptr;
     hipStream_t stream = nullptr;
+    int steps_ok = -1;  // -1 = not checked yet: do all step handles name a segment? (host-side walks index by them)
 
     ~CStore() {
         if (plan) flatgfa_dev_plan_destroy(plan);
@@ -43,6 +44,14 @@ struct CStore {
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
+
+// Host code that follows step handles into the segment pool (path lengths, the GFA printer, the
+// interval walk) asks this first; the kernels check the ids themselves.
+static bool steps_name_segments(CStore *cs) {
+    if (cs->steps_ok < 0) cs->steps_ok = fgfa::validate_step_ids(cs->view) ? 1 : 0;
+    if (!cs->steps_ok) set_error("a step refers to a segment id that is out of range");
+    return cs->steps_ok == 1;
+}
 
 #define CAPI_HIP(expr)                                                                      \
     do {                                                                                    \
@@ -188,6 +197,7 @@ static int give_text(const std::string &s, char **text, size_t *len) {
 
 int flatgfa_print_gfa(flatgfa_t gfa, char **text, size_t *len) {
     if (!gfa || !text) { set_error("flatgfa_print_gfa: NULL argument"); return FLATGFA_ERR_ARG; }
+    if (!steps_name_segments(gfa)) return FLATGFA_ERR_BOUNDS;
     std::string out, err;
     if (!fgfa::print_gfa(gfa->view, &out, &err)) { set_error(err); return FLATGFA_ERR_BOUNDS; }
     return give_text(out, text, len);
@@ -280,43 +290,76 @@ static int ensure_device(CStore *cs, int device) {
         fprintf(stderr, "to_device: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
         t = n;
     };
-    CAPI_HIP(hipSetDevice(device));
-    cs->device = device;
-    CAPI_HIP(hipStreamCreateWithFlags(&cs->stream, hipStreamNonBlocking));
-    tick("device + stream");
+    // reversed or overlong step spans: where the reference would panic on the slice index (pool.rs:341-347)
     const size_t N = v.steps.len, P = v.paths.len, S = v.segs.len;
-    // AoS (packed, align-1) -> SoA.  Byte copies only: the file regions may be unaligned.
-    cs->h_path_begin.resize(P);
-    cs->h_path_end.resize(P);
     for (size_t i = 0; i < P; ++i) {
-        cs->h_path_begin[i] = v.paths[i].steps.start;
-        cs->h_path_end[i] = v.paths[i].steps.end;
+        const fgfa::Span sp = v.paths[i].steps;
+        if (sp.start > sp.end || (size_t)sp.end > N) {
+            set_error("path " + std::to_string(i) + " has a step span outside the steps pool");
+            return FLATGFA_ERR_BOUNDS;
+        }
+    }
+    CAPI_HIP(hipSetDevice(device));
+    // Everything is built into locals and handed to the handle only when all of it exists: a
+    // failure half way (out of memory, say) leaves the handle as it was, and releases the rest.
+    struct Image {
+        hipStream_t stream = nullptr;
+        uint32_t *steps = nullptr, *pb = nullptr, *pe = nullptr, *seg_len = nullptr, *depth = nullptr, *uniq = nullptr;
+        flatgfa_dev_plan_t *plan = nullptr;
+        bool keep = false;
+        ~Image() {
+            if (keep) return;
+            if (plan) flatgfa_dev_plan_destroy(plan);
+            for (uint32_t *p : {steps, pb, pe, seg_len, depth, uniq})
+                if (p) (void)hipFree(p);
+            if (stream) (void)hipStreamDestroy(stream);
+        }
+    } im;
+    CAPI_HIP(hipStreamCreateWithFlags(&im.stream, hipStreamNonBlocking));
+    tick("device + stream");
+    // AoS (packed, align-1) -> SoA.  Byte copies only: the file regions may be unaligned.
+    std::vector<uint32_t> h_pb(P), h_pe(P);
+    for (size_t i = 0; i < P; ++i) {
+        h_pb[i] = v.paths[i].steps.start;
+        h_pe[i] = v.paths[i].steps.end;
     }
     std::vector<uint32_t> seg_len(S);
     for (size_t i = 0; i < S; ++i) seg_len[i] = v.segs[i].seq.len();
     tick("span arrays on the host");
     if (N) {
-        CAPI_HIP(hipMalloc(&cs->d_steps, N * 4));
-        CAPI_HIP(upload(cs->d_steps, v.steps.data, N * 4, cs->stream));
+        CAPI_HIP(hipMalloc(&im.steps, N * 4));
+        CAPI_HIP(upload(im.steps, v.steps.data, N * 4, im.stream));
     }
     tick("steps: hipMalloc + upload");
     if (P) {
-        CAPI_HIP(hipMalloc(&cs->d_path_begin, P * 4));
-        CAPI_HIP(hipMalloc(&cs->d_path_end, P * 4));
-        CAPI_HIP(hipMemcpy(cs->d_path_begin, cs->h_path_begin.data(), P * 4, hipMemcpyHostToDevice));
-        CAPI_HIP(hipMemcpy(cs->d_path_end, cs->h_path_end.data(), P * 4, hipMemcpyHostToDevice));
+        CAPI_HIP(hipMalloc(&im.pb, P * 4));
+        CAPI_HIP(hipMalloc(&im.pe, P * 4));
+        CAPI_HIP(hipMemcpy(im.pb, h_pb.data(), P * 4, hipMemcpyHostToDevice));
+        CAPI_HIP(hipMemcpy(im.pe, h_pe.data(), P * 4, hipMemcpyHostToDevice));
     }
     if (S) {
-        CAPI_HIP(hipMalloc(&cs->d_seg_len, S * 4));
-        CAPI_HIP(hipMemcpy(cs->d_seg_len, seg_len.data(), S * 4, hipMemcpyHostToDevice));
-        CAPI_HIP(hipMalloc(&cs->d_depth, S * 4));
-        CAPI_HIP(hipMalloc(&cs->d_uniq, S * 4));
+        CAPI_HIP(hipMalloc(&im.seg_len, S * 4));
+        CAPI_HIP(hipMemcpy(im.seg_len, seg_len.data(), S * 4, hipMemcpyHostToDevice));
+        CAPI_HIP(hipMalloc(&im.depth, S * 4));
+        CAPI_HIP(hipMalloc(&im.uniq, S * 4));
     }
-    flatgfa_dev_graph_t g{cs->d_steps, (uint64_t)N, cs->d_path_begin, cs->d_path_end, (uint32_t)P, (uint32_t)S, cs->d_seg_len};
+    flatgfa_dev_graph_t g{im.steps, (uint64_t)N, im.pb, im.pe, (uint32_t)P, (uint32_t)S, im.seg_len};
     tick("paths, segments, outputs");
-    cs->plan = flatgfa_dev_plan_create(&g, cs->h_path_begin.data(), cs->h_path_end.data());
+    im.plan = flatgfa_dev_plan_create(&g, h_pb.data(), h_pe.data());
     tick("plan (scratch + item lists)");
-    if (!cs->plan) return FLATGFA_ERR_BOUNDS;
+    if (!im.plan) return FLATGFA_ERR_HIP;  // the spans were checked above: what is left is the HIP runtime (see flatgfa_last_error)
+    im.keep = true;
+    cs->device = device;
+    cs->stream = im.stream;
+    cs->d_steps = im.steps;
+    cs->d_path_begin = im.pb;
+    cs->d_path_end = im.pe;
+    cs->d_seg_len = im.seg_len;
+    cs->d_depth = im.depth;
+    cs->d_uniq = im.uniq;
+    cs->h_path_begin.swap(h_pb);
+    cs->h_path_end.swap(h_pe);
+    cs->plan = im.plan;
     cs->on_device = true;
     return FLATGFA_OK;
 }
@@ -416,6 +459,29 @@ int flatgfa_path_depth_table(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n
     return give_text(out, text, len);
 }
 
+int flatgfa_path_depth_bed(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, char **text, size_t *len) {
+    if (!gfa || !text) { set_error("flatgfa_path_depth_bed: NULL argument"); return FLATGFA_ERR_ARG; }
+    std::vector<uint32_t> all;
+    if (!path_ids) {
+        all.resize(gfa->view.paths.len);
+        for (size_t i = 0; i < all.size(); ++i) all[i] = (uint32_t)i;
+        path_ids = all.data();
+        n_ids = (uint32_t)all.size();
+    }
+    // as_bed keeps what path_depth computed as `lengths` (depth.rs:104-108, 173-183): same call, depths dropped
+    std::vector<uint64_t> lens(n_ids);
+    std::vector<double> means(n_ids);
+    int rc = flatgfa_path_depth(gfa, path_ids, n_ids, lens.data(), means.data());
+    if (rc) return rc;
+    std::string out;
+    for (uint32_t k = 0; k < n_ids; ++k) {
+        const fgfa::Path &p = gfa->view.paths[path_ids[k]];
+        out.append((const char *)gfa->view.name_data.data + p.name.start, p.name.len());
+        out += "\t0\t" + std::to_string(lens[k]) + "\n";
+    }
+    return give_text(out, text, len);
+}
+
 // ---- f1: path-pair overlap (slow_odgi/overlap.py) ----
 
 int flatgfa_path_overlaps(flatgfa_t gfa, const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out) {
@@ -447,6 +513,7 @@ int flatgfa_overlap_table(flatgfa_t gfa, const uint32_t *query_ids, uint32_t n_q
     std::vector<uint8_t> touch((size_t)n_q * P);
     int rc = flatgfa_path_overlaps(gfa, query_ids, n_q, touch.data());
     if (rc) return rc;
+    if (!steps_name_segments(gfa)) return FLATGFA_ERR_BOUNDS;
     std::vector<uint64_t> plen(n_q);  // len(pathseq[ip]): the path's length in base pairs
     for (uint32_t k = 0; k < n_q; ++k) plen[k] = fgfa::path_length(gfa->view, query_ids[k]);
     std::string out;
@@ -484,6 +551,7 @@ int flatgfa_window_depth_table(flatgfa_t gfa, uint32_t path_index, uint64_t wind
     if (!gfa || !text) { set_error("flatgfa_window_depth_table: NULL argument"); return FLATGFA_ERR_ARG; }
     if (path_index >= gfa->view.paths.len) { set_error("window depth: path not found"); return FLATGFA_ERR_BOUNDS; }
     if (window == 0) { set_error("window depth: window size must be positive"); return FLATGFA_ERR_ARG; }  // div_ceil by zero panics
+    if (!steps_name_segments(gfa)) return FLATGFA_ERR_BOUNDS;
     const fgfa::Path &p = gfa->view.paths[path_index];
     fgfa::Bed bed;
     fgfa::make_windows(gfa->view.name_data.data + p.name.start, p.name.len(), 0, fgfa::path_length(gfa->view, path_index),
@@ -528,8 +596,13 @@ int flatgfa_seg_depth_subset(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n
     if (n_ids) {
         CAPI_HIP(hipMalloc(&d_b, (size_t)n_ids * 4));
         if (hipMalloc(&d_e, (size_t)n_ids * 4) != hipSuccess) { (void)hipFree(d_b); set_error("hipMalloc failed"); return FLATGFA_ERR_HIP; }
-        (void)hipMemcpy(d_b, hb.data(), (size_t)n_ids * 4, hipMemcpyHostToDevice);
-        (void)hipMemcpy(d_e, he.data(), (size_t)n_ids * 4, hipMemcpyHostToDevice);
+        if (hipMemcpy(d_b, hb.data(), (size_t)n_ids * 4, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_e, he.data(), (size_t)n_ids * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d_b);
+            (void)hipFree(d_e);
+            set_error("flatgfa_seg_depth_subset: copying the path spans to the device failed");
+            return FLATGFA_ERR_HIP;
+        }
     }
     flatgfa_dev_graph_t g{gfa->d_steps, (uint64_t)gfa->view.steps.len, d_b, d_e, n_ids, (uint32_t)S, gfa->d_seg_len};
     flatgfa_dev_plan_t *plan = flatgfa_dev_plan_create(&g, hb.data(), he.data());

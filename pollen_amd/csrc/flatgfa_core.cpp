@@ -363,7 +363,41 @@ bool view_flatgfa(const uint8_t *data, size_t n, View *out, std::string *err) {
     out->name_data = {(const uint8_t *)ptr[pNameData], (size_t)toc.pool[pNameData].len};
     out->optional_data = {(const uint8_t *)ptr[pOptionalData], (size_t)toc.pool[pOptionalData].len};
     out->line_order = {(const uint8_t *)ptr[pLineOrder], (size_t)toc.pool[pLineOrder].len};
+    return validate_spans(*out, err);
+}
+
+// Every span stored inside a pool must lie inside the pool it points into, and every link handle
+// must name a segment: the reference finds out when it indexes (pool.rs:341-347 panics); here a
+// file that fails is rejected when it is opened, so that the accessors can index unchecked.
+// O(segments + paths + links); the step ids are checked by the kernels (and by
+// validate_step_ids before a host-side walk).
+bool validate_spans(const View &v, std::string *err) {
+    const auto inside = [](const Span &sp, size_t n) { return sp.start <= sp.end && (size_t)sp.end <= n; };
+    for (size_t i = 0; i < v.segs.len; ++i) {
+        const Segment sg = v.segs[i];
+        if (!inside(sg.seq, v.seq_data.len)) { *err = "flatgfa file: segment " + std::to_string(i) + ": sequence span outside seq_data"; return false; }
+        if (!inside(sg.optional, v.optional_data.len)) { *err = "flatgfa file: segment " + std::to_string(i) + ": optional span outside optional_data"; return false; }
+    }
+    for (size_t i = 0; i < v.paths.len; ++i) {
+        const Path p = v.paths[i];
+        if (!inside(p.name, v.name_data.len)) { *err = "flatgfa file: path " + std::to_string(i) + ": name span outside name_data"; return false; }
+        if (!inside(p.steps, v.steps.len)) { *err = "flatgfa file: path " + std::to_string(i) + ": step span outside the steps pool"; return false; }
+        if (!inside(p.overlaps, v.overlaps.len)) { *err = "flatgfa file: path " + std::to_string(i) + ": overlap span outside the overlaps pool"; return false; }
+    }
+    for (size_t i = 0; i < v.overlaps.len; ++i)
+        if (!inside(v.overlaps[i], v.alignment.len)) { *err = "flatgfa file: overlap " + std::to_string(i) + ": span outside the alignment pool"; return false; }
+    for (size_t i = 0; i < v.links.len; ++i) {
+        const Link l = v.links[i];
+        if (!inside(l.overlap, v.alignment.len)) { *err = "flatgfa file: link " + std::to_string(i) + ": overlap span outside the alignment pool"; return false; }
+        if ((size_t)(l.from >> 1) >= v.segs.len || (size_t)(l.to >> 1) >= v.segs.len) { *err = "flatgfa file: link " + std::to_string(i) + ": segment id out of range"; return false; }
+    }
     return true;
+}
+
+bool validate_step_ids(const View &v) {
+    uint32_t mx = 0;
+    for (size_t i = 0; i < v.steps.len; ++i) mx = std::max(mx, v.steps[i].bits);
+    return v.steps.len == 0 || (size_t)(mx >> 1) < v.segs.len;
 }
 
 size_t flatgfa_file_size(const View &v) {

@@ -139,6 +139,9 @@ void dump_flatgfa(const View &v, uint8_t *buf);
 
 // print.rs:99-153 (preserved order when line_order is non-empty, else normalized)
 bool print_gfa(const View &v, std::string *out, std::string *err);
+// see flatgfa_core.cpp: what view_flatgfa checks, and what a host-side walk of the steps needs
+bool validate_spans(const View &v, std::string *err);
+bool validate_step_ids(const View &v);
 
 // ops/depth.rs:192-197
 std::string format_float(double x, int digits);

@@ -124,6 +124,12 @@ extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int 
         hipLaunchKernelGGL(k_handle_bits, dim3((uint32_t)std::min<uint64_t>(jobs, (uint64_t)n_cus * 16u)),
                            dim3(kBitsThreads), lds, stream, g->steps, g->path_begin, g->path_end, g->n_paths, g->n_segs,
                            words, *bits_cache, status);
+        if (hipGetLastError() != hipSuccess) {  // never keep bitsets that were not built
+            (void)hipFree(*bits_cache);
+            *bits_cache = nullptr;
+            set_error("path overlaps: kernel launch failed");
+            return FLATGFA_ERR_HIP;
+        }
     }
     {
         const uint64_t pairs = (uint64_t)n_q * g->n_paths;

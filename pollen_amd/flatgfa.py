@@ -213,6 +213,18 @@ class FlatGFA:
         _check(rc, "path_depth_table")
         return _take_text(p, n)
 
+    def path_depth_bed(self, names: Optional[Iterable[bytes]] = None) -> bytes:
+        """PathDepth::as_bed (depth.rs:173-183) as three-column BED text: `name\\t0\\tlength` per path."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        if names is None:
+            rc = _lib.lib().flatgfa_path_depth_bed(self._h, None, 0, ctypes.byref(p), ctypes.byref(n))
+        else:
+            found = [self.find_path(nm) for nm in names]
+            ids = np.array([i for i in found if i is not None] + [0], dtype=np.uint32)
+            rc = _lib.lib().flatgfa_path_depth_bed(self._h, ids.ctypes.data, len(ids) - 1, ctypes.byref(p), ctypes.byref(n))
+        _check(rc, "path_depth_bed")
+        return _take_text(p, n)
+
 
     # ---- the rows next to the depth path (SURVEY.md 8f) ----
     def _ids(self, paths) -> np.ndarray:

@@ -106,6 +106,15 @@ def test_window_and_bed_depth_known_answers(tmp_path):
         g.window_depth_table(b"5", 0)
 
 
+def test_window_depth_hand_computed():
+    # the hand-computed table of tests/test_next_rows_oracle.py (non-uniform depth, windows that cut segments)
+    from test_next_rows_oracle import WINDOW_KATS
+    g = pa.parse(os.path.join(GOLDEN, "kat_window_depth.gfa"))
+    for kind, a, b, want in WINDOW_KATS:
+        got = g.window_depth_table(a, b) if kind == "window" else g.bed_depth_table(a)
+        assert got == want, (kind, a, b)
+
+
 @pytest.mark.parametrize("window", [1, 7, 64, 1000, 10**9])
 def test_window_depth_synthetic_matches_oracle_bitwise(window):
     g = pa.synth(6, 20_000, 30, 4000, "pangenome", True)
@@ -116,3 +125,15 @@ def test_window_depth_synthetic_matches_oracle_bitwise(window):
     got = g.interval_depth(b"p7", edges[:-1], edges[1:])
     want = fo.interval_depth(pools, 7, edges[:-1], edges[1:])
     assert got.tobytes() == want.tobytes()       # f64 accumulated in the reference's order: bit-identical
+
+
+def test_path_depth_as_bed():
+    # PathDepth::as_bed (depth.rs:173-183): {name, 0, length} per path, depths dropped
+    g = pa.parse(os.path.join(GOLDEN, "standin_note5.gfa"))
+    assert g.path_depth_bed() == b"5\t0\t13\n5-\t0\t13\n"
+    assert g.path_depth_bed([b"zzz", b"5-"]) == b"5-\t0\t13\n"
+    g = pa.synth(4, 3000, 12, 500, "pangenome", True)
+    pools = pools_of(g)
+    ln, _ = fo.path_depth(pools)
+    want = b"".join(pools.path_name(i) + b"\t0\t" + str(int(ln[i])).encode() + b"\n" for i in range(12))
+    assert g.path_depth_bed() == want

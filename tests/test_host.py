@@ -161,6 +161,49 @@ def test_flatgfa_view_honours_capacity_and_rejects_garbage(tmp_path):
         pa.parse(str(tmp_path / "missing.gfa"))
 
 
+def test_flatgfa_view_rejects_spans_that_leave_their_pool(tmp_path):
+    """A span stored inside a pool that points outside its target pool: the reference panics when
+    it indexes (pool.rs:341-347); here the file is refused when it is opened, so no accessor can
+    run off a pool.  A step that names no segment is refused by whatever would follow it."""
+    pools = fo.parse_gfa(read(os.path.join(GOLDEN, "ref_ex2.gfa")))
+
+    def written(mutate, name):
+        import copy
+        q = copy.deepcopy(pools)
+        mutate(q)
+        f = tmp_path / name
+        f.write_bytes(fo.dump_flatgfa(q))
+        return str(f)
+
+    def set_field(pool, idx, field, value):
+        def m(q):
+            a = getattr(q, pool).copy()
+            a[field][idx] = value
+            setattr(q, pool, a)
+        return m
+
+    for k, (pool, field) in enumerate([("paths", "steps_end"), ("paths", "name_end"), ("paths", "ov_end"),
+                                       ("segs", "seq_end"), ("segs", "opt_end")]):
+        with pytest.raises(pa.FlatGFAError):
+            pa.load(written(set_field(pool, 0, field, 0x40000000), f"bad{k}.flatgfa"))
+    with pytest.raises(pa.FlatGFAError):   # reversed span
+        pa.load(written(set_field("paths", 1, "steps_start", 0x7FFFFFF0), "rev.flatgfa"))
+    if len(pools.links):
+        with pytest.raises(pa.FlatGFAError):
+            pa.load(written(set_field("links", 0, "from_", 0x7FFFFFF0), "link.flatgfa"))
+
+    def bad_step(q):
+        a = q.steps.copy()
+        a[1] = np.uint32((len(q.segs) + 5) << 1)
+        q.steps = a
+    g = pa.load(written(bad_step, "step.flatgfa"))     # loads: spans are fine
+    assert g.get_path_step_count(0) == len(pools.steps[pools.paths["steps_start"][0]:pools.paths["steps_end"][0]])
+    with pytest.raises(pa.FlatGFAError):
+        g.gfa_text()
+    with pytest.raises(pa.FlatGFAError):
+        g.window_depth_table(0, 2)
+
+
 ROUNDTRIP_OK = [g for g in golden_gfas() if "no-test-flip4" not in g and "edge_names_loops" not in g]
 
 
