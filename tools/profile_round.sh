@@ -2,12 +2,12 @@
 # Produces the committed profile summaries for one round (run via gpurun from the repo root):
 #   tools/profile_round.sh r01
 # Writes gpurun_out/profiles/<tag>_*; copy them into profiles/ afterwards.
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/profiles; mkdir -p $OUT; cd $R
 CMD="bench.py --steps 20 --warmup 3"
 # 1. the bench line itself (all workloads; cfgL is the headline)
-for w in cfgL cfgL-uniform cfgL-short cfgL-fewlong cfgS; do
+for w in cfgL cfgL-uniform cfgL-short cfgL-fewlong cfgL-medium cfgL-32k cfgL-4Mseg cfgL-16Mseg cfgS; do
   python3 bench.py --steps 20 --warmup 3 --workload $w 2>/dev/null | tail -1 > $OUT/${TAG}_bench_$w.json
 done
 # 2. kernel trace + stats of the same command (csv)
@@ -22,8 +22,12 @@ done
 python3 - <<PY > $OUT/${TAG}_pmc_summary.txt
 import sqlite3,glob,re
 def short(k):
-    m=re.search(r"(k_\w+<[^>]*>)",k)
-    return m.group(1) if m else k[:40]
+    m=re.search(r"(k_\w+)(<[^>]*>)?\(",k)
+    if not m: return k[:40]
+    n,t=m.group(1),m.group(2) or ""
+    if n=="k_accum": return n+("<uniq>" if t.startswith("<true") else "<depth>")
+    if n=="k_scan": return n
+    return n+t
 print("# rocprofv3 --pmc, averages per dispatch over the bench run (python3 $CMD); FETCH_SIZE/WRITE_SIZE in KB")
 print("# (gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -- MI355X_MICROARCH.md; double it)")
 for d in sorted(glob.glob("$OUT/_pmc_*/**/*.db", recursive=True)):
@@ -41,11 +45,14 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
         db=sqlite3.connect(d)
         for k,v in db.execute("select kernel_name,avg(value) from counters_collection where counter_name=? group by kernel_name",(c,)):
             if 'fgfa_dev' not in k: continue
-            m=re.search(r"(k_\w+<[^>]*>)",k)
-            name=m.group(1) if m else k[:40]
-            name=name.replace("<true, false>","<uniq>").replace("<true, true>","<uniq>").replace("<false, false>","<depth>").replace("<true>","<uniq>").replace("<false>","<depth>")
+            m=re.search(r"(k_\w+)(<[^>]*>)?\(",k)
+            if not m: continue
+            name=m.group(1)
+            if name=="k_accum": name+="<uniq>" if (m.group(2) or "").startswith("<true") else "<depth>"
             vals.setdefault(name,{})[c]=v
-out={"source":"profiles/${TAG}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; KB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 note)","workload":"cfgL","kernels":{}}
+import subprocess
+commit=subprocess.run(["git","-C","$R","rev-parse","--short","HEAD"],capture_output=True,text=True).stdout.strip() or None
+out={"commit":commit,"source":"profiles/${TAG}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; KB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 note)","workload":"cfgL","kernels":{}}
 for n,v in vals.items():
     f=v.get("FETCH_SIZE",0)*1024*2; w=v.get("WRITE_SIZE",0)*1024
     out["kernels"][n]={"fetch_bytes":f,"write_bytes":w,"hbm_bytes":f+w}
