@@ -325,21 +325,25 @@ def main():
         fpath = os.path.join(tmpdir, f"bench_{os.getpid()}.flatgfa")
         try:
             g.write_flatgfa(fpath)
-            c0 = time.perf_counter()
-            g2 = pa.load(fpath)
-            c1 = time.perf_counter()
-            g2.to_device(local_rank)
-            c2 = time.perf_counter()
-            g2.seg_depth_with_uniq()
-            c3 = time.perf_counter()
-            text = g2.depth_table()
-            c4 = time.perf_counter()
-            extras["end_to_end"] = {
-                "what": ".flatgfa mmap -> H2D -> seg_depth_with_uniq (kernels + D2H + widen to u64) -> depth table text",
-                "load_ms": round((c1 - c0) * 1e3, 3), "h2d_and_plan_ms": round((c2 - c1) * 1e3, 3),
-                "first_query_ms": round((c3 - c2) * 1e3, 3), "table_ms": round((c4 - c3) * 1e3, 3),
-                "table_bytes": len(text), "total_ms": round((c4 - c0) * 1e3, 3),
-                "steps_per_s": round(N / (c4 - c0), 1)}
+            runs = []
+            for rep in range(2):  # the first run also pays for this process's first pinned staging buffers and worker threads
+                if rep:
+                    g2.close()
+                c0 = time.perf_counter()
+                g2 = pa.load(fpath)
+                c1 = time.perf_counter()
+                g2.to_device(local_rank)
+                c2 = time.perf_counter()
+                g2.seg_depth_with_uniq()
+                c3 = time.perf_counter()
+                text = g2.depth_table()
+                c4 = time.perf_counter()
+                runs.append({"load_ms": round((c1 - c0) * 1e3, 3), "h2d_and_plan_ms": round((c2 - c1) * 1e3, 3),
+                             "first_query_ms": round((c3 - c2) * 1e3, 3), "table_ms": round((c4 - c3) * 1e3, 3),
+                             "total_ms": round((c4 - c0) * 1e3, 3), "steps_per_s": round(N / (c4 - c0), 1)})
+            extras["end_to_end"] = dict(runs[1], what=".flatgfa mmap -> H2D -> seg_depth_with_uniq (kernels + D2H + widen to u64) -> "
+                                        "depth table text; a fresh handle each time, second of two runs in this process",
+                                        table_bytes=len(text), first_run=runs[0])
             # the same on the host alone: oracle compute + oracle emitter (one core, as the reference runs)
             from oracle import flatgfa_oracle as fo
             pools = fo.Pools(**{n: g.pool(n) for n in fo.POOL_ORDER})

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <sys/mman.h>
 #include <atomic>
 #include <chrono>
 #include <mutex>
@@ -30,7 +31,9 @@ struct CStore {
     std::mutex dev_mu;
     bool on_device = false;
     int device = 0;
-    uint32_t *d_steps = nullptr, *d_path_begin = nullptr, *d_path_end = nullptr, *d_seg_len = nullptr;
+    uint32_t *d_steps = nullptr;
+    uint32_t *d_small = nullptr;  // one allocation behind the five arrays below
+    uint32_t *d_path_begin = nullptr, *d_path_end = nullptr, *d_seg_len = nullptr;
     uint32_t *d_depth = nullptr, *d_uniq = nullptr;
     std::vector<uint32_t> h_path_begin, h_path_end;
     flatgfa_dev_plan_t *plan = nullptr;
@@ -39,7 +42,7 @@ struct CStore {
 
     ~CStore() {
         if (plan) flatgfa_dev_plan_destroy(plan);
-        for (uint32_t *p : {d_steps, d_path_begin, d_path_end, d_seg_len, d_depth, d_uniq})
+        for (uint32_t *p : {d_steps, d_small})
             if (p) (void)hipFree(p);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -246,6 +249,13 @@ static hipError_t upload(void *dst, const void *src, size_t bytes, hipStream_t s
                     hipError_t e = round >= 2 ? hipEventSynchronize(ev[b]) : hipSuccess;  // the buffer's previous copy is done
                     const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
                     if (e == hipSuccess) {
+#ifdef MADV_POPULATE_READ
+                        {   // a freshly mapped file: let the kernel map the chunk's pages in one go instead of
+                            // taking a fault per page inside the memcpy (fails harmlessly on anonymous memory)
+                            const uintptr_t a0 = ((uintptr_t)src + off) & ~(uintptr_t)4095;
+                            (void)madvise((void *)a0, ((uintptr_t)src + off + len) - a0, MADV_POPULATE_READ);
+                        }
+#endif
                         memcpy(stage[b], (const char *)src + off, len);
                         e = hipMemcpyAsync((char *)dst + off, stage[b], len, hipMemcpyHostToDevice, stream);
                     }
@@ -304,61 +314,63 @@ static int ensure_device(CStore *cs, int device) {
     // failure half way (out of memory, say) leaves the handle as it was, and releases the rest.
     struct Image {
         hipStream_t stream = nullptr;
-        uint32_t *steps = nullptr, *pb = nullptr, *pe = nullptr, *seg_len = nullptr, *depth = nullptr, *uniq = nullptr;
+        uint32_t *steps = nullptr, *small = nullptr;
+        uint32_t *pb = nullptr, *pe = nullptr, *seg_len = nullptr, *depth = nullptr, *uniq = nullptr;  // inside `small`
         flatgfa_dev_plan_t *plan = nullptr;
         bool keep = false;
         ~Image() {
             if (keep) return;
             if (plan) flatgfa_dev_plan_destroy(plan);
-            for (uint32_t *p : {steps, pb, pe, seg_len, depth, uniq})
+            for (uint32_t *p : {steps, small})
                 if (p) (void)hipFree(p);
             if (stream) (void)hipStreamDestroy(stream);
         }
     } im;
     CAPI_HIP(hipStreamCreateWithFlags(&im.stream, hipStreamNonBlocking));
     tick("device + stream");
-    // AoS (packed, align-1) -> SoA.  Byte copies only: the file regions may be unaligned.
-    std::vector<uint32_t> h_pb(P), h_pe(P);
+    // AoS (packed, align-1) -> SoA.  Byte copies only: the file regions may be unaligned.  The
+    // small arrays -- path spans, segment lengths, the two result vectors -- share one device
+    // allocation and one copy: a hipMalloc costs about a millisecond whatever its size.
+    const size_t Pa = (P + 63) & ~(size_t)63, Sa = (S + 63) & ~(size_t)63;  // 256-byte aligned sub-arrays
+    std::vector<uint32_t> host(2 * Pa + Sa);
+    uint32_t *h_pb = host.data(), *h_pe = host.data() + Pa, *h_len = host.data() + 2 * Pa;
     for (size_t i = 0; i < P; ++i) {
         h_pb[i] = v.paths[i].steps.start;
         h_pe[i] = v.paths[i].steps.end;
     }
-    std::vector<uint32_t> seg_len(S);
-    for (size_t i = 0; i < S; ++i) seg_len[i] = v.segs[i].seq.len();
+    for (size_t i = 0; i < S; ++i) h_len[i] = v.segs[i].seq.len();
     tick("span arrays on the host");
     if (N) {
         CAPI_HIP(hipMalloc(&im.steps, N * 4));
         CAPI_HIP(upload(im.steps, v.steps.data, N * 4, im.stream));
     }
     tick("steps: hipMalloc + upload");
-    if (P) {
-        CAPI_HIP(hipMalloc(&im.pb, P * 4));
-        CAPI_HIP(hipMalloc(&im.pe, P * 4));
-        CAPI_HIP(hipMemcpy(im.pb, h_pb.data(), P * 4, hipMemcpyHostToDevice));
-        CAPI_HIP(hipMemcpy(im.pe, h_pe.data(), P * 4, hipMemcpyHostToDevice));
-    }
-    if (S) {
-        CAPI_HIP(hipMalloc(&im.seg_len, S * 4));
-        CAPI_HIP(hipMemcpy(im.seg_len, seg_len.data(), S * 4, hipMemcpyHostToDevice));
-        CAPI_HIP(hipMalloc(&im.depth, S * 4));
-        CAPI_HIP(hipMalloc(&im.uniq, S * 4));
+    if (P || S) {
+        CAPI_HIP(hipMalloc(&im.small, (2 * Pa + 3 * Sa) * 4));
+        CAPI_HIP(hipMemcpy(im.small, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+        im.pb = im.small;
+        im.pe = im.small + Pa;
+        im.seg_len = im.small + 2 * Pa;
+        im.depth = im.seg_len + Sa;
+        im.uniq = im.depth + Sa;
     }
     flatgfa_dev_graph_t g{im.steps, (uint64_t)N, im.pb, im.pe, (uint32_t)P, (uint32_t)S, im.seg_len};
     tick("paths, segments, outputs");
-    im.plan = flatgfa_dev_plan_create(&g, h_pb.data(), h_pe.data());
+    im.plan = flatgfa_dev_plan_create(&g, h_pb, h_pe);
     tick("plan (scratch + item lists)");
     if (!im.plan) return FLATGFA_ERR_HIP;  // the spans were checked above: what is left is the HIP runtime (see flatgfa_last_error)
     im.keep = true;
     cs->device = device;
     cs->stream = im.stream;
     cs->d_steps = im.steps;
+    cs->d_small = im.small;
     cs->d_path_begin = im.pb;
     cs->d_path_end = im.pe;
     cs->d_seg_len = im.seg_len;
     cs->d_depth = im.depth;
     cs->d_uniq = im.uniq;
-    cs->h_path_begin.swap(h_pb);
-    cs->h_path_end.swap(h_pe);
+    cs->h_path_begin.assign(h_pb, h_pb + P);
+    cs->h_path_end.assign(h_pe, h_pe + P);
     cs->plan = im.plan;
     cs->on_device = true;
     return FLATGFA_OK;

@@ -8,6 +8,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <memory>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 
@@ -562,13 +564,11 @@ static inline char *write_u64(char *p, uint64_t x) {
     return p;
 }
 
-void emit_seg_depth(const View &v, const uint64_t *depth, const uint64_t *uniq, std::string *out) {
-    out->append("#node.id\tdepth\tdepth.uniq\n");
-    // one line is at most 10 + 20 + 20 digits, two tabs and a newline
-    const size_t head = out->size();
-    out->resize(head + v.segs.len * 53);
-    char *p = &(*out)[head];
-    for (size_t i = 0; i < v.segs.len; ++i) {
+// One line per segment, in pool order: `{seg.name as u32}\t{depth}\t{uniq}\n` (depth.rs:70-79).
+// A million lines are 13 MB of decimal digits: big tables are formatted by several threads, each
+// its own stretch of segments into its own buffer, and stitched together in order.
+static char *emit_seg_lines(const View &v, const uint64_t *depth, const uint64_t *uniq, size_t lo, size_t hi, char *p) {
+    for (size_t i = lo; i < hi; ++i) {
         p = write_u64(p, (uint32_t)v.segs[i].name);  // `seg.name as u32`, depth.rs:71
         *p++ = '\t';
         p = write_u64(p, depth[i]);
@@ -576,7 +576,46 @@ void emit_seg_depth(const View &v, const uint64_t *depth, const uint64_t *uniq, 
         p = write_u64(p, uniq[i]);
         *p++ = '\n';
     }
-    out->resize((size_t)(p - out->data()));
+    return p;
+}
+
+void emit_seg_depth(const View &v, const uint64_t *depth, const uint64_t *uniq, std::string *out) {
+    out->append("#node.id\tdepth\tdepth.uniq\n");
+    constexpr size_t kLineMax = 53;  // at most 10 + 20 + 20 digits, two tabs and a newline
+    const size_t S = v.segs.len;
+    unsigned nthr = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (S < (1u << 16)) nthr = 1;
+    if (nthr == 1) {
+        const size_t head = out->size();
+        out->resize(head + S * kLineMax);
+        char *p = emit_seg_lines(v, depth, uniq, 0, S, &(*out)[head]);
+        out->resize((size_t)(p - out->data()));
+        return;
+    }
+    struct Part {
+        std::unique_ptr<char[]> buf;
+        size_t len = 0;
+    };
+    std::vector<Part> parts(nthr);
+    std::vector<std::thread> workers;
+    for (unsigned t = 0; t < nthr; ++t)
+        workers.emplace_back([&, t]() {
+            const size_t lo = S * t / nthr, hi = S * (t + 1) / nthr;
+            parts[t].buf.reset(new char[(hi - lo) * kLineMax + 1]);
+            parts[t].len = (size_t)(emit_seg_lines(v, depth, uniq, lo, hi, parts[t].buf.get()) - parts[t].buf.get());
+        });
+    for (auto &w : workers) w.join();
+    size_t total = out->size();
+    std::vector<size_t> at(nthr);
+    for (unsigned t = 0; t < nthr; ++t) {
+        at[t] = total;
+        total += parts[t].len;
+    }
+    out->resize(total);
+    workers.clear();
+    for (unsigned t = 0; t < nthr; ++t)
+        workers.emplace_back([&, t]() { memcpy(&(*out)[at[t]], parts[t].buf.get(), parts[t].len); });
+    for (auto &w : workers) w.join();
 }
 
 void emit_path_depth(const View &v, const uint32_t *path_ids, size_t n, const uint64_t *lengths,
