@@ -281,10 +281,11 @@ def main():
         len_out = torch.zeros(P, dtype=torch.int64, device=device)
         wsum_out = torch.zeros(P, dtype=torch.int64, device=device)
 
-        def path_depth_all():
+        def path_depth_two_walks():  # round 1: node depth, then a second walk of the steps with one gather each
             plan.seg_depth(d_only, None)
             plan.path_sums(ids, d_only, len_out, wsum_out)
-        extras["path_depth_all_paths_ms"] = round(timed(path_depth_all), 5)
+        extras["path_depth_all_paths_ms"] = round(timed(lambda: plan.path_depth_all(d_only, len_out, wsum_out)), 5)
+        extras["path_depth_all_paths_two_walks_ms"] = round(timed(path_depth_two_walks), 5)
         plan.status()
         # The timed loop walks the same 400 MB image every step; MI355X has 256 MiB of Infinity
         # Cache and FETCH_SIZE counts its hits as fetches.  Cycle K resident images (> 1 GB): if

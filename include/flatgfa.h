@@ -195,6 +195,14 @@ int flatgfa_dev_seg_depth(flatgfa_dev_plan_t *plan, uint32_t *depth_out, uint32_
  * division per path is left to the host. */
 int flatgfa_dev_path_sums(flatgfa_dev_plan_t *plan, const uint32_t *path_ids, uint32_t n_ids, const uint32_t *depth,
                           uint64_t *length_out, uint64_t *weighted_out, void *stream);
+/* path_depth for ALL paths of the plan in one go (ops/depth.rs:88-111 with every path requested --
+ * what `fgfa depth` prints, cmds.rs:256-262): node depth into depth_out u32[n_segs], and per path
+ * the two integer sums of measure_path into length_out / weighted_out u64[n_paths] (device
+ * memory), indexed by path.  The sums of the paths the step-scan kernel walks are formed in the
+ * same pass that accumulates node depth -- a run of segments contributes two differences of
+ * window-local prefix sums -- so the steps are read once. */
+int flatgfa_dev_path_depth_all(flatgfa_dev_plan_t *plan, uint32_t *depth_out, uint64_t *length_out,
+                               uint64_t *weighted_out, void *stream);
 /* Path-pair overlap on device (slow_odgi/slow_odgi/overlap.py:6-14): touch_out[k * n_paths + j] = 1
  * iff path j is a different path from path_ids[k] and the two share at least one ORIENTED handle.
  * query_ids u32[n_q] and touch_out u8[n_q * n_paths] are device memory.  The per-path handle

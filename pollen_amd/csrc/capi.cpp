@@ -416,28 +416,27 @@ int flatgfa_path_depth(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, 
     }
     for (uint32_t k = 0; k < n_ids; ++k)
         if (path_ids[k] >= gfa->view.paths.len) { set_error("flatgfa_path_depth: path id out of range"); return FLATGFA_ERR_BOUNDS; }
-    // pass 1 over ALL paths (depth.rs:94-99), pass 2 over the requested ones (:104-108)
+    // pass 1 over ALL paths (depth.rs:94-99), pass 2 over the requested ones (:104-108).  The device
+    // forms every path's two sums in the pass that accumulates node depth (one read of the
+    // steps); the requested ones are picked here.
     std::lock_guard<std::mutex> op(gfa->op_mu);
-    int rc = run_seg_depth(gfa, false);
-    if (rc || n_ids == 0) return rc;
-    uint32_t *d_ids = nullptr;
+    int rc = ensure_device(gfa, -1);
+    if (rc) return rc;
+    const size_t P = gfa->view.paths.len;
+    if (n_ids == 0 || P == 0) return run_seg_depth(gfa, false);
     uint64_t *d_sums = nullptr;
-    CAPI_HIP(hipMalloc(&d_ids, (size_t)n_ids * 4));
-    hipError_t e = hipMalloc(&d_sums, (size_t)n_ids * 16);
-    if (e != hipSuccess) { (void)hipFree(d_ids); set_error("hipMalloc failed"); return FLATGFA_ERR_HIP; }
-    std::vector<uint64_t> sums((size_t)n_ids * 2);
-    rc = FLATGFA_OK;
-    if (hipMemcpyAsync(d_ids, path_ids, (size_t)n_ids * 4, hipMemcpyHostToDevice, gfa->stream) != hipSuccess) rc = FLATGFA_ERR_HIP;
-    if (!rc) rc = flatgfa_dev_path_sums(gfa->plan, d_ids, n_ids, gfa->d_depth, d_sums, d_sums + n_ids, gfa->stream);
+    CAPI_HIP(hipMalloc(&d_sums, P * 16));
+    std::vector<uint64_t> sums(P * 2);
+    rc = flatgfa_dev_path_depth_all(gfa->plan, gfa->d_depth, d_sums, d_sums + P, gfa->stream);
     if (!rc) rc = flatgfa_dev_status(gfa->plan, gfa->stream);
-    if (!rc && hipMemcpy(sums.data(), d_sums, (size_t)n_ids * 16, hipMemcpyDeviceToHost) != hipSuccess) rc = FLATGFA_ERR_HIP;
-    (void)hipFree(d_ids);
+    if (!rc && hipMemcpy(sums.data(), d_sums, P * 16, hipMemcpyDeviceToHost) != hipSuccess) rc = FLATGFA_ERR_HIP;
     (void)hipFree(d_sums);
     if (rc) return rc;
     for (uint32_t k = 0; k < n_ids; ++k) {
-        length_out[k] = sums[k];
+        const uint64_t ln = sums[path_ids[k]], ws = sums[P + path_ids[k]];
+        length_out[k] = ln;
         // the one floating-point operation on this path: depth.rs:129
-        mean_out[k] = (double)sums[n_ids + k] / (double)sums[k];
+        mean_out[k] = (double)ws / (double)ln;
     }
     return FLATGFA_OK;
 }

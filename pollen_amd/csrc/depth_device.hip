@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kSumThreads) void k_path_sums(const uint32_t *__res
                                                             const uint32_t *__restrict__ path_end, uint32_t n_paths,
                                                             uint32_t n_segs, const uint2 *__restrict__ tab,
                                                             const uint32_t *__restrict__ path_ids, uint32_t n_ids,
-                                                            uint32_t split,
+                                                            uint32_t split, uint32_t by_path,
                                                             unsigned long long *__restrict__ length_out,
                                                             unsigned long long *__restrict__ weighted_out,
                                                             uint32_t *__restrict__ status) {
@@ -190,8 +190,9 @@ __global__ __launch_bounds__(kSumThreads) void k_path_sums(const uint32_t *__res
                 a += red[0][w];
                 c += red[1][w];
             }
-            if (a) atomicAdd(&length_out[k], a);
-            if (c) atomicAdd(&weighted_out[k], c);
+            const uint32_t at = by_path ? p : k;  // results in the order of the request, or indexed by path
+            if (a) atomicAdd(&length_out[at], a);
+            if (c) atomicAdd(&weighted_out[at], c);
         }
         __syncthreads();
     }
@@ -217,7 +218,9 @@ struct flatgfa_dev_plan {
     // the outputs of the last node-depth call through the bucketed path: flatgfa_dev_status
     // completes that call if its records did not fit the sub-buckets
     uint32_t *last_depth = nullptr, *last_uniq = nullptr;
+    uint64_t *last_len = nullptr, *last_weighted = nullptr;  // (a path_depth_all call)
     bool last_fast = false;
+    uint32_t *all_ids = nullptr;       // 0..n_paths-1 (path_depth_all without the bucketed path)
 };
 
 extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int n_cus, uint32_t **bits_cache,
@@ -308,6 +311,7 @@ extern "C" void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *pl) {
     fast_plan_destroy(&pl->fast);
     if (pl->overlap_bits) (void)hipFree(pl->overlap_bits);
     if (pl->len_depth) (void)hipFree(pl->len_depth);
+    if (pl->all_ids) (void)hipFree(pl->all_ids);
     if (pl->items) (void)hipFree(pl->items);
     if (pl->status) (void)hipFree(pl->status);
     delete pl;
@@ -347,10 +351,34 @@ extern "C" int flatgfa_dev_seg_depth(flatgfa_dev_plan_t *pl, uint32_t *depth_out
     pl->last_fast = pl->fast.eligible;
     pl->last_depth = depth_out;
     pl->last_uniq = uniq_out;
+    pl->last_len = pl->last_weighted = nullptr;
     if (pl->fast.eligible) {
         return fast_seg_depth(pl->fast, g, depth_out, uniq_out, pl->status, stream);
     }
     return atomic_seg_depth(pl, depth_out, uniq_out, stream);
+}
+
+// the sums of `n_ids` paths (device array) through k_path_sums, results indexed by path when by_path
+static int path_sums_launch(flatgfa_dev_plan_t *pl, const uint32_t *path_ids, uint32_t n_ids, const uint32_t *depth,
+                            uint64_t *length_out, uint64_t *weighted_out, uint32_t by_path, hipStream_t stream) {
+    const flatgfa_dev_graph_t &g = pl->g;
+    uint32_t split = std::max<uint32_t>(1u, std::min<uint32_t>(64u, (uint32_t)(pl->n_cus * 16) / n_ids));
+    uint64_t jobs = (uint64_t)n_ids * split;
+    uint32_t grid = (uint32_t)std::min<uint64_t>(jobs, (uint64_t)pl->n_cus * 32u);
+    if (!pl->len_depth) HIP_TRY(hipMalloc(&pl->len_depth, (size_t)std::max<uint32_t>(g.n_segs, 1u) * sizeof(uint2)), return FLATGFA_ERR_HIP);
+    {
+        ProfScope ps("k_pack_len_depth", stream);
+        const uint32_t pgrid = std::max<uint32_t>(1u, std::min<uint32_t>((g.n_segs + 255) / 256, (uint32_t)pl->n_cus * 8u));
+        hipLaunchKernelGGL(k_pack_len_depth, dim3(pgrid), dim3(256), 0, stream, g.seg_len, depth, g.n_segs, pl->len_depth);
+    }
+    {
+        ProfScope ps("k_path_sums", stream);
+        hipLaunchKernelGGL(k_path_sums, dim3(grid), dim3(kSumThreads), 0, stream, g.steps, g.path_begin, g.path_end,
+                           g.n_paths, g.n_segs, pl->len_depth, path_ids, n_ids, split, by_path,
+                           (unsigned long long *)length_out, (unsigned long long *)weighted_out, pl->status);
+    }
+    HIP_TRY(hipGetLastError(), return FLATGFA_ERR_HIP);
+    return FLATGFA_OK;
 }
 
 extern "C" int flatgfa_dev_path_sums(flatgfa_dev_plan_t *pl, const uint32_t *path_ids, uint32_t n_ids,
@@ -369,23 +397,58 @@ extern "C" int flatgfa_dev_path_sums(flatgfa_dev_plan_t *pl, const uint32_t *pat
         HIP_TRY(hipMemsetAsync(length_out, 0, (size_t)n_ids * 8, stream), return FLATGFA_ERR_HIP);
         HIP_TRY(hipMemsetAsync(weighted_out, 0, (size_t)n_ids * 8, stream), return FLATGFA_ERR_HIP);
     }
-    uint32_t split = std::max<uint32_t>(1u, std::min<uint32_t>(64u, (uint32_t)(pl->n_cus * 16) / n_ids));
-    uint64_t jobs = (uint64_t)n_ids * split;
-    uint32_t grid = (uint32_t)std::min<uint64_t>(jobs, (uint64_t)pl->n_cus * 32u);
-    if (!pl->len_depth) HIP_TRY(hipMalloc(&pl->len_depth, (size_t)std::max<uint32_t>(g.n_segs, 1u) * sizeof(uint2)), return FLATGFA_ERR_HIP);
+    return path_sums_launch(pl, path_ids, n_ids, depth, length_out, weighted_out, 0u, stream);
+}
+
+static int path_depth_all_enqueue(flatgfa_dev_plan_t *pl, uint32_t *depth_out, uint64_t *length_out, uint64_t *weighted_out,
+                                  hipStream_t stream, bool use_fast) {
+    const flatgfa_dev_graph_t &g = pl->g;
     {
-        ProfScope ps("k_pack_len_depth", stream);
-        const uint32_t pgrid = std::max<uint32_t>(1u, std::min<uint32_t>((g.n_segs + 255) / 256, (uint32_t)pl->n_cus * 8u));
-        hipLaunchKernelGGL(k_pack_len_depth, dim3(pgrid), dim3(256), 0, stream, g.seg_len, depth, g.n_segs, pl->len_depth);
+        ProfScope ps("memset_path_sums", stream);
+        HIP_TRY(hipMemsetAsync(length_out, 0, (size_t)g.n_paths * 8, stream), return FLATGFA_ERR_HIP);
+        HIP_TRY(hipMemsetAsync(weighted_out, 0, (size_t)g.n_paths * 8, stream), return FLATGFA_ERR_HIP);
     }
-    {
-        ProfScope ps("k_path_sums", stream);
-        hipLaunchKernelGGL(k_path_sums, dim3(grid), dim3(kSumThreads), 0, stream, g.steps, g.path_begin, g.path_end,
-                           g.n_paths, g.n_segs, pl->len_depth, path_ids, n_ids, split,
-                           (unsigned long long *)length_out, (unsigned long long *)weighted_out, pl->status);
+    use_fast = use_fast && pl->fast.eligible;
+    if (use_fast && fast_plan_want_path_sums(&pl->fast)) {
+        // pass 2 adds up the paths k_scan walked; the wave-per-path kernels' paths take the gather kernel
+        const PathSums ps{length_out, weighted_out};
+        int rc = fast_seg_depth(pl->fast, g, depth_out, nullptr, pl->status, stream, &ps);
+        if (rc) return rc;
+        if (pl->fast.n_other) rc = path_sums_launch(pl, pl->fast.other_ids, pl->fast.n_other, depth_out, length_out, weighted_out, 1u, stream);
+        return rc;
     }
-    HIP_TRY(hipGetLastError(), return FLATGFA_ERR_HIP);
-    return FLATGFA_OK;
+    int rc = use_fast ? fast_seg_depth(pl->fast, g, depth_out, nullptr, pl->status, stream)
+                      : atomic_seg_depth(pl, depth_out, nullptr, stream);
+    if (rc) return rc;
+    if (!pl->all_ids) {
+        std::vector<uint32_t> ids(g.n_paths);
+        for (uint32_t i = 0; i < g.n_paths; ++i) ids[i] = i;
+        HIP_TRY(hipMalloc(&pl->all_ids, (size_t)g.n_paths * 4), return FLATGFA_ERR_HIP);
+        HIP_TRY(hipMemcpy(pl->all_ids, ids.data(), (size_t)g.n_paths * 4, hipMemcpyHostToDevice), return FLATGFA_ERR_HIP);
+    }
+    return path_sums_launch(pl, pl->all_ids, g.n_paths, depth_out, length_out, weighted_out, 1u, stream);
+}
+
+extern "C" int flatgfa_dev_path_depth_all(flatgfa_dev_plan_t *pl, uint32_t *depth_out, uint64_t *length_out,
+                                          uint64_t *weighted_out, void *stream_) {
+    if (!pl || (pl->g.n_segs && !depth_out) || (pl->g.n_paths && (!length_out || !weighted_out))) {
+        set_error("dev_path_depth_all: NULL argument");
+        return FLATGFA_ERR_ARG;
+    }
+    const flatgfa_dev_graph_t &g = pl->g;
+    if (g.n_paths == 0) return g.n_segs ? flatgfa_dev_seg_depth(pl, depth_out, nullptr, stream_) : FLATGFA_OK;
+    if (!g.seg_len && g.n_segs) { set_error("dev_path_depth_all: graph image has no seg_len array"); return FLATGFA_ERR_ARG; }
+    if (g.n_segs == 0) {
+        HIP_TRY(hipMemsetAsync(length_out, 0, (size_t)g.n_paths * 8, (hipStream_t)stream_), return FLATGFA_ERR_HIP);
+        HIP_TRY(hipMemsetAsync(weighted_out, 0, (size_t)g.n_paths * 8, (hipStream_t)stream_), return FLATGFA_ERR_HIP);
+        return FLATGFA_OK;
+    }
+    pl->last_fast = pl->fast.eligible;
+    pl->last_depth = depth_out;
+    pl->last_uniq = nullptr;
+    pl->last_len = length_out;
+    pl->last_weighted = weighted_out;
+    return path_depth_all_enqueue(pl, depth_out, length_out, weighted_out, (hipStream_t)stream_, true);
 }
 
 extern "C" int flatgfa_dev_path_overlaps(flatgfa_dev_plan_t *pl, const uint32_t *query_ids, uint32_t n_q,
@@ -419,12 +482,11 @@ extern "C" int flatgfa_dev_status(flatgfa_dev_plan_t *pl, void *stream_) {
             return FLATGFA_ERR_HIP;
         }
         int rc;
-        if (fast_plan_grow(&pl->fast)) {
-            rc = fast_seg_depth(pl->fast, pl->g, pl->last_depth, pl->last_uniq, pl->status, stream);
-        } else {
-            pl->last_fast = false;
-            rc = atomic_seg_depth(pl, pl->last_depth, pl->last_uniq, stream);
-        }
+        const bool grown = fast_plan_grow(&pl->fast);
+        if (!grown) pl->last_fast = false;
+        if (pl->last_len) rc = path_depth_all_enqueue(pl, pl->last_depth, pl->last_len, pl->last_weighted, stream, grown);
+        else if (grown) rc = fast_seg_depth(pl->fast, pl->g, pl->last_depth, pl->last_uniq, pl->status, stream);
+        else rc = atomic_seg_depth(pl, pl->last_depth, pl->last_uniq, stream);
         if (rc) return rc;
     }
 }

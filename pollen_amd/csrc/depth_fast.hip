@@ -538,6 +538,7 @@ struct ShortBlk {
     uint32_t b, e;     // the path's steps
     uint32_t pos;      // first step of the block (a multiple of 16)
     uint32_t nl;       // lanes holding steps
+    uint32_t item;     // the path's position in the list of short paths
     bool last, valid;  // last block of its path; there is a block at all
 };
 
@@ -558,6 +559,7 @@ __device__ __forceinline__ ShortBlk stream_next(const ScanArgs &A, ShortStream &
     k.b = g.b;
     k.e = g.e;
     k.pos = g.pos;
+    k.item = g.gi;
     const uint32_t left = k.valid ? (g.end - g.pos) / 16u : 0u;
     k.nl = min(left, 64u);
     k.last = left <= 64u;
@@ -639,7 +641,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
             if (handed_back) {                                                                          \
                 if (lane == 0) {                                                                        \
                     const uint32_t k = atomicAdd(A.work_counter, 1u);                                   \
-                    if (k < A.max_back) A.items[A.n_items + k] = make_uint4(cur.b, cur.e, kNoSlot, 0u); \
+                    if (k < A.max_back) A.items[A.n_items + k] = make_uint4(cur.b, cur.e, kNoSlot, A.short_items[cur.item].w); \
                     else atomicOr(A.status, kStOverflow);                                               \
                 }                                                                                       \
                 handed_back = false;                                                                    \
@@ -1065,6 +1067,11 @@ struct AccArgs {
     uint32_t *uniq_out;
     uint32_t *status;
     uint32_t dbg;  // FLATGFA_DEBUG_SKIP ablations (results are then wrong by construction)
+    // path depth in the same walk (k_accum<false, 12, true>): per path of k_scan's items, the sums of
+    // measure_path (depth.rs:116-131) over the steps that fall into this window
+    const uint4 *items;                  // item j belongs to path items[j].w
+    const uint32_t *seg_len;
+    ulonglong2 *psum_part;               // [n_win][dstride] {sum len, sum depth * len} of item j in this window
 };
 
 // Pass 2 keeps two difference arrays over the window in LDS: D for depth and R for revisits (steps
@@ -1461,7 +1468,102 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
     run_pending<WB>(pq, R, mybits, A.dbg, 1u);
 }
 
-template <bool UNIQ, int WB>
+// the sum of a 64-bit value over the wave, uniform, by DPP adds on its halves
+__device__ __forceinline__ unsigned long long wave_total_u64(unsigned long long x) {
+#define FGFA_DPP_ADD64(CTRL, ROWMASK, BC)                                                                            \
+    x += ((unsigned long long)(uint32_t)__builtin_amdgcn_update_dpp(0u, (uint32_t)(x >> 32), CTRL, ROWMASK, 0xf, BC) << 32) | \
+         (uint32_t)__builtin_amdgcn_update_dpp(0u, (uint32_t)x, CTRL, ROWMASK, 0xf, BC)
+    FGFA_DPP_ADD64(0x111 /* row_shr:1 */, 0xf, true);
+    FGFA_DPP_ADD64(0x112 /* row_shr:2 */, 0xf, true);
+    FGFA_DPP_ADD64(0x114 /* row_shr:4 */, 0xf, true);
+    FGFA_DPP_ADD64(0x118 /* row_shr:8 */, 0xf, true);
+    FGFA_DPP_ADD64(0x142 /* row_bcast:15 */, 0xa, true);
+    FGFA_DPP_ADD64(0x143 /* row_bcast:31 */, 0xc, true);
+#undef FGFA_DPP_ADD64
+    return ((unsigned long long)__builtin_amdgcn_readlane((uint32_t)(x >> 32), 63) << 32) | __builtin_amdgcn_readlane((uint32_t)x, 63);
+}
+
+// measure_path (depth.rs:116-131) without a second walk of the steps: a record (first segment,
+// length) of path p contributes sum(len) and sum(depth * len) over its segments, which are two
+// differences of the window's prefix sums Lw / Ww (built in LDS once the window's depth is
+// final).  Each wave walks its stretch of k_scan's items as in apply_groups; the first 64 records
+// of eight items are requested before any is used; an item's contribution in this window is
+// reduced across the wave and stored -- plain stores: an atomic per item would sit in the way of
+// the loads behind it until memory had acknowledged it -- and k_path_reduce adds the windows up.
+template <int WB>
+__device__ __forceinline__ void sum_groups(const AccArgs &A, const unsigned long long *Lw, const unsigned long long *Ww,
+                                           const uint32_t *wbase, uint32_t win) {
+    constexpr uint32_t kW = 1u << WB;
+    constexpr int kAhead = 8;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t e0 = __builtin_amdgcn_readfirstlane(A.wave_off[wave]), e1 = __builtin_amdgcn_readfirstlane(A.wave_off[wave + 1]);
+    ulonglong2 *part = A.psum_part + (size_t)win * A.dstride;
+    const auto add = [&](uint32_t rec, unsigned long long &ls, unsigned long long &ws) {
+        const uint32_t rel = rec & (kW - 1), e1x = rel + ((rec >> WB) & 1023u) + 1u;  // one past the run's last segment
+        ls += Lw[e1x] - Lw[rel];
+        ws += Ww[e1x] - Ww[rel];
+    };
+    for (uint32_t mb = e0; mb < e1; mb += 64u) {
+        const uint32_t cntE = min(64u, e1 - mb);
+        const bool have = (uint32_t)lane < cntE;
+        const uint32_t j = have ? (A.elist[mb + lane] & 0x7FFFFFFFu) : 0u;
+        const uint2 be = have ? A.dir[(size_t)win * A.dstride + j] : make_uint2(0u, 0u);
+        const uint32_t sl = have ? A.islot[j] : 0u;
+        const uint32_t b = min(be.x, A.cap), en = max(b, min(be.y, A.cap));
+        const uint32_t n = en - b, off = sl * A.cap + b;
+        unsigned long long myL = 0, myW = 0;  // lane i: item i's sums in this window
+        for (uint32_t i0 = 0; i0 < cntE; i0 += kAhead) {
+            uint32_t r[kAhead], nn[kAhead], oo[kAhead];
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                const uint32_t i = min(i0 + (uint32_t)k, cntE - 1u);
+                nn[k] = i0 + k < cntE ? __builtin_amdgcn_readlane(n, i) : 0u;
+                oo[k] = __builtin_amdgcn_readlane(off, i);
+                r[k] = wbase[oo[k] + ((uint32_t)lane < nn[k] ? (uint32_t)lane : 0u)];  // unconditional: a predicated load would be waited for on the spot
+            }
+#pragma unroll
+            for (int k = 0; k < kAhead; ++k) {
+                if (nn[k] == 0u) continue;
+                unsigned long long ls = 0, ws = 0;
+                if ((uint32_t)lane < nn[k]) add(r[k], ls, ws);
+                for (uint32_t c = 64u; c < nn[k]; c += 64u)
+                    if (c + (uint32_t)lane < nn[k]) add(wbase[oo[k] + c + lane], ls, ws);
+                ls = wave_total_u64(ls);  // by DPP: __shfl_down would go through LDS twelve times per value
+                ws = wave_total_u64(ws);
+                if ((uint32_t)lane == i0 + (uint32_t)k) {
+                    myL = ls;
+                    myW = ws;
+                }
+            }
+        }
+        if (have) part[j] = make_ulonglong2(myL, myW);
+    }
+}
+
+// Adds an item's per-window sums up and credits them to its path.  One wave per item.
+__global__ __launch_bounds__(256) void k_path_reduce(const uint4 *__restrict__ items, uint32_t n_items, uint32_t n_win,
+                                                     uint32_t dstride, const ulonglong2 *__restrict__ part,
+                                                     unsigned long long *__restrict__ psum_len,
+                                                     unsigned long long *__restrict__ psum_w) {
+    const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (j >= n_items) return;
+    unsigned long long l = 0, w = 0;
+    for (uint32_t wdw = lane; wdw < n_win; wdw += 64u) {
+        const ulonglong2 v = part[(size_t)wdw * dstride + j];
+        l += v.x;
+        w += v.y;
+    }
+    l = wave_total_u64(l);
+    w = wave_total_u64(w);
+    if (lane == 0 && (l | w)) {
+        const uint32_t p = items[j].w;
+        atomicAdd(&psum_len[p], l);
+        atomicAdd(&psum_w[p], w);
+    }
+}
+
+template <bool UNIQ, int WB, bool PSUM = false>
 __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     constexpr uint32_t kW = 1u << WB;
     constexpr int kPer = kW / kAccThreads;  // cells per thread: 4 or 8
@@ -1473,6 +1575,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     __shared__ __attribute__((aligned(16))) uint32_t bits[UNIQ ? kAccWaves * kSlots * (kW / 32) : 4];
     __shared__ uint32_t marks[UNIQ ? kAccWaves * 64 : 4];
     __shared__ __attribute__((aligned(8))) uint32_t pend[UNIQ ? kAccWaves * 3 * kPend : 4];
+    __shared__ unsigned long long Lw[PSUM ? kW + 1 : 1], Ww[PSUM ? kW + 1 : 1];  // prefix sums of len and depth * len
     int *D = cells, *R = cells + (UNIQ ? kW + 64 : 0);
     const int tid = threadIdx.x, wave = tid >> 6;
     const uint32_t win = blockIdx.x, w0 = win * kW;
@@ -1518,6 +1621,25 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
 #pragma unroll
         for (int k = 0; k < kPer; ++k) d[k] = (uint32_t)v[k];
         store_n<kPer>(A.depth_out + w0, i0, nvalid, d);
+        if (PSUM) {
+            unsigned long long l[kPer], w[kPer];
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                const uint32_t len = i0 + k < nvalid ? A.seg_len[w0 + i0 + k] : 0u;
+                l[k] = len;
+                w[k] = (unsigned long long)d[k] * len;
+            }
+            block_scan<unsigned long long, kPer>(wave_tot, l);
+            block_scan<unsigned long long, kPer>(wave_tot, w);
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                Lw[i0 + k + 1] = l[k];
+                Ww[i0 + k + 1] = w[k];
+            }
+            if (tid == 0) Lw[0] = Ww[0] = 0ull;
+            __syncthreads();
+            sum_groups<WB>(A, Lw, Ww, wbase, win);
+        }
     }
 }
 
@@ -1744,6 +1866,16 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
         FAST_TRY(hipMalloc(&fp->medium_items, medium_items.size() * sizeof(uint4)));
         FAST_TRY(hipMemcpy(fp->medium_items, medium_items.data(), medium_items.size() * sizeof(uint4), hipMemcpyHostToDevice));
     }
+    {
+        std::vector<uint32_t> other;
+        for (const uint4 &it : short_items) other.push_back(it.w);
+        for (const uint4 &it : medium_items) other.push_back(it.w);
+        fp->n_other = (uint32_t)other.size();
+        if (!other.empty()) {
+            FAST_TRY(hipMalloc(&fp->other_ids, other.size() * 4));
+            FAST_TRY(hipMemcpy(fp->other_ids, other.data(), other.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     fp->lds_bytes_short = (kShortMaxWin + kWaves * (kQCap + 2 * kPCap + (2u << kShortHash))) * 4u;
     fp->lds_bytes_medium = (kShortMaxWin + kMediumWaves * (kQCap + 2 * kPCap + (2u << kMediumHash))) * 4u;
     FAST_TRY(hipFuncSetAttribute((const void *)k_walk_short<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_short));
@@ -1755,6 +1887,21 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_scan));
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_scan));
     fp->eligible = true;
+    return true;
+}
+
+// Scratch for path sums riding on seg_depth: one {sum len, sum depth * len} per (window, item).
+// False when that would be out of proportion (then the caller walks the steps a second time).
+bool fast_plan_want_path_sums(FastPlan *fp) {
+    if (!fp->eligible || fp->wb != 12) return false;
+    if (fp->psum_part) return true;
+    const uint64_t bytes = (uint64_t)fp->n_win * fp->dstride * 16;
+    if (bytes > (256ull << 20)) return false;
+    if (hipMalloc(&fp->psum_part, std::max<uint64_t>(bytes, 16)) != hipSuccess) {
+        fp->psum_part = nullptr;
+        (void)hipGetLastError();
+        return false;
+    }
     return true;
 }
 
@@ -1776,13 +1923,17 @@ bool fast_plan_grow(FastPlan *fp) {
 void fast_plan_destroy(FastPlan *fp) {
     for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot,
                     (void *)fp->elist, (void *)fp->wave_off, (void *)fp->items, (void *)fp->short_items,
-                    (void *)fp->medium_items, (void *)fp->work_counter})
+                    (void *)fp->medium_items, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part})
         if (p) (void)hipFree(p);
     *fp = FastPlan();
 }
 
 int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
-                   uint32_t *status, hipStream_t stream) {
+                   uint32_t *status, hipStream_t stream, const PathSums *ps) {
+    if (ps && (uniq_out || fp.wb != 12 || !g.seg_len || !fp.psum_part)) {
+        set_error("fast_seg_depth: path sums ride on seg_depth with 4096-segment windows only");
+        return FLATGFA_ERR_ARG;
+    }
     const uint32_t stride = fp.n_slots * fp.cap;
     const bool has_pre = fp.n_short || fp.n_medium;
     // one persistent workgroup per CU; k_scan may be handed short paths back, so it gets a full grid when there are any
@@ -1815,11 +1966,12 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
     sa.dbg = fp.dbg;
     AccArgs aa{g.n_segs, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.counts0, has_pre ? 1u : 0u, fp.buckets,
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
-               fp.work_counter, fp.max_back, depth_out, uniq_out, status, fp.dbg};
+               fp.work_counter, fp.max_back, depth_out, uniq_out, status, fp.dbg,
+               reinterpret_cast<const uint4 *>(fp.items), g.seg_len, ps ? reinterpret_cast<ulonglong2 *>(fp.psum_part) : nullptr};
     if (fp.n_short) {
         if (hipMemsetAsync(fp.work_counter, 0, 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
         const uint32_t sgrid = std::min<uint32_t>((fp.n_short + kWaves - 1) / kWaves, fp.n_slots);
-        ProfScope ps(uniq_out ? "k_scan_short<uniq>" : "k_scan_short<depth>", stream);
+        ProfScope pscope(uniq_out ? "k_scan_short<uniq>" : "k_scan_short<depth>", stream);
         if (uniq_out) hipLaunchKernelGGL(k_walk_short<true>, dim3(sgrid), dim3(kThreads), fp.lds_bytes_short, stream, sa);
         else hipLaunchKernelGGL(k_walk_short<false>, dim3(sgrid), dim3(kThreads), fp.lds_bytes_short, stream, sa);
     }
@@ -1828,26 +1980,33 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
         sm.short_items = reinterpret_cast<const uint4 *>(fp.medium_items);
         sm.n_short = fp.n_medium;
         const uint32_t mgrid = std::min<uint32_t>((fp.n_medium + kMediumWaves - 1) / kMediumWaves, fp.n_slots);
-        ProfScope ps(uniq_out ? "k_scan_medium<uniq>" : "k_scan_medium<depth>", stream);
+        ProfScope pscope(uniq_out ? "k_scan_medium<uniq>" : "k_scan_medium<depth>", stream);
         if (uniq_out) hipLaunchKernelGGL(k_walk_medium<true>, dim3(mgrid), dim3(kMediumWaves * 64), fp.lds_bytes_medium, stream, sm);
         else hipLaunchKernelGGL(k_walk_medium<false>, dim3(mgrid), dim3(kMediumWaves * 64), fp.lds_bytes_medium, stream, sm);
     }
     if (grid) {
-        ProfScope ps("k_scan", stream);
+        ProfScope pscope("k_scan", stream);
         if (fp.dbg) hipLaunchKernelGGL(k_scan<true>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
         else hipLaunchKernelGGL(k_scan<false>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
     }
     {
-        ProfScope ps(uniq_out ? "k_accum<uniq>" : "k_accum<depth>", stream);
+        ProfScope pscope(uniq_out ? "k_accum<uniq>" : (ps ? "k_accum<depth+paths>" : "k_accum<depth>"), stream);
         if (uniq_out) {
             if (fp.wb == 11) hipLaunchKernelGGL((k_accum<true, 11>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
             else if (fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
             else hipLaunchKernelGGL((k_accum<true, 13>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
         } else {
             if (fp.wb == 11) hipLaunchKernelGGL((k_accum<false, 11>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
+            else if (fp.wb == 12 && ps) hipLaunchKernelGGL((k_accum<false, 12, true>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
             else if (fp.wb == 12) hipLaunchKernelGGL((k_accum<false, 12>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
             else hipLaunchKernelGGL((k_accum<false, 13>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
         }
+    }
+    if (ps && fp.n_items) {
+        ProfScope pscope("k_path_reduce", stream);
+        hipLaunchKernelGGL(k_path_reduce, dim3((fp.n_items + 3) / 4), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(fp.items),
+                           fp.n_items, fp.n_win, fp.dstride, reinterpret_cast<const ulonglong2 *>(fp.psum_part),
+                           (unsigned long long *)ps->len_out, (unsigned long long *)ps->weighted_out);
     }
     if (hipGetLastError() != hipSuccess) {
         set_error("fast_seg_depth: kernel launch failed");

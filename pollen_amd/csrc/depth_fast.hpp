@@ -38,6 +38,9 @@ struct FastPlan {
     uint32_t n_medium = 0;
     uint32_t lds_bytes_medium = 0;
     uint32_t *work_counter = nullptr;  // how many short paths were handed back in this call
+    void *psum_part = nullptr;         // ulonglong2[n_win * dstride] per-window path sums of k_scan's items (on first use)
+    uint32_t *other_ids = nullptr;     // u32[n_other] the paths k_scan_short walks (their sums need k_path_sums)
+    uint32_t n_other = 0;
 };
 
 // Decides eligibility (at most 2048 windows, 16-byte aligned steps, a directory that stays small
@@ -48,8 +51,16 @@ void fast_plan_destroy(FastPlan *fp);
 // After a call whose records did not fit their sub-buckets (status bit 4): quadruple the capacity.
 // Returns false -- and marks the plan ineligible -- when that is not possible.
 bool fast_plan_grow(FastPlan *fp);
-// Enqueues the kernels.  uniq_out may be NULL (seg_depth).
+// Per-path sums of measure_path (depth.rs:116-131), accumulated by pass 2 of a seg_depth call for
+// the paths k_scan walks (plan.other_ids lists the rest): u64[n_paths] each, zeroed by the caller.
+struct PathSums {
+    uint64_t *len_out, *weighted_out;
+};
+// Allocates (once) the scratch `ps` needs; false = not possible for this plan.
+bool fast_plan_want_path_sums(FastPlan *fp);
+// Enqueues the kernels.  uniq_out may be NULL (seg_depth); `ps` only with uniq_out == NULL and
+// after fast_plan_want_path_sums.
 int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
-                   uint32_t *status, hipStream_t stream);
+                   uint32_t *status, hipStream_t stream, const PathSums *ps = nullptr);
 
 }  // namespace fgfa_dev

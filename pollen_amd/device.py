@@ -113,6 +113,21 @@ class DepthPlan:
                                                     weighted_out.data_ptr() if n else None, self._stream()),
                    "dev_path_sums")
 
+    def path_depth_all(self, depth_out, length_out, weighted_out) -> None:
+        """Enqueue node depth AND measure_path's two integer sums for every path of the graph
+        (what `fgfa depth` needs) in one pass over the steps.  depth_out: int32[n_segs]; the sums:
+        int64[n_paths] CUDA tensors (u64 bits), indexed by path."""
+        torch = _torch()
+        S, P = self.graph.n_segs, self.graph.n_paths
+        assert depth_out.dtype == torch.int32 and depth_out.numel() == S and depth_out.is_contiguous()
+        for t in (length_out, weighted_out):
+            assert t.dtype == torch.int64 and t.is_cuda and t.is_contiguous() and t.numel() == P
+        with torch.cuda.device(self.graph.device):
+            _check(_lib.lib().flatgfa_dev_path_depth_all(self._p, depth_out.data_ptr() if S else None,
+                                                         length_out.data_ptr() if P else None,
+                                                         weighted_out.data_ptr() if P else None, self._stream()),
+                   "dev_path_depth_all")
+
     def status(self) -> None:
         """Synchronize the current stream and raise if a kernel saw an out-of-range id."""
         with _torch().cuda.device(self.graph.device):

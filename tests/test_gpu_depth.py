@@ -297,3 +297,48 @@ def test_linearity_over_path_subsets():
         acc += part
     got = acc.cpu().numpy().view(np.uint32)
     assert (got[:30_000] == whole_d).all() and (got[30_000:] == whole_u).all()
+
+
+def test_device_path_depth_all_matches_two_walks(device_path):
+    """flatgfa_dev_path_depth_all (sums formed in pass 2 from the run records) against
+    seg_depth + path_sums (a second walk of the steps) and against the oracle, on a graph with
+    short, medium, long and split paths."""
+    import torch
+    from pollen_amd import device as dev
+    g = pa.synth(12, 60_000, 40, 30_000, "pangenome", True)
+    pools = pools_of(g)
+    steps, pb, pe, seg_len = g.soa()
+    # mix in short paths: cut the first ten paths into pieces of 700 steps
+    nb, ne = [], []
+    for p in range(len(pb)):
+        if p < 10:
+            for s in range(int(pb[p]), int(pe[p]), 700):
+                nb.append(s)
+                ne.append(min(s + 700, int(pe[p])))
+        else:
+            nb.append(int(pb[p]))
+            ne.append(int(pe[p]))
+    nb, ne = np.array(nb, np.uint32), np.array(ne, np.uint32)
+    S, P = len(seg_len), len(nb)
+    graph = dev.DeviceGraph(steps, nb, ne, S, seg_len)
+    plan = dev.DepthPlan(graph)
+    d = torch.zeros(S, dtype=torch.int32, device="cuda")
+    ln = torch.zeros(P, dtype=torch.int64, device="cuda")
+    ws = torch.zeros(P, dtype=torch.int64, device="cuda")
+    plan.path_depth_all(d, ln, ws)
+    plan.status()
+    d2 = torch.zeros_like(d)
+    ln2, ws2 = torch.zeros_like(ln), torch.zeros_like(ws)
+    plan.seg_depth(d2, None)
+    plan.status()   # (with 8-record buckets the call is only complete after this)
+    plan.path_sums(torch.arange(P, dtype=torch.int32, device="cuda"), d2, ln2, ws2)
+    plan.status()
+    assert torch.equal(d, d2) and torch.equal(ln, ln2) and torch.equal(ws, ws2)
+    want_d, _ = fo.seg_depth_with_uniq(pools)
+    assert (d.cpu().numpy().view(np.uint32) == want_d).all()
+    ids_all = steps >> 1
+    lens = seg_len.astype(np.uint64)
+    want_ln = np.array([lens[ids_all[b:e]].sum() for b, e in zip(nb, ne)], dtype=np.uint64)
+    want_ws = np.array([(want_d[ids_all[b:e]].astype(np.uint64) * lens[ids_all[b:e]]).sum() for b, e in zip(nb, ne)], dtype=np.uint64)
+    assert (ln.cpu().numpy().view(np.uint64) == want_ln).all() and (ws.cpu().numpy().view(np.uint64) == want_ws).all()
+    plan.close()
