@@ -205,8 +205,10 @@ int flatgfa_dev_path_depth_all(flatgfa_dev_plan_t *plan, uint32_t *depth_out, ui
                                uint64_t *weighted_out, void *stream);
 /* Path-pair overlap on device (slow_odgi/slow_odgi/overlap.py:6-14): touch_out[k * n_paths + j] = 1
  * iff path j is a different path from path_ids[k] and the two share at least one ORIENTED handle.
- * query_ids u32[n_q] and touch_out u8[n_q * n_paths] are device memory.  The per-path handle
- * bitsets are built on the first call and kept with the plan. */
+ * query_ids u32[n_q] and touch_out u8[n_q * n_paths] are device memory.  A coarse bitmap per path
+ * (one bit per 2048 handles) is built on the first call and kept with the plan; exact handle
+ * bitsets are built for the query paths only, per call -- memory follows the queries, not the
+ * number of paths. */
 int flatgfa_dev_path_overlaps(flatgfa_dev_plan_t *plan, const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out,
                               void *stream);
 /* Synchronizes `stream`, then returns FLATGFA_OK, or FLATGFA_ERR_BOUNDS if any kernel since the

@@ -213,7 +213,9 @@ struct flatgfa_dev_plan {
     uint32_t *status = nullptr;
     uint32_t n_windows = 1;
     FastPlan fast;  // the bucketed two-kernel path, used whenever the graph is eligible
-    uint32_t *overlap_bits = nullptr;  // per-path oriented-handle bitsets (built on first overlap query)
+    uint32_t *overlap_bits = nullptr;  // per-path coarse handle bitmaps (built on first overlap query)
+    uint32_t *overlap_qbits = nullptr; // exact handle bitsets of the queries of the last overlap call (scratch)
+    size_t overlap_qbytes = 0;
     uint2 *len_depth = nullptr;        // (seg_len, depth) table of the last path_sums call (built on first use)
     // the outputs of the last node-depth call through the bucketed path: flatgfa_dev_status
     // completes that call if its records did not fit the sub-buckets
@@ -223,8 +225,8 @@ struct flatgfa_dev_plan {
     uint32_t *all_ids = nullptr;       // 0..n_paths-1 (path_depth_all without the bucketed path)
 };
 
-extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int n_cus, uint32_t **bits_cache,
-                                              const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out,
+extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int n_cus, uint32_t **coarse_cache,
+                                              uint32_t **qbits_cache, size_t *qbits_bytes, const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out,
                                               uint32_t *status, hipStream_t stream);
 
 #define HIP_TRY(expr, fail_stmt)                                                            \
@@ -310,6 +312,7 @@ extern "C" void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *pl) {
     if (!pl) return;
     fast_plan_destroy(&pl->fast);
     if (pl->overlap_bits) (void)hipFree(pl->overlap_bits);
+    if (pl->overlap_qbits) (void)hipFree(pl->overlap_qbits);
     if (pl->len_depth) (void)hipFree(pl->len_depth);
     if (pl->all_ids) (void)hipFree(pl->all_ids);
     if (pl->items) (void)hipFree(pl->items);
@@ -454,7 +457,8 @@ extern "C" int flatgfa_dev_path_depth_all(flatgfa_dev_plan_t *pl, uint32_t *dept
 extern "C" int flatgfa_dev_path_overlaps(flatgfa_dev_plan_t *pl, const uint32_t *query_ids, uint32_t n_q,
                                          uint8_t *touch_out, void *stream_) {
     if (!pl || (n_q && (!query_ids || !touch_out))) { set_error("dev_path_overlaps: NULL argument"); return FLATGFA_ERR_ARG; }
-    return flatgfa_dev_path_overlaps_impl(&pl->g, pl->n_cus, &pl->overlap_bits, query_ids, n_q, touch_out, pl->status,
+    return flatgfa_dev_path_overlaps_impl(&pl->g, pl->n_cus, &pl->overlap_bits, &pl->overlap_qbits, &pl->overlap_qbytes,
+                                          query_ids, n_q, touch_out, pl->status,
                                           (hipStream_t)stream_);
 }
 

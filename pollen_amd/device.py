@@ -128,6 +128,17 @@ class DepthPlan:
                                                          weighted_out.data_ptr() if P else None, self._stream()),
                    "dev_path_depth_all")
 
+    def path_overlaps(self, query_ids, touch_out) -> None:
+        """Enqueue path-pair overlap (slow_odgi/overlap.py:6-14): touch_out[k * n_paths + j] = 1 iff path
+        j touches path query_ids[k].  query_ids: int32[n_q], touch_out: uint8[n_q * n_paths], CUDA tensors."""
+        torch = _torch()
+        n = int(query_ids.numel())
+        assert query_ids.dtype == torch.int32 and touch_out.dtype == torch.uint8 and touch_out.numel() == n * self.graph.n_paths
+        with torch.cuda.device(self.graph.device):
+            _check(_lib.lib().flatgfa_dev_path_overlaps(self._p, query_ids.data_ptr() if n else None, n,
+                                                        touch_out.data_ptr() if touch_out.numel() else None,
+                                                        self._stream()), "dev_path_overlaps")
+
     def status(self) -> None:
         """Synchronize the current stream and raise if a kernel saw an out-of-range id."""
         with _torch().cuda.device(self.graph.device):

@@ -137,3 +137,36 @@ def test_path_depth_as_bed():
     ln, _ = fo.path_depth(pools)
     want = b"".join(pools.path_name(i) + b"\t0\t" + str(int(ln[i])).encode() + b"\n" for i in range(12))
     assert g.path_depth_bed() == want
+
+
+@pytest.mark.parametrize("dense", ["all-paths", "queries-only"])
+def test_overlap_few_pairs_touch(dense, monkeypatch):
+    """Paths folded into (overlapping) bands of the segments: most pairs are settled by the coarse
+    bitmaps, neighbours need the exact walk; more queries than one batch of exact bitsets is not
+    needed here, but orientation is: half the paths are flipped, and a flipped path touches nobody
+    that walks the same segments forward (overlap.py compares oriented handles)."""
+    if dense == "queries-only":  # exact bitsets for the query paths only: candidates are walked step by step
+        monkeypatch.setenv("FLATGFA_OVERLAP_DENSE_MAX", "0")
+    S, P, L = 40_000, 40, 3000
+    g = pa.synth(21, S, P, L, "pangenome", True)
+    pools = pools_of(g)
+    band = S // P
+    steps = pools.steps.copy().reshape(P, L)
+    ids = steps >> 1
+    folded = (np.arange(P, dtype=np.uint32)[:, None] * np.uint32(band) + ids % np.uint32(2 * band)) % np.uint32(S)
+    orient = steps & 1
+    orient[1::4] ^= 1
+    pools.steps = ((folded << 1) | orient).reshape(-1).astype(np.uint32)
+    h = pa.load_bytes(fo.dump_flatgfa(pools)) if hasattr(pa, "load_bytes") else None
+    if h is None:
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".flatgfa") as f:
+            f.write(fo.dump_flatgfa(pools))
+            f.flush()
+            h = pa.load(f.name)
+            got = h.path_overlaps(list(range(P)))
+    else:
+        got = h.path_overlaps(list(range(P)))
+    want = fo.path_touches(pools, np.arange(P, dtype=np.uint32))
+    assert (got == want.reshape(P, P)).all()
+    assert 0 < int(got.sum()) < P * P // 4
