@@ -101,7 +101,9 @@ def main():
         d2 = torch.zeros(S, dtype=torch.int32, device="cuda:0")
         for _ in range(2):  # twice: the scratch must be clean again
             plan.seg_depth(d, u)
+            plan.status()   # (a forced 8-record capacity: the call is only complete after this)
             plan.seg_depth(d2, None)
+            plan.status()
         # path depth of a strided subset of the paths: integer sums on the device, one f64 division here
         ids = np.arange(P - 1, -1, -3, dtype=np.uint32)
         t_ids = torch.from_numpy(ids.view(np.int32)).to("cuda:0")
