@@ -1132,19 +1132,19 @@ __device__ __forceinline__ uint32_t claim_word(uint32_t *bits, bool act, uint32_
 __device__ __forceinline__ void park_rest(Pending &q, bool e, uint32_t val) {
     const unsigned long long mk = __builtin_amdgcn_ballot_w64(e);
     if (e) q.m[q.mcnt + lane_rank(mk)] = val;
-    q.mcnt += (uint32_t)__builtin_popcountll(mk);
+    q.mcnt = __builtin_amdgcn_readfirstlane(q.mcnt + (uint32_t)__builtin_popcountll(mk));  // (tells the compiler it is wave-uniform)
 }
 __device__ __forceinline__ void park_revisit(Pending &q, bool e, uint32_t base, uint32_t rv) {
     const unsigned long long mk = __builtin_amdgcn_ballot_w64(e);
     if (e) q.r[q.rcnt + lane_rank(mk)] = make_uint2(base, rv);
-    q.rcnt += (uint32_t)__builtin_popcountll(mk);
+    q.rcnt = __builtin_amdgcn_readfirstlane(q.rcnt + (uint32_t)__builtin_popcountll(mk));
 }
 // the newest (up to) 64 parked records: one more word each
 template <int WB>
 __device__ __forceinline__ void run_rest(Pending &q, uint32_t *mybits, uint32_t dbg) {
     constexpr uint32_t kNW = (1u << WB) / 32u;
-    const uint32_t n = min(q.mcnt, 64u);
-    q.mcnt -= n;
+    const uint32_t n = __builtin_amdgcn_readfirstlane(min(q.mcnt, 64u));
+    q.mcnt = __builtin_amdgcn_readfirstlane(q.mcnt - n);
     const bool act = (uint32_t)q.lane < n;
     const uint32_t v = act ? q.m[q.mcnt + q.lane] : 0u;
     asm volatile("" ::: "memory");  // the slots read here are written again below, by other lanes
@@ -1157,8 +1157,8 @@ __device__ __forceinline__ void run_rest(Pending &q, uint32_t *mybits, uint32_t 
 }
 // the newest (up to) 64 parked words: one stretch of revisited segments each
 __device__ __forceinline__ void run_revisits(Pending &q, int *R) {
-    const uint32_t n = min(q.rcnt, 64u);
-    q.rcnt -= n;
+    const uint32_t n = __builtin_amdgcn_readfirstlane(min(q.rcnt, 64u));
+    q.rcnt = __builtin_amdgcn_readfirstlane(q.rcnt - n);
     const bool act = (uint32_t)q.lane < n;
     const uint2 v = act ? q.r[q.rcnt + q.lane] : make_uint2(0u, 0u);
     asm volatile("" ::: "memory");
@@ -1206,7 +1206,7 @@ __device__ __forceinline__ Claim claim_begin(int *D, Pending &q, uint32_t *mybit
     c.mask = (0xFFFFFFFFu >> (32u - width)) << lo;
     c.p = wl + 1u;
     c.old = c.act ? atomicOr(&mybits[slot * kNW + (rel >> 5)], c.mask) : 0u;
-    if (q.mcnt == 0u) q.moldest = hfirst;
+    if (q.mcnt == 0u) q.moldest = __builtin_amdgcn_readfirstlane(hfirst);
     return c;
 }
 template <int WB>
