@@ -49,7 +49,7 @@ def _check(rc: int, what: str) -> None:
 
 
 def _take_text(ptr: ctypes.c_void_p, n: ctypes.c_size_t) -> bytes:
-    out = ctypes.string_at(ptr.value, n.value) if ptr.value else b""
+    out = bytes((ctypes.c_char * n.value).from_address(ptr.value)) if ptr.value and n.value else b""  # (string_at takes a C int)
     _lib.lib().flatgfa_free_text(ptr)
     return out
 
@@ -141,7 +141,8 @@ class FlatGFA:
         assert dt.itemsize == es.value
         if n.value == 0:
             return np.zeros(0, dtype=dt)
-        raw = ctypes.string_at(data.value, n.value * es.value)
+        # (ctypes.string_at takes a C int: pools beyond 2 GiB would be cut short)
+        raw = (ctypes.c_char * (n.value * es.value)).from_address(data.value)
         return np.frombuffer(raw, dtype=dt).copy()
 
     def soa(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
