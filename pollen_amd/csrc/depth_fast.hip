@@ -90,6 +90,7 @@ struct ScanArgs {
                          // for the short paths k_scan_short hands back (counted in *work_counter)
     const uint4 *short_items;  // paths of at most kShortMax steps, longest first
     uint32_t n_short;
+    uint64_t n_steps;
     uint32_t n_items, n_segs, n_win, n_slots;
     uint32_t wb;         // log2 of the window size (k_scan; k_scan_short always uses 12)
     uint32_t nwp;        // n_win rounded up to a multiple of 64 (LDS table size)
@@ -178,7 +179,10 @@ __device__ __forceinline__ void flag_if_any(const ScanArgs &A, bool b, uint32_t 
 // fully coalesced loads, tools/loadpat.hip).  No nontemporal hint here: the sectors must survive
 // in cache from the first of the four instructions to the last.
 #ifndef FGFA_LOAD_POLICY
-#define FGFA_LOAD_POLICY ""  /* cache-policy bits of the step loads (experiments: " nt", " sc1", ...) */
+#define FGFA_LOAD_POLICY ""  /* cache-policy bits of k_scan_short's step loads: they need their lines to survive from the first of a lane's four loads to the last */
+#endif
+#ifndef FGFA_COAL_POLICY
+#define FGFA_COAL_POLICY " nt"  /* k_scan's step loads are whole lines read once: streamed past the L2, whose lines are left to the records (measured: k_scan 116 -> 104 us; " sc1" / " sc0 sc1": no change) */
 #endif
 #define FGFA_CLOB_A "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111"
 #define FGFA_CLOB_C "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95"
@@ -202,6 +206,29 @@ __device__ __forceinline__ void load_block_async(W &w, const uint4 *p) {
                      "global_load_dwordx4 v[84:87], %0, off offset:16" FGFA_LOAD_POLICY "\n\t"
                      "global_load_dwordx4 v[88:91], %0, off offset:32" FGFA_LOAD_POLICY "\n\t"
                      "global_load_dwordx4 v[92:95], %0, off offset:48" FGFA_LOAD_POLICY "" ::"v"(p) : "memory", FGFA_CLOB_C);
+}
+// k_scan's pattern: instruction k of a block reads the block's k-th KiB, 16 bytes per lane -- each
+// instruction is one fully coalesced 1 KiB read -- so that lane l ends up with four groups of four
+// consecutive steps: steps 256k + 4l .. 256k + 4l + 3 of the block in registers 4k .. 4k + 3.
+template <int SET, typename W>
+__device__ __forceinline__ void load_block_coal(W &w, const uint4 *p) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w.vm[k] = k == SET ? 0u : w.vm[k] + 4u;
+    if (SET == 0)
+        asm volatile("global_load_dwordx4 v[96:99], %0, off" FGFA_COAL_POLICY "\n\t"
+                     "global_load_dwordx4 v[100:103], %0, off offset:1024" FGFA_COAL_POLICY "\n\t"
+                     "global_load_dwordx4 v[104:107], %0, off offset:2048" FGFA_COAL_POLICY "\n\t"
+                     "global_load_dwordx4 v[108:111], %0, off offset:3072" FGFA_COAL_POLICY "" ::"v"(p) : "memory", FGFA_CLOB_A);
+    else if (SET == 1)
+        asm volatile("global_load_dwordx4 v[112:115], %0, off" FGFA_COAL_POLICY "\n\t"
+                     "global_load_dwordx4 v[116:119], %0, off offset:1024" FGFA_COAL_POLICY "\n\t"
+                     "global_load_dwordx4 v[120:123], %0, off offset:2048" FGFA_COAL_POLICY "\n\t"
+                     "global_load_dwordx4 v[124:127], %0, off offset:3072" FGFA_COAL_POLICY "" ::"v"(p) : "memory", FGFA_CLOB_B);
+    else
+        asm volatile("global_load_dwordx4 v[80:83], %0, off" FGFA_COAL_POLICY "\n\t"
+                     "global_load_dwordx4 v[84:87], %0, off offset:1024" FGFA_COAL_POLICY "\n\t"
+                     "global_load_dwordx4 v[88:91], %0, off offset:2048" FGFA_COAL_POLICY "\n\t"
+                     "global_load_dwordx4 v[92:95], %0, off offset:3072" FGFA_COAL_POLICY "" ::"v"(p) : "memory", FGFA_CLOB_C);
 }
 // Waits until the loads into landing set SET have returned.  `w.vm[SET]` counts the memory
 // instructions this wave is known to have issued since (the other set's loads and the record
@@ -697,46 +724,40 @@ __device__ __forceinline__ void tmark(const ScanArgs &A, RWave &w, int ph) {
     }
 }
 
-// Pass A for eight consecutive steps of every lane: Mj (a lane mask in an SGPR pair) = "step j
+// Pass A for four consecutive steps of every lane: Mj (a lane mask in an SGPR pair) = "step j
 // starts a run" = its id is not the id before it plus one; CNT += Mj per lane.  Three vector
 // instructions per step.  PM is the id before step 0.
 #define FGFA_PA_STEP(PMJ, XJ, MJ)                            \
     "v_add_u32 %[t], 1, %[" PMJ "]\n\t"                      \
     "v_cmp_ne_u32 %[" MJ "], %[" XJ "], %[t]\n\t"            \
     "v_addc_co_u32_e64 %[cnt], vcc, 0, %[cnt], %[" MJ "]\n\t"
-#define FGFA_PA8(CNT, PM, X0, X1, X2, X3, X4, X5, X6, X7, M0, M1, M2, M3, M4, M5, M6, M7)                            \
+#define FGFA_PA4(CNT, PM, X0, X1, X2, X3, M0, M1, M2, M3)                                                            \
     do {                                                                                                             \
         uint32_t t_;                                                                                                 \
         asm volatile(FGFA_PA_STEP("pm", "x0", "m0") FGFA_PA_STEP("x0", "x1", "m1") FGFA_PA_STEP("x1", "x2", "m2")    \
-                         FGFA_PA_STEP("x2", "x3", "m3") FGFA_PA_STEP("x3", "x4", "m4") FGFA_PA_STEP("x4", "x5", "m5") \
-                             FGFA_PA_STEP("x5", "x6", "m6") FGFA_PA_STEP("x6", "x7", "m7")                           \
-                     : [cnt] "+v"(CNT), [t] "=&v"(t_), [m0] "=&s"(M0), [m1] "=&s"(M1), [m2] "=&s"(M2),               \
-                       [m3] "=&s"(M3), [m4] "=&s"(M4), [m5] "=&s"(M5), [m6] "=&s"(M6), [m7] "=&s"(M7)                \
-                     : [pm] "v"(PM), [x0] "v"(X0), [x1] "v"(X1), [x2] "v"(X2), [x3] "v"(X3), [x4] "v"(X4),           \
-                       [x5] "v"(X5), [x6] "v"(X6), [x7] "v"(X7)                                                      \
+                         FGFA_PA_STEP("x2", "x3", "m3")                                                              \
+                     : [cnt] "+v"(CNT), [t] "=&v"(t_), [m0] "=&s"(M0), [m1] "=&s"(M1), [m2] "=&s"(M2), [m3] "=&s"(M3) \
+                     : [pm] "v"(PM), [x0] "v"(X0), [x1] "v"(X1), [x2] "v"(X2), [x3] "v"(X3)                          \
                      : "vcc");                                                                                       \
     } while (0)
 
-// Pass B for eight consecutive steps of every lane: for step j, the lanes where a run starts
-// (mask Mj) append (step j's id, step j's position) at their queue cursor `p`.  One scalar, one
-// LDS and one vector instruction per step, no branches; exec is restored before the statement
-// ends.  Pj holds 16 * lane + j for the whole kernel.
+// Pass B for four consecutive steps of every lane: for step j, the lanes of ACT where a run
+// starts (mask Mj) append (step j's id, step j's position) at their queue cursor `p`.  One scalar,
+// one LDS and one vector instruction per step, no branches; exec is restored before the statement
+// ends.  Pj holds the position of the lane's step j in the block for the whole kernel.
 #define FGFA_PB_STEP(XJ, PJ, MJ)                                       \
-    "s_and_b64 exec, %[sv], %[" MJ "]\n\t"                             \
+    "s_and_b64 exec, %[act], %[" MJ "]\n\t"                            \
     "ds_write2_b32 %[p], %[" XJ "], %[" PJ "] offset1:1\n\t"           \
     "v_add_u32 %[p], 8, %[p]\n\t"
-#define FGFA_PB8(P, X0, X1, X2, X3, X4, X5, X6, X7, P0, P1, P2, P3, P4, P5, P6, P7, M0, M1, M2, M3, M4, M5, M6, M7)  \
+#define FGFA_PB4(P, ACT, X0, X1, X2, X3, P0, P1, P2, P3, M0, M1, M2, M3)                                             \
     do {                                                                                                             \
         unsigned long long sv_;                                                                                      \
         asm volatile("s_mov_b64 %[sv], exec\n\t" FGFA_PB_STEP("x0", "p0", "m0") FGFA_PB_STEP("x1", "p1", "m1")       \
-                         FGFA_PB_STEP("x2", "p2", "m2") FGFA_PB_STEP("x3", "p3", "m3") FGFA_PB_STEP("x4", "p4", "m4") \
-                             FGFA_PB_STEP("x5", "p5", "m5") FGFA_PB_STEP("x6", "p6", "m6")                           \
-                                 FGFA_PB_STEP("x7", "p7", "m7") "s_mov_b64 exec, %[sv]"                              \
+                         FGFA_PB_STEP("x2", "p2", "m2") FGFA_PB_STEP("x3", "p3", "m3") "s_mov_b64 exec, %[sv]"       \
                      : [p] "+v"(P), [sv] "=&s"(sv_)                                                                  \
-                     : [x0] "v"(X0), [x1] "v"(X1), [x2] "v"(X2), [x3] "v"(X3), [x4] "v"(X4), [x5] "v"(X5),           \
-                       [x6] "v"(X6), [x7] "v"(X7), [p0] "v"(P0), [p1] "v"(P1), [p2] "v"(P2), [p3] "v"(P3),           \
-                       [p4] "v"(P4), [p5] "v"(P5), [p6] "v"(P6), [p7] "v"(P7), [m0] "s"(M0), [m1] "s"(M1),           \
-                       [m2] "s"(M2), [m3] "s"(M3), [m4] "s"(M4), [m5] "s"(M5), [m6] "s"(M6), [m7] "s"(M7)            \
+                     : [act] "s"(ACT), [x0] "v"(X0), [x1] "v"(X1), [x2] "v"(X2), [x3] "v"(X3), [p0] "v"(P0),         \
+                       [p1] "v"(P1), [p2] "v"(P2), [p3] "v"(P3), [m0] "s"(M0), [m1] "s"(M1), [m2] "s"(M2),           \
+                       [m3] "s"(M3)                                                                                  \
                      : "memory", "scc");                                                                             \
     } while (0)
 
@@ -801,8 +822,8 @@ __device__ __forceinline__ void drain_raw(const ScanArgs &A, RWave &w, uint32_t 
     }
 }
 
-// Up to 15 consecutive steps, one per lane (what lies before an item's first 64-byte boundary,
-// and behind its last).  Queued as a segment of its own, terminator included.
+// Up to 64 consecutive steps, one per lane (what lies before an item's first 64-byte boundary
+// and behind its last block).  Queued as a segment of its own, terminator included.
 __device__ __forceinline__ void tile_narrow_raw(const ScanArgs &A, RWave &w, uint64_t t, uint32_t count) {
     const bool valid = (uint32_t)w.lane < count;
     const uint32_t id = valid ? A.steps[t + w.lane] >> 1 : 0u;
@@ -823,7 +844,7 @@ __device__ __forceinline__ void tile_narrow_raw(const ScanArgs &A, RWave &w, uin
 struct Item {
     uint64_t b, e, t0, tail;
     uint32_t nblk, nl_last;
-    const uint4 *src;  // this lane's 64 bytes of block 0
+    const uint4 *src;  // this lane's first 16 bytes of block 0
 };
 
 // Which item a workgroup takes in its r-th turn.  Items are sorted longest first and dealt out
@@ -844,38 +865,47 @@ __device__ __forceinline__ Item make_item(const ScanArgs &A, bool have, uint4 d,
         it.e = d.y;
         const uint64_t up = (it.b + 15) & ~(uint64_t)15;
         it.t0 = up < it.e ? up : it.e;
-        const uint64_t chunks = (it.e - it.t0) / 16;
+        uint64_t chunks = (it.e - it.t0) / 16;
+        // a block is read as four whole KiB: a last, partial block that would reach past the step
+        // array is left to the tail tiles instead
+        if ((chunks % 64) && it.t0 + ((chunks + 63) / 64) * 1024 > A.n_steps) chunks -= chunks % 64;
         it.tail = it.t0 + chunks * 16;
         it.nblk = (uint32_t)((chunks + 63) / 64);
         it.nl_last = (chunks % 64) ? (uint32_t)(chunks % 64) : 64u;
         // kDbgHotLoads (diagnostic): every item reads the same cache-resident megabyte
-        it.src = reinterpret_cast<const uint4 *>(A.steps + ((A.dbg & kDbgHotLoads) ? (it.t0 & 0x3FFF0u) : it.t0)) + lane * 4;
+        it.src = reinterpret_cast<const uint4 *>(A.steps + ((A.dbg & kDbgHotLoads) ? (it.t0 & 0x3FFF0u) : it.t0)) + lane;
     }
     return it;
 }
 
-// One block: 1024 consecutive steps, sixteen per lane; only the first `nl` lanes hold steps.
-// Pass A marks the run starts and counts them per lane (the block's first step always starts
-// one); a wave prefix sum gives every lane its own stretch of the queue; pass B appends.  If the
-// queue cannot take the block's starts, or holds a chunk's worth and this wave may emit, the
-// oldest entries are emitted first.
+// One block: 1024 consecutive steps, of which the first `nsteps` (a multiple of 16) count.  Lane l
+// holds four groups of four consecutive steps: group k = steps 256k + 4l .. + 3 (a[4k .. 4k + 3]).
+// Pass A marks the run starts and counts them per lane and group (a group's first step compares
+// with the last step of the lane below; lane 0 always starts a run); two wave prefix sums (two
+// 16-bit counts each) give every (group, lane) its own stretch of the queue, in path order; pass B
+// appends.  If the queue cannot take the block's starts, or holds a chunk's worth and this wave may
+// emit, the oldest entries are emitted first.
 template <bool DBG>
 __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *bcur, uint32_t *mine, uint32_t *ctl, uint32_t rr,
-                                         uint32_t (&a)[16], const uint32_t (&pj)[16], uint32_t nl) {
-    const bool active = (uint32_t)w.lane < nl;
-    const bool closes = (uint32_t)w.lane + 1u == nl && nl < 64u;  // a partial block ends with a terminator
-    const uint32_t prev = __builtin_amdgcn_update_dpp(0u, a[15], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    unsigned long long m[16];
-    uint32_t cnt = 0;
-    FGFA_PA8(cnt, prev, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
-    FGFA_PA8(cnt, a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15]);
-    const uint32_t add0 = 1u & ~(uint32_t)m[0];
-    m[0] |= 1ull;
-    cnt += (w.lane == 0) ? add0 : 0u;
-    cnt = active ? cnt : 0u;
-    const uint32_t slots = cnt + (closes ? 1u : 0u);
-    const uint32_t incl = wave_scan_incl(slots);
-    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+                                         uint32_t (&a)[16], const uint32_t (&pj)[16], uint32_t nsteps) {
+    unsigned long long m[16], act[4];
+    uint32_t cnt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t prev = __builtin_amdgcn_update_dpp(0u, a[4 * k + 3], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        cnt[k] = 0;
+        FGFA_PA4(cnt[k], prev, a[4 * k], a[4 * k + 1], a[4 * k + 2], a[4 * k + 3], m[4 * k], m[4 * k + 1], m[4 * k + 2], m[4 * k + 3]);
+        const uint32_t add0 = 1u & ~(uint32_t)m[4 * k];  // lane 0's first step of the group starts a run whatever is below
+        m[4 * k] |= 1ull;
+        const bool on = 256u * (uint32_t)k + 4u * (uint32_t)w.lane < nsteps;
+        act[k] = __builtin_amdgcn_ballot_w64(on);
+        cnt[k] = on ? cnt[k] + ((w.lane == 0) ? add0 : 0u) : 0u;
+    }
+    const uint32_t s01 = wave_scan_incl(cnt[0] | (cnt[1] << 16)), s23 = wave_scan_incl(cnt[2] | (cnt[3] << 16));
+    const uint32_t t01 = __builtin_amdgcn_readlane(s01, 63), t23 = __builtin_amdgcn_readlane(s23, 63);
+    const uint32_t t0 = t01 & 0xFFFFu, t1 = t01 >> 16, t2 = t23 & 0xFFFFu, t3 = t23 >> 16;
+    const bool partial = nsteps < 1024u;  // a partial block ends with a terminator
+    const uint32_t total = t0 + t1 + t2 + t3 + (partial ? 1u : 0u);
     tmark<DBG>(A, w, 2);
     if (FGFA_SKIP(kDbgNoEmit)) {
         w.fill = 0;
@@ -892,16 +922,17 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
         if (w.epoch_ok) drain_raw<DBG>(A, w, bcur, mine, false);
         tmark<DBG>(A, w, 3);
     }
-    uint32_t p = lds_addr(w.q + w.fill + (incl - slots));
-    if (active && !FGFA_SKIP(kDbgNoPassB)) {
-        FGFA_PB8(p, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], pj[0], pj[1], pj[2], pj[3], pj[4], pj[5], pj[6], pj[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
-        FGFA_PB8(p, a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], pj[8], pj[9], pj[10], pj[11], pj[12], pj[13], pj[14], pj[15], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15]);
+    const uint32_t off[4] = {(s01 & 0xFFFFu) - cnt[0], t0 + (s01 >> 16) - cnt[1], t0 + t1 + (s23 & 0xFFFFu) - cnt[2],
+                             t0 + t1 + t2 + (s23 >> 16) - cnt[3]};
+    if (!FGFA_SKIP(kDbgNoPassB)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t p = lds_addr(w.q + w.fill + off[k]);
+            FGFA_PB4(p, act[k], a[4 * k], a[4 * k + 1], a[4 * k + 2], a[4 * k + 3], pj[4 * k], pj[4 * k + 1], pj[4 * k + 2], pj[4 * k + 3],
+                     m[4 * k], m[4 * k + 1], m[4 * k + 2], m[4 * k + 3]);
+        }
     }
-    if (closes) {
-        lds_u32 *tp = reinterpret_cast<lds_u32 *>((uintptr_t)p);
-        tp[0] = kInvalid;
-        tp[1] = 16u * nl;
-    }
+    if (partial && w.lane == 0) w.q[w.fill + total - 1u] = make_uint2(kInvalid, nsteps);
     w.fill += total;
     tmark<DBG>(A, w, 2);
 }
@@ -936,7 +967,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     uint32_t pj[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        pj[j] = 16u * (uint32_t)lane + (uint32_t)j;
+        pj[j] = 256u * (uint32_t)(j >> 2) + 4u * (uint32_t)lane + (uint32_t)(j & 3);
         asm volatile("" : "+v"(pj[j]));
     }
     __syncthreads();
@@ -950,18 +981,17 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     Item it = make_item(A, job < n_items, job < n_items ? A.items[job] : make_uint4(0u, 0u, 0u, 0u), lane);
     uint32_t blk[3];  // the block each landing set holds (or will hold next)
     uint32_t resv;    // the block this wave takes after those
-    // lanes beyond a partial block's last one re-read lane 0's chunk: same instruction stream for all
-#define FGFA_BLOCK_PTR(j) \
-    (it.src + (size_t)(j) * 256 - (((j) + 1 == it.nblk && (uint32_t)lane >= it.nl_last) ? lane * 4 : 0))
+    // (a partial block is read whole: make_item has made sure that stays inside the step array)
+#define FGFA_BLOCK_PTR(j) (it.src + (size_t)(j) * 256)
 #define FGFA_PRELOAD()                                                      \
     do {                                                                    \
         blk[0] = (uint32_t)wave;                                            \
         blk[1] = (uint32_t)wave + kWaves;                                   \
         blk[2] = (uint32_t)wave + 2u * kWaves;                              \
         resv = (uint32_t)wave + 3u * kWaves;                                \
-        if (blk[0] < it.nblk) load_block_async<0>(w, FGFA_BLOCK_PTR(blk[0])); \
-        if (blk[1] < it.nblk) load_block_async<1>(w, FGFA_BLOCK_PTR(blk[1])); \
-        if (blk[2] < it.nblk) load_block_async<2>(w, FGFA_BLOCK_PTR(blk[2])); \
+        if (blk[0] < it.nblk) load_block_coal<0>(w, FGFA_BLOCK_PTR(blk[0])); \
+        if (blk[1] < it.nblk) load_block_coal<1>(w, FGFA_BLOCK_PTR(blk[1])); \
+        if (blk[2] < it.nblk) load_block_coal<2>(w, FGFA_BLOCK_PTR(blk[2])); \
     } while (0)
     // one block: wait for its data, take the next free block for its register set, process it
 #define FGFA_BLOCK(SET)                                                                       \
@@ -973,11 +1003,11 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         take_block<SET>(a);                                                                   \
         const uint32_t mine_now = blk[SET];                                                   \
         blk[SET] = resv;  /* taken one block ago, so that the LDS round trip is off this path */ \
-        if (blk[SET] < it.nblk) load_block_async<SET>(w, FGFA_BLOCK_PTR(blk[SET]));           \
+        if (blk[SET] < it.nblk) load_block_coal<SET>(w, FGFA_BLOCK_PTR(blk[SET]));            \
         uint32_t got = 0;                                                                     \
         if (lane == 0) got = atomicAdd(&ctl[kCtlNext + (rr & 1u)], 1u);                       \
         if (!FGFA_SKIP(kDbgNoTiles)) {                                                        \
-            block16r<DBG>(A, w, bcur, mine, ctl, rr, a, pj, mine_now + 1 == it.nblk ? it.nl_last : 64u); \
+            block16r<DBG>(A, w, bcur, mine, ctl, rr, a, pj, mine_now + 1 == it.nblk ? 16u * it.nl_last : 1024u); \
         } else if (a[0] == 0x3FFFFFFFu) {                                                     \
             atomicOr(A.status, kStDebug);                                                     \
         }                                                                                     \
@@ -990,7 +1020,16 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         const uint4 next_item = next_job < n_items ? A.items[next_job] : make_uint4(0u, 0u, 0u, 0u);
         // the few steps outside the blocks are walked on their own, by the first and the last wave
         if (wave == 0 && it.t0 > it.b) tile_narrow_raw(A, w, it.b, (uint32_t)(it.t0 - it.b));
-        if (wave == kWaves - 1 && it.e > it.tail) tile_narrow_raw(A, w, it.tail, (uint32_t)(it.e - it.tail));
+        if (wave == kWaves - 1) {
+            for (uint64_t t = it.tail; t < it.e; t += 64) {  // fewer than 16 steps, but for a block left out by make_item
+                if (w.fill + 66u > kQ2) {
+                    while (epoch_now(ctl) < rr) __builtin_amdgcn_s_sleep(2);
+                    w.epoch_ok = true;
+                    drain_raw<DBG>(A, w, bcur, mine, false);
+                }
+                tile_narrow_raw(A, w, t, (uint32_t)min((uint64_t)64, it.e - t));
+            }
+        }
 #pragma unroll 1
         while (blk[0] < it.nblk || blk[1] < it.nblk || blk[2] < it.nblk) {
             FGFA_BLOCK(0)
@@ -1941,6 +1980,7 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
     const uint32_t grid = has_pre ? fp.n_slots : std::min<uint32_t>(fp.n_items, fp.n_slots);
     ScanArgs sa;
     sa.steps = g.steps;
+    sa.n_steps = g.n_steps;
     sa.items = reinterpret_cast<uint4 *>(fp.items);
     sa.short_items = reinterpret_cast<const uint4 *>(fp.short_items);
     sa.n_short = fp.n_short;

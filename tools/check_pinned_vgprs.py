@@ -24,7 +24,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 PINNED = set(range(80, 128))
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
-OK_LOAD = re.compile(r"^global_load_dwordx4 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], off( offset:(16|32|48))?$")
+OK_LOAD = re.compile(r"^global_load_dwordx4 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], off( offset:(16|32|48|1024|2048|3072))?( nt)?$")
 OK_TAKE = re.compile(r"^v_lshrrev_b32(_e32)? v(\d+), 1, v(\d+)$")
 
 
