@@ -1351,9 +1351,12 @@ __device__ __forceinline__ void apply_flat(const AccArgs &A, int *D, int *R, con
 // counted wait: the two younger requests are the only other vector-memory operations in flight.
 template <int K>
 __device__ __forceinline__ void rec_request(const uint32_t *p) {
-    if (K == 0) asm volatile("global_load_dword v120, %0, off" ::"v"(p) : "memory", "v120");
-    else if (K == 1) asm volatile("global_load_dword v121, %0, off" ::"v"(p) : "memory", "v121");
-    else asm volatile("global_load_dword v122, %0, off" ::"v"(p) : "memory", "v122");
+#ifndef FGFA_REC_POLICY
+#define FGFA_REC_POLICY ""
+#endif
+    if (K == 0) asm volatile("global_load_dword v120, %0, off" FGFA_REC_POLICY ::"v"(p) : "memory", "v120");
+    else if (K == 1) asm volatile("global_load_dword v121, %0, off" FGFA_REC_POLICY ::"v"(p) : "memory", "v121");
+    else asm volatile("global_load_dword v122, %0, off" FGFA_REC_POLICY ::"v"(p) : "memory", "v122");
 }
 template <int K>
 __device__ __forceinline__ uint32_t rec_take() {

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Cache-policy experiment for k_scan's step loads / record stores: rebuilds depth_fast.o on the GPU box per variant.
+# Cache-policy experiments (rebuilds depth_fast.o on the GPU box per variant).
 cd $GRAFT_REPO_ROOT
 BASE="-O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wextra -Wno-unused-parameter -Wno-unused-result"
 run() {
@@ -10,9 +10,6 @@ import json,sys
 d=json.loads(sys.stdin.read()); print('$1', d['ms_per_step'], d['bit_exact_vs_oracle'], d['roofline']['kernels_avg_ms'])"
 }
 run base ""
-run load_nt "-DFGFA_LOAD_POLICY='\" nt\"'"
-run load_sc1 "-DFGFA_LOAD_POLICY='\" sc1\"'"
-run load_sc0sc1 "-DFGFA_LOAD_POLICY='\" sc0 sc1\"'"
-run load_sc0_nt "-DFGFA_LOAD_POLICY='\" sc0 nt\"'"
-run load_sc1_nt "-DFGFA_LOAD_POLICY='\" sc1 nt\"'"
-run load_nt_store_nt "-DFGFA_NT_STORE -DFGFA_LOAD_POLICY='\" nt\"'"
+run rec_nt "-DFGFA_REC_POLICY='\" nt\"'"
+run rec_sc1 "-DFGFA_REC_POLICY='\" sc1\"'"
+run base2 ""
