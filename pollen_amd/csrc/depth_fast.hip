@@ -890,6 +890,7 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
                                          uint32_t (&a)[16], const uint32_t (&pj)[16], uint32_t nsteps) {
     unsigned long long m[16], act[4];
     uint32_t cnt[4];
+    const bool partial = nsteps < 1024u;  // (wave-uniform) a partial block ends with a terminator
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t prev = __builtin_amdgcn_update_dpp(0u, a[4 * k + 3], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
@@ -897,14 +898,20 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
         FGFA_PA4(cnt[k], prev, a[4 * k], a[4 * k + 1], a[4 * k + 2], a[4 * k + 3], m[4 * k], m[4 * k + 1], m[4 * k + 2], m[4 * k + 3]);
         const uint32_t add0 = 1u & ~(uint32_t)m[4 * k];  // lane 0's first step of the group starts a run whatever is below
         m[4 * k] |= 1ull;
-        const bool on = 256u * (uint32_t)k + 4u * (uint32_t)w.lane < nsteps;
-        act[k] = __builtin_amdgcn_ballot_w64(on);
-        cnt[k] = on ? cnt[k] + ((w.lane == 0) ? add0 : 0u) : 0u;
+        cnt[k] += (w.lane == 0) ? add0 : 0u;
+        act[k] = ~0ull;
+    }
+    if (partial) {  // which (group, lane) pairs hold steps at all
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool on = 256u * (uint32_t)k + 4u * (uint32_t)w.lane < nsteps;
+            act[k] = __builtin_amdgcn_ballot_w64(on);
+            cnt[k] = on ? cnt[k] : 0u;
+        }
     }
     const uint32_t s01 = wave_scan_incl(cnt[0] | (cnt[1] << 16)), s23 = wave_scan_incl(cnt[2] | (cnt[3] << 16));
     const uint32_t t01 = __builtin_amdgcn_readlane(s01, 63), t23 = __builtin_amdgcn_readlane(s23, 63);
     const uint32_t t0 = t01 & 0xFFFFu, t1 = t01 >> 16, t2 = t23 & 0xFFFFu, t3 = t23 >> 16;
-    const bool partial = nsteps < 1024u;  // a partial block ends with a terminator
     const uint32_t total = t0 + t1 + t2 + t3 + (partial ? 1u : 0u);
     tmark<DBG>(A, w, 2);
     if (FGFA_SKIP(kDbgNoEmit)) {
