@@ -143,19 +143,22 @@ SHAPES = [
     (7, 100_000, 3, 1, "uniform"),
     (8, 65_537, 257, 1023, "uniform"),
     (9, 1_048_576, 8, 20_000, "pangenome"),  # exactly one LDS window
-    (10, 1_048_577, 8, 20_000, "uniform"),   # past one LDS bitset: two segment-range passes
-    (11, 2_500_000, 6, 30_000, "uniform"),   # three passes
+    (10, 1_048_577, 8, 20_000, "uniform"),   # one segment past 256 windows: every path is a k_scan item
+    (11, 2_500_000, 6, 30_000, "uniform"),   # 611 windows
     (12, 50_000, 3, 700_001, "pangenome"),   # few long paths: split into pieces by default
     (13, 3_000, 2, 400_000, "uniform"),      # pieces of one path revisit the same segments heavily
     (14, 200_000, 5000, 1000, "pangenome"),  # short paths, one block each (k_scan_short)
     (15, 50_000, 300, 2048, "uniform"),      # short paths with too many runs: handed back to k_scan
     (16, 70_000, 900, 1500, "pangenome"),    # two blocks per short path
     (17, 999, 4000, 17, "pangenome"),        # paths shorter than a lane chunk, every alignment
-    (18, 1_500_000, 3000, 700, "pangenome"),   # two segment-range passes over short paths
-    (19, 1_200_000, 5, 300_000, "uniform"),    # two segment-range passes over long paths cut into pieces
+    (18, 1_500_000, 3000, 700, "pangenome"),   # short paths beyond 256 windows: 3000 k_scan items of less than a block
+    (19, 1_200_000, 5, 300_000, "uniform"),    # long paths cut into pieces, beyond 256 windows
     (20, 400_000, 600, 9000, "pangenome"),     # medium paths: single waves with the larger hash set
-    (21, 1_300_000, 90, 15_000, "pangenome"),  # medium paths in two segment-range passes
+    (21, 1_300_000, 90, 15_000, "pangenome"),  # medium-length paths beyond 256 windows
     (22, 90_000, 40, 6000, "uniform"),         # too many runs for the medium kernel: k_scan
+    (23, 5_000_000, 7, 60_000, "pangenome"),   # more than 4 M segments: 8192-segment windows in both passes
+    (24, 9_000_001, 40, 3000, "uniform"),      # 8192-segment windows, short paths as k_scan items, a ragged last window
+    (25, 70_000, 3, 1_048_576 + 1040, "pangenome"),  # long paths whose pieces end in partial blocks and odd tails
 ]
 
 
