@@ -2,9 +2,10 @@
 // no global atomics on the data path.  DESIGN.md section 3 is the long version.
 //
 //   k_scan        (pass 1, stateless)  persistent workgroups walk one path (or one piece of a long
-//                 path) at a time.  The steps are cut into blocks of 1024; a wave takes a block,
-//                 every lane owns sixteen consecutive steps (its own 64 bytes), finds where the
-//                 maximal +1 runs of segment ids start, and queues (start id, position) per run.
+//                 path) at a time.  The steps are cut into blocks of 1024; a wave takes a block
+//                 with four fully coalesced 1 KiB reads (streamed past the L2: nt), so that every
+//                 lane holds four groups of four consecutive steps, finds where the maximal +1
+//                 runs of segment ids start, and queues (start id, position) per run.
 //                 A run's length is the distance to the next queued start, so each run becomes
 //                 ONE range record (start, length) instead of `length` histogram updates.  A
 //                 record goes to the bucket of its segment window; buckets are split into one
@@ -18,14 +19,16 @@
 //   k_accum       (pass 2)  one workgroup per window.  The "seen" bitset of depth.rs:23-34 lives
 //                 here, per (path, window): 512 bytes of LDS instead of one bit per segment of the
 //                 whole graph.  A wave walks the records of one path's group after the other,
-//                 claims each record's segments with returning LDS ORs (the bits that were clear
-//                 are the (path, segment) pairs met for the first time), and applies the record as
-//                 a +1/-1 pair to an LDS difference array (depth and uniq packed in 64-bit cells),
-//                 which is prefix-summed and written with 16-byte stores.
+//                 claims each record's segments with returning LDS ORs (the bits that were already
+//                 set are revisits), and applies the record as a +1/-1 pair to an LDS difference
+//                 array for depth -- and its revisited stretches to a second one; uniq = depth -
+//                 revisits -- which are prefix-summed and written with 16-byte stores.  For path
+//                 depth the same kernel, once the window's depth is final, turns every record
+//                 into two differences of window-local prefix sums (sum len, sum depth * len).
 //
 // Exactness: every step lies in exactly one run, so it contributes +1 to exactly one depth
-// record; every (path, segment) pair that occurs sets exactly one bit of its path's bitset, and
-// the lane whose OR found it clear adds it to uniq.  Sums of +1s are order-independent, hence the
+// record; every (path, segment) pair that occurs sets exactly one bit of its path's bitset: the
+// lane whose OR found it clear met a first visit, every other a revisit.  Sums of +1s are order-independent, hence the
 // results equal depth.rs bit for bit under any scheduling.  Sub-buckets have a fixed capacity; a
 // record that does not fit raises a flag, and flatgfa_dev_status completes the call on a larger
 // plan (or through the atomic kernels) before it reports success.
@@ -164,18 +167,18 @@ __device__ __forceinline__ void flag_if_any(const ScanArgs &A, bool b, uint32_t 
 // Two blocks per wave (8 KiB; 128 KiB per CU) are kept in flight across loop iterations.  hipcc
 // cannot express that: it drains vmcnt to 0 at the top of the loop, and an inline-asm load into a
 // compiler-allocated register is unsafe because the compiler may copy the register (to rotate it
-// through the loop) while the load is still in flight.  So the landing registers are two fixed
-// sets of sixteen, v[96:111] and v[112:127], which the compiler is told are clobbered and never
-// otherwise allocates (the kernels need < 96 VGPRs; 128 is the budget of a 1024-thread
-// workgroup).  tools/check_pinned_vgprs.py checks the generated ISA for exactly that (`make
+// through the loop) while the load is still in flight.  So the landing registers are fixed sets
+// of sixteen -- v[96:111] and v[112:127], and v[80:95] in k_scan, which keeps three blocks in
+// flight -- which the compiler is told are clobbered and never otherwise allocates (the kernels
+// need < 80 VGPRs; 128 is the budget of a 1024-thread workgroup).  tools/check_pinned_vgprs.py checks the generated ISA for exactly that (`make
 // check`, and the CPU test suite).
 // A block is taken out of its set, already shifted down to segment ids, by v_lshrrevs issued
 // after a counted s_waitcnt (wait_block).  On gfx950 vmcnt counts loads and stores alike and they
 // return in issue order (hipcc itself relies on that: it waits vmcnt(2) for a load followed by
 // two stores), so the wait counts the record stores issued since, too -- otherwise every block
 // would wait for the stores of the block before it to be acknowledged.
-// The four loads of a lane cover its own 64 bytes; the wave's four instructions together cover
-// 4 KiB, every 64-byte sector exactly once per instruction (measured at the same 5.9 TB/s as
+// k_scan_short's pattern (load_block_async): the four loads of a lane cover its own 64 bytes; the
+// wave's four instructions together cover 4 KiB, every 64-byte sector exactly once per instruction (measured at the same 5.9 TB/s as
 // fully coalesced loads, tools/loadpat.hip).  No nontemporal hint here: the sectors must survive
 // in cache from the first of the four instructions to the last.
 #ifndef FGFA_LOAD_POLICY
