@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <memory>
 #include <sys/mman.h>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <mutex>
@@ -38,10 +39,16 @@ struct CStore {
     std::vector<uint32_t> h_path_begin, h_path_end;
     flatgfa_dev_plan_t *plan = nullptr;
     hipStream_t stream = nullptr;
+    // the prepared query of the last flatgfa_seg_depth_subset call, reused while the subset is the same
+    std::vector<uint32_t> sub_ids;
+    flatgfa_dev_plan_t *sub_plan = nullptr;
+    uint32_t *d_sub_spans = nullptr;  // the subset's begin[] then end[]
     int steps_ok = -1;  // -1 = not checked yet: do all step handles name a segment? (host-side walks index by them)
 
     ~CStore() {
         if (plan) flatgfa_dev_plan_destroy(plan);
+        if (sub_plan) flatgfa_dev_plan_destroy(sub_plan);
+        if (d_sub_spans) (void)hipFree(d_sub_spans);
         for (uint32_t *p : {d_steps, d_small})
             if (p) (void)hipFree(p);
         if (stream) (void)hipStreamDestroy(stream);
@@ -597,34 +604,40 @@ int flatgfa_seg_depth_subset(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n
     std::lock_guard<std::mutex> op(gfa->op_mu);
     int rc = ensure_device(gfa, -1);
     if (rc) return rc;
-    // a prepared query over the same resident steps, with only the chosen paths' spans
-    std::vector<uint32_t> hb(n_ids), he(n_ids);
-    for (uint32_t k = 0; k < n_ids; ++k) {
-        hb[k] = gfa->h_path_begin[path_ids[k]];
-        he[k] = gfa->h_path_end[path_ids[k]];
-    }
-    uint32_t *d_b = nullptr, *d_e = nullptr;
-    if (n_ids) {
-        CAPI_HIP(hipMalloc(&d_b, (size_t)n_ids * 4));
-        if (hipMalloc(&d_e, (size_t)n_ids * 4) != hipSuccess) { (void)hipFree(d_b); set_error("hipMalloc failed"); return FLATGFA_ERR_HIP; }
-        if (hipMemcpy(d_b, hb.data(), (size_t)n_ids * 4, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(d_e, he.data(), (size_t)n_ids * 4, hipMemcpyHostToDevice) != hipSuccess) {
-            (void)hipFree(d_b);
-            (void)hipFree(d_e);
-            set_error("flatgfa_seg_depth_subset: copying the path spans to the device failed");
-            return FLATGFA_ERR_HIP;
+    // A prepared query over the same resident steps, with only the chosen paths' spans.  It is kept:
+    // asking again for the same subset (a table after the vectors, say) costs the kernels alone.
+    const bool same = gfa->sub_plan && gfa->sub_ids.size() == n_ids &&
+                      std::equal(gfa->sub_ids.begin(), gfa->sub_ids.end(), path_ids);
+    if (!same) {
+        if (gfa->sub_plan) flatgfa_dev_plan_destroy(gfa->sub_plan);
+        if (gfa->d_sub_spans) (void)hipFree(gfa->d_sub_spans);
+        gfa->sub_plan = nullptr;
+        gfa->d_sub_spans = nullptr;
+        gfa->sub_ids.clear();
+        std::vector<uint32_t> span(2 * (size_t)n_ids);
+        for (uint32_t k = 0; k < n_ids; ++k) {
+            span[k] = gfa->h_path_begin[path_ids[k]];
+            span[n_ids + k] = gfa->h_path_end[path_ids[k]];
         }
+        if (n_ids) {
+            CAPI_HIP(hipMalloc(&gfa->d_sub_spans, span.size() * 4));
+            if (hipMemcpy(gfa->d_sub_spans, span.data(), span.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(gfa->d_sub_spans);
+                gfa->d_sub_spans = nullptr;
+                set_error("flatgfa_seg_depth_subset: copying the path spans to the device failed");
+                return FLATGFA_ERR_HIP;
+            }
+        }
+        flatgfa_dev_graph_t g{gfa->d_steps, (uint64_t)gfa->view.steps.len, gfa->d_sub_spans,
+                              gfa->d_sub_spans ? gfa->d_sub_spans + n_ids : nullptr, n_ids, (uint32_t)S, gfa->d_seg_len};
+        gfa->sub_plan = flatgfa_dev_plan_create(&g, span.data(), span.data() + n_ids);
+        if (!gfa->sub_plan) return FLATGFA_ERR_HIP;
+        gfa->sub_ids.assign(path_ids, path_ids + n_ids);
     }
-    flatgfa_dev_graph_t g{gfa->d_steps, (uint64_t)gfa->view.steps.len, d_b, d_e, n_ids, (uint32_t)S, gfa->d_seg_len};
-    flatgfa_dev_plan_t *plan = flatgfa_dev_plan_create(&g, hb.data(), he.data());
-    rc = plan ? FLATGFA_OK : FLATGFA_ERR_HIP;
-    if (!rc) rc = flatgfa_dev_seg_depth(plan, gfa->d_depth, uniq_out ? gfa->d_uniq : nullptr, gfa->stream);
-    if (!rc) rc = flatgfa_dev_status(plan, gfa->stream);
+    rc = flatgfa_dev_seg_depth(gfa->sub_plan, gfa->d_depth, uniq_out ? gfa->d_uniq : nullptr, gfa->stream);
+    if (!rc) rc = flatgfa_dev_status(gfa->sub_plan, gfa->stream);
     if (!rc) rc = fetch_widen(gfa, gfa->d_depth, depth_out);
     if (!rc && uniq_out) rc = fetch_widen(gfa, gfa->d_uniq, uniq_out);
-    if (plan) flatgfa_dev_plan_destroy(plan);
-    if (d_b) (void)hipFree(d_b);
-    if (d_e) (void)hipFree(d_e);
     return rc;
 }
 
