@@ -159,6 +159,7 @@ SHAPES = [
     (23, 5_000_000, 7, 60_000, "pangenome"),   # more than 4 M segments: 8192-segment windows in both passes
     (24, 9_000_001, 40, 3000, "uniform"),      # 8192-segment windows, short paths as k_scan items, a ragged last window
     (25, 70_000, 3, 1_048_576 + 1040, "pangenome"),  # long paths whose pieces end in partial blocks and odd tails
+    (26, 17_000_000, 3, 4000, "uniform"),      # beyond 2048 windows of 8192 segments: the atomic kernels take over
 ]
 
 
