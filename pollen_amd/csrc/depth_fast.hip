@@ -331,6 +331,36 @@ __device__ __forceinline__ uint32_t claim_hashed(const ScanArgs &A, uint32_t *ta
     return old;
 }
 
+// Slots in the sub-buckets of `win`, one per valid lane.  A path that runs along the graph puts
+// neighbouring lanes' runs in the same window, and 64 LDS atomics on one address take 64 turns.
+// Three cases, by what the wave holds: one window for all lanes (the common case on such a path:
+// one atomic for the wave, a handful of vector instructions); mostly different windows (paths that
+// jump about: one atomic per lane); in between, the first lane of every stretch of equal windows
+// takes the slots of its stretch.
+__device__ __forceinline__ uint32_t take_slots(uint32_t *bcur, int lane, bool valid, uint32_t win) {
+#if FGFA_SLOTS_MODE == 1
+    const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
+    if (vm == 0) return 0u;
+    const uint32_t win0 = __builtin_amdgcn_readlane(win, (int)__builtin_ctzll(vm));
+    if (__builtin_amdgcn_ballot_w64(valid && win != win0) == 0) {
+        uint32_t first = 0;
+        if (lane == 0) first = atomicAdd(&bcur[win0], (uint32_t)__builtin_popcountll(vm));
+        return __builtin_amdgcn_readfirstlane(first) + lane_rank(vm);
+    }
+#endif
+    const uint32_t key = valid ? win : 0x80000000u | (uint32_t)lane;
+    const uint32_t kprev = __builtin_amdgcn_update_dpp(~0u, key, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    const unsigned long long heads = __builtin_amdgcn_ballot_w64(lane == 0 || key != kprev);
+#if FGFA_SLOTS_MODE >= 1
+    if (__builtin_popcountll(heads) > 48) return valid ? atomicAdd(&bcur[win], 1u) : 0u;
+#endif
+    const uint32_t head = 63u - (uint32_t)__builtin_clzll(heads & (~0ull >> (63 - lane)));
+    const unsigned long long rest = (heads >> 1) >> lane;
+    const uint32_t cnt = rest ? (uint32_t)__builtin_ctzll(rest) + 1u : 64u - (uint32_t)lane;
+    const uint32_t first = valid && head == (uint32_t)lane ? atomicAdd(&bcur[win], cnt) : 0u;
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(head << 2), (int)first) + ((uint32_t)lane - head);
+}
+
 // Emit up to 64 queued runs, one per lane.  Each run becomes one depth record.  For unique
 // depth the lane claims the run's segments with ONE returning OR (runs are cut at multiples of
 // 32, so a run lies inside one word): the bits that were still clear are exactly the (path,
@@ -347,12 +377,12 @@ __device__ __forceinline__ void emit_chunk(const ScanArgs &A, Wave &w, uint32_t 
     if (UNIQ) {
         const uint32_t mask = valid ? (0xFFFFFFFFu >> (31u - lenm1)) << (id & 31u) : 0u;
         const uint32_t old = claim_hashed<HASH>(A, seen, valid, id >> 5, mask);
-        pos = valid ? atomicAdd(&bcur[win], 1u) : 0u;
+        pos = take_slots(bcur, w.lane, valid, win);
         const uint32_t nb = mask & ~old;
         kind = (nb == mask) ? 2u : 0u;
         push_partial(w, (nb != mask) & (nb != 0u), id >> 5, nb);
     } else {
-        pos = valid ? atomicAdd(&bcur[win], 1u) : 0u;
+        pos = take_slots(bcur, w.lane, valid, win);
     }
     const uint32_t word = (id & ((1u << kShortWinBits) - 1u)) | (lenm1 << kShortWinBits) | ((kind + 1u) << 24);  // bit 24: counts for depth, bit 25: for uniq
     flag_if_any(A, put<false>(A, w, mine, valid, pos, win, word), kStOverflow);
@@ -767,6 +797,13 @@ __device__ __forceinline__ void tmark(const ScanArgs &A, RWave &w, int ph) {
 // LDS control words of k_scan, behind the two cursor tables: the next block of the current /
 // next item nobody has taken yet (two cells, by item parity), how many waves have left the item
 // (two cells), and how many items are complete.
+#ifndef FGFA_SLOTS_MODE
+#define FGFA_SLOTS_MODE 0
+#endif
+#ifndef FGFA_WIDE
+#define FGFA_WIDE 4
+#endif
+constexpr int kWide = FGFA_WIDE;  // chunks of 64 queue entries k_scan emits side by side
 constexpr uint32_t kCtlNext = 0, kCtlArrive = 2, kCtlEpoch = 4, kCtlWords = 8;
 
 __device__ __forceinline__ uint32_t epoch_now(uint32_t *ctl) {
@@ -777,41 +814,73 @@ __device__ __forceinline__ uint32_t epoch_now(uint32_t *ctl) {
 // the last run).  The whole run must lie below n_segs: that is the bounds check of every step in
 // it.  A run that crosses into the next window (at most one: runs are shorter than a window) is
 // emitted as two records.
-template <bool DBG>
+template <bool DBG, int K>
 __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *bcur, uint32_t *mine, uint32_t base, uint32_t n) {
-    const bool have = (uint32_t)w.lane < n;
-    const uint32_t idx = base + (have ? (uint32_t)w.lane : 0u);
-    const uint2 e = w.q[idx], s = w.q[idx + 1u];
-    const uint32_t id = e.x, lenm1 = (s.y - e.y - 1u) & 1023u;
-    bool valid = have && id != kInvalid;
-    const bool bad = valid && id + lenm1 >= A.n_segs;
-    flag_if_any(A, bad, kStBounds);
-    valid = valid && !bad;
+    // K chunks of 64 entries side by side (n counts the entries of the last one; the others are
+    // full): each chunk is a chain of LDS read, cursor atomic, permute and store, and the waves of
+    // a CU are too few to hide one chain at a time when most steps start a run.
     const uint32_t wb = A.wb, wmask = (1u << wb) - 1u;
-    const uint32_t win = id >> wb, rel = id & wmask;
-    const bool cross = valid && rel + lenm1 > wmask;
-    const uint32_t l1 = cross ? wmask - rel : lenm1;
-    const uint32_t pos = valid ? atomicAdd(&bcur[win], 1u) : 0u;
-    bool ovf = put<DBG>(A, w, mine, valid, pos, win, rel | (l1 << wb) | (1u << 24));
-    if (__builtin_amdgcn_ballot_w64(cross)) {
-        const uint32_t pos2 = cross ? atomicAdd(&bcur[win + 1u], 1u) : 0u;
-        ovf |= put<DBG>(A, w, mine, cross, pos2, win + 1u, ((lenm1 - (wmask - rel) - 1u) << wb) | (1u << 24));
+    uint2 e[K], s[K];
+    bool valid[K], cross[K];
+    uint32_t win[K], rel[K], lenm1[K], pos[K];
+    bool bad = false, any_cross = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        valid[k] = k + 1 < K || (uint32_t)w.lane < n;
+        const uint32_t idx = base + 64u * (uint32_t)k + (valid[k] ? (uint32_t)w.lane : 0u);
+        e[k] = w.q[idx];
+        s[k] = w.q[idx + 1u];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t id = e[k].x;
+        lenm1[k] = (s[k].y - e[k].y - 1u) & 1023u;
+        valid[k] = valid[k] && id != kInvalid;
+        const bool b = valid[k] && id + lenm1[k] >= A.n_segs;
+        bad |= b;
+        valid[k] = valid[k] && !b;
+        win[k] = id >> wb;
+        rel[k] = id & wmask;
+        cross[k] = valid[k] && rel[k] + lenm1[k] > wmask;
+        any_cross |= cross[k];
+    }
+    flag_if_any(A, bad, kStBounds);
+#pragma unroll
+    for (int k = 0; k < K; ++k) pos[k] = take_slots(bcur, w.lane, valid[k], win[k]);
+    bool ovf = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t l1 = cross[k] ? wmask - rel[k] : lenm1[k];
+        ovf |= put<DBG>(A, w, mine, valid[k], pos[k], win[k], rel[k] | (l1 << wb) | (1u << 24));
+    }
+    if (__builtin_amdgcn_ballot_w64(any_cross)) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t pos2 = cross[k] ? atomicAdd(&bcur[win[k] + 1u], 1u) : 0u;
+            ovf |= put<DBG>(A, w, mine, cross[k], pos2, win[k] + 1u, ((lenm1[k] - (wmask - rel[k]) - 1u) << wb) | (1u << 24));
+        }
     }
     flag_if_any(A, ovf, kStOverflow);
 }
 
 // Emit the oldest entries, 64 at a time, while at least 65 are queued, then move what is left to
 // the front of the queue.  With `all`, a terminator is appended and everything is emitted.
-template <bool DBG>
+template <bool DBG, int WIDE = 1>
 __device__ __forceinline__ void drain_raw(const ScanArgs &A, RWave &w, uint32_t *bcur, uint32_t *mine, bool all) {
     if (all) {
         if (w.lane == 0) w.q[w.fill] = make_uint2(kInvalid, 0u);
         w.fill += 1u;
     }
     uint32_t base = 0;
+    if (WIDE > 1) {
+        while (w.fill - base >= 64u * WIDE + 1u) {
+            emit_raw<DBG, WIDE>(A, w, bcur, mine, base, 64u);
+            base += 64u * WIDE;
+        }
+    }
     while (w.fill - base >= 65u || (all && w.fill - base >= 2u)) {
         const uint32_t n = min(64u, w.fill - 1u - base);
-        emit_raw<DBG>(A, w, bcur, mine, base, n);
+        emit_raw<DBG, 1>(A, w, bcur, mine, base, n);
         base += n;
     }
     if (all) {
@@ -919,17 +988,15 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
     tmark<DBG>(A, w, 2);
     if (FGFA_SKIP(kDbgNoEmit)) {
         w.fill = 0;
-    } else if (w.fill >= 65u || w.fill + total + 2u > kQ2) {
+    } else if (w.fill + total + 2u > kQ2) {
+        // Only a wave that ran ahead into an item whose predecessor is not wrapped up yet gets
+        // here: it could not drain at the end of its last blocks, and now it has to.
         if (!w.epoch_ok) {
-            if (epoch_now(ctl) >= rr) {
-                w.epoch_ok = true;
-            } else if (w.fill + total + 2u > kQ2) {
-                while (epoch_now(ctl) < rr) __builtin_amdgcn_s_sleep(2);
-                w.epoch_ok = true;
-            }
+            while (epoch_now(ctl) < rr) __builtin_amdgcn_s_sleep(2);
+            w.epoch_ok = true;
             tmark<DBG>(A, w, 1);
         }
-        if (w.epoch_ok) drain_raw<DBG>(A, w, bcur, mine, false);
+        drain_raw<DBG>(A, w, bcur, mine, false);
         tmark<DBG>(A, w, 3);
     }
     const uint32_t off[4] = {(s01 & 0xFFFFu) - cnt[0], t0 + (s01 >> 16) - cnt[1], t0 + t1 + (s23 & 0xFFFFu) - cnt[2],
@@ -945,6 +1012,13 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
     if (partial && w.lane == 0) w.q[w.fill + total - 1u] = make_uint2(kInvalid, nsteps);
     w.fill += total;
     tmark<DBG>(A, w, 2);
+    // The queue is drained here, where the block's ids are dead, kWide chunks of 64 side by side.
+    if (!FGFA_SKIP(kDbgNoEmit) && w.fill >= 65u) {
+        if (!w.epoch_ok && epoch_now(ctl) >= rr) w.epoch_ok = true;
+        tmark<DBG>(A, w, 1);
+        if (w.epoch_ok) drain_raw<DBG, kWide>(A, w, bcur, mine, false);
+        tmark<DBG>(A, w, 3);
+    }
 }
 
 template <bool DBG>
@@ -1054,7 +1128,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             w.epoch_ok = true;
         }
         tmark<DBG>(A, w, 1);
-        drain_raw<DBG>(A, w, bcur, mine, true);
+        drain_raw<DBG, kWide>(A, w, bcur, mine, true);
         tmark<DBG>(A, w, 3);
         // This wave is done with the item: it requests its first two blocks of the next one right away.
         const uint32_t done_job = job;
