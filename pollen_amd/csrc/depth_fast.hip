@@ -739,6 +739,7 @@ constexpr auto k_walk_medium = k_scan_short<UNIQ, kMediumWaves, kMediumHash, fal
 // number of steps).  Entries leave the queue oldest first, 64 at a time, each as one record.
 
 struct RWave {
+    uint32_t dir;  // +1 / -1 (as unsigned): which way the current item's runs go (uniform; the queue never holds two items)
     uint2 *q;
     uint32_t fill;
     uint32_t vm[3];
@@ -758,19 +759,21 @@ __device__ __forceinline__ void tmark(const ScanArgs &A, RWave &w, int ph) {
 }
 
 // Pass A for four consecutive steps of every lane: Mj (a lane mask in an SGPR pair) = "step j
-// starts a run" = its id is not the id before it plus one; CNT += Mj per lane.  Three vector
-// instructions per step.  PM is the id before step 0.
+// starts a run" = its id is not the id before it plus DIR; CNT += Mj per lane.  Three vector
+// instructions per step.  PM is the id before step 0.  DIR (an SGPR) is +1 or -1: the way the
+// item's path mostly runs through the segment ids (a contig on the reverse strand walks them
+// downwards; its runs are found just the same and emitted from their low end).
 #define FGFA_PA_STEP(PMJ, XJ, MJ)                            \
-    "v_add_u32 %[t], 1, %[" PMJ "]\n\t"                      \
+    "v_add_u32 %[t], %[dir], %[" PMJ "]\n\t"                 \
     "v_cmp_ne_u32 %[" MJ "], %[" XJ "], %[t]\n\t"            \
     "v_addc_co_u32_e64 %[cnt], vcc, 0, %[cnt], %[" MJ "]\n\t"
-#define FGFA_PA4(CNT, PM, X0, X1, X2, X3, M0, M1, M2, M3)                                                            \
+#define FGFA_PA4(CNT, DIR, PM, X0, X1, X2, X3, M0, M1, M2, M3)                                                          \
     do {                                                                                                             \
         uint32_t t_;                                                                                                 \
         asm volatile(FGFA_PA_STEP("pm", "x0", "m0") FGFA_PA_STEP("x0", "x1", "m1") FGFA_PA_STEP("x1", "x2", "m2")    \
                          FGFA_PA_STEP("x2", "x3", "m3")                                                              \
                      : [cnt] "+v"(CNT), [t] "=&v"(t_), [m0] "=&s"(M0), [m1] "=&s"(M1), [m2] "=&s"(M2), [m3] "=&s"(M3) \
-                     : [pm] "v"(PM), [x0] "v"(X0), [x1] "v"(X1), [x2] "v"(X2), [x3] "v"(X3)                          \
+                     : [dir] "s"(DIR), [pm] "v"(PM), [x0] "v"(X0), [x1] "v"(X1), [x2] "v"(X2), [x3] "v"(X3)          \
                      : "vcc");                                                                                       \
     } while (0)
 
@@ -820,6 +823,7 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
     // full): each chunk is a chain of LDS read, cursor atomic, permute and store, and the waves of
     // a CU are too few to hide one chain at a time when most steps start a run.
     const uint32_t wb = A.wb, wmask = (1u << wb) - 1u;
+    const uint32_t down = w.dir == 1u ? 0u : ~0u;
     uint2 e[K], s[K];
     bool valid[K], cross[K];
     uint32_t win[K], rel[K], lenm1[K], pos[K];
@@ -833,9 +837,9 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const uint32_t id = e[k].x;
         lenm1[k] = (s[k].y - e[k].y - 1u) & 1023u;
-        valid[k] = valid[k] && id != kInvalid;
+        valid[k] = valid[k] && e[k].x != kInvalid;
+        const uint32_t id = e[k].x - (lenm1[k] & down);  // a downward run is emitted from its low end
         const bool b = valid[k] && id + lenm1[k] >= A.n_segs;
         bad |= b;
         valid[k] = valid[k] && !b;
@@ -900,7 +904,7 @@ __device__ __forceinline__ void tile_narrow_raw(const ScanArgs &A, RWave &w, uin
     const bool valid = (uint32_t)w.lane < count;
     const uint32_t id = valid ? A.steps[t + w.lane] >> 1 : 0u;
     const uint32_t prev = __builtin_amdgcn_update_dpp(0u, id, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-    const bool s = valid && (w.lane == 0 || id != prev + 1u);
+    const bool s = valid && (w.lane == 0 || id != prev + w.dir);
     const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
     if (s) w.q[w.fill + lane_rank(m)] = make_uint2(id, (uint32_t)w.lane);
     const uint32_t ns = (uint32_t)__builtin_popcountll(m);
@@ -916,6 +920,7 @@ __device__ __forceinline__ void tile_narrow_raw(const ScanArgs &A, RWave &w, uin
 struct Item {
     uint64_t b, e, t0, tail;
     uint32_t nblk, nl_last;
+    uint32_t dir;      // +1, or -1 for an item marked as running down the segment ids (items[].z == 1)
     const uint4 *src;  // this lane's first 16 bytes of block 0
 };
 
@@ -931,8 +936,10 @@ __device__ __forceinline__ Item make_item(const ScanArgs &A, bool have, uint4 d,
     it.b = it.e = it.t0 = it.tail = 0;
     it.nblk = 0;
     it.nl_last = 64;
+    it.dir = 1u;
     it.src = nullptr;
     if (have) {
+        it.dir = d.z == 1u ? ~0u : 1u;
         it.b = d.x;
         it.e = d.y;
         const uint64_t up = (it.b + 15) & ~(uint64_t)15;
@@ -955,8 +962,8 @@ __device__ __forceinline__ Item make_item(const ScanArgs &A, bool have, uint4 d,
 // Pass A marks the run starts and counts them per lane and group (a group's first step compares
 // with the last step of the lane below; lane 0 always starts a run); two wave prefix sums (two
 // 16-bit counts each) give every (group, lane) its own stretch of the queue, in path order; pass B
-// appends.  If the queue cannot take the block's starts, or holds a chunk's worth and this wave may
-// emit, the oldest entries are emitted first.
+// appends.  The queue is drained at the end, where the block's ids are dead (and before pass B
+// only by a wave that ran ahead into the next item and could not drain when it wanted to).
 template <bool DBG>
 __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *bcur, uint32_t *mine, uint32_t *ctl, uint32_t rr,
                                          uint32_t (&a)[16], const uint32_t (&pj)[16], uint32_t nsteps) {
@@ -967,7 +974,7 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
     for (int k = 0; k < 4; ++k) {
         const uint32_t prev = __builtin_amdgcn_update_dpp(0u, a[4 * k + 3], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
         cnt[k] = 0;
-        FGFA_PA4(cnt[k], prev, a[4 * k], a[4 * k + 1], a[4 * k + 2], a[4 * k + 3], m[4 * k], m[4 * k + 1], m[4 * k + 2], m[4 * k + 3]);
+        FGFA_PA4(cnt[k], w.dir, prev, a[4 * k], a[4 * k + 1], a[4 * k + 2], a[4 * k + 3], m[4 * k], m[4 * k + 1], m[4 * k + 2], m[4 * k + 3]);
         const uint32_t add0 = 1u & ~(uint32_t)m[4 * k];  // lane 0's first step of the group starts a run whatever is below
         m[4 * k] |= 1ull;
         cnt[k] += (w.lane == 0) ? add0 : 0u;
@@ -1063,6 +1070,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     uint32_t rr = 0;  // this workgroup's items so far
     uint32_t job = item_of(0, blockIdx.x, gridDim.x);
     Item it = make_item(A, job < n_items, job < n_items ? A.items[job] : make_uint4(0u, 0u, 0u, 0u), lane);
+    w.dir = __builtin_amdgcn_readfirstlane(it.dir);
     uint32_t blk[3];  // the block each landing set holds (or will hold next)
     uint32_t resv;    // the block this wave takes after those
     // (a partial block is read whole: make_item has made sure that stays inside the step array)
@@ -1134,6 +1142,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         const uint32_t done_job = job;
         job = next_job;
         it = make_item(A, job < n_items, next_item, lane);
+        w.dir = __builtin_amdgcn_readfirstlane(it.dir);  // the queue is empty here
         FGFA_PRELOAD();
         // The last wave to leave the item snapshots the cursors: dir[window][item] = the item's
         // stretch of this workgroup's sub-bucket, which is how pass 2 tells the paths apart.
@@ -1793,6 +1802,35 @@ __global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__
     }
 }
 
+// Plan time: which way each of k_scan's items runs through the segment ids.  items[j].z = 1 when
+// more of its steps follow their predecessor downwards (id - 1) than upwards (id + 1), else 0.
+// One workgroup per item at a time.
+__global__ __launch_bounds__(256) void k_item_dirs(const uint32_t *__restrict__ steps, uint4 *__restrict__ items, uint32_t n_items) {
+    __shared__ uint32_t up, down;
+    for (uint32_t j = blockIdx.x; j < n_items; j += gridDim.x) {
+        if (threadIdx.x == 0) up = down = 0;
+        __syncthreads();
+        const uint64_t b = items[j].x, e = items[j].y;
+        uint32_t u = 0, d = 0;
+        for (uint64_t i = b + 1 + threadIdx.x; i < e; i += 256) {
+            const uint32_t id = steps[i] >> 1, before = steps[i - 1] >> 1;
+            u += id == before + 1u ? 1u : 0u;
+            d += id + 1u == before ? 1u : 0u;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            u += __shfl_down(u, off, 64);
+            d += __shfl_down(d, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&up, u);
+            atomicAdd(&down, d);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) items[j].z = down > up ? 1u : 0u;
+        __syncthreads();
+    }
+}
+
 uint32_t scan_lds_bytes(uint32_t nwp) { return (2u * nwp + kCtlWords + kWaves * kQ2 * 2u) * 4u; }
 
 #define FAST_TRY(expr)                                                                      \
@@ -1983,7 +2021,14 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     FAST_TRY(hipMalloc(&fp->islot, (size_t)fp->dstride * 4));
     FAST_TRY(hipMemset(fp->islot, 0, (size_t)fp->dstride * 4));
     FAST_TRY(hipMalloc(&fp->items, (items.size() + fp->max_back + 1) * sizeof(uint4)));
-    if (!items.empty()) FAST_TRY(hipMemcpy(fp->items, items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    if (!items.empty()) {
+        FAST_TRY(hipMemcpy(fp->items, items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        if (!getenv("FLATGFA_NO_ITEM_DIRS")) {  // (knob for measurements: every item taken as running upwards)
+            hipLaunchKernelGGL(k_item_dirs, dim3(std::min<uint32_t>(fp->n_items, fp->n_cus * 8u)), dim3(256), 0, nullptr, g.steps,
+                               reinterpret_cast<uint4 *>(fp->items), fp->n_items);
+            FAST_TRY(hipDeviceSynchronize());
+        }
+    }
     if (!short_items.empty()) {
         FAST_TRY(hipMalloc(&fp->short_items, short_items.size() * sizeof(uint4)));
         FAST_TRY(hipMemcpy(fp->short_items, short_items.data(), short_items.size() * sizeof(uint4), hipMemcpyHostToDevice));

@@ -282,6 +282,55 @@ def test_runs_that_end_at_the_last_segment(n_segs, device_path):
         assert (d.cpu().numpy().view(np.uint32) == want_d).all()
 
 
+@pytest.mark.parametrize("n_segs,density", [(60_000, 0.5), (300_000, 0.97), (1_300_000, 0.7), (5_000_000, 0.6)])
+def test_paths_that_run_along_the_graph(n_segs, density, device_path):
+    """Paths shaped like real chromosome walks rather than the benchmark's random one: each visits
+    a random subset of the segments in order -- upwards, downwards (a contig on the reverse
+    strand: k_scan finds its runs with step -1), or switching direction a few times -- and one
+    walks a stretch twice.  A wave's runs then fall into one window, downward runs are emitted
+    from their low end, and a piece that runs both ways is scanned in its majority direction."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    rng = np.random.default_rng(n_segs)
+    S = n_segs
+    walks = []
+    for p in range(9):
+        lo = int(rng.integers(0, S // 3))
+        hi = int(rng.integers(2 * S // 3, S))
+        ids = lo + np.nonzero(rng.random(hi - lo) < density)[0]
+        if p % 3 == 1:
+            ids = ids[::-1]
+        elif p % 3 == 2:  # up, down, up, down over different stretches
+            cuts = np.sort(rng.integers(0, len(ids), size=3))
+            parts = np.split(ids, cuts)
+            ids = np.concatenate([part[::-1] if k % 2 else part for k, part in enumerate(parts)])
+        if p == 4:
+            ids = np.concatenate([ids, ids[: len(ids) // 3]])  # revisits, downwards
+        walks.append(ids.astype(np.uint32))
+    walks.append(np.arange(S - 1, S - 1 - min(S, 3000), -1, dtype=np.uint32))  # down from the last segment
+    walks.append(np.arange(min(S, 2500) - 1, -1, -1, dtype=np.uint32))         # down to segment 0
+    lens = np.array([len(x) for x in walks], dtype=np.uint32)
+    steps = (np.concatenate(walks) << 1) | rng.integers(0, 2, size=int(lens.sum())).astype(np.uint32)
+    pe = np.cumsum(lens).astype(np.uint32)
+    pb = (pe - lens).astype(np.uint32)
+    paths = np.zeros(len(lens), dtype=fo.PATH_DT)
+    paths["steps_start"], paths["steps_end"] = pb, pe
+    pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
+    pools.paths, pools.steps, pools.segs = paths, steps, np.zeros(S, dtype=fo.SEG_DT)
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    plan = DepthPlan(DeviceGraph(steps, pb, pe, S))
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    for _ in range(2):
+        plan.seg_depth(d, u)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == want_d).all()
+        assert (u.cpu().numpy().view(np.uint32) == want_u).all()
+    plan.seg_depth(d, None)
+    plan.status()
+    assert (d.cpu().numpy().view(np.uint32) == want_d).all()
+
+
 def test_linearity_over_path_subsets():
     # depth and uniq are sums of per-path contributions: computing two disjoint path groups
     # separately and adding must equal the whole (this is what multi-GPU sharding relies on).
