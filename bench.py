@@ -46,6 +46,7 @@ WORKLOADS = {
     # name: (S, P, L, model)
     "cfgL": (1_000_000, 1000, 100_000, "pangenome"),
     "cfgL-uniform": (1_000_000, 1000, 100_000, "uniform"),
+    "cfgL-chrom": (1_000_000, 1000, 100_000, "chromosome"),   # paths along the graph, half of them downwards, runs of 3.3
     "cfgL-short": (1_000_000, 100_000, 1000, "pangenome"),
     "cfgL-fewlong": (1_000_000, 100, 1_000_000, "pangenome"),
     "cfgL-medium": (1_000_000, 10_000, 10_000, "pangenome"),  # paths of ten blocks each

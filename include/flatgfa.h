@@ -94,7 +94,8 @@ int flatgfa_write_flatgfa(flatgfa_t gfa, const char *filename);
 /* GFA text (flatgfa/src/print.rs:99-153).  *text is malloc'd; release with flatgfa_free_text. */
 int flatgfa_print_gfa(flatgfa_t gfa, char **text, size_t *len);
 void flatgfa_free_text(char *text);
-/* Deterministic synthetic graph; model 0 = pangenome walk, 1 = uniform. */
+/* Deterministic synthetic graph; model 0 = pangenome walk, 1 = uniform,
+ * 2 = chromosome (paths walk along the graph, every other one downwards). */
 flatgfa_t flatgfa_synth(uint64_t seed, uint32_t n_segs, uint32_t n_paths, uint32_t steps_per_path, int model,
                         bool with_seq);
 

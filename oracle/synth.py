@@ -16,6 +16,9 @@ bit-for-bit.  This file is the readable definition:
                 u = (r>>8) % 100; k = (r>>16) & 0xFF; j = r>>32
                 pangenome: u<90: cur+1 | u<95: cur+2+(k&7) | u<99: max(cur-1-(k&3), 0) | else: j%S
                 uniform:   cur = j % S
+                chromosome (paths walk along the graph; odd paths downwards, handles flipped):
+                           d = u<70: 1 | u<95: 2+(k&3) | u<99: 8+(k&63) | else: jump to j%S
+                           even p: cur+d, odd p: cur-d (mod S); handle orientation bit ^= p&1
                 cur %= S
   steps of path p occupy steps[p*L:(p+1)*L]  (contiguous, in order: parse.rs:149-159)
 """
@@ -47,7 +50,7 @@ def seg_lens(seed: int, S: int) -> np.ndarray:
 
 def steps(seed: int, S: int, P: int, L: int, model: str = "pangenome") -> np.ndarray:
     """Returns the flat u32 handle array, shape (P*L,)."""
-    assert model in ("pangenome", "uniform")
+    assert model in ("pangenome", "uniform", "chromosome")
     out = np.zeros((P, L), dtype=np.uint32)
     with np.errstate(over="ignore"):
         state = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) * GOLDEN + np.arange(P, dtype=np.uint64)
@@ -61,6 +64,15 @@ def steps(seed: int, S: int, P: int, L: int, model: str = "pangenome") -> np.nda
             j = r >> np.uint64(32)
             if model == "uniform":
                 cur = j % np.uint64(S)
+            elif model == "chromosome":
+                odd = np.arange(P, dtype=np.uint64) & np.uint64(1)
+                out[:, t] ^= odd.astype(np.uint32)
+                u = (r >> np.uint64(8)) % np.uint64(100)
+                k = (r >> np.uint64(16)) & np.uint64(0xFF)
+                d = np.where(u < 70, np.uint64(1), np.where(u < 95, np.uint64(2) + (k & np.uint64(3)), np.uint64(8) + (k & np.uint64(63))))
+                d = d % np.uint64(S)
+                moved = np.where(odd == 1, cur + np.uint64(S) - d, cur + d) % np.uint64(S)
+                cur = np.where(u < 99, moved, j % np.uint64(S))
             else:
                 u = (r >> np.uint64(8)) % np.uint64(100)
                 k = (r >> np.uint64(16)) & np.uint64(0xFF)

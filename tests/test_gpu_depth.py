@@ -159,6 +159,9 @@ SHAPES = [
     (23, 5_000_000, 7, 60_000, "pangenome"),   # more than 4 M segments: 8192-segment windows in both passes
     (24, 9_000_001, 40, 3000, "uniform"),      # 8192-segment windows, short paths as k_scan items, a ragged last window
     (25, 70_000, 3, 1_048_576 + 1040, "pangenome"),  # long paths whose pieces end in partial blocks and odd tails
+    (27, 200_000, 12, 40_000, "chromosome"),   # paths along the graph, every other one downwards (k_scan's step -1 runs)
+    (28, 1_500_000, 7, 250_000, "chromosome"),
+    (29, 30_000, 200, 900, "chromosome"),      # the wave-per-path kernels see downward paths as runs of one
     (26, 17_000_000, 3, 4000, "uniform"),      # beyond 2048 windows of 8192 segments: the atomic kernels take over
 ]
 
@@ -221,7 +224,7 @@ def test_more_synthetic_graphs_match_slow_odgi_goldens(name, cfg, device_path):
     assert g.depth_table() == read(os.path.join(GOLDEN, name + ".depth.tsv"))
 
 
-@pytest.mark.parametrize("model", ["pangenome", "uniform"])
+@pytest.mark.parametrize("model", ["pangenome", "uniform", "chromosome"])
 def test_cfgL_full_size(model):
     # BASELINE.json configs[2]: 1M segments / 100M steps.  Checked against the oracle (a few
     # seconds of CPU) and through size-independent properties.

@@ -41,6 +41,8 @@ def random_graph(rng):
             u = rng.integers(0, 100, size=L)
             j = rng.integers(0, 1 << 30, size=L)
             inc = np.where(u < 90, 1, np.where(u < 95, 2 + (j & 7), np.where(u < 99, -(1 + (j & 3)), 0))).astype(np.int64)
+            if rng.integers(0, 3) == 0:
+                inc = -inc  # a walk down the segment ids (k_scan's step -1 runs)
             jump = u >= 99
             jump[0] = True
             base = np.where(jump, j % S, 0).astype(np.int64)
