@@ -962,8 +962,9 @@ __device__ __forceinline__ Item make_item(const ScanArgs &A, bool have, uint4 d,
 // Pass A marks the run starts and counts them per lane and group (a group's first step compares
 // with the last step of the lane below; lane 0 always starts a run); two wave prefix sums (two
 // 16-bit counts each) give every (group, lane) its own stretch of the queue, in path order; pass B
-// appends.  The queue is drained at the end, where the block's ids are dead (and before pass B
-// only by a wave that ran ahead into the next item and could not drain when it wanted to).
+// appends.  If the queue cannot take the block's starts, or holds a chunk's worth and this wave may
+// emit, the oldest entries are emitted first, one chunk at a time; a block that queues a lot is
+// followed by a wide drain.
 template <bool DBG>
 __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *bcur, uint32_t *mine, uint32_t *ctl, uint32_t rr,
                                          uint32_t (&a)[16], const uint32_t (&pj)[16], uint32_t nsteps) {
@@ -995,15 +996,17 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
     tmark<DBG>(A, w, 2);
     if (FGFA_SKIP(kDbgNoEmit)) {
         w.fill = 0;
-    } else if (w.fill + total + 2u > kQ2) {
-        // Only a wave that ran ahead into an item whose predecessor is not wrapped up yet gets
-        // here: it could not drain at the end of its last blocks, and now it has to.
+    } else if (w.fill >= 65u || w.fill + total + 2u > kQ2) {
         if (!w.epoch_ok) {
-            while (epoch_now(ctl) < rr) __builtin_amdgcn_s_sleep(2);
-            w.epoch_ok = true;
+            if (epoch_now(ctl) >= rr) {
+                w.epoch_ok = true;
+            } else if (w.fill + total + 2u > kQ2) {
+                while (epoch_now(ctl) < rr) __builtin_amdgcn_s_sleep(2);
+                w.epoch_ok = true;
+            }
             tmark<DBG>(A, w, 1);
         }
-        drain_raw<DBG>(A, w, bcur, mine, false);
+        if (w.epoch_ok) drain_raw<DBG>(A, w, bcur, mine, false);
         tmark<DBG>(A, w, 3);
     }
     const uint32_t off[4] = {(s01 & 0xFFFFu) - cnt[0], t0 + (s01 >> 16) - cnt[1], t0 + t1 + (s23 & 0xFFFFu) - cnt[2],
@@ -1019,8 +1022,11 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
     if (partial && w.lane == 0) w.q[w.fill + total - 1u] = make_uint2(kInvalid, nsteps);
     w.fill += total;
     tmark<DBG>(A, w, 2);
-    // The queue is drained here, where the block's ids are dead, kWide chunks of 64 side by side.
-    if (!FGFA_SKIP(kDbgNoEmit) && w.fill >= 65u) {
+    // A block that leaves kWide chunks' worth in the queue (paths whose runs are short) has them
+    // emitted here, where the block's ids are dead and there are registers for kWide chunks side
+    // by side.  (Draining only here was measured: no gain on such paths, and short items -- 32 k
+    // steps -- lost 15 %: their waves more often find the item before them not wrapped up yet.)
+    if (kWide > 1 && !FGFA_SKIP(kDbgNoEmit) && w.fill >= 64u * kWide + 1u) {
         if (!w.epoch_ok && epoch_now(ctl) >= rr) w.epoch_ok = true;
         tmark<DBG>(A, w, 1);
         if (w.epoch_ok) drain_raw<DBG, kWide>(A, w, bcur, mine, false);
