@@ -1900,11 +1900,6 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     fp->lds_bytes_scan = scan_lds_bytes(fp->nwp);
     if (fp->lds_bytes_scan + 64 > kLdsLimit) return true;
     if (const char *d = getenv("FLATGFA_DEBUG_SKIP")) fp->dbg = (uint32_t)strtoul(d, nullptr, 10);
-    // Work items: whole paths, except that a path longer than `piece` steps is cut into pieces so
-    // that graphs with few long paths still fill the chip.
-    uint64_t piece = std::max<uint64_t>(65536, (g.n_steps + 2ull * fp->n_cus - 1) / (2ull * fp->n_cus));
-    if (const char *forced = getenv("FLATGFA_PIECE_STEPS")) piece = std::max<uint64_t>(256, strtoull(forced, nullptr, 10));
-    piece = (piece + 255) & ~255ull;
     // Paths of at most `short_max` steps are walked by single waves (k_scan_short), unless their
     // last block would reach beyond the step array.  Those kernels address at most 256 windows
     // of 4096 segments.
@@ -1925,7 +1920,7 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
         FAST_TRY(e);
     }
     const bool short_any = getenv("FLATGFA_SHORT_ANY") != nullptr;  // tests: let k_scan_short find out and hand back
-    std::vector<uint4> items, short_items, medium_items;
+    std::vector<uint4> items, short_items, medium_items, whole;
     for (uint32_t p = 0; p < g.n_paths; ++p) {
         const uint64_t b = hb[p], e = he[p], n = e - b;
         if (n == 0) continue;
@@ -1935,17 +1930,54 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
             short_items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
         } else if (short_max && in_reach && runs[p] <= kMediumRuns) {
             medium_items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
-        } else if (n <= piece) {
-            items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
         } else {
-            const uint32_t k = (uint32_t)((n + piece - 1) / piece);
-            for (uint32_t j = 0; j < k; ++j) {
-                const uint64_t pb = b + n * j / k, pe = b + n * (j + 1) / k;
-                items.push_back(make_uint4((uint32_t)pb, (uint32_t)pe, kNoSlot, p));
-            }
+            whole.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
         }
     }
+    // k_scan's work items: whole paths, except that a path longer than `piece` steps is cut into
+    // equal pieces, so that graphs with few long paths still fill the chip.  The workgroups take the
+    // items, longest first, in a fixed snake order (item_of): with a hundred paths of a million steps
+    // and pieces of N / (2 CUs), three pieces fall to some workgroups and two to most (+28 % on the
+    // longest).  So the deal is played through on the host for a few piece sizes, every item charged
+    // a few blocks' worth for its turnaround, and the size with the shortest longest hand is taken
+    // (the largest such size: for 1000 paths of 100 k steps, no cutting at all).
+    const auto cut = [&](uint64_t piece, std::vector<uint4> *out) {
+        for (const uint4 &w : whole) {
+            const uint64_t b = w.x, n = (uint64_t)w.y - w.x;
+            const uint32_t k = (uint32_t)((n + piece - 1) / piece);
+            for (uint32_t j = 0; j < k; ++j)
+                out->push_back(make_uint4((uint32_t)(b + n * j / k), (uint32_t)(b + n * (j + 1) / k), kNoSlot, w.w));
+        }
+    };
     const auto longer = [](const uint4 &a, const uint4 &b) { return a.y - a.x > b.y - b.x; };
+    uint64_t piece = 0;
+    if (const char *forced = getenv("FLATGFA_PIECE_STEPS")) {
+        piece = (std::max<uint64_t>(256, strtoull(forced, nullptr, 10)) + 255) & ~255ull;
+    } else {
+        constexpr uint64_t kTurnaround = 8192;  // steps a workgroup could have walked while it changes items
+        uint64_t long_steps = 0;
+        for (const uint4 &w : whole) long_steps += w.y - w.x;
+        uint64_t best = ~0ull;
+        for (const uint32_t twice_m : {4u, 5u, 6u, 8u, 10u, 12u, 16u, 20u, 24u}) {  // pieces of N / (m CUs), m = 2 .. 12
+            uint64_t cand = std::max<uint64_t>(32768, (2 * long_steps + (uint64_t)twice_m * fp->n_slots - 1) / ((uint64_t)twice_m * fp->n_slots));
+            cand = (cand + 255) & ~255ull;
+            std::vector<uint4> trial;
+            cut(cand, &trial);
+            std::stable_sort(trial.begin(), trial.end(), longer);
+            std::vector<uint64_t> hand(fp->n_slots, 0);
+            for (size_t i = 0; i < trial.size(); ++i) {
+                const size_t round = i / fp->n_slots, pos = i % fp->n_slots;
+                hand[(round & 1) ? fp->n_slots - 1 - pos : pos] += (uint64_t)(trial[i].y - trial[i].x) + kTurnaround;
+            }
+            const uint64_t longest = *std::max_element(hand.begin(), hand.end());
+            if (longest + longest / 64 < best) {  // smaller pieces have to win by more than 1.5 %
+                best = longest;
+                piece = cand;
+            }
+            if (cand == 32768) break;
+        }
+    }
+    cut(piece ? piece : 32768, &items);
     std::stable_sort(items.begin(), items.end(), longer);
     std::stable_sort(short_items.begin(), short_items.end(), longer);
     std::stable_sort(medium_items.begin(), medium_items.end(), longer);
