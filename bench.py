@@ -51,6 +51,7 @@ WORKLOADS = {
     "cfgL-fewlong": (1_000_000, 100, 1_000_000, "pangenome"),
     "cfgL-medium": (1_000_000, 10_000, 10_000, "pangenome"),  # paths of ten blocks each
     "cfgL-32k": (1_000_000, 3125, 32_000, "pangenome"),       # mid-length paths
+    "cfgL-100kseg": (100_000, 1000, 100_000, "pangenome"),    # deep coverage of a small graph: 25 windows
     "cfgL-4Mseg": (4_000_000, 1000, 100_000, "pangenome"),
     "cfgL-16Mseg": (16_000_000, 1000, 100_000, "pangenome"),
     "cfgL-x16": (1_000_000, 16_000, 100_000, "pangenome"),    # 1.6 G steps = 6.4 GB of steps per GPU: the weak-scaling size

@@ -88,6 +88,7 @@ constexpr uint32_t kDbgNoStore = 1, kDbgNoTiles = 8, kDbgHotLoads = 16, kDbgTime
 #define FGFA_SKIP(bit) (DBG && (A.dbg & (bit)))
 
 struct ScanArgs {
+    uint32_t *zero_a, *zero_b;  // k_scan clears these vectors of n_segs counts first (pass 2 adds to them when windows are shared); or null
     const uint32_t *steps;
     uint4 *items;        // work items, longest first: {begin, end, -, path}; room behind the first n_items
                          // for the short paths k_scan_short hands back (counted in *work_counter)
@@ -1052,6 +1053,12 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     w.epoch_ok = true;
     for (int k = 0; k < 8; ++k) w.tacc[k] = 0;
     w.tlast = (DBG && (A.dbg & kDbgTime)) ? __builtin_readcyclecounter() : 0ull;
+    if (A.zero_a) {  // small graphs: pass 2 adds to the outputs (AccArgs::parts)
+        for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < A.n_segs; i += gridDim.x * kThreads) {
+            A.zero_a[i] = 0u;
+            if (A.zero_b) A.zero_b[i] = 0u;
+        }
+    }
     // the cursors continue where k_scan_short (if it ran) left this workgroup's sub-buckets
     for (uint32_t i = threadIdx.x; i < A.nwp; i += kThreads) {
         const uint32_t c = i < A.n_win ? A.counts[(size_t)i * A.n_slots + blockIdx.x] : 0u;
@@ -1197,7 +1204,7 @@ struct AccArgs {
     const uint32_t *islot;    // [dstride]
     uint32_t dstride;
     const uint32_t *elist;    // k_scan's items in the order pass 2 walks them: item | first-of-its-path << 31
-    const uint32_t *wave_off; // [kAccWaves + 1] which stretch of elist each wave walks
+    const uint32_t *wave_off; // [parts * kAccWaves + 1] which stretch of elist each wave (of each of a window's workgroups) walks
     uint32_t n_items;         // static items; handed-back ones follow (one path each)
     const uint32_t *work_counter;
     uint32_t max_back;
@@ -1210,6 +1217,7 @@ struct AccArgs {
     const uint4 *items;                  // item j belongs to path items[j].w
     const uint32_t *seg_len;
     ulonglong2 *psum_part;               // [n_win][dstride] {sum len, sum depth * len} of item j in this window
+    uint32_t parts;  // workgroups per window (blockIdx.y): each walks its share of the paths / sub-buckets and ADDS its counts to the (zeroed) outputs
 };
 
 // Pass 2 keeps two difference arrays over the window in LDS: D for depth and R for revisits (steps
@@ -1395,6 +1403,14 @@ __device__ __forceinline__ void store_n(uint32_t *out, uint32_t i0, uint32_t nva
     }
 }
 
+// The same for a window shared by several workgroups: each adds what it counted.
+template <int N>
+__device__ __forceinline__ void add_n(uint32_t *out, uint32_t i0, uint32_t nvalid, const uint32_t (&a)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        if (a[k] && i0 + k < nvalid) atomicAdd(out + i0 + k, a[k]);
+}
+
 // Apply the records [0, scnt[slot]) of every sub-bucket of the window as they are (they say what
 // they count for).  Each wave takes sixteen sub-buckets per round and requests the first 64 x 16
 // bytes of every one before it applies any, so a round pays the memory latency once.
@@ -1402,13 +1418,14 @@ template <bool UNIQ, int WB>
 __device__ __forceinline__ void apply_flat(const AccArgs &A, int *D, int *R, const uint32_t *scnt, const uint32_t *wbase) {
     constexpr int kPerRound = 16;
     const int lane = threadIdx.x & 63;
-    const uint32_t uw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: sub-bucket addressing stays scalar
-    for (uint32_t s0 = uw; s0 < A.n_slots; s0 += kPerRound * kAccWaves) {
+    // wave-uniform: sub-bucket addressing stays scalar.  The waves of all of the window's workgroups share the sub-buckets out.
+    const uint32_t uw = __builtin_amdgcn_readfirstlane(blockIdx.y * kAccWaves + (threadIdx.x >> 6)), nw = A.parts * kAccWaves;
+    for (uint32_t s0 = uw; s0 < A.n_slots; s0 += kPerRound * nw) {
         uint4 r[kPerRound];
         uint32_t cnt[kPerRound];
 #pragma unroll
         for (int k = 0; k < kPerRound; ++k) {
-            const uint32_t s = s0 + k * kAccWaves;
+            const uint32_t s = s0 + k * nw;
             const uint32_t sc = s < A.n_slots ? s : 0u;
             cnt[k] = s < A.n_slots ? scnt[sc] : 0u;
             // unconditional (slot 0 always exists): a predicated load would be waited for on the spot
@@ -1426,7 +1443,7 @@ __device__ __forceinline__ void apply_flat(const AccArgs &A, int *D, int *R, con
         // what does not fit the first pass (skewed sub-buckets), and the last 1..3 records
 #pragma unroll 1
         for (int k = 0; k < kPerRound; ++k) {
-            const uint32_t s = s0 + k * kAccWaves;
+            const uint32_t s = s0 + k * nw;
             if (s >= A.n_slots) break;
             const uint32_t c = scnt[s];
             const uint32_t *bk = wbase + (size_t)s * A.cap;
@@ -1487,11 +1504,11 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
     constexpr uint32_t kNW = (1u << WB) / 32u;             // words per bitset
     constexpr uint32_t kSlots = WB <= 12 ? 8u : 4u;
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.y * kAccWaves + (threadIdx.x >> 6)), nw = A.parts * kAccWaves;
     const uint32_t e0 = __builtin_amdgcn_readfirstlane(A.wave_off[wave]), e1 = __builtin_amdgcn_readfirstlane(A.wave_off[wave + 1]);
     const uint32_t nback = A.has_pre ? min(__builtin_amdgcn_readfirstlane(*A.work_counter), A.max_back) : 0u;
     const uint32_t nst = e1 - e0;
-    const uint32_t nE = nst + (nback > wave ? (nback - wave + kAccWaves - 1u) / kAccWaves : 0u);
+    const uint32_t nE = nst + (nback > wave ? (nback - wave + nw - 1u) / nw : 0u);
     uint32_t gbase = 0, carryG = 0;  // path ordinals are 1-based: 0 = none yet
     uint32_t hbase = 0, hdone = 0;   // ordinals (mod 256 where compared) of the paths that have records in this window
     Pending pq;
@@ -1504,7 +1521,7 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
         const uint32_t x = mb + (uint32_t)lane;
         const bool have = (uint32_t)lane < cntE;
         uint32_t ent = 0;
-        if (have) ent = x < nst ? A.elist[e0 + x] : ((A.n_items + wave + kAccWaves * (x - nst)) | 0x80000000u);
+        if (have) ent = x < nst ? A.elist[e0 + x] : ((A.n_items + wave + nw * (x - nst)) | 0x80000000u);
         const uint32_t j = ent & 0x7FFFFFFFu, first = have ? ent >> 31 : 0u;
         const uint2 be = have ? A.dir[(size_t)win * A.dstride + j] : make_uint2(0u, 0u);
         const uint32_t sl = have ? A.islot[j] : 0u;
@@ -1724,7 +1741,9 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     // the scratch is clean for the next call.  With unique depth, k_scan's records are found
     // through the directory; the counts staged are those of the records that came before them.
     const bool flat = !UNIQ || A.has_pre;
+    const uint32_t nw = A.parts * kAccWaves;  // a window's sub-buckets are shared out to the waves of its A.parts workgroups
     for (uint32_t sl = tid; sl < A.n_slots; sl += kAccThreads) {
+        if ((sl % nw) / kAccWaves != blockIdx.y) continue;  // (whoever walks a sub-bucket reads and clears its count)
         uint32_t *c = A.counts + (size_t)win * A.n_slots + sl;
         uint32_t v = *c;
         *c = 0u;
@@ -1752,8 +1771,13 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
             d[k] = (uint32_t)v[k];
             u[k] = d[k] - (uint32_t)(v[k] >> 32);
         }
-        store_n<kPer>(A.depth_out + w0, i0, nvalid, d);
-        store_n<kPer>(A.uniq_out + w0, i0, nvalid, u);
+        if (A.parts > 1) {
+            add_n<kPer>(A.depth_out + w0, i0, nvalid, d);
+            add_n<kPer>(A.uniq_out + w0, i0, nvalid, u);
+        } else {
+            store_n<kPer>(A.depth_out + w0, i0, nvalid, d);
+            store_n<kPer>(A.uniq_out + w0, i0, nvalid, u);
+        }
     } else {
         int v[kPer];
 #pragma unroll
@@ -1761,7 +1785,8 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
         block_scan<int, kPer>(reinterpret_cast<int *>(wave_tot), v);
 #pragma unroll
         for (int k = 0; k < kPer; ++k) d[k] = (uint32_t)v[k];
-        store_n<kPer>(A.depth_out + w0, i0, nvalid, d);
+        if (!PSUM && A.parts > 1) add_n<kPer>(A.depth_out + w0, i0, nvalid, d);
+        else store_n<kPer>(A.depth_out + w0, i0, nvalid, d);
         if (PSUM) {
             unsigned long long l[kPer], w[kPer];
 #pragma unroll
@@ -1992,9 +2017,15 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
         *fp = FastPlan();
         return true;
     }
+    // Pass 2 runs one workgroup per window -- or, when the graph has fewer windows than half the
+    // CUs, several that share the window's paths and sub-buckets and add their counts up (1000
+    // paths over 100 k segments: 25 workgroups took 0.48 ms where 250 take 0.06).
+    fp->acc_parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({16, fp->n_cus / n_win, (g.n_steps / n_win + (256u << 10) - 1) >> 18}));  // a workgroup per 256 k steps
+    if (const char *f = getenv("FLATGFA_ACC_PARTS")) fp->acc_parts = std::max(1u, std::min(64u, (uint32_t)strtoul(f, nullptr, 10)));
+    const uint32_t acc_waves = fp->acc_parts * kAccWaves;
     // Pass 2 walks k_scan's items grouped by path (the pieces of a split path share a bitset),
-    // each of its sixteen waves a contiguous stretch of the list: paths are dealt to the waves
-    // longest first, each to the wave with the least steps so far.
+    // each of its waves a contiguous stretch of the list: paths are dealt to the waves longest
+    // first, each to the wave with the least steps so far.
     {
         std::vector<std::vector<uint32_t>> by_path;  // item indices per path that has items
         std::vector<uint64_t> path_steps;
@@ -2012,8 +2043,8 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
         std::vector<uint32_t> order(by_path.size());
         std::iota(order.begin(), order.end(), 0u);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return path_steps[a] > path_steps[b]; });
-        std::vector<std::vector<uint32_t>> per_wave(kAccWaves);
-        std::vector<uint64_t> load(kAccWaves, 0);
+        std::vector<std::vector<uint32_t>> per_wave(acc_waves);
+        std::vector<uint64_t> load(acc_waves, 0);
         for (uint32_t gi : order) {
             const uint32_t wv = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
             load[wv] += path_steps[gi] + 64;
@@ -2023,12 +2054,12 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
                 first = false;
             }
         }
-        std::vector<uint32_t> elist, wave_off(kAccWaves + 1, 0);
-        for (uint32_t wv = 0; wv < kAccWaves; ++wv) {
+        std::vector<uint32_t> elist, wave_off(acc_waves + 1, 0);
+        for (uint32_t wv = 0; wv < acc_waves; ++wv) {
             wave_off[wv] = (uint32_t)elist.size();
             elist.insert(elist.end(), per_wave[wv].begin(), per_wave[wv].end());
         }
-        wave_off[kAccWaves] = (uint32_t)elist.size();
+        wave_off[acc_waves] = (uint32_t)elist.size();
         FAST_TRY(hipMalloc(&fp->elist, (elist.size() + 1) * 4));
         if (!elist.empty()) FAST_TRY(hipMemcpy(fp->elist, elist.data(), elist.size() * 4, hipMemcpyHostToDevice));
         FAST_TRY(hipMalloc(&fp->wave_off, wave_off.size() * 4));
@@ -2102,7 +2133,7 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
 // Scratch for path sums riding on seg_depth: one {sum len, sum depth * len} per (window, item).
 // False when that would be out of proportion (then the caller walks the steps a second time).
 bool fast_plan_want_path_sums(FastPlan *fp) {
-    if (!fp->eligible || fp->wb != 12) return false;
+    if (!fp->eligible || fp->wb != 12 || fp->acc_parts > 1) return false;  // (the fused form needs a window's final depth in one workgroup)
     if (fp->psum_part) return true;
     const uint64_t bytes = (uint64_t)fp->n_win * fp->dstride * 16;
     if (bytes > (256ull << 20)) return false;
@@ -2149,6 +2180,7 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
     // (and whenever the wave-per-path kernels ran: it saves their cursors for pass 2)
     const uint32_t grid = has_pre ? fp.n_slots : std::min<uint32_t>(fp.n_items, fp.n_slots);
     ScanArgs sa;
+    sa.zero_a = sa.zero_b = nullptr;
     sa.steps = g.steps;
     sa.n_steps = g.n_steps;
     sa.items = reinterpret_cast<uint4 *>(fp.items);
@@ -2177,7 +2209,8 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
     AccArgs aa{g.n_segs, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.counts0, has_pre ? 1u : 0u, fp.buckets,
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
                fp.work_counter, fp.max_back, depth_out, uniq_out, status, fp.dbg,
-               reinterpret_cast<const uint4 *>(fp.items), g.seg_len, ps ? reinterpret_cast<ulonglong2 *>(fp.psum_part) : nullptr};
+               reinterpret_cast<const uint4 *>(fp.items), g.seg_len, ps ? reinterpret_cast<ulonglong2 *>(fp.psum_part) : nullptr,
+               fp.acc_parts};
     if (fp.n_short) {
         if (hipMemsetAsync(fp.work_counter, 0, 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
         const uint32_t sgrid = std::min<uint32_t>((fp.n_short + kWaves - 1) / kWaves, fp.n_slots);
@@ -2195,21 +2228,31 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
         else hipLaunchKernelGGL(k_walk_medium<false>, dim3(mgrid), dim3(kMediumWaves * 64), fp.lds_bytes_medium, stream, sm);
     }
     if (grid) {
+        if (fp.acc_parts > 1) {
+            sa.zero_a = depth_out;
+            sa.zero_b = uniq_out;
+        }
         ProfScope pscope("k_scan", stream);
         if (fp.dbg) hipLaunchKernelGGL(k_scan<true>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
         else hipLaunchKernelGGL(k_scan<false>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
     }
+    if (fp.acc_parts > 1 && !grid) {  // the window's workgroups add to the outputs: cleared by k_scan, or here when it does not run
+        ProfScope pscope("memset_outputs", stream);
+        if (hipMemsetAsync(depth_out, 0, (size_t)g.n_segs * 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
+        if (uniq_out && hipMemsetAsync(uniq_out, 0, (size_t)g.n_segs * 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
+    }
     {
         ProfScope pscope(uniq_out ? "k_accum<uniq>" : (ps ? "k_accum<depth+paths>" : "k_accum<depth>"), stream);
+        const dim3 agrid(fp.n_win, fp.acc_parts);
         if (uniq_out) {
-            if (fp.wb == 11) hipLaunchKernelGGL((k_accum<true, 11>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
-            else if (fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
-            else hipLaunchKernelGGL((k_accum<true, 13>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
+            if (fp.wb == 11) hipLaunchKernelGGL((k_accum<true, 11>), agrid, dim3(kAccThreads), 0, stream, aa);
+            else if (fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12>), agrid, dim3(kAccThreads), 0, stream, aa);
+            else hipLaunchKernelGGL((k_accum<true, 13>), agrid, dim3(kAccThreads), 0, stream, aa);
         } else {
-            if (fp.wb == 11) hipLaunchKernelGGL((k_accum<false, 11>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
-            else if (fp.wb == 12 && ps) hipLaunchKernelGGL((k_accum<false, 12, true>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
-            else if (fp.wb == 12) hipLaunchKernelGGL((k_accum<false, 12>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
-            else hipLaunchKernelGGL((k_accum<false, 13>), dim3(fp.n_win), dim3(kAccThreads), 0, stream, aa);
+            if (fp.wb == 11) hipLaunchKernelGGL((k_accum<false, 11>), agrid, dim3(kAccThreads), 0, stream, aa);
+            else if (fp.wb == 12 && ps) hipLaunchKernelGGL((k_accum<false, 12, true>), agrid, dim3(kAccThreads), 0, stream, aa);
+            else if (fp.wb == 12) hipLaunchKernelGGL((k_accum<false, 12>), agrid, dim3(kAccThreads), 0, stream, aa);
+            else hipLaunchKernelGGL((k_accum<false, 13>), agrid, dim3(kAccThreads), 0, stream, aa);
         }
     }
     if (ps && fp.n_items) {

@@ -12,6 +12,7 @@ struct FastPlan {
     bool eligible = false;
     bool cap_forced = false;   // FLATGFA_BUCKET_CAP (tests): the capacity must not grow
     uint32_t n_cus = 256;
+    uint32_t acc_parts = 1;  // workgroups per window in pass 2 (small graphs: fewer windows than CUs)
     uint32_t n_slots = 0;      // sub-buckets per window = persistent workgroups of pass 1
     uint32_t n_win = 0;        // accumulation windows
     uint32_t wb = 12;          // log2 of the window size (4096 segments, 8192 beyond 4 M segments)

@@ -18,19 +18,23 @@ pytestmark = pytest.mark.gpu
 FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
-@pytest.fixture(params=["auto", "atomic", "tinycap", "pieces", "noshort", "handback"])
+@pytest.fixture(params=["auto", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3"])
 def device_path(request, monkeypatch):
     """Runs a test once per device path: the bucketed path (default: short paths walked by single
     waves, k_scan_short; the rest by whole workgroups, k_scan), the simple global-atomic kernels,
     the bucketed path with 8-record buckets so that nearly every record takes the overflow route,
     long paths cut into 512-step pieces, k_scan alone (no wave-per-path kernels), and short paths
-    sent to k_scan_short regardless of their run count (so that it has to hand some back).  The variables
-    are read when a graph becomes resident."""
+    sent to k_scan_short regardless of their run count (so that it has to hand some back), and
+    three pass-2 workgroups per window whatever the graph's size (by default only small graphs
+    share their windows out).  The variables are read when a graph becomes resident."""
     monkeypatch.delenv("FLATGFA_DEPTH_PATH", raising=False)
     monkeypatch.delenv("FLATGFA_BUCKET_CAP", raising=False)
     monkeypatch.delenv("FLATGFA_PIECE_STEPS", raising=False)
     monkeypatch.delenv("FLATGFA_SHORT_MAX", raising=False)
     monkeypatch.delenv("FLATGFA_SHORT_ANY", raising=False)
+    monkeypatch.delenv("FLATGFA_ACC_PARTS", raising=False)
+    if request.param == "parts3":
+        monkeypatch.setenv("FLATGFA_ACC_PARTS", "3")
     if request.param == "noshort":
         monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
     if request.param == "handback":  # short paths go to k_scan_short whatever their run count: it hands back what does not fit
