@@ -49,6 +49,7 @@ WORKLOADS = {
     "cfgL-chrom": (1_000_000, 1000, 100_000, "chromosome"),   # paths along the graph, half of them downwards, runs of 3.3
     "cfgL-short": (1_000_000, 100_000, 1000, "pangenome"),
     "cfgL-fewlong": (1_000_000, 100, 1_000_000, "pangenome"),
+    "cfgL-4paths": (1_000_000, 4, 25_000_000, "pangenome"),   # fewer paths than pass 2 has waves per window
     "cfgL-medium": (1_000_000, 10_000, 10_000, "pangenome"),  # paths of ten blocks each
     "cfgL-32k": (1_000_000, 3125, 32_000, "pangenome"),       # mid-length paths
     "cfgL-100kseg": (100_000, 1000, 100_000, "pangenome"),    # deep coverage of a small graph: 25 windows

@@ -1217,6 +1217,11 @@ struct AccArgs {
     const uint4 *items;                  // item j belongs to path items[j].w
     const uint32_t *seg_len;
     ulonglong2 *psum_part;               // [n_win][dstride] {sum len, sum depth * len} of item j in this window
+    // Paths too long for one wave (more than half a wave's even share of the steps) are walked by
+    // all sixteen waves of one of the window's workgroups together, one such path after the
+    // other, on one shared bitset:
+    const uint32_t *fat_off;   // [parts + 1] which of these paths workgroup blockIdx.y walks
+    const uint32_t *fat_woff;  // [n_fat][kAccWaves + 1] which stretch of elist each wave walks of the path's items
     uint32_t parts;  // workgroups per window (blockIdx.y): each walks its share of the paths / sub-buckets and ADDS its counts to the (zeroed) outputs
 };
 
@@ -1499,14 +1504,16 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
 // then walked as one stream, 64 records per step whatever the items' sizes, every lane knowing
 // which item (hence which path's bitset) its record belongs to.  A wave keeps kSlots bitsets: a
 // step never spans more paths than that.  Three steps' records are requested ahead of their use.
-template <int WB>
-__device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, uint32_t *mybits, uint32_t *mark, uint32_t *pend, const uint32_t *wbase, uint32_t win) {
+// SHARED: the stretch [e0, e1) is this wave's share of ONE path's items, `mybits` is the same
+// for all waves of the workgroup and has been cleared by it: no hand-backs, no clearing here.
+template <int WB, bool SHARED>
+__device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, uint32_t *mybits, uint32_t *mark, uint32_t *pend, const uint32_t *wbase, uint32_t win,
+                                             uint32_t e0, uint32_t e1) {
     constexpr uint32_t kNW = (1u << WB) / 32u;             // words per bitset
     constexpr uint32_t kSlots = WB <= 12 ? 8u : 4u;
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(blockIdx.y * kAccWaves + (threadIdx.x >> 6)), nw = A.parts * kAccWaves;
-    const uint32_t e0 = __builtin_amdgcn_readfirstlane(A.wave_off[wave]), e1 = __builtin_amdgcn_readfirstlane(A.wave_off[wave + 1]);
-    const uint32_t nback = A.has_pre ? min(__builtin_amdgcn_readfirstlane(*A.work_counter), A.max_back) : 0u;
+    const uint32_t nback = (A.has_pre && !SHARED) ? min(__builtin_amdgcn_readfirstlane(*A.work_counter), A.max_back) : 0u;
     const uint32_t nst = e1 - e0;
     const uint32_t nE = nst + (nback > wave ? (nback - wave + nw - 1u) / nw : 0u);
     uint32_t gbase = 0, carryG = 0;  // path ordinals are 1-based: 0 = none yet
@@ -1592,7 +1599,7 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
                 }
                 run_pending<WB>(pq, R, mybits, A.dbg, kPendRun);
             }
-            for (uint32_t k = 1; k <= fresh; ++k) {
+            for (uint32_t k = 1; !SHARED && k <= fresh; ++k) {
                 uint32_t *bs = mybits + ((hdone + k) & (kSlots - 1u)) * kNW;
                 for (uint32_t i = lane; i < kNW / 2u; i += 64) reinterpret_cast<uint2 *>(bs)[i] = make_uint2(0u, 0u);
             }
@@ -1650,12 +1657,10 @@ __device__ __forceinline__ unsigned long long wave_total_u64(unsigned long long 
 // the loads behind it until memory had acknowledged it -- and k_path_reduce adds the windows up.
 template <int WB>
 __device__ __forceinline__ void sum_groups(const AccArgs &A, const unsigned long long *Lw, const unsigned long long *Ww,
-                                           const uint32_t *wbase, uint32_t win) {
+                                           const uint32_t *wbase, uint32_t win, uint32_t e0, uint32_t e1) {
     constexpr uint32_t kW = 1u << WB;
     constexpr int kAhead = 8;
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t e0 = __builtin_amdgcn_readfirstlane(A.wave_off[wave]), e1 = __builtin_amdgcn_readfirstlane(A.wave_off[wave + 1]);
     ulonglong2 *part = A.psum_part + (size_t)win * A.dstride;
     const auto add = [&](uint32_t rec, unsigned long long &ls, unsigned long long &ws) {
         const uint32_t rel = rec & (kW - 1), e1x = rel + ((rec >> WB) & 1023u) + 1u;  // one past the run's last segment
@@ -1755,7 +1760,20 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     __syncthreads();
     const uint32_t *wbase = A.buckets + (size_t)win * A.n_slots * A.cap;
     if (flat) apply_flat<UNIQ, WB>(A, D, R, scnt, wbase);
-    if (UNIQ) apply_groups<WB>(A, D, R, bits + wave * (kSlots * (kW / 32)), marks + wave * 64, pend + wave * (3 * kPend), wbase, win);
+    const uint32_t vwave = __builtin_amdgcn_readfirstlane(blockIdx.y * kAccWaves + wave);
+    if (UNIQ) {
+        apply_groups<WB, false>(A, D, R, bits + wave * (kSlots * (kW / 32)), marks + wave * 64, pend + wave * (3 * kPend), wbase, win,
+                                __builtin_amdgcn_readfirstlane(A.wave_off[vwave]), __builtin_amdgcn_readfirstlane(A.wave_off[vwave + 1]));
+        // the long paths, one after the other, all waves on each: the bitset is slot 1 of wave 0's
+        for (uint32_t f = A.fat_off[blockIdx.y]; f < A.fat_off[blockIdx.y + 1]; ++f) {
+            __syncthreads();
+            for (uint32_t i = tid; i < kW / 32; i += kAccThreads) bits[kW / 32 + i] = 0u;
+            __syncthreads();
+            const uint32_t *wo = A.fat_woff + (size_t)f * (kAccWaves + 1) + wave;
+            apply_groups<WB, true>(A, D, R, bits, marks + wave * 64, pend + wave * (3 * kPend), wbase, win,
+                                   __builtin_amdgcn_readfirstlane(wo[0]), __builtin_amdgcn_readfirstlane(wo[1]));
+        }
+    }
     __syncthreads();
     const uint32_t i0 = kPer * tid;
     uint32_t d[kPer], u[kPer];
@@ -1804,7 +1822,11 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
             }
             if (tid == 0) Lw[0] = Ww[0] = 0ull;
             __syncthreads();
-            sum_groups<WB>(A, Lw, Ww, wbase, win);
+            sum_groups<WB>(A, Lw, Ww, wbase, win, __builtin_amdgcn_readfirstlane(A.wave_off[vwave]), __builtin_amdgcn_readfirstlane(A.wave_off[vwave + 1]));
+            for (uint32_t f = A.fat_off[blockIdx.y]; f < A.fat_off[blockIdx.y + 1]; ++f) {
+                const uint32_t *wo = A.fat_woff + (size_t)f * (kAccWaves + 1) + wave;
+                sum_groups<WB>(A, Lw, Ww, wbase, win, __builtin_amdgcn_readfirstlane(wo[0]), __builtin_amdgcn_readfirstlane(wo[1]));
+            }
         }
     }
 }
@@ -2043,9 +2065,28 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
         std::vector<uint32_t> order(by_path.size());
         std::iota(order.begin(), order.end(), 0u);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return path_steps[a] > path_steps[b]; });
-        std::vector<std::vector<uint32_t>> per_wave(acc_waves);
-        std::vector<uint64_t> load(acc_waves, 0);
+        // A path with more than half a wave's even share of the steps would hold its wave up (four
+        // paths of 25 M steps: four waves busy out of sixteen, pass 2 2.6 times slower).  Such
+        // paths go to the window's workgroups whole -- to the one with the least so far -- and
+        // their pieces to its sixteen waves in turn; the others are dealt to single waves as before.
+        uint64_t total_steps = 0;
+        for (uint64_t v : path_steps) total_steps += v;
+        const uint64_t fat_min = total_steps / (2ull * acc_waves) + 1;
+        std::vector<std::vector<uint32_t>> per_wave(acc_waves), fat_of_part(fp->acc_parts);
+        std::vector<uint64_t> load(acc_waves, 0), part_load(fp->acc_parts, 0);
         for (uint32_t gi : order) {
+            if (path_steps[gi] < fat_min || by_path[gi].size() < 2 || getenv("FLATGFA_NO_FAT_PATHS")) continue;
+            const uint32_t q = (uint32_t)(std::min_element(part_load.begin(), part_load.end()) - part_load.begin());
+            part_load[q] += path_steps[gi];
+            fat_of_part[q].push_back(gi);
+        }
+        for (uint32_t q = 0; q < fp->acc_parts; ++q)
+            for (uint32_t wv = 0; wv < kAccWaves; ++wv) load[q * kAccWaves + wv] = part_load[q] / kAccWaves;
+        std::vector<bool> is_fat(by_path.size(), false);
+        for (const auto &v : fat_of_part)
+            for (uint32_t gi : v) is_fat[gi] = true;
+        for (uint32_t gi : order) {
+            if (is_fat[gi]) continue;
             const uint32_t wv = (uint32_t)(std::min_element(load.begin(), load.end()) - load.begin());
             load[wv] += path_steps[gi] + 64;
             bool first = true;
@@ -2060,6 +2101,28 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
             elist.insert(elist.end(), per_wave[wv].begin(), per_wave[wv].end());
         }
         wave_off[acc_waves] = (uint32_t)elist.size();
+        std::vector<uint32_t> fat_off(fp->acc_parts + 1, 0), fat_woff;
+        for (uint32_t q = 0; q < fp->acc_parts; ++q) {
+            fat_off[q] = fp->n_fat;
+            for (uint32_t gi : fat_of_part[q]) {
+                const std::vector<uint32_t> &its = by_path[gi];
+                for (uint32_t wv = 0; wv < kAccWaves; ++wv) {
+                    fat_woff.push_back((uint32_t)elist.size());
+                    bool first = true;
+                    for (size_t k = wv; k < its.size(); k += kAccWaves) {
+                        elist.push_back(its[k] | (first ? 0x80000000u : 0u));
+                        first = false;
+                    }
+                }
+                fat_woff.push_back((uint32_t)elist.size());
+                fp->n_fat += 1;
+            }
+        }
+        fat_off[fp->acc_parts] = fp->n_fat;
+        FAST_TRY(hipMalloc(&fp->fat_off, fat_off.size() * 4));
+        FAST_TRY(hipMemcpy(fp->fat_off, fat_off.data(), fat_off.size() * 4, hipMemcpyHostToDevice));
+        FAST_TRY(hipMalloc(&fp->fat_woff, (fat_woff.size() + 1) * 4));
+        if (!fat_woff.empty()) FAST_TRY(hipMemcpy(fp->fat_woff, fat_woff.data(), fat_woff.size() * 4, hipMemcpyHostToDevice));
         FAST_TRY(hipMalloc(&fp->elist, (elist.size() + 1) * 4));
         if (!elist.empty()) FAST_TRY(hipMemcpy(fp->elist, elist.data(), elist.size() * 4, hipMemcpyHostToDevice));
         FAST_TRY(hipMalloc(&fp->wave_off, wave_off.size() * 4));
@@ -2162,7 +2225,7 @@ bool fast_plan_grow(FastPlan *fp) {
 
 void fast_plan_destroy(FastPlan *fp) {
     for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot,
-                    (void *)fp->elist, (void *)fp->wave_off, (void *)fp->items, (void *)fp->short_items,
+                    (void *)fp->elist, (void *)fp->wave_off, (void *)fp->fat_off, (void *)fp->fat_woff, (void *)fp->items, (void *)fp->short_items,
                     (void *)fp->medium_items, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part})
         if (p) (void)hipFree(p);
     *fp = FastPlan();
@@ -2210,7 +2273,7 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
                fp.work_counter, fp.max_back, depth_out, uniq_out, status, fp.dbg,
                reinterpret_cast<const uint4 *>(fp.items), g.seg_len, ps ? reinterpret_cast<ulonglong2 *>(fp.psum_part) : nullptr,
-               fp.acc_parts};
+               fp.fat_off, fp.fat_woff, fp.acc_parts};
     if (fp.n_short) {
         if (hipMemsetAsync(fp.work_counter, 0, 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
         const uint32_t sgrid = std::min<uint32_t>((fp.n_short + kWaves - 1) / kWaves, fp.n_slots);

@@ -27,7 +27,10 @@ struct FastPlan {
     uint32_t *islot = nullptr;     // u32[dstride] the sub-bucket that holds item j's records
     uint32_t dstride = 0;          // n_items + max_back + 1
     uint32_t *elist = nullptr;     // k_scan's items in pass 2's order (grouped by path, split among its waves)
-    uint32_t *wave_off = nullptr;  // u32[17] the stretch of elist each wave of pass 2 walks
+    uint32_t *wave_off = nullptr;  // u32[16 * acc_parts + 1] the stretch of elist each wave of pass 2 walks
+    uint32_t *fat_off = nullptr;   // u32[acc_parts + 1] the long paths each of a window's workgroups walks with all its waves
+    uint32_t *fat_woff = nullptr;  // u32[n_fat][17] the stretch of elist each wave walks of such a path's items
+    uint32_t n_fat = 0;
     void *items = nullptr;         // uint4[n_items + max_back] whole paths and pieces of long paths, longest first,
                                    // with room for the short paths k_scan_short hands back
     uint32_t n_items = 0;
