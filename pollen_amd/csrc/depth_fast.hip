@@ -88,6 +88,7 @@ constexpr uint32_t kDbgNoStore = 1, kDbgNoTiles = 8, kDbgHotLoads = 16, kDbgTime
 #define FGFA_SKIP(bit) (DBG && (A.dbg & (bit)))
 
 struct ScanArgs {
+    uint32_t seg_base, n_total, ranged;  // ranged: this walk keeps what falls into [seg_base, seg_base + n_segs) of the graph's n_total segments
     uint32_t *zero_a, *zero_b;  // k_scan clears these vectors of n_segs counts first (pass 2 adds to them when windows are shared); or null
     const uint32_t *steps;
     uint4 *items;        // work items, longest first: {begin, end, -, path}; room behind the first n_items
@@ -746,15 +747,15 @@ struct RWave {
     uint32_t vm[3];
     int lane;
     bool epoch_ok;  // the item before the current one is complete: this wave may append records
-    unsigned long long tacc[8], tlast;  // kDbgTime (diagnostic): cycles per phase of this wave
+    uint32_t tacc[8], tlast;  // kDbgTime (diagnostic): cycles per phase of this wave (scalar registers; a kernel is far shorter than 2^32 cycles)
 };
 
 // kDbgTime: charge the cycles since the last mark to phase `ph`
 template <bool DBG>
 __device__ __forceinline__ void tmark(const ScanArgs &A, RWave &w, int ph) {
     if (DBG && (A.dbg & kDbgTime)) {
-        const unsigned long long t = __builtin_readcyclecounter();
-        w.tacc[ph] += t - w.tlast;
+        const uint32_t t = __builtin_amdgcn_readfirstlane((uint32_t)__builtin_readcyclecounter());
+        w.tacc[ph] = __builtin_amdgcn_readfirstlane(w.tacc[ph] + (t - w.tlast));
         w.tlast = t;
     }
 }
@@ -801,6 +802,8 @@ __device__ __forceinline__ void tmark(const ScanArgs &A, RWave &w, int ph) {
 // LDS control words of k_scan, behind the two cursor tables: the next block of the current /
 // next item nobody has taken yet (two cells, by item parity), how many waves have left the item
 // (two cells), and how many items are complete.
+// k_scan's builds: plain, diagnostic (FLATGFA_DEBUG_SKIP), ranged (one of several walks of a graph beyond 16 M segments)
+constexpr int kModePlain = 0, kModeDbg = 1, kModeRanged = 2;
 #ifndef FGFA_SLOTS_MODE
 #define FGFA_SLOTS_MODE 0
 #endif
@@ -818,8 +821,9 @@ __device__ __forceinline__ uint32_t epoch_now(uint32_t *ctl) {
 // the last run).  The whole run must lie below n_segs: that is the bounds check of every step in
 // it.  A run that crosses into the next window (at most one: runs are shorter than a window) is
 // emitted as two records.
-template <bool DBG, int K>
+template <int MODE, int K>
 __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *bcur, uint32_t *mine, uint32_t base, uint32_t n) {
+    constexpr bool DBG = MODE == kModeDbg;
     // K chunks of 64 entries side by side (n counts the entries of the last one; the others are
     // full): each chunk is a chain of LDS read, cursor atomic, permute and store, and the waves of
     // a CU are too few to hide one chain at a time when most steps start a run.
@@ -840,7 +844,16 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
     for (int k = 0; k < K; ++k) {
         lenm1[k] = (s[k].y - e[k].y - 1u) & 1023u;
         valid[k] = valid[k] && e[k].x != kInvalid;
-        const uint32_t id = e[k].x - (lenm1[k] & down);  // a downward run is emitted from its low end
+        uint32_t id = e[k].x - (lenm1[k] & down);  // a downward run is emitted from its low end
+        if (MODE == kModeRanged) {  // (uniform) the run's part inside this walk's range, if any; beyond the graph: the bounds check below
+            const uint32_t hi = id + lenm1[k];
+            const bool outside = hi >= A.n_total;
+            const uint32_t lo2 = max(id, A.seg_base), hi2 = min(hi, A.seg_base + A.n_segs - 1u);
+            const bool keep = lo2 <= hi2;
+            valid[k] = valid[k] && (keep || outside);
+            id = outside ? A.n_segs : lo2 - A.seg_base;
+            lenm1[k] = outside ? 0u : hi2 - lo2;
+        }
         const bool b = valid[k] && id + lenm1[k] >= A.n_segs;
         bad |= b;
         valid[k] = valid[k] && !b;
@@ -870,7 +883,7 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
 
 // Emit the oldest entries, 64 at a time, while at least 65 are queued, then move what is left to
 // the front of the queue.  With `all`, a terminator is appended and everything is emitted.
-template <bool DBG, int WIDE = 1>
+template <int MODE, int WIDE = 1>
 __device__ __forceinline__ void drain_raw(const ScanArgs &A, RWave &w, uint32_t *bcur, uint32_t *mine, bool all) {
     if (all) {
         if (w.lane == 0) w.q[w.fill] = make_uint2(kInvalid, 0u);
@@ -879,13 +892,13 @@ __device__ __forceinline__ void drain_raw(const ScanArgs &A, RWave &w, uint32_t 
     uint32_t base = 0;
     if (WIDE > 1) {
         while (w.fill - base >= 64u * WIDE + 1u) {
-            emit_raw<DBG, WIDE>(A, w, bcur, mine, base, 64u);
+            emit_raw<MODE, WIDE>(A, w, bcur, mine, base, 64u);
             base += 64u * WIDE;
         }
     }
     while (w.fill - base >= 65u || (all && w.fill - base >= 2u)) {
         const uint32_t n = min(64u, w.fill - 1u - base);
-        emit_raw<DBG, 1>(A, w, bcur, mine, base, n);
+        emit_raw<MODE, 1>(A, w, bcur, mine, base, n);
         base += n;
     }
     if (all) {
@@ -966,9 +979,10 @@ __device__ __forceinline__ Item make_item(const ScanArgs &A, bool have, uint4 d,
 // appends.  If the queue cannot take the block's starts, or holds a chunk's worth and this wave may
 // emit, the oldest entries are emitted first, one chunk at a time; a block that queues a lot is
 // followed by a wide drain.
-template <bool DBG>
+template <int MODE>
 __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *bcur, uint32_t *mine, uint32_t *ctl, uint32_t rr,
                                          uint32_t (&a)[16], const uint32_t (&pj)[16], uint32_t nsteps) {
+    constexpr bool DBG = MODE == kModeDbg;
     unsigned long long m[16], act[4];
     uint32_t cnt[4];
     const bool partial = nsteps < 1024u;  // (wave-uniform) a partial block ends with a terminator
@@ -1007,7 +1021,7 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
             }
             tmark<DBG>(A, w, 1);
         }
-        if (w.epoch_ok) drain_raw<DBG>(A, w, bcur, mine, false);
+        if (w.epoch_ok) drain_raw<MODE>(A, w, bcur, mine, false);
         tmark<DBG>(A, w, 3);
     }
     const uint32_t off[4] = {(s01 & 0xFFFFu) - cnt[0], t0 + (s01 >> 16) - cnt[1], t0 + t1 + (s23 & 0xFFFFu) - cnt[2],
@@ -1027,16 +1041,18 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
     // emitted here, where the block's ids are dead and there are registers for kWide chunks side
     // by side.  (Draining only here was measured: no gain on such paths, and short items -- 32 k
     // steps -- lost 15 %: their waves more often find the item before them not wrapped up yet.)
-    if (kWide > 1 && !FGFA_SKIP(kDbgNoEmit) && w.fill >= 64u * kWide + 1u) {
+    // (the diagnostic build keeps cycle counters in registers and has room for two chunks only)
+    if (kWide > 1 && !FGFA_SKIP(kDbgNoEmit) && w.fill >= 64u * (DBG ? 2 : kWide) + 1u) {
         if (!w.epoch_ok && epoch_now(ctl) >= rr) w.epoch_ok = true;
         tmark<DBG>(A, w, 1);
-        if (w.epoch_ok) drain_raw<DBG, kWide>(A, w, bcur, mine, false);
+        if (w.epoch_ok) drain_raw<MODE, (DBG ? 2 : kWide)>(A, w, bcur, mine, false);
         tmark<DBG>(A, w, 3);
     }
 }
 
-template <bool DBG>
+template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
+    constexpr bool DBG = MODE == kModeDbg;
     extern __shared__ uint32_t lds[];
     // layout: [bcur: nwp][snap: nwp][control words][run queues: kWaves * kQ2 entries of 8 bytes]
     uint32_t *bcur = lds;
@@ -1052,7 +1068,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     w.lane = lane;
     w.epoch_ok = true;
     for (int k = 0; k < 8; ++k) w.tacc[k] = 0;
-    w.tlast = (DBG && (A.dbg & kDbgTime)) ? __builtin_readcyclecounter() : 0ull;
+    w.tlast = (DBG && (A.dbg & kDbgTime)) ? __builtin_amdgcn_readfirstlane((uint32_t)__builtin_readcyclecounter()) : 0u;
     if (A.zero_a) {  // small graphs: pass 2 adds to the outputs (AccArgs::parts)
         for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < A.n_segs; i += gridDim.x * kThreads) {
             A.zero_a[i] = 0u;
@@ -1112,7 +1128,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         uint32_t got = 0;                                                                     \
         if (lane == 0) got = atomicAdd(&ctl[kCtlNext + (rr & 1u)], 1u);                       \
         if (!FGFA_SKIP(kDbgNoTiles)) {                                                        \
-            block16r<DBG>(A, w, bcur, mine, ctl, rr, a, pj, mine_now + 1 == it.nblk ? 16u * it.nl_last : 1024u); \
+            block16r<MODE>(A, w, bcur, mine, ctl, rr, a, pj, mine_now + 1 == it.nblk ? 16u * it.nl_last : 1024u); \
         } else if (a[0] == 0x3FFFFFFFu) {                                                     \
             atomicOr(A.status, kStDebug);                                                     \
         }                                                                                     \
@@ -1130,7 +1146,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
                 if (w.fill + 66u > kQ2) {
                     while (epoch_now(ctl) < rr) __builtin_amdgcn_s_sleep(2);
                     w.epoch_ok = true;
-                    drain_raw<DBG>(A, w, bcur, mine, false);
+                    drain_raw<MODE>(A, w, bcur, mine, false);
                 }
                 tile_narrow_raw(A, w, t, (uint32_t)min((uint64_t)64, it.e - t));
             }
@@ -1149,7 +1165,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             w.epoch_ok = true;
         }
         tmark<DBG>(A, w, 1);
-        drain_raw<DBG, kWide>(A, w, bcur, mine, true);
+        drain_raw<MODE, (DBG ? 2 : kWide)>(A, w, bcur, mine, true);
         tmark<DBG>(A, w, 3);
         // This wave is done with the item: it requests its first two blocks of the next one right away.
         const uint32_t done_job = job;
@@ -1181,7 +1197,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     }
     if (DBG && (A.dbg & kDbgTime) && lane == 0) {
         unsigned long long *acc = reinterpret_cast<unsigned long long *>(A.status + 8);
-        for (int k = 0; k < 8; ++k) atomicAdd(&acc[k], w.tacc[k]);
+        for (int k = 0; k < 8; ++k) atomicAdd(&acc[k], (unsigned long long)w.tacc[k]);
     }
 #undef FGFA_PRELOAD
 #undef FGFA_BLOCK
@@ -1921,19 +1937,20 @@ int alloc_buckets(FastPlan *fp, uint64_t want_cap) {
 
 }  // namespace
 
-bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp) {
+// The plan of one range of segments, [seg_base, seg_base + n_range): the whole graph, or one of
+// the ranges of a graph beyond 16 M segments.
+static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp, uint32_t seg_base,
+                         uint32_t n_range) {
     *fp = FastPlan();
-    if (g.n_segs == 0 || g.n_paths == 0 || g.n_steps == 0) return true;
-    if ((reinterpret_cast<uintptr_t>(g.steps) & 15u) != 0) return true;  // 16-byte step loads
+    fp->seg_base = seg_base;
+    fp->n_range = n_range;
+    const bool ranged = seg_base != 0 || n_range != g.n_segs;
     // Windows of 4096 segments up to 4 M segments, of 8192 beyond (pass 2 keeps a window's
-    // difference array and per-path bitsets in LDS); beyond 16 M the atomic kernels take over.
+    // difference array and per-path bitsets in LDS).
     uint32_t wb = g.n_segs <= 1024u * 4096u ? 12u : 13u;
     if (const char *f = getenv("FLATGFA_WB")) wb = (uint32_t)strtoul(f, nullptr, 10);
-    const uint32_t n_win = (uint32_t)(((uint64_t)g.n_segs + (1u << wb) - 1) >> wb);
+    const uint32_t n_win = (uint32_t)(((uint64_t)n_range + (1u << wb) - 1) >> wb);
     if (n_win > kMaxWin) return true;
-    if (const char *off = getenv("FLATGFA_MAX_WINDOWS")) {
-        if (n_win > strtoul(off, nullptr, 10)) return true;
-    }
     hipDeviceProp_t prop;
     int dev = 0;
     FAST_TRY(hipGetDevice(&dev));
@@ -1947,10 +1964,11 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     fp->lds_bytes_scan = scan_lds_bytes(fp->nwp);
     if (fp->lds_bytes_scan + 64 > kLdsLimit) return true;
     if (const char *d = getenv("FLATGFA_DEBUG_SKIP")) fp->dbg = (uint32_t)strtoul(d, nullptr, 10);
+    if (fp->dbg && ranged) return true;  // the diagnostic build of k_scan has no registers left for ranges
     // Paths of at most `short_max` steps are walked by single waves (k_scan_short), unless their
     // last block would reach beyond the step array.  Those kernels address at most 256 windows
     // of 4096 segments.
-    uint64_t short_max = (fp->dbg || wb != kShortWinBits || n_win > kShortMaxWin || g.n_segs > kShortMaxSegs) ? 0 : kShortMax;
+    uint64_t short_max = (fp->dbg || ranged || wb != kShortWinBits || n_win > kShortMaxWin || g.n_segs > kShortMaxSegs) ? 0 : kShortMax;  // (the wave-per-path kernels know nothing of ranges)
     if (const char *forced = getenv("FLATGFA_SHORT_MAX")) short_max = std::min<uint64_t>(short_max, strtoull(forced, nullptr, 10));
     // Which kernel walks a path depends on how many runs it has: short paths must fit the run queue,
     // paths with at most kMediumRuns runs are walked by single waves too, eight per CU, each with a
@@ -2181,22 +2199,57 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     }
     fp->lds_bytes_short = (kShortMaxWin + kWaves * (kQCap + 2 * kPCap + (2u << kShortHash))) * 4u;
     fp->lds_bytes_medium = (kShortMaxWin + kMediumWaves * (kQCap + 2 * kPCap + (2u << kMediumHash))) * 4u;
-    FAST_TRY(hipFuncSetAttribute((const void *)k_walk_short<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_short));
-    FAST_TRY(hipFuncSetAttribute((const void *)k_walk_short<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_short));
-    FAST_TRY(hipFuncSetAttribute((const void *)k_walk_medium<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_medium));
-    FAST_TRY(hipFuncSetAttribute((const void *)k_walk_medium<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_medium));
+    // (the attribute belongs to the kernel, not to the plan: plans of different sizes live side by side)
+    FAST_TRY(hipFuncSetAttribute((const void *)k_walk_short<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_walk_short<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_walk_medium<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_walk_medium<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     FAST_TRY(hipMalloc(&fp->work_counter, 256));
     FAST_TRY(hipMemset(fp->work_counter, 0, 256));
-    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_scan));
-    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fp->lds_bytes_scan));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModePlain>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeDbg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeRanged>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     fp->eligible = true;
+    return true;
+}
+
+bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp) {
+    *fp = FastPlan();
+    if (g.n_segs == 0 || g.n_paths == 0 || g.n_steps == 0) return true;
+    if ((reinterpret_cast<uintptr_t>(g.steps) & 15u) != 0) return true;  // 16-byte step loads
+    // One range while the graph fits 2048 windows of 8192 segments (16 M); beyond, ranges of equal
+    // size, each a walk of the steps per call (64 M segments / 100 M steps: four walks, 0.5 ms,
+    // against 7.4 ms for the atomic kernels).  FLATGFA_MAX_WINDOWS keeps the old cut-off (tests).
+    uint64_t max_range = (uint64_t)kMaxWin << 13;
+    if (const char *f = getenv("FLATGFA_RANGE_SEGS")) max_range = std::max<uint64_t>(8192, strtoull(f, nullptr, 10) & ~8191ull);  // tests
+    if (const char *off = getenv("FLATGFA_MAX_WINDOWS")) {
+        const uint32_t wb = g.n_segs <= 1024u * 4096u ? 12u : 13u;
+        if ((((uint64_t)g.n_segs + (1u << wb) - 1) >> wb) > strtoul(off, nullptr, 10)) return true;
+    }
+    const uint32_t n_ranges = (uint32_t)((g.n_segs + max_range - 1) / max_range);
+    if (n_ranges > 64) return true;
+    const uint32_t per = (uint32_t)((((uint64_t)g.n_segs + n_ranges - 1) / n_ranges + 8191) & ~8191ull);
+    if (!create_range(g, hb, he, fp, 0, std::min<uint32_t>(per, g.n_segs))) return false;
+    if (n_ranges == 1 || !fp->eligible) return true;
+    fp->more = new FastPlan[n_ranges - 1];
+    fp->n_more = n_ranges - 1;
+    bool ok = true, all = true;
+    for (uint32_t r = 1; r < n_ranges && ok; ++r) {
+        const uint32_t base = r * per;
+        ok = create_range(g, hb, he, &fp->more[r - 1], base, std::min<uint32_t>(per, g.n_segs - base));
+        all = all && fp->more[r - 1].eligible;
+    }
+    if (!ok || !all) {  // all ranges or none
+        fast_plan_destroy(fp);
+        return ok;
+    }
     return true;
 }
 
 // Scratch for path sums riding on seg_depth: one {sum len, sum depth * len} per (window, item).
 // False when that would be out of proportion (then the caller walks the steps a second time).
 bool fast_plan_want_path_sums(FastPlan *fp) {
-    if (!fp->eligible || fp->wb != 12 || fp->acc_parts > 1) return false;  // (the fused form needs a window's final depth in one workgroup)
+    if (!fp->eligible || fp->wb != 12 || fp->acc_parts > 1 || fp->n_more) return false;  // (the fused form needs a window's final depth in one workgroup)
     if (fp->psum_part) return true;
     const uint64_t bytes = (uint64_t)fp->n_win * fp->dstride * 16;
     if (bytes > (256ull << 20)) return false;
@@ -2209,21 +2262,23 @@ bool fast_plan_want_path_sums(FastPlan *fp) {
 }
 
 // After a call that ran out of sub-bucket room: four times the capacity, if that is possible.
+static bool grow_range(FastPlan *fp) {
+    const uint32_t before = fp->cap;
+    if (alloc_buckets(fp, (uint64_t)before * 4) <= 0) return false;
+    return fp->cap > before;  // else the slot arithmetic allows no more
+}
+
 bool fast_plan_grow(FastPlan *fp) {
     if (!fp->eligible || fp->cap_forced) return false;
-    const uint32_t before = fp->cap;
-    if (alloc_buckets(fp, (uint64_t)before * 4) <= 0) {
-        fp->eligible = false;
-        return false;
-    }
-    if (fp->cap <= before) {
-        fp->eligible = false;  // the slot arithmetic allows no more: the atomic kernels take over
-        return false;
-    }
-    return true;
+    bool ok = grow_range(fp);
+    for (uint32_t r = 0; r < fp->n_more && ok; ++r) ok = grow_range(&fp->more[r]);  // (the status word does not say which range ran out)
+    if (!ok) fp->eligible = false;  // the atomic kernels take over
+    return ok;
 }
 
 void fast_plan_destroy(FastPlan *fp) {
+    for (uint32_t r = 0; r < fp->n_more; ++r) fast_plan_destroy(&fp->more[r]);
+    delete[] fp->more;
     for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot,
                     (void *)fp->elist, (void *)fp->wave_off, (void *)fp->fat_off, (void *)fp->fat_woff, (void *)fp->items, (void *)fp->short_items,
                     (void *)fp->medium_items, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part})
@@ -2231,9 +2286,10 @@ void fast_plan_destroy(FastPlan *fp) {
     *fp = FastPlan();
 }
 
-int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
-                   uint32_t *status, hipStream_t stream, const PathSums *ps) {
-    if (ps && (uniq_out || fp.wb != 12 || !g.seg_len || !fp.psum_part)) {
+// One range of the graph: the outputs are the range's own stretch of the result vectors.
+static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
+                     uint32_t *status, hipStream_t stream, const PathSums *ps) {
+    if (ps && (uniq_out || fp.wb != 12 || !g.seg_len || !fp.psum_part || fp.n_range != g.n_segs)) {
         set_error("fast_seg_depth: path sums ride on seg_depth with 4096-segment windows only");
         return FLATGFA_ERR_ARG;
     }
@@ -2250,7 +2306,10 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
     sa.short_items = reinterpret_cast<const uint4 *>(fp.short_items);
     sa.n_short = fp.n_short;
     sa.n_items = fp.n_items;
-    sa.n_segs = g.n_segs;
+    sa.n_segs = fp.n_range;
+    sa.seg_base = fp.seg_base;
+    sa.n_total = g.n_segs;
+    sa.ranged = (fp.seg_base != 0 || fp.n_range != g.n_segs) ? 1u : 0u;
     sa.n_win = fp.n_win;
     sa.n_slots = fp.n_slots;
     sa.wb = fp.wb;
@@ -2269,7 +2328,7 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
     sa.sink = fp.n_win * stride;
     sa.status = status;
     sa.dbg = fp.dbg;
-    AccArgs aa{g.n_segs, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.counts0, has_pre ? 1u : 0u, fp.buckets,
+    AccArgs aa{fp.n_range, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.counts0, has_pre ? 1u : 0u, fp.buckets,
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
                fp.work_counter, fp.max_back, depth_out, uniq_out, status, fp.dbg,
                reinterpret_cast<const uint4 *>(fp.items), g.seg_len, ps ? reinterpret_cast<ulonglong2 *>(fp.psum_part) : nullptr,
@@ -2296,13 +2355,14 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
             sa.zero_b = uniq_out;
         }
         ProfScope pscope("k_scan", stream);
-        if (fp.dbg) hipLaunchKernelGGL(k_scan<true>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
-        else hipLaunchKernelGGL(k_scan<false>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
+        if (fp.dbg) hipLaunchKernelGGL(k_scan<kModeDbg>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
+        else if (sa.ranged) hipLaunchKernelGGL(k_scan<kModeRanged>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
+        else hipLaunchKernelGGL(k_scan<kModePlain>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
     }
     if (fp.acc_parts > 1 && !grid) {  // the window's workgroups add to the outputs: cleared by k_scan, or here when it does not run
         ProfScope pscope("memset_outputs", stream);
-        if (hipMemsetAsync(depth_out, 0, (size_t)g.n_segs * 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
-        if (uniq_out && hipMemsetAsync(uniq_out, 0, (size_t)g.n_segs * 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
+        if (hipMemsetAsync(depth_out, 0, (size_t)fp.n_range * 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
+        if (uniq_out && hipMemsetAsync(uniq_out, 0, (size_t)fp.n_range * 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
     }
     {
         ProfScope pscope(uniq_out ? "k_accum<uniq>" : (ps ? "k_accum<depth+paths>" : "k_accum<depth>"), stream);
@@ -2338,6 +2398,16 @@ int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *d
                 acc[0] / waves, acc[1] / waves, acc[2] / waves, acc[3] / waves, acc[4] / waves, acc[5] / waves);
     }
     return FLATGFA_OK;
+}
+
+int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
+                   uint32_t *status, hipStream_t stream, const PathSums *ps) {
+    int rc = run_range(fp, g, depth_out, uniq_out, status, stream, ps);
+    for (uint32_t r = 0; r < fp.n_more && rc == FLATGFA_OK; ++r) {
+        const FastPlan &q = fp.more[r];
+        rc = run_range(q, g, depth_out + q.seg_base, uniq_out ? uniq_out + q.seg_base : nullptr, status, stream, nullptr);
+    }
+    return rc;
 }
 
 }  // namespace fgfa_dev

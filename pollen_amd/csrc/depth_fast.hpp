@@ -11,6 +11,12 @@ namespace fgfa_dev {
 struct FastPlan {
     bool eligible = false;
     bool cap_forced = false;   // FLATGFA_BUCKET_CAP (tests): the capacity must not grow
+    // A plan covers the segments [seg_base, seg_base + n_range).  A graph beyond 16 M segments gets
+    // several (`more`: a heap array of n_more further plans); each call then walks the steps once
+    // per range, every walk keeping only the part of each run that falls into its range.
+    uint32_t seg_base = 0, n_range = 0;
+    FastPlan *more = nullptr;
+    uint32_t n_more = 0;
     uint32_t n_cus = 256;
     uint32_t acc_parts = 1;  // workgroups per window in pass 2 (small graphs: fewer windows than CUs)
     uint32_t n_slots = 0;      // sub-buckets per window = persistent workgroups of pass 1
@@ -47,8 +53,8 @@ struct FastPlan {
     uint32_t n_other = 0;
 };
 
-// Decides eligibility (at most 2048 windows, 16-byte aligned steps, a directory that stays small
-// next to the steps) and allocates the scratch.  Returns false only on a HIP error.
+// Decides eligibility (16-byte aligned steps, directories that stay small next to the steps) and
+// allocates the scratch: one range of at most 2048 windows, or several.  Returns false only on a HIP error.
 bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *host_path_begin, const uint32_t *host_path_end,
                       FastPlan *fp);
 void fast_plan_destroy(FastPlan *fp);

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
-@pytest.fixture(params=["auto", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3"])
+@pytest.fixture(params=["auto", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3", "ranges"])
 def device_path(request, monkeypatch):
     """Runs a test once per device path: the bucketed path (default: short paths walked by single
     waves, k_scan_short; the rest by whole workgroups, k_scan), the simple global-atomic kernels,
@@ -26,13 +26,18 @@ def device_path(request, monkeypatch):
     long paths cut into 512-step pieces, k_scan alone (no wave-per-path kernels), and short paths
     sent to k_scan_short regardless of their run count (so that it has to hand some back), and
     three pass-2 workgroups per window whatever the graph's size (by default only small graphs
-    share their windows out).  The variables are read when a graph becomes resident."""
+    share their windows out), and the segments cut into ranges of 40960 with one walk of the
+    steps per range (by default only graphs beyond 16 M segments are; more than 64 ranges: the
+    atomic kernels).  The variables are read when a graph becomes resident."""
     monkeypatch.delenv("FLATGFA_DEPTH_PATH", raising=False)
     monkeypatch.delenv("FLATGFA_BUCKET_CAP", raising=False)
     monkeypatch.delenv("FLATGFA_PIECE_STEPS", raising=False)
     monkeypatch.delenv("FLATGFA_SHORT_MAX", raising=False)
     monkeypatch.delenv("FLATGFA_SHORT_ANY", raising=False)
     monkeypatch.delenv("FLATGFA_ACC_PARTS", raising=False)
+    monkeypatch.delenv("FLATGFA_RANGE_SEGS", raising=False)
+    if request.param == "ranges":
+        monkeypatch.setenv("FLATGFA_RANGE_SEGS", "40960")
     if request.param == "parts3":
         monkeypatch.setenv("FLATGFA_ACC_PARTS", "3")
     if request.param == "noshort":
@@ -166,7 +171,8 @@ SHAPES = [
     (27, 200_000, 12, 40_000, "chromosome"),   # paths along the graph, every other one downwards (k_scan's step -1 runs)
     (28, 1_500_000, 7, 250_000, "chromosome"),
     (29, 30_000, 200, 900, "chromosome"),      # the wave-per-path kernels see downward paths as runs of one
-    (26, 17_000_000, 3, 4000, "uniform"),      # beyond 2048 windows of 8192 segments: the atomic kernels take over
+    (26, 17_000_000, 3, 4000, "uniform"),      # beyond 2048 windows of 8192 segments: two ranges, two walks of the steps
+    (30, 40_000_000, 5, 60_000, "chromosome"), # three ranges; runs that straddle a range boundary are split between the walks
 ]
 
 
