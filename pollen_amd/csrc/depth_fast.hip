@@ -2152,6 +2152,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // capacity starts at the even share of N records + 25% and grows on demand (fast_plan_grow).
     const uint64_t slots = (uint64_t)n_win * fp->n_slots;
     uint64_t cap = (g.n_steps + slots - 1) / slots;
+    if (ranged) cap = (uint64_t)((double)cap * n_range / g.n_segs) + 1;  // a range sees its share of the runs
     cap = cap + cap / 4 + 256;
     if (const char *forced = getenv("FLATGFA_BUCKET_CAP")) {  // tests: force the overflow route
         cap = strtoull(forced, nullptr, 10);
