@@ -13,7 +13,9 @@ import pollen_amd as pa  # noqa: E402
 from oracle import flatgfa_oracle as fo  # noqa: E402
 
 ENVS = [{}, {"FLATGFA_SHORT_MAX": "0"}, {"FLATGFA_BUCKET_CAP": "8"}, {"FLATGFA_PIECE_STEPS": "512"},
-        {"FLATGFA_SHORT_MAX": "300"}, {"FLATGFA_DEPTH_PATH": "atomic"}]
+        {"FLATGFA_SHORT_MAX": "300"}, {"FLATGFA_DEPTH_PATH": "atomic"}, {"FLATGFA_ACC_PARTS": "5"},
+        {"FLATGFA_RANGE_SEGS": "65536"}, {"FLATGFA_RANGE_SEGS": "40960", "FLATGFA_PIECE_STEPS": "2048"},
+        {"FLATGFA_ACC_PARTS": "2", "FLATGFA_PIECE_STEPS": "1024"}]
 
 
 def random_graph(rng):
@@ -93,7 +95,7 @@ def main():
         pools.paths, pools.steps, pools.segs = paths, steps, segs
         want_d, want_u = fo.seg_depth_with_uniq(pools)
         env = ENVS[case % len(ENVS)]
-        for k in ("FLATGFA_SHORT_MAX", "FLATGFA_BUCKET_CAP", "FLATGFA_PIECE_STEPS", "FLATGFA_DEPTH_PATH"):
+        for k in ("FLATGFA_SHORT_MAX", "FLATGFA_BUCKET_CAP", "FLATGFA_PIECE_STEPS", "FLATGFA_DEPTH_PATH", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS"):
             os.environ.pop(k, None)
         os.environ.update(env)
         graph = dev.DeviceGraph(steps, pb, pe, S, seg_len, device="cuda:0")
