@@ -55,9 +55,11 @@ WORKLOADS = {
     "cfgL-100kseg": (100_000, 1000, 100_000, "pangenome"),    # deep coverage of a small graph: 25 windows
     "cfgL-4Mseg": (4_000_000, 1000, 100_000, "pangenome"),
     "cfgL-16Mseg": (16_000_000, 1000, 100_000, "pangenome"),
+    "16Mseg-tiny": (16_000_000, 10, 1000, "pangenome"),       # what a call costs when there is next to nothing to count
     "cfgL-64Mseg": (64_000_000, 1000, 100_000, "pangenome"),  # beyond the bucketed path's 16 M segments
     "cfgL-x16": (1_000_000, 16_000, 100_000, "pangenome"),    # 1.6 G steps = 6.4 GB of steps per GPU: the weak-scaling size
     "cfgS": (10_000, 100, 10_000, "pangenome"),
+    "cfgM": (100_000, 100, 100_000, "pangenome"),             # 10 M steps
 }
 
 

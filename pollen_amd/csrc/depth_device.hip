@@ -238,6 +238,8 @@ extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int 
         }                                                                                   \
     } while (0)
 
+static int atomic_seg_depth(flatgfa_dev_plan_t *pl, uint32_t *depth_out, uint32_t *uniq_out, hipStream_t stream);
+
 extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t *g, const uint32_t *hb,
                                                         const uint32_t *he) {
     if (!g) { set_error("plan_create: NULL graph"); return nullptr; }
@@ -302,6 +304,35 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
             }
             if (!(st & 4u)) break;  // (an out-of-range id is reported by the query that meets it)
             (void)fast_plan_grow(&pl->fast);
+        }
+        // Small graphs are launch-bound: three kernels of the bucketed path against one of the
+        // atomic path (10 k segments / 1 M steps: 76 us against 26).  Up to 8 M steps both are
+        // timed here, on this graph, and the plan keeps the faster one.  FLATGFA_DEPTH_PATH=bucketed
+        // (or any of the knobs that shape the bucketed path) skips the comparison.
+        bool shaped = force != nullptr;
+        for (const char *k : {"FLATGFA_PIECE_STEPS", "FLATGFA_SHORT_MAX", "FLATGFA_SHORT_ANY", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS",
+                              "FLATGFA_DEBUG_SKIP", "FLATGFA_WB"})
+            shaped = shaped || getenv(k) != nullptr;
+        if (pl->fast.eligible && !shaped && g->n_steps <= (8u << 20)) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            float best[2] = {1e30f, 1e30f};
+            bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+            for (int which = 0; which < 2 && ok; ++which) {
+                for (int rep = 0; rep < 4 && ok; ++rep) {
+                    ok = hipEventRecord(e0, nullptr) == hipSuccess;
+                    const int rc = which ? atomic_seg_depth(pl, tmp, tmp + g->n_segs, nullptr)
+                                         : fast_seg_depth(pl->fast, pl->g, tmp, tmp + g->n_segs, pl->status, nullptr);
+                    float ms = 0;
+                    ok = ok && rc == FLATGFA_OK && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+                         hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+                    if (ok && rep) best[which] = std::min(best[which], ms);
+                }
+            }
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            (void)hipMemset(pl->status, 0, 4);  // (an out-of-range id shows up again in the caller's own first query)
+            if (ok && best[1] < best[0]) fast_plan_destroy(&pl->fast);
+            if (getenv("FLATGFA_TIMING")) fprintf(stderr, "plan: bucketed %.1f us, atomic %.1f us\n", best[0] * 1e3, best[1] * 1e3);
         }
         (void)hipFree(tmp);
     }

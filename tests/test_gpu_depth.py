@@ -18,10 +18,11 @@ pytestmark = pytest.mark.gpu
 FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
-@pytest.fixture(params=["auto", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3", "ranges"])
+@pytest.fixture(params=["auto", "bucketed", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3", "ranges"])
 def device_path(request, monkeypatch):
-    """Runs a test once per device path: the bucketed path (default: short paths walked by single
-    waves, k_scan_short; the rest by whole workgroups, k_scan), the simple global-atomic kernels,
+    """Runs a test once per device path: the default (up to 8 M steps the plan times the bucketed
+    path against the atomic kernels on the graph at hand and keeps the faster), the bucketed path
+    (short paths walked by single waves, k_scan_short; the rest by whole workgroups, k_scan), the simple global-atomic kernels,
     the bucketed path with 8-record buckets so that nearly every record takes the overflow route,
     long paths cut into 512-step pieces, k_scan alone (no wave-per-path kernels), and short paths
     sent to k_scan_short regardless of their run count (so that it has to hand some back), and
@@ -46,6 +47,8 @@ def device_path(request, monkeypatch):
         monkeypatch.setenv("FLATGFA_SHORT_ANY", "1")
     if request.param == "pieces":   # every path longer than 512 steps is scanned as several pieces + k_merge
         monkeypatch.setenv("FLATGFA_PIECE_STEPS", "512")
+    if request.param == "bucketed":
+        monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
     if request.param == "atomic":
         monkeypatch.setenv("FLATGFA_DEPTH_PATH", "atomic")
     elif request.param == "tinycap":

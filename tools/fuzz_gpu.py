@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import pollen_amd as pa  # noqa: E402
 from oracle import flatgfa_oracle as fo  # noqa: E402
 
-ENVS = [{}, {"FLATGFA_SHORT_MAX": "0"}, {"FLATGFA_BUCKET_CAP": "8"}, {"FLATGFA_PIECE_STEPS": "512"},
+ENVS = [{}, {"FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0"}, {"FLATGFA_BUCKET_CAP": "8"}, {"FLATGFA_PIECE_STEPS": "512"},
         {"FLATGFA_SHORT_MAX": "300"}, {"FLATGFA_DEPTH_PATH": "atomic"}, {"FLATGFA_ACC_PARTS": "5"},
         {"FLATGFA_RANGE_SEGS": "65536"}, {"FLATGFA_RANGE_SEGS": "40960", "FLATGFA_PIECE_STEPS": "2048"},
         {"FLATGFA_ACC_PARTS": "2", "FLATGFA_PIECE_STEPS": "1024"}]
