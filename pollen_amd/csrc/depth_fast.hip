@@ -2060,7 +2060,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // Pass 2 runs one workgroup per window -- or, when the graph has fewer windows than half the
     // CUs, several that share the window's paths and sub-buckets and add their counts up (1000
     // paths over 100 k segments: 25 workgroups took 0.48 ms where 250 take 0.06).
-    fp->acc_parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({16, fp->n_cus / n_win, (g.n_steps / n_win + (256u << 10) - 1) >> 18}));  // a workgroup per 256 k steps
+    fp->acc_parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({16, fp->n_cus / n_win, (g.n_steps / n_win + (32u << 10) - 1) >> 15}));  // a workgroup per 32 k steps: a wave's walk is a chain of dependent round trips, a microsecond per 64 records
     if (const char *f = getenv("FLATGFA_ACC_PARTS")) fp->acc_parts = std::max(1u, std::min(64u, (uint32_t)strtoul(f, nullptr, 10)));
     const uint32_t acc_waves = fp->acc_parts * kAccWaves;
     // Pass 2 walks k_scan's items grouped by path (the pieces of a split path share a bitset),
@@ -2093,7 +2093,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         std::vector<std::vector<uint32_t>> per_wave(acc_waves), fat_of_part(fp->acc_parts);
         std::vector<uint64_t> load(acc_waves, 0), part_load(fp->acc_parts, 0);
         for (uint32_t gi : order) {
-            if (path_steps[gi] < fat_min || by_path[gi].size() < 2 || getenv("FLATGFA_NO_FAT_PATHS")) continue;
+            if (path_steps[gi] < fat_min || by_path[gi].size() < kAccWaves / 2 || getenv("FLATGFA_NO_FAT_PATHS")) continue;  // (fewer pieces than half the waves: better one wave busy all the time than three)
             const uint32_t q = (uint32_t)(std::min_element(part_load.begin(), part_load.end()) - part_load.begin());
             part_load[q] += path_steps[gi];
             fat_of_part[q].push_back(gi);
