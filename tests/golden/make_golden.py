@@ -40,11 +40,13 @@ from oracle import synth  # noqa: E402
 CFG_S = dict(seed=1, S=10_000, P=100, L=10_000, model="pangenome")
 # Further synthetic graphs, chosen so that each of the device kernels that walk paths is pinned to
 # slow_odgi by at least one golden table: paths of 10 k steps (cfg-S: the medium-path kernel),
-# short paths (k_scan_short), long paths (k_scan), and uniform-random ids (no runs to speak of).
+# short paths (k_scan_short), long paths (k_scan), uniform-random ids (no runs to speak of), and
+# paths that run along the graph, half of them downwards (k_scan with step -1).
 SYNTH_MORE = {
     "synth_short": dict(seed=7, S=8_000, P=600, L=800, model="pangenome"),
     "synth_long": dict(seed=9, S=12_000, P=8, L=70_000, model="pangenome"),
     "synth_uniform": dict(seed=11, S=6_000, P=40, L=3_000, model="uniform"),
+    "synth_chrom": dict(seed=13, S=15_000, P=12, L=50_000, model="chromosome"),  # paths along the graph, every other one downwards
 }
 
 

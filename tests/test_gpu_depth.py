@@ -231,6 +231,7 @@ def test_cfgS_matches_slow_odgi_golden():
     ("synth_short", (7, 8_000, 600, 800, "pangenome")),    # k_scan_short
     ("synth_long", (9, 12_000, 8, 70_000, "pangenome")),   # k_scan
     ("synth_uniform", (11, 6_000, 40, 3_000, "uniform")),  # hardly any runs
+    ("synth_chrom", (13, 15_000, 12, 50_000, "chromosome")),  # k_scan's downward runs
 ])
 def test_more_synthetic_graphs_match_slow_odgi_goldens(name, cfg, device_path):
     g = pa.synth(*cfg, True)

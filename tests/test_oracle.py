@@ -103,6 +103,7 @@ SYNTH_MORE = {  # tests/golden/make_golden.py
     "synth_short": dict(seed=7, S=8_000, P=600, L=800, model="pangenome"),
     "synth_long": dict(seed=9, S=12_000, P=8, L=70_000, model="pangenome"),
     "synth_uniform": dict(seed=11, S=6_000, P=40, L=3_000, model="uniform"),
+    "synth_chrom": dict(seed=13, S=15_000, P=12, L=50_000, model="chromosome"),  # paths along the graph, every other one downwards
 }
 
 
