@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/profiles; mkdir -p $OUT; cd $R
 CMD="bench.py --steps 20 --warmup 3"
 # 1. the bench line itself (all workloads; cfgL is the headline)
-for w in cfgL cfgL-uniform cfgL-chrom cfgL-short cfgL-fewlong cfgL-medium cfgL-32k cfgL-4Mseg cfgL-16Mseg cfgS; do
+for w in cfgL cfgL-uniform cfgL-chrom cfgL-short cfgL-fewlong cfgL-4paths cfgL-medium cfgL-32k cfgL-100kseg cfgL-4Mseg cfgL-16Mseg cfgL-64Mseg cfgM cfgS; do
   python3 bench.py --steps 20 --warmup 3 --workload $w 2>/dev/null | tail -1 > $OUT/${TAG}_bench_$w.json
 done
 # 2. kernel trace + stats of the same command (csv)
