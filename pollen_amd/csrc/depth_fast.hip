@@ -5,7 +5,8 @@
 //                 path) at a time.  The steps are cut into blocks of 1024; a wave takes a block
 //                 with four fully coalesced 1 KiB reads (streamed past the L2: nt), so that every
 //                 lane holds four groups of four consecutive steps, finds where the maximal +1
-//                 runs of segment ids start, and queues (start id, position) per run.
+//                 runs of segment ids start (-1 runs in an item that mostly walks the ids
+//                 downwards: a contig on the reverse strand), and queues (start id, position) per run.
 //                 A run's length is the distance to the next queued start, so each run becomes
 //                 ONE range record (start, length) instead of `length` histogram updates.  A
 //                 record goes to the bucket of its segment window; buckets are split into one
@@ -13,12 +14,16 @@
 //                 workgroup's partial lines stay in its own XCD's L2.  The kernel keeps no
 //                 per-path state: after the last wave has left an item it snapshots the cursors,
 //                 which tells pass 2 which records of a sub-bucket belong to which path.
+//                 A graph beyond 16 M segments is walked once per range of 16 M (k_scan<ranged>
+//                 clips every run to the range).
 //   k_scan_short  (pass 1 for paths of at most 2048 steps, and "medium" paths with few runs)
 //                 every wave walks whole paths on its own and claims the path's segments in a
 //                 per-wave hash set of bitset words; its records carry what they count for.
-//   k_accum       (pass 2)  one workgroup per window.  The "seen" bitset of depth.rs:23-34 lives
+//   k_accum       (pass 2)  one workgroup per window (several, adding their counts up, when the
+//                 graph has fewer windows than CUs).  The "seen" bitset of depth.rs:23-34 lives
 //                 here, per (path, window): 512 bytes of LDS instead of one bit per segment of the
-//                 whole graph.  A wave walks the records of one path's group after the other,
+//                 whole graph.  A wave walks the records of one path's group after the other (a
+//                 path too long for one wave is walked by all sixteen on a shared bitset),
 //                 claims each record's segments with returning LDS ORs (the bits that were already
 //                 set are revisits), and applies the record as a +1/-1 pair to an LDS difference
 //                 array for depth -- and its revisited stretches to a second one; uniq = depth -
