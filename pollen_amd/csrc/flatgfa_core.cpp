@@ -8,6 +8,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
+#include <functional>
+#include <atomic>
 #include <memory>
 #include <thread>
 #include <cmath>
@@ -182,10 +185,118 @@ bool make_handle(uint32_t seg, bool forward, Handle *h, const char **why) {
     return true;
 }
 
+// Where each path's steps go, when parse_steps_parallel has put them there.
+struct StepsPre {
+    bool ok = false;
+    std::vector<uint64_t> begin;  // [paths + 1]
+};
+
+// One chunk of one path's step field: whole items, `want` of them, to be written from `out` on.
+struct StepChunk {
+    const uint8_t *p, *e;
+    uint64_t want, out;
+};
+
+// Strict form of StepsParser (gfaline.rs:200-263) over whole items: digits, a sign, then a comma
+// or the end of the chunk.  False for anything else; the caller then falls back to the sequential
+// parser, which decides whether it is an error and which.
+bool parse_step_chunk(const StepChunk &c, const NameMap &names, Handle *steps) {
+    const uint8_t *s = c.p;
+    uint64_t n = 0;
+    while (s < c.e) {
+        uint64_t seg = 0;
+        const uint8_t *d = s;
+        while (s < c.e && *s >= '0' && *s <= '9') seg = seg * 10 + (uint64_t)(*s++ - '0');
+        if (s == d || s == c.e || (*s != '+' && *s != '-')) return false;
+        uint32_t id;
+        if (!names.get(seg, &id) || (id & 0x80000000u) || n == c.want) return false;
+        steps[c.out + n++].bits = (id << 1) | (*s == '+' ? 0u : 1u);
+        ++s;
+        if (s < c.e && *s++ != ',') return false;
+    }
+    return n == c.want;
+}
+
+void parse_steps_parallel(const std::vector<Cursor> &deferred, const NameMap &names, Store *st, StepsPre *pre) {
+    size_t kChunk = 1 << 20, min_bytes = 4u << 20;
+    if (const char *f = getenv("FLATGFA_PARSE_CHUNK")) kChunk = std::max<size_t>(1, strtoull(f, nullptr, 10));      // tests
+    if (const char *f = getenv("FLATGFA_PARSE_MIN_BYTES")) min_bytes = strtoull(f, nullptr, 10);                    // tests
+    // the step field of every path line, cut after commas into chunks of about a megabyte
+    std::vector<StepChunk> chunks;
+    std::vector<size_t> first_chunk;  // per path
+    size_t bytes = 0;
+    for (const Cursor &line : deferred) {
+        if (*line.p != 'P') continue;
+        if (line.size() < 2 || line.p[1] != '\t') return;
+        Cursor rest{line.p + 2, line.e};
+        parse_field(&rest);
+        const Cursor steps = parse_field(&rest);
+        first_chunk.push_back(chunks.size());
+        if (!steps.empty() && steps.e[-1] == ',') return;  // (accepted by the reference: not the plain case)
+        const uint8_t *a = steps.p;
+        while (a < steps.e) {
+            const uint8_t *b = steps.e;
+            if ((size_t)(steps.e - a) > kChunk + kChunk / 2) {
+                const uint8_t *c = (const uint8_t *)memchr(a + kChunk, ',', (size_t)(steps.e - a) - kChunk);
+                if (c) b = c + 1;
+            }
+            chunks.push_back(StepChunk{a, b, b == steps.e ? 1u : 0u, 0});
+            a = b;
+        }
+        bytes += steps.size();
+    }
+    first_chunk.push_back(chunks.size());
+    if (bytes < min_bytes || chunks.empty()) return;  // small inputs: the sequential loop is as fast
+    unsigned nt = std::max(1u, std::min({std::thread::hardware_concurrency(), 32u, (unsigned)chunks.size()}));
+    if (const char *f = getenv("FLATGFA_PARSE_THREADS")) {  // 0 = the sequential parser only
+        if (strtol(f, nullptr, 10) <= 0) return;
+        nt = (unsigned)std::min(64l, strtol(f, nullptr, 10));
+    }
+    std::atomic<size_t> next{0};
+    const auto run = [&](const std::function<void(size_t)> &fn) {
+        next = 0;
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < nt; ++t)
+            th.emplace_back([&] {
+                for (size_t i = next++; i < chunks.size(); i = next++) fn(i);
+            });
+        for (auto &x : th) x.join();
+    };
+    // items per chunk = its commas (every one ends an item; the field's last item has none)
+    run([&](size_t i) {
+        uint64_t n = 0;
+        for (const uint8_t *q = chunks[i].p; (q = (const uint8_t *)memchr(q, ',', (size_t)(chunks[i].e - q))) != nullptr; ++q) ++n;
+        chunks[i].want += n;
+    });
+    uint64_t total = st->steps.size();
+    pre->begin.assign(first_chunk.size(), 0);
+    for (size_t pth = 0; pth + 1 < first_chunk.size(); ++pth) {
+        pre->begin[pth] = total;
+        for (size_t i = first_chunk[pth]; i < first_chunk[pth + 1]; ++i) {
+            chunks[i].out = total;
+            total += chunks[i].want;
+        }
+    }
+    pre->begin.back() = total;
+    if (total > 0xFFFFFFFFull) return;  // (spans are 32-bit; the sequential loop reports what the reference would)
+    const size_t before = st->steps.size();
+    st->steps.resize(total);
+    std::atomic<bool> plain{true};
+    run([&](size_t i) {
+        if (plain.load(std::memory_order_relaxed) && !parse_step_chunk(chunks[i], names, st->steps.data())) plain = false;
+    });
+    if (!plain) {
+        st->steps.resize(before);
+        return;
+    }
+    pre->ok = true;
+}
+
 }  // namespace
 
 bool parse_gfa(const uint8_t *buf, size_t n, Store *st, std::string *err, bool stream_mode) {
     *st = Store();
+    const auto t_begin = std::chrono::steady_clock::now();
     NameMap names;
     std::vector<Cursor> deferred;
     auto fail = [&](const char *why, size_t lineno) {
@@ -243,6 +354,15 @@ bool parse_gfa(const uint8_t *buf, size_t n, Store *st, std::string *err, bool s
     size_t dn = 0;
     if (stream_mode)  // parse_stream unwinds links first, then paths (parse.rs:63-72)
         std::stable_partition(deferred.begin(), deferred.end(), [](const Cursor &c) { return *c.p == 'L'; });
+    // The step lists are nearly all of a pangenome's text.  When every one of them is plain
+    // -- `name(+|-)` items with known names, separated by single commas -- they are parsed by
+    // several threads straight into place; anything else (an error the reference would report, an
+    // oddity it accepts) leaves `pre.ok` false and the loop below does it all, in order.
+    StepsPre pre;
+    const auto t_lines = std::chrono::steady_clock::now();
+    parse_steps_parallel(deferred, names, st, &pre);
+    const auto t_steps = std::chrono::steady_clock::now();
+    size_t n_paths_seen = 0;
     for (Cursor line : deferred) {
         ++dn;
         if (line.size() < 2 || line.p[1] != '\t') return fail("expected marker and tab (deferred)", dn);
@@ -285,36 +405,42 @@ bool parse_gfa(const uint8_t *buf, size_t n, Store *st, std::string *err, bool s
             // StepsParser, gfaline.rs:200-263.  The byte that stops the scan is
             // consumed before `rest()` is examined (parse.rs:155).
             Path p;
-            p.steps.start = (uint32_t)st->steps.size();
-            const uint8_t *s = steps.p;
-            uint64_t seg = 0;
-            bool want_seg = true;
-            while (s < steps.e) {
-                uint8_t b = *s++;
-                if (want_seg) {
-                    if (b == '+' || b == '-') {
-                        want_seg = false;
-                        uint32_t id;
-                        Handle h;
-                        if (!names.get(seg, &id)) return fail("path: unknown segment", dn);
-                        if (!make_handle(id, b == '+', &h, &why)) return fail(why, dn);
-                        st->steps.push_back(h);
-                    } else if (b >= '0' && b <= '9') {
-                        seg = seg * 10 + (uint64_t)(b - '0');
+            if (pre.ok) {  // the steps are already in place (parse_steps_parallel)
+                p.steps.start = (uint32_t)pre.begin[n_paths_seen];
+                p.steps.end = (uint32_t)pre.begin[n_paths_seen + 1];
+                ++n_paths_seen;
+            } else {
+                p.steps.start = (uint32_t)st->steps.size();
+                const uint8_t *s = steps.p;
+                uint64_t seg = 0;
+                bool want_seg = true;
+                while (s < steps.e) {
+                    uint8_t b = *s++;
+                    if (want_seg) {
+                        if (b == '+' || b == '-') {
+                            want_seg = false;
+                            uint32_t id;
+                            Handle h;
+                            if (!names.get(seg, &id)) return fail("path: unknown segment", dn);
+                            if (!make_handle(id, b == '+', &h, &why)) return fail(why, dn);
+                            st->steps.push_back(h);
+                        } else if (b >= '0' && b <= '9') {
+                            seg = seg * 10 + (uint64_t)(b - '0');
+                        } else {
+                            break;
+                        }
                     } else {
-                        break;
-                    }
-                } else {
-                    if (b == ',') {
-                        want_seg = true;
-                        seg = 0;
-                    } else {
-                        break;
+                        if (b == ',') {
+                            want_seg = true;
+                            seg = 0;
+                        } else {
+                            break;
+                        }
                     }
                 }
+                if (s != steps.e) return fail("path steps: trailing bytes", dn);
+                p.steps.end = (uint32_t)st->steps.size();
             }
-            if (s != steps.e) return fail("path steps: trailing bytes", dn);
-            p.steps.end = (uint32_t)st->steps.size();
             p.overlaps.start = (uint32_t)st->overlaps.size();
             for (auto &ops : ovs) {
                 Span a;
@@ -329,6 +455,11 @@ bool parse_gfa(const uint8_t *buf, size_t n, Store *st, std::string *err, bool s
             p.name.end = (uint32_t)st->name_data.size();
             st->paths.push_back(p);
         }
+    }
+    if (getenv("FLATGFA_TIMING")) {
+        const auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "parse_gfa: lines %.1f ms, steps %.1f ms (%s), links/paths %.1f ms\n", ms(t_begin, t_lines), ms(t_lines, t_steps),
+                pre.ok ? "threads" : "in order", ms(t_steps, std::chrono::steady_clock::now()));
     }
     return true;
 }

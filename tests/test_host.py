@@ -63,8 +63,15 @@ QUIRKS = [
 ]
 
 
-@pytest.mark.parametrize("text", QUIRKS, ids=range(len(QUIRKS)))
-def test_parser_quirks_match_oracle(text):
+@pytest.mark.parametrize("text", QUIRKS + [
+    b"S\t1\tA\nS\t2\tC\nP\tp\t1+,2-,1+,2+,\t*\n",      # a trailing comma is accepted
+    b"S\t1\tA\nS\t2\tC\nP\tp\t1+,2-,,1+\t*\n",         # an empty item is not
+    b"S\t1\tA\nS\t2\tC\nP\tp\t1+,2-,1+,3+,1+\t*\n",    # unknown segment in a later chunk
+    b"S\t1\tA\nS\t2\tC\nP\tp\t1+,2-,1+2+\t*\n",        # a missing comma
+    b"S\t1\tA\nS\t2\tC\nP\tp\t1+,2-,+,1+\t*\n",        # a sign without a name
+    b"S\t1\tA\nS\t2\tC\nP\tp\t1+,2-,1+,2+\t*\nL\t1\t+\t2\t+\t0M\nP\tq\t2+,2+,1-\t1M,2M\n",
+], ids=lambda t: None)
+def test_parser_quirks_match_oracle(text, step_parser):
     try:
         want = fo.parse_gfa(text)
     except fo.ParseError:
@@ -78,7 +85,20 @@ def test_parser_quirks_match_oracle(text):
         assert_same_pools(got, want)
 
 
-def test_parser_differential_fuzz():
+@pytest.fixture(params=["in order", "threads"])
+def step_parser(request, monkeypatch):
+    """The parser reads step lists in order, or -- large inputs; here forced, with 5-byte chunks --
+    with several threads when all of them are plain (anything else must fall back)."""
+    for k in ("FLATGFA_PARSE_THREADS", "FLATGFA_PARSE_CHUNK", "FLATGFA_PARSE_MIN_BYTES"):
+        monkeypatch.delenv(k, raising=False)
+    if request.param == "threads":
+        monkeypatch.setenv("FLATGFA_PARSE_THREADS", "3")
+        monkeypatch.setenv("FLATGFA_PARSE_CHUNK", "5")
+        monkeypatch.setenv("FLATGFA_PARSE_MIN_BYTES", "0")
+    return request.param
+
+
+def test_parser_differential_fuzz(step_parser):
     # Byte-level mutations of real fixtures: the product must fail exactly when the oracle fails
     # and otherwise build identical pools.
     rng = np.random.default_rng(1234)
