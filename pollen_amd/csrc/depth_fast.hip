@@ -111,7 +111,8 @@ struct ScanArgs {
     uint32_t *counts0;   // [n_win][n_slots] copy of the cursors k_scan started from
     uint32_t *buckets;   // [n_win + 1][n_slots][cap]; window n_win is a write sink
     uint2 *dir;          // [n_win][dstride] {cursor before, cursor after} item j in its workgroup's sub-bucket
-    uint32_t *islot;     // [dstride] the sub-bucket (workgroup) that walked item j
+    uint32_t *islot;     // [dstride] the sub-bucket (workgroup) that walked the item at each position of pass 2's walk order | first of its path << 31
+    const uint32_t *perm;  // [n_items] item j's position in that order | first of its path << 31 (handed-back items keep their index)
     uint32_t dstride;
     uint32_t cap;
     uint32_t stride;     // n_slots * cap: elements between consecutive windows (< 2^30 in total)
@@ -1046,11 +1047,11 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
     // emitted here, where the block's ids are dead and there are registers for kWide chunks side
     // by side.  (Draining only here was measured: no gain on such paths, and short items -- 32 k
     // steps -- lost 15 %: their waves more often find the item before them not wrapped up yet.)
-    // (the diagnostic build keeps cycle counters in registers and has room for two chunks only)
-    if (kWide > 1 && !FGFA_SKIP(kDbgNoEmit) && w.fill >= 64u * (DBG ? 2 : kWide) + 1u) {
+    // (the diagnostic build keeps cycle counters in registers and has room for one chunk at a time only)
+    if (kWide > 1 && !FGFA_SKIP(kDbgNoEmit) && w.fill >= 64u * (DBG ? 1 : kWide) + 1u) {
         if (!w.epoch_ok && epoch_now(ctl) >= rr) w.epoch_ok = true;
         tmark<DBG>(A, w, 1);
-        if (w.epoch_ok) drain_raw<MODE, (DBG ? 2 : kWide)>(A, w, bcur, mine, false);
+        if (w.epoch_ok) drain_raw<MODE, (DBG ? 1 : kWide)>(A, w, bcur, mine, false);
         tmark<DBG>(A, w, 3);
     }
 }
@@ -1104,6 +1105,8 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     uint32_t rr = 0;  // this workgroup's items so far
     uint32_t job = item_of(0, blockIdx.x, gridDim.x);
     Item it = make_item(A, job < n_items, job < n_items ? A.items[job] : make_uint4(0u, 0u, 0u, 0u), lane);
+    // where pass 2 looks for the item: fetched with its descriptor, long before it is needed
+    uint32_t place = job < A.n_items ? A.perm[job] : job | 0x80000000u;
     w.dir = __builtin_amdgcn_readfirstlane(it.dir);
     uint32_t blk[3];  // the block each landing set holds (or will hold next)
     uint32_t resv;    // the block this wave takes after those
@@ -1144,6 +1147,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     while (job < n_items) {
         const uint32_t next_job = item_of(rr + 1u, blockIdx.x, gridDim.x);
         const uint4 next_item = next_job < n_items ? A.items[next_job] : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t next_place = next_job < A.n_items ? A.perm[next_job] : next_job | 0x80000000u;
         // the few steps outside the blocks are walked on their own, by the first and the last wave
         if (wave == 0 && it.t0 > it.b) tile_narrow_raw(A, w, it.b, (uint32_t)(it.t0 - it.b));
         if (wave == kWaves - 1) {
@@ -1170,10 +1174,11 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             w.epoch_ok = true;
         }
         tmark<DBG>(A, w, 1);
-        drain_raw<MODE, (DBG ? 2 : kWide)>(A, w, bcur, mine, true);
+        drain_raw<MODE, (DBG ? 1 : kWide)>(A, w, bcur, mine, true);
         tmark<DBG>(A, w, 3);
         // This wave is done with the item: it requests its first two blocks of the next one right away.
-        const uint32_t done_job = job;
+        const uint32_t pe = place;
+        place = next_place;
         job = next_job;
         it = make_item(A, job < n_items, next_item, lane);
         w.dir = __builtin_amdgcn_readfirstlane(it.dir);  // the queue is empty here
@@ -1184,13 +1189,15 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         if (lane == 0) old = __hip_atomic_fetch_add(&ctl[kCtlArrive + (rr & 1u)], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = __builtin_amdgcn_readfirstlane(old);
         if (old == kWaves - 1u) {
+            // (pass 2 finds the item at its place in ITS walk order: one coalesced read per 64 items there)
+            const uint32_t at = __builtin_amdgcn_readfirstlane(pe & 0x7FFFFFFFu);
             for (uint32_t i = lane; i < A.n_win; i += 64) {
                 const uint32_t c = bcur[i];
-                A.dir[(size_t)i * A.dstride + done_job] = make_uint2(snap[i], c);
+                A.dir[(size_t)i * A.dstride + at] = make_uint2(snap[i], c);
                 snap[i] = c;
             }
             if (lane == 0) {
-                A.islot[done_job] = blockIdx.x;
+                A.islot[at] = blockIdx.x | (pe & 0x80000000u);
                 ctl[kCtlArrive + (rr & 1u)] = 0u;
                 ctl[kCtlNext + (rr & 1u)] = 4u * kWaves;  // for the item after the next one
             }
@@ -1544,15 +1551,23 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
     pq.r = reinterpret_cast<uint2 *>(pend + kPend);
     pq.mcnt = pq.rcnt = pq.moldest = 0;
     pq.lane = lane;
-    for (uint32_t mb = 0; mb < nE; mb += 64u) {
-        const uint32_t cntE = min(64u, nE - mb);
+    // An item's place in the walk order is where k_scan left its cursors and its sub-bucket: two
+    // coalesced reads per 64 items, requested one round ahead (they are older than every record
+    // request of the round, so the counted waits on those still hold).
+    uint2 be_next = make_uint2(0u, 0u);
+    uint32_t slf_next = 0u;
+    const auto fetch = [&](uint32_t mb) {
         const uint32_t x = mb + (uint32_t)lane;
-        const bool have = (uint32_t)lane < cntE;
-        uint32_t ent = 0;
-        if (have) ent = x < nst ? A.elist[e0 + x] : ((A.n_items + wave + nw * (x - nst)) | 0x80000000u);
-        const uint32_t j = ent & 0x7FFFFFFFu, first = have ? ent >> 31 : 0u;
-        const uint2 be = have ? A.dir[(size_t)win * A.dstride + j] : make_uint2(0u, 0u);
-        const uint32_t sl = have ? A.islot[j] : 0u;
+        const uint32_t at = x < nst ? e0 + x : A.n_items + wave + nw * (x - nst);
+        be_next = x < nE ? A.dir[(size_t)win * A.dstride + at] : make_uint2(0u, 0u);
+        slf_next = x < nE ? A.islot[at] : 0u;
+    };
+    fetch(0);
+    for (uint32_t mb = 0; mb < nE; mb += 64u) {
+        const uint2 be = be_next;
+        const uint32_t slf = slf_next;
+        fetch(mb + 64u);
+        const uint32_t sl = slf & 0x7FFFFFFFu, first = slf >> 31;
         const uint32_t b = min(be.x, A.cap), en = max(b, min(be.y, A.cap));
         const uint32_t n = en - b;
         const uint32_t incl = wave_scan_incl(n), P = incl - n;
@@ -1691,9 +1706,9 @@ __device__ __forceinline__ void sum_groups(const AccArgs &A, const unsigned long
     for (uint32_t mb = e0; mb < e1; mb += 64u) {
         const uint32_t cntE = min(64u, e1 - mb);
         const bool have = (uint32_t)lane < cntE;
-        const uint32_t j = have ? (A.elist[mb + lane] & 0x7FFFFFFFu) : 0u;
-        const uint2 be = have ? A.dir[(size_t)win * A.dstride + j] : make_uint2(0u, 0u);
-        const uint32_t sl = have ? A.islot[j] : 0u;
+        const uint32_t at = mb + (uint32_t)lane;
+        const uint2 be = have ? A.dir[(size_t)win * A.dstride + at] : make_uint2(0u, 0u);
+        const uint32_t sl = have ? A.islot[at] & 0x7FFFFFFFu : 0u;
         const uint32_t b = min(be.x, A.cap), en = max(b, min(be.y, A.cap));
         const uint32_t n = en - b, off = sl * A.cap + b;
         unsigned long long myL = 0, myW = 0;  // lane i: item i's sums in this window
@@ -1721,12 +1736,12 @@ __device__ __forceinline__ void sum_groups(const AccArgs &A, const unsigned long
                 }
             }
         }
-        if (have) part[j] = make_ulonglong2(myL, myW);
+        if (have) part[at] = make_ulonglong2(myL, myW);
     }
 }
 
 // Adds an item's per-window sums up and credits them to its path.  One wave per item.
-__global__ __launch_bounds__(256) void k_path_reduce(const uint4 *__restrict__ items, uint32_t n_items, uint32_t n_win,
+__global__ __launch_bounds__(256) void k_path_reduce(const uint4 *__restrict__ items, const uint32_t *__restrict__ elist, uint32_t n_items, uint32_t n_win,
                                                      uint32_t dstride, const ulonglong2 *__restrict__ part,
                                                      unsigned long long *__restrict__ psum_len,
                                                      unsigned long long *__restrict__ psum_w) {
@@ -1741,7 +1756,7 @@ __global__ __launch_bounds__(256) void k_path_reduce(const uint4 *__restrict__ i
     l = wave_total_u64(l);
     w = wave_total_u64(w);
     if (lane == 0 && (l | w)) {
-        const uint32_t p = items[j].w;
+        const uint32_t p = items[elist[j] & 0x7FFFFFFFu].w;  // (j is a position in pass 2's walk order)
         atomicAdd(&psum_len[p], l);
         atomicAdd(&psum_w[p], w);
     }
@@ -2146,6 +2161,11 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         FAST_TRY(hipMemcpy(fp->fat_off, fat_off.data(), fat_off.size() * 4, hipMemcpyHostToDevice));
         FAST_TRY(hipMalloc(&fp->fat_woff, (fat_woff.size() + 1) * 4));
         if (!fat_woff.empty()) FAST_TRY(hipMemcpy(fp->fat_woff, fat_woff.data(), fat_woff.size() * 4, hipMemcpyHostToDevice));
+        // k_scan leaves an item's cursors and sub-bucket at the item's place in this order
+        std::vector<uint32_t> perm(fp->n_items + 1, 0);
+        for (size_t at = 0; at < elist.size(); ++at) perm[elist[at] & 0x7FFFFFFFu] = (uint32_t)at | (elist[at] & 0x80000000u);
+        FAST_TRY(hipMalloc(&fp->perm, perm.size() * 4));
+        FAST_TRY(hipMemcpy(fp->perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
         FAST_TRY(hipMalloc(&fp->elist, (elist.size() + 1) * 4));
         if (!elist.empty()) FAST_TRY(hipMemcpy(fp->elist, elist.data(), elist.size() * 4, hipMemcpyHostToDevice));
         FAST_TRY(hipMalloc(&fp->wave_off, wave_off.size() * 4));
@@ -2285,7 +2305,7 @@ bool fast_plan_grow(FastPlan *fp) {
 void fast_plan_destroy(FastPlan *fp) {
     for (uint32_t r = 0; r < fp->n_more; ++r) fast_plan_destroy(&fp->more[r]);
     delete[] fp->more;
-    for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot,
+    for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot, (void *)fp->perm,
                     (void *)fp->elist, (void *)fp->wave_off, (void *)fp->fat_off, (void *)fp->fat_woff, (void *)fp->items, (void *)fp->short_items,
                     (void *)fp->medium_items, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part})
         if (p) (void)hipFree(p);
@@ -2328,6 +2348,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     sa.buckets = fp.buckets;
     sa.dir = reinterpret_cast<uint2 *>(fp.dir);
     sa.islot = fp.islot;
+    sa.perm = fp.perm;
     sa.dstride = fp.dstride;
     sa.cap = fp.cap;
     sa.stride = stride;
@@ -2387,7 +2408,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     if (ps && fp.n_items) {
         ProfScope pscope("k_path_reduce", stream);
         hipLaunchKernelGGL(k_path_reduce, dim3((fp.n_items + 3) / 4), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(fp.items),
-                           fp.n_items, fp.n_win, fp.dstride, reinterpret_cast<const ulonglong2 *>(fp.psum_part),
+                           fp.elist, fp.n_items, fp.n_win, fp.dstride, reinterpret_cast<const ulonglong2 *>(fp.psum_part),
                            (unsigned long long *)ps->len_out, (unsigned long long *)ps->weighted_out);
     }
     if (hipGetLastError() != hipSuccess) {

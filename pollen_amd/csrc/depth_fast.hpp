@@ -29,8 +29,9 @@ struct FastPlan {
     uint32_t *counts = nullptr;    // u32[n_win * n_slots] cursors, zero between calls (pass 2 resets)
     uint32_t *counts0 = nullptr;   // u32[n_win * n_slots] the cursors k_scan started from
     uint32_t *buckets = nullptr;   // u32[(n_win + 1) * n_slots * cap]
-    void *dir = nullptr;           // uint2[n_win * dstride] {cursor before, after} each item, per window
-    uint32_t *islot = nullptr;     // u32[dstride] the sub-bucket that holds item j's records
+    void *dir = nullptr;           // uint2[n_win * dstride] {cursor before, after} each item, per window, in pass 2's walk order
+    uint32_t *islot = nullptr;     // u32[dstride] per position of pass 2's walk order: the sub-bucket that holds the item's records | first of its path << 31
+    uint32_t *perm = nullptr;      // u32[n_items] where item j stands in pass 2's walk order | first of its path << 31
     uint32_t dstride = 0;          // n_items + max_back + 1
     uint32_t *elist = nullptr;     // k_scan's items in pass 2's order (grouped by path, split among its waves)
     uint32_t *wave_off = nullptr;  // u32[16 * acc_parts + 1] the stretch of elist each wave of pass 2 walks
