@@ -294,6 +294,25 @@ def main():
         extras["path_depth_all_paths_ms"] = round(timed(lambda: plan.path_depth_all(d_only, len_out, wsum_out)), 5)
         extras["path_depth_all_paths_two_walks_ms"] = round(timed(path_depth_two_walks), 5)
         plan.status()
+        # The benchmark's walk continues 90 % of its steps (runs of 10).  The same shape with paths
+        # that run along the graph, every other one downwards, 70 % continuing (0.3 records per
+        # step): what a chromosome graph looks like to the kernels.
+        if args.workload == "cfgL":
+            gc = pa.synth(1, S, P, L, "chromosome", False)
+            cs, cb, ce, cl = gc.soa()
+            cplan = dev.DepthPlan(dev.DeviceGraph(cs, cb, ce, S, cl, device=str(device)))
+            cd = torch.zeros(S, dtype=torch.int32, device=device)
+            cu = torch.zeros(S, dtype=torch.int32, device=device)
+            chrom_ms = timed(lambda: cplan.seg_depth(cd, cu))
+            cplan.status()
+            want = fo.seg_depth_with_uniq(fo.Pools(**{n: gc.pool(n) for n in fo.POOL_ORDER})) if not args.no_verify else None
+            extras["chromosome_model"] = {
+                "what": f"seg_depth_with_uniq on synth(seed=1, S={S}, P={P}, L={L}, model=chromosome)", "ms_per_call": round(chrom_ms, 5),
+                "steps_per_s": round(N / (chrom_ms * 1e-3), 1),
+                "bit_exact_vs_oracle": None if want is None else bool(
+                    (cd.cpu().numpy().view(np.uint32) == want[0]).all() and (cu.cpu().numpy().view(np.uint32) == want[1]).all())}
+            cplan.close()
+            del gc, cs, cplan, cd, cu
         # The timed loop walks the same 400 MB image every step; MI355X has 256 MiB of Infinity
         # Cache and FETCH_SIZE counts its hits as fetches.  Cycle K resident images (> 1 GB): if
         # the cache helped, this is slower.
