@@ -180,6 +180,10 @@ typedef struct flatgfa_dev_graph_t {
  * spans and the step values it was created with (how many runs each path has decides which
  * kernel walks it): neither may change while it lives.  Every call still checks the step values
  * against n_segs, and reports an error rather than a wrong answer if they no longer fit the plan.
+ * Creation runs the query a few times into scratch outputs: once to size the record buckets for
+ * this graph (so that no later call runs out of room), and, up to 8 M steps, to time the bucketed
+ * kernels against the atomic ones and keep the faster.  A graph beyond 16 M segments is walked in
+ * ranges of at most 16 M (one pass over the steps per range and call).
  * Calls on one plan must not overlap in time. */
 typedef struct flatgfa_dev_plan flatgfa_dev_plan_t;
 flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t *g, const uint32_t *host_path_begin,
