@@ -1536,7 +1536,7 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
 // for all waves of the workgroup and has been cleared by it: no hand-backs, no clearing here.
 template <int WB, bool SHARED>
 __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, uint32_t *mybits, uint32_t *mark, uint32_t *pend, const uint32_t *wbase, uint32_t win,
-                                             uint32_t e0, uint32_t e1) {
+                                             uint32_t e0, uint32_t e1, bool have_first = false, uint2 be_first = make_uint2(0u, 0u), uint32_t slf_first = 0u) {
     constexpr uint32_t kNW = (1u << WB) / 32u;             // words per bitset
     constexpr uint32_t kSlots = WB <= 12 ? 8u : 4u;
     const int lane = threadIdx.x & 63;
@@ -1562,7 +1562,12 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
         be_next = x < nE ? A.dir[(size_t)win * A.dstride + at] : make_uint2(0u, 0u);
         slf_next = x < nE ? A.islot[at] : 0u;
     };
-    fetch(0);
+    if (have_first) {  // (requested by the kernel before it set itself up)
+        be_next = be_first;
+        slf_next = slf_first;
+    } else {
+        fetch(0);
+    }
     for (uint32_t mb = 0; mb < nE; mb += 64u) {
         const uint2 be = be_next;
         const uint32_t slf = slf_next;
@@ -1783,6 +1788,24 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     // through the directory; the counts staged are those of the records that came before them.
     const bool flat = !UNIQ || A.has_pre;
     const uint32_t nw = A.parts * kAccWaves;  // a window's sub-buckets are shared out to the waves of its A.parts workgroups
+    // The first round of directory entries of this wave's items is requested right away: it is on
+    // its way while the workgroup clears its arrays (a round trip of the twelve microseconds a
+    // launch costs before it has counted anything).
+    const uint32_t vwave = __builtin_amdgcn_readfirstlane(blockIdx.y * kAccWaves + wave);
+    uint32_t ge0 = 0, ge1 = 0, slf_first = 0;
+    uint2 be_first = make_uint2(0u, 0u);
+    if (UNIQ) {
+        ge0 = __builtin_amdgcn_readfirstlane(A.wave_off[vwave]);
+        ge1 = __builtin_amdgcn_readfirstlane(A.wave_off[vwave + 1]);
+        const uint32_t nback = A.has_pre ? min(__builtin_amdgcn_readfirstlane(*A.work_counter), A.max_back) : 0u;
+        const uint32_t nst = ge1 - ge0, nE = nst + (nback > vwave ? (nback - vwave + nw - 1u) / nw : 0u);
+        const uint32_t x = (uint32_t)(tid & 63);
+        const uint32_t at = x < nst ? ge0 + x : A.n_items + vwave + nw * (x - nst);
+        if (x < nE) {
+            be_first = A.dir[(size_t)win * A.dstride + at];
+            slf_first = A.islot[at];
+        }
+    }
     for (uint32_t sl = tid; sl < A.n_slots; sl += kAccThreads) {
         if ((sl % nw) / kAccWaves != blockIdx.y) continue;  // (whoever walks a sub-bucket reads and clears its count)
         uint32_t *c = A.counts + (size_t)win * A.n_slots + sl;
@@ -1796,10 +1819,9 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     __syncthreads();
     const uint32_t *wbase = A.buckets + (size_t)win * A.n_slots * A.cap;
     if (flat) apply_flat<UNIQ, WB>(A, D, R, scnt, wbase);
-    const uint32_t vwave = __builtin_amdgcn_readfirstlane(blockIdx.y * kAccWaves + wave);
     if (UNIQ) {
         apply_groups<WB, false>(A, D, R, bits + wave * (kSlots * (kW / 32)), marks + wave * 64, pend + wave * (3 * kPend), wbase, win,
-                                __builtin_amdgcn_readfirstlane(A.wave_off[vwave]), __builtin_amdgcn_readfirstlane(A.wave_off[vwave + 1]));
+                                ge0, ge1, true, be_first, slf_first);
         // the long paths, one after the other, all waves on each: the bitset is slot 1 of wave 0's
         for (uint32_t f = A.fat_off[blockIdx.y]; f < A.fat_off[blockIdx.y + 1]; ++f) {
             __syncthreads();
