@@ -264,6 +264,12 @@ def main():
                     "kernels_avg_ms": {k: round(v, 5) for k, v in kern_avg_ms.items()},
                     "kernel_timing": f"HIP events around each launch on steps 0, {EVENT_EVERY}, {2 * EVENT_EVERY}, ... "
                                      f"of the timed region ({n_timed_steps} of {args.steps} steps)"}
+        # An event pair also contains the launch itself; what it reads around a kernel of k_scan's
+        # shape that does nothing is reported beside the kernel times, not subtracted from them
+        # (rocprofv3's dispatch durations, profiles/, do not contain it).
+        ov = dev.profile_overhead_ms(256, 142 * 1024, 20)
+        if ov >= 0:
+            roofline["event_pair_around_an_empty_launch_ms"] = round(ov, 5)
 
     # ---- secondary measurements, rank 0 at N=1 only, outside the timed region ----
     extras = None

@@ -229,6 +229,10 @@ int flatgfa_dev_status(flatgfa_dev_plan_t *plan, void *stream);
  * `cap` kernels since the last read, the kernel name and elapsed milliseconds. */
 void flatgfa_dev_profile_enable(int on);
 int flatgfa_dev_profile_read(const char **names, float *ms, int cap);
+/* What such an event pair reads around a kernel that does nothing, launched with `n_workgroups`
+ * workgroups of 1024 threads and `lds_bytes` of dynamic LDS (median of `reps`; < 0 on error):
+ * the part of a profiled kernel's time that rocprofv3's dispatch duration does not contain. */
+float flatgfa_dev_profile_overhead_ms(int n_workgroups, int lds_bytes, int reps, void *stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -71,6 +71,7 @@ SIGNATURES = {
     "flatgfa_dev_status": (c_int, [c_void_p, c_void_p]),
     "flatgfa_dev_profile_enable": (None, [c_int]),
     "flatgfa_dev_profile_read": (c_int, [POINTER(c_char_p), POINTER(c_float), c_int]),
+    "flatgfa_dev_profile_overhead_ms": (c_float, [c_int, c_int, c_int, c_void_p]),
 }
 
 _lib = None

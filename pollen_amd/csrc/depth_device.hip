@@ -559,6 +559,37 @@ extern "C" int flatgfa_dev_profile_read(const char **names, float *ms, int cap) 
     return n;
 }
 
+// What the event pair around a launch measures when the kernel does nothing: a launch of k_scan's
+// shape (one workgroup of 1024 threads per CU, `lds_bytes` of dynamic LDS), bracketed like every
+// profiled kernel.  bench.py reports it beside the kernel times (rocprofv3's dispatch durations do
+// not contain it).
+__global__ __launch_bounds__(1024) void k_nothing(uint32_t *sink) {
+    extern __shared__ uint32_t lds_nothing[];
+    if (sink && threadIdx.x == 4096) sink[0] = lds_nothing[0];
+}
+
+extern "C" float flatgfa_dev_profile_overhead_ms(int n_workgroups, int lds_bytes, int reps, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_workgroups <= 0 || reps <= 0 || lds_bytes < 0 || lds_bytes > 160 * 1024) return -1.f;
+    if (hipFuncSetAttribute((const void *)k_nothing, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1.f;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.f;
+    std::vector<float> ts;
+    for (int r = 0; r < reps + 2; ++r) {
+        (void)hipEventRecord(a, stream);
+        hipLaunchKernelGGL(k_nothing, dim3(n_workgroups), dim3(1024), (size_t)lds_bytes, stream, (uint32_t *)nullptr);
+        (void)hipEventRecord(b, stream);
+        float t = 0.f;
+        if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&t, a, b) != hipSuccess) { ts.clear(); break; }
+        if (r >= 2) ts.push_back(t);
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (ts.empty()) return -1.f;
+    std::sort(ts.begin(), ts.end());
+    return ts[ts.size() / 2];
+}
+
 extern "C" int flatgfa_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -149,6 +149,12 @@ def profile_enable(on: bool) -> None:
     _lib.lib().flatgfa_dev_profile_enable(1 if on else 0)
 
 
+def profile_overhead_ms(n_workgroups: int = 256, lds_bytes: int = 142 * 1024, reps: int = 20) -> float:
+    """What the event pair of a profiled kernel reads around a launch that does nothing."""
+    import torch
+    return float(_lib.lib().flatgfa_dev_profile_overhead_ms(n_workgroups, lds_bytes, reps, torch.cuda.current_stream().cuda_stream))
+
+
 def profile_read(cap: int = 4096) -> List[Tuple[str, float]]:
     names = (ctypes.c_char_p * cap)()
     ms = (ctypes.c_float * cap)()
