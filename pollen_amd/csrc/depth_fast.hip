@@ -340,11 +340,15 @@ __device__ __forceinline__ uint32_t claim_hashed(const ScanArgs &A, uint32_t *ta
 }
 
 // Slots in the sub-buckets of `win`, one per valid lane.  A path that runs along the graph puts
-// neighbouring lanes' runs in the same window, and 64 LDS atomics on one address take 64 turns.
-// Three cases, by what the wave holds: one window for all lanes (the common case on such a path:
-// one atomic for the wave, a handful of vector instructions); mostly different windows (paths that
-// jump about: one atomic per lane); in between, the first lane of every stretch of equal windows
-// takes the slots of its stretch.
+// neighbouring lanes' runs in the same window, and 64 LDS atomics on one address take 64 turns:
+// the first lane of every stretch of equal windows takes the slots of its stretch.  Branch free,
+// so that the chunks of a wide drain overlap their LDS round trips.  (FGFA_SLOTS_MODE, measured on
+// one box: 1 adds a wave-uniform shortcut for "all lanes one window" and one atomic per lane
+// when most lanes differ -- fewer instructions, but a branch between the chunks: +4 % on paths
+// along the graph; 2 only the latter: +7 %; cfg-L is the same with all three.)
+#ifndef FGFA_SLOTS_MODE
+#define FGFA_SLOTS_MODE 0
+#endif
 __device__ __forceinline__ uint32_t take_slots(uint32_t *bcur, int lane, bool valid, uint32_t win) {
 #if FGFA_SLOTS_MODE == 1
     const unsigned long long vm = __builtin_amdgcn_ballot_w64(valid);
@@ -810,9 +814,6 @@ __device__ __forceinline__ void tmark(const ScanArgs &A, RWave &w, int ph) {
 // (two cells), and how many items are complete.
 // k_scan's builds: plain, diagnostic (FLATGFA_DEBUG_SKIP), ranged (one of several walks of a graph beyond 16 M segments)
 constexpr int kModePlain = 0, kModeDbg = 1, kModeRanged = 2;
-#ifndef FGFA_SLOTS_MODE
-#define FGFA_SLOTS_MODE 0
-#endif
 #ifndef FGFA_WIDE
 #define FGFA_WIDE 4
 #endif
