@@ -320,7 +320,7 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
         // (or any of the knobs that shape the bucketed path) skips the comparison.
         bool shaped = force != nullptr;
         for (const char *k : {"FLATGFA_PIECE_STEPS", "FLATGFA_SHORT_MAX", "FLATGFA_SHORT_ANY", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS",
-                              "FLATGFA_DEBUG_SKIP", "FLATGFA_WB"})
+                              "FLATGFA_DEBUG_SKIP", "FLATGFA_WB", "FLATGFA_DENSE"})
             shaped = shaped || getenv(k) != nullptr;
         if (pl->fast.eligible && !shaped && g->n_steps <= (8u << 20)) {
             hipEvent_t e0 = nullptr, e1 = nullptr;

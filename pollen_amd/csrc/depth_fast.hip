@@ -1914,10 +1914,145 @@ __global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__
     }
 }
 
+// ================================================== pass 1 for graphs without runs ===
+//
+// k_scan_dense: when nearly every step starts a run (ids that jump about: the plan counts
+// more than three records for four steps), finding runs is wasted work and k_scan's emit -- 64
+// records, 64 windows, 64 scattered 4-byte stores -- is bound by the L2s' request rate (0.48 ms
+// for 100 M steps).  Here the workgroup partitions a tile of 8192 steps by window in LDS --
+// one returning LDS atomic per step gives its rank within its window's bin, a prefix sum gives the
+// bins their places -- and writes the sorted tile out, so that the records of a window leave as
+// stretches of consecutive addresses.  Every step is a record of length one.
+// The cursors, their snapshots per item and everything pass 2 reads are k_scan's.
+#ifndef FGFA_DENSE_TILE
+#define FGFA_DENSE_TILE 8192
+#endif
+constexpr uint32_t kDenseTile = FGFA_DENSE_TILE;
+constexpr int kDensePer = kDenseTile / kThreads;  // steps per thread and tile
+
+// A barrier for LDS traffic only: __syncthreads() also waits for every global load in flight, and
+// the next tile's steps are meant to stay in flight across the barriers of this tile.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+uint32_t dense_lds_bytes(uint32_t nwp) { return (5u * nwp + 64u + kDenseTile) * 4u; }
+
+__global__ __launch_bounds__(kThreads) void k_scan_dense(const ScanArgs A) {
+    extern __shared__ uint32_t lds[];
+    uint32_t *bcur = lds, *snap = lds + A.nwp, *base = lds + 2u * A.nwp, *delta = lds + 3u * A.nwp, *hist = lds + 4u * A.nwp, *stage = lds + 5u * A.nwp + 64u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    if (A.zero_a) {
+        for (uint32_t i = blockIdx.x * kThreads + tid; i < A.n_segs; i += gridDim.x * kThreads) {
+            A.zero_a[i] = 0u;
+            if (A.zero_b) A.zero_b[i] = 0u;
+        }
+    }
+    for (uint32_t i = tid; i < A.nwp; i += kThreads) {
+        const uint32_t c = i < A.n_win ? A.counts[(size_t)i * A.n_slots + blockIdx.x] : 0u;
+        bcur[i] = c;
+        snap[i] = c;
+        hist[i] = 0u;
+        if (A.has_pre && i < A.n_win) A.counts0[(size_t)i * A.n_slots + blockIdx.x] = c;
+    }
+    __syncthreads();
+    const uint32_t back = A.n_short ? min(*A.work_counter, A.max_back) : 0u;
+    const uint32_t n_items = A.n_items + back;
+    const uint32_t wb = A.wb, wmask = (1u << wb) - 1u;
+    uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;
+    bool bad = false, ovf = false;
+    for (uint32_t rr = 0;; ++rr) {
+        const uint32_t job = item_of(rr, blockIdx.x, gridDim.x);
+        if (job >= n_items) break;
+        const uint4 d = A.items[job];
+        const uint32_t place = job < A.n_items ? A.perm[job] : job | 0x80000000u;
+        // the next tile's steps are requested before this one is partitioned
+        uint32_t nxt[kDensePer];
+        const auto request = [&](uint64_t t0) {
+#pragma unroll
+            for (int k = 0; k < kDensePer; ++k) {
+                const uint64_t i = t0 + (uint32_t)k * kThreads + tid;
+                nxt[k] = i < d.y ? A.steps[i] : 0u;
+            }
+        };
+        request(d.x);
+        for (uint64_t t0 = d.x; t0 < d.y; t0 += kDenseTile) {
+            const uint32_t cnt = (uint32_t)min((uint64_t)kDenseTile, (uint64_t)d.y - t0);
+            uint32_t lr[kDensePer], cur[kDensePer];  // a step's rank in its window's bin; its (range-relative) id, or ~0 if it does not count
+#pragma unroll
+            for (int k = 0; k < kDensePer; ++k) cur[k] = nxt[k];
+            if (t0 + kDenseTile < d.y) request(t0 + kDenseTile);
+#pragma unroll
+            for (int k = 0; k < kDensePer; ++k) {
+                const uint32_t i = (uint32_t)k * kThreads + tid;
+                bool valid = i < cnt;
+                uint32_t id = cur[k] >> 1;
+                if (A.ranged) {
+                    bad |= valid && id >= A.n_total;
+                    valid = valid && id - A.seg_base < A.n_segs;
+                    id -= A.seg_base;
+                } else {
+                    bad |= valid && id >= A.n_segs;
+                    valid = valid && id < A.n_segs;
+                }
+                cur[k] = valid ? id : ~0u;
+                lr[k] = valid ? atomicAdd(&hist[id >> wb], 1u) : 0u;
+            }
+            lds_barrier();
+            if (tid < 64u) {  // exclusive prefix sum of the bins, by one wave: nwp / 64 consecutive bins per lane
+                const uint32_t per = A.nwp >> 6;
+                uint32_t sum = 0;
+                for (uint32_t k = 0; k < per; ++k) sum += hist[lane * per + k];
+                uint32_t run = wave_scan_incl(sum) - sum;
+                for (uint32_t k = 0; k < per; ++k) {
+                    base[lane * per + k] = run;
+                    delta[lane * per + k] = bcur[lane * per + k] - run;  // place in the stage -> slot in the sub-bucket
+                    run += hist[lane * per + k];
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int k = 0; k < kDensePer; ++k) {
+                if (cur[k] != ~0u) {
+                    stage[base[cur[k] >> wb] + lr[k]] = cur[k];  // (the id: its window and its place in the window)
+                }
+            }
+            lds_barrier();
+            // The stage holds the tile sorted by window: consecutive places are consecutive slots of
+            // a sub-bucket until the window changes.  (A wave per bin instead -- uniform addresses, no
+            // bin lookup per record -- was measured 20 % slower: sixteen bins in a row, each waiting
+            // for its own LDS reads.)
+            const uint32_t total = base[A.nwp - 1u] + hist[A.nwp - 1u];
+            for (uint32_t j = tid; j < total; j += kThreads) {
+                const uint32_t id = stage[j], wn = id >> wb;
+                const uint32_t pos = delta[wn] + j;
+                if (pos < A.cap) mine[(size_t)wn * A.stride + pos] = (id & wmask) | (1u << 24);
+                else ovf = true;
+            }
+            lds_barrier();
+            for (uint32_t i = tid; i < A.nwp; i += kThreads) {
+                bcur[i] += hist[i];
+                hist[i] = 0u;
+            }
+            lds_barrier();
+        }
+        const uint32_t at = place & 0x7FFFFFFFu;
+        for (uint32_t i = tid; i < A.n_win; i += kThreads) {
+            const uint32_t c = bcur[i];
+            A.dir[(size_t)i * A.dstride + at] = make_uint2(snap[i], c);
+            snap[i] = c;
+        }
+        if (tid == 0) A.islot[at] = blockIdx.x | (place & 0x80000000u);
+        __syncthreads();
+    }
+    flag_if_any(A, bad, kStBounds);
+    flag_if_any(A, ovf, kStOverflow);
+    for (uint32_t i = tid; i < A.n_win; i += kThreads) A.counts[(size_t)i * A.n_slots + blockIdx.x] = bcur[i];
+}
+
 // Plan time: which way each of k_scan's items runs through the segment ids.  items[j].z = 1 when
 // more of its steps follow their predecessor downwards (id - 1) than upwards (id + 1), else 0.
 // One workgroup per item at a time.
-__global__ __launch_bounds__(256) void k_item_dirs(const uint32_t *__restrict__ steps, uint4 *__restrict__ items, uint32_t n_items) {
+__global__ __launch_bounds__(256) void k_item_dirs(const uint32_t *__restrict__ steps, uint4 *__restrict__ items, uint32_t n_items,
+                                                    unsigned long long *__restrict__ n_runs) {
     __shared__ uint32_t up, down;
     for (uint32_t j = blockIdx.x; j < n_items; j += gridDim.x) {
         if (threadIdx.x == 0) up = down = 0;
@@ -1938,7 +2073,10 @@ __global__ __launch_bounds__(256) void k_item_dirs(const uint32_t *__restrict__ 
             atomicAdd(&down, d);
         }
         __syncthreads();
-        if (threadIdx.x == 0) items[j].z = down > up ? 1u : 0u;
+        if (threadIdx.x == 0) {
+            items[j].z = down > up ? 1u : 0u;
+            atomicAdd(n_runs, (unsigned long long)(e - b) - max(up, down));  // the records k_scan will make of the item (but for window crossings)
+        }
         __syncthreads();
     }
 }
@@ -2223,10 +2361,19 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     if (!items.empty()) {
         FAST_TRY(hipMemcpy(fp->items, items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
         if (!getenv("FLATGFA_NO_ITEM_DIRS")) {  // (knob for measurements: every item taken as running upwards)
+            unsigned long long *d_runs64 = nullptr, runs64 = 0, item_steps = 0;
+            FAST_TRY(hipMalloc(&d_runs64, 8));
+            FAST_TRY(hipMemset(d_runs64, 0, 8));
             hipLaunchKernelGGL(k_item_dirs, dim3(std::min<uint32_t>(fp->n_items, fp->n_cus * 8u)), dim3(256), 0, nullptr, g.steps,
-                               reinterpret_cast<uint4 *>(fp->items), fp->n_items);
-            FAST_TRY(hipDeviceSynchronize());
+                               reinterpret_cast<uint4 *>(fp->items), fp->n_items, d_runs64);
+            const hipError_t e = hipMemcpy(&runs64, d_runs64, 8, hipMemcpyDeviceToHost);
+            (void)hipFree(d_runs64);
+            FAST_TRY(e);
+            for (const uint4 &it : items) item_steps += it.y - it.x;
+            // more than three records for four steps: not worth looking for runs (k_scan_dense)
+            fp->dense = !fp->dbg && runs64 * 4 > item_steps * 3 && dense_lds_bytes(fp->nwp) + 64 <= kLdsLimit;
         }
+        if (const char *f = getenv("FLATGFA_DENSE")) fp->dense = !fp->dbg && strtol(f, nullptr, 10) != 0 && dense_lds_bytes(fp->nwp) + 64 <= kLdsLimit;  // tests, measurements
     }
     if (!short_items.empty()) {
         FAST_TRY(hipMalloc(&fp->short_items, short_items.size() * sizeof(uint4)));
@@ -2258,6 +2405,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModePlain>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeDbg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeRanged>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     fp->eligible = true;
     return true;
 }
@@ -2404,8 +2552,9 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
             sa.zero_a = depth_out;
             sa.zero_b = uniq_out;
         }
-        ProfScope pscope("k_scan", stream);
-        if (fp.dbg) hipLaunchKernelGGL(k_scan<kModeDbg>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
+        ProfScope pscope(fp.dense ? "k_scan_dense" : "k_scan", stream);
+        if (fp.dense) hipLaunchKernelGGL(k_scan_dense, dim3(grid), dim3(kThreads), dense_lds_bytes(fp.nwp), stream, sa);
+        else if (fp.dbg) hipLaunchKernelGGL(k_scan<kModeDbg>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
         else if (sa.ranged) hipLaunchKernelGGL(k_scan<kModeRanged>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
         else hipLaunchKernelGGL(k_scan<kModePlain>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
     }

@@ -18,6 +18,7 @@ struct FastPlan {
     FastPlan *more = nullptr;
     uint32_t n_more = 0;
     uint32_t n_cus = 256;
+    bool dense = false;        // nearly every step starts a run: pass 1 partitions the steps themselves (k_scan_dense)
     uint32_t acc_parts = 1;  // workgroups per window in pass 2 (small graphs: fewer windows than CUs)
     uint32_t n_slots = 0;      // sub-buckets per window = persistent workgroups of pass 1
     uint32_t n_win = 0;        // accumulation windows

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
-@pytest.fixture(params=["auto", "bucketed", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3", "ranges"])
+@pytest.fixture(params=["auto", "bucketed", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3", "ranges", "dense"])
 def device_path(request, monkeypatch):
     """Runs a test once per device path: the default (up to 8 M steps the plan times the bucketed
     path against the atomic kernels on the graph at hand and keeps the faster), the bucketed path
@@ -29,7 +29,9 @@ def device_path(request, monkeypatch):
     three pass-2 workgroups per window whatever the graph's size (by default only small graphs
     share their windows out), and the segments cut into ranges of 40960 with one walk of the
     steps per range (by default only graphs beyond 16 M segments are; more than 64 ranges: the
-    atomic kernels).  The variables are read when a graph becomes resident."""
+    atomic kernels), and pass 1 without run detection (k_scan_dense: every step a record,
+    partitioned by window in LDS; by default only for graphs with next to no runs).  The variables
+    are read when a graph becomes resident."""
     monkeypatch.delenv("FLATGFA_DEPTH_PATH", raising=False)
     monkeypatch.delenv("FLATGFA_BUCKET_CAP", raising=False)
     monkeypatch.delenv("FLATGFA_PIECE_STEPS", raising=False)
@@ -37,6 +39,9 @@ def device_path(request, monkeypatch):
     monkeypatch.delenv("FLATGFA_SHORT_ANY", raising=False)
     monkeypatch.delenv("FLATGFA_ACC_PARTS", raising=False)
     monkeypatch.delenv("FLATGFA_RANGE_SEGS", raising=False)
+    monkeypatch.delenv("FLATGFA_DENSE", raising=False)
+    if request.param == "dense":
+        monkeypatch.setenv("FLATGFA_DENSE", "1")
     if request.param == "ranges":
         monkeypatch.setenv("FLATGFA_RANGE_SEGS", "40960")
     if request.param == "parts3":

@@ -67,7 +67,7 @@ def main():
                 else:
                     bad.append(f"{func}: {s}")
             continue
-        if "k_scan" not in func:  # only the kernels that use the landing sets (everything is inlined into them)
+        if "k_scan" not in func or "k_scan_dense" in func:  # only the kernels that use the landing sets (everything is inlined into them)
             continue
         touched = regs_of(s) & PINNED
         if not touched:
