@@ -1389,10 +1389,17 @@ __device__ __forceinline__ Claim claim_begin(int *D, Pending &q, uint32_t *mybit
     if (q.mcnt == 0u) q.moldest = __builtin_amdgcn_readfirstlane(hfirst);
     return c;
 }
-template <int WB>
+template <int WB, bool POINT = false>
 __device__ __forceinline__ void claim_end(int *R, Pending &q, uint32_t *mybits, const Claim &c, uint32_t dbg) {
     uint32_t rv = c.act ? (c.mask & c.old) : 0u;
     if (dbg & kDbgNoRevisit) rv = 0;
+    if (POINT) {  // every record is one segment (k_scan_dense): nothing to park, the revisit is the record
+        if (rv) {
+            atomicAdd(&R[c.e], 1);
+            atomicAdd(&R[c.e + 1u], -1);
+        }
+        return;
+    }
     park_rest(q, c.act && c.p <= c.e, c.p | (c.e << 13) | (c.slot << 26));
     park_revisit(q, rv != 0u, c.base, rv);
     run_pending<WB>(q, R, mybits, dbg, kPendRun);
@@ -1535,7 +1542,10 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
 // step never spans more paths than that.  Three steps' records are requested ahead of their use.
 // SHARED: the stretch [e0, e1) is this wave's share of ONE path's items, `mybits` is the same
 // for all waves of the workgroup and has been cleared by it: no hand-backs, no clearing here.
-template <int WB, bool SHARED>
+// BIG: before a step's records are mapped to their items, look whether the step lies inside the item
+// of the step before (a build of its own: the few instructions cost 3-5 % where paths have a dozen
+// records per window, and save 10-35 % where they have hundreds; the plan's creator times both).
+template <int WB, bool SHARED, bool POINT, bool BIG>
 __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, uint32_t *mybits, uint32_t *mark, uint32_t *pend, const uint32_t *wbase, uint32_t win,
                                              uint32_t e0, uint32_t e1, bool have_first = false, uint2 be_first = make_uint2(0u, 0u), uint32_t slf_first = 0u) {
     constexpr uint32_t kNW = (1u << WB) / 32u;             // words per bitset
@@ -1593,6 +1603,7 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
         // the item's first record (an element offset from the window's bucket base, < 2^24) and H mod 256
         const uint32_t offH = (sl * A.cap + b) | (H << 24);
         uint32_t cs = 0, lastE = 0;  // position in the stream; the item the stream's last prepared record lies in
+        uint32_t curEnd = 0;         // where that item's records end in the stream
         uint32_t hseen = hdone;      // ordinal of the last record's path in the steps prepared so far
         struct Chunk {
             const uint32_t *src;  // per lane: where its record is (the bucket base for lanes without one)
@@ -1609,6 +1620,17 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
         auto prep = [&]() -> Chunk {
             Chunk c;
             const uint32_t q = cs + (uint32_t)lane;
+            if (BIG && cs + 64u <= curEnd) {  // (uniform) the whole step lies inside the item of the step before: nothing to look up
+                const uint32_t oh = __builtin_amdgcn_readlane(offH, lastE), Ps = __builtin_amdgcn_readlane(P, lastE);
+                const uint32_t h = oh >> 24;
+                c.hf = c.hl = h;
+                c.nv = 64u;
+                c.src = wbase + (oh & 0xFFFFFFu) + (q - Ps);
+                c.slot = h & (kSlots - 1u);
+                hseen = h;
+                cs += 64u;
+                return c;
+            }
             const uint32_t relp = P - cs;
             mark[lane] = 0u;
             if (n != 0u && relp < 64u) mark[relp] = (uint32_t)lane + 1u;
@@ -1626,6 +1648,7 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
             const uint32_t last = c.nv ? c.nv - 1u : 0u;
             c.hl = c.nv ? __builtin_amdgcn_readlane(h, last) : hseen;
             lastE = c.nv ? __builtin_amdgcn_readlane(sel, last) : lastE;
+            if (BIG) curEnd = __builtin_amdgcn_readlane(incl, lastE);
             hseen = c.hl;
             cs += c.nv;
             return c;
@@ -1663,7 +1686,7 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
         const Claim cl = begin(CK, rec_take<K>());            \
         CK = prep();                                          \
         rec_request<K>(CK.src);                               \
-        claim_end<WB>(R, pq, mybits, cl, A.dbg);              \
+        claim_end<WB, POINT>(R, pq, mybits, cl, A.dbg);       \
     }
         while (true) {
             FGFA_ACC_STEP(0, c0)
@@ -1768,7 +1791,7 @@ __global__ __launch_bounds__(256) void k_path_reduce(const uint4 *__restrict__ i
     }
 }
 
-template <bool UNIQ, int WB, bool PSUM = false>
+template <bool UNIQ, int WB, bool PSUM = false, bool POINT = false, bool BIG = false>
 __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     constexpr uint32_t kW = 1u << WB;
     constexpr int kPer = kW / kAccThreads;  // cells per thread: 4 or 8
@@ -1821,7 +1844,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     const uint32_t *wbase = A.buckets + (size_t)win * A.n_slots * A.cap;
     if (flat) apply_flat<UNIQ, WB>(A, D, R, scnt, wbase);
     if (UNIQ) {
-        apply_groups<WB, false>(A, D, R, bits + wave * (kSlots * (kW / 32)), marks + wave * 64, pend + wave * (3 * kPend), wbase, win,
+        apply_groups<WB, false, POINT, BIG>(A, D, R, bits + wave * (kSlots * (kW / 32)), marks + wave * 64, pend + wave * (3 * kPend), wbase, win,
                                 ge0, ge1, true, be_first, slf_first);
         // the long paths, one after the other, all waves on each: the bitset is slot 1 of wave 0's
         for (uint32_t f = A.fat_off[blockIdx.y]; f < A.fat_off[blockIdx.y + 1]; ++f) {
@@ -1829,7 +1852,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
             for (uint32_t i = tid; i < kW / 32; i += kAccThreads) bits[kW / 32 + i] = 0u;
             __syncthreads();
             const uint32_t *wo = A.fat_woff + (size_t)f * (kAccWaves + 1) + wave;
-            apply_groups<WB, true>(A, D, R, bits, marks + wave * 64, pend + wave * (3 * kPend), wbase, win,
+            apply_groups<WB, true, POINT, BIG>(A, D, R, bits, marks + wave * 64, pend + wave * (3 * kPend), wbase, win,
                                    __builtin_amdgcn_readfirstlane(wo[0]), __builtin_amdgcn_readfirstlane(wo[1]));
         }
     }
@@ -2567,7 +2590,14 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
         ProfScope pscope(uniq_out ? "k_accum<uniq>" : (ps ? "k_accum<depth+paths>" : "k_accum<depth>"), stream);
         const dim3 agrid(fp.n_win, fp.acc_parts);
         if (uniq_out) {
-            if (fp.wb == 11) hipLaunchKernelGGL((k_accum<true, 11>), agrid, dim3(kAccThreads), 0, stream, aa);
+            // (k_scan_dense's records are single segments: the walk has nothing to park)
+            const bool big = fp.big_groups;
+            if (fp.dense && fp.wb == 12 && big) hipLaunchKernelGGL((k_accum<true, 12, false, true, true>), agrid, dim3(kAccThreads), 0, stream, aa);
+            else if (fp.dense && fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12, false, true, false>), agrid, dim3(kAccThreads), 0, stream, aa);
+            else if (fp.dense && fp.wb == 13) hipLaunchKernelGGL((k_accum<true, 13, false, true, true>), agrid, dim3(kAccThreads), 0, stream, aa);
+            else if (fp.wb == 12 && big) hipLaunchKernelGGL((k_accum<true, 12, false, false, true>), agrid, dim3(kAccThreads), 0, stream, aa);
+            else if (fp.wb == 13 && big) hipLaunchKernelGGL((k_accum<true, 13, false, false, true>), agrid, dim3(kAccThreads), 0, stream, aa);
+            else if (fp.wb == 11) hipLaunchKernelGGL((k_accum<true, 11>), agrid, dim3(kAccThreads), 0, stream, aa);
             else if (fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12>), agrid, dim3(kAccThreads), 0, stream, aa);
             else hipLaunchKernelGGL((k_accum<true, 13>), agrid, dim3(kAccThreads), 0, stream, aa);
         } else {

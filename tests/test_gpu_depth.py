@@ -40,8 +40,11 @@ def device_path(request, monkeypatch):
     monkeypatch.delenv("FLATGFA_ACC_PARTS", raising=False)
     monkeypatch.delenv("FLATGFA_RANGE_SEGS", raising=False)
     monkeypatch.delenv("FLATGFA_DENSE", raising=False)
+    monkeypatch.delenv("FLATGFA_BIG_GROUPS", raising=False)
     if request.param == "dense":
         monkeypatch.setenv("FLATGFA_DENSE", "1")
+    if request.param in ("dense", "pieces", "ranges"):  # pass 2's one-item shortcut on (elsewhere the plan times it)
+        monkeypatch.setenv("FLATGFA_BIG_GROUPS", "1")
     if request.param == "ranges":
         monkeypatch.setenv("FLATGFA_RANGE_SEGS", "40960")
     if request.param == "parts3":

@@ -15,7 +15,7 @@ from oracle import flatgfa_oracle as fo  # noqa: E402
 ENVS = [{}, {"FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0"}, {"FLATGFA_BUCKET_CAP": "8"}, {"FLATGFA_PIECE_STEPS": "512"},
         {"FLATGFA_SHORT_MAX": "300"}, {"FLATGFA_DEPTH_PATH": "atomic"}, {"FLATGFA_ACC_PARTS": "5"},
         {"FLATGFA_RANGE_SEGS": "65536"}, {"FLATGFA_RANGE_SEGS": "40960", "FLATGFA_PIECE_STEPS": "2048"},
-        {"FLATGFA_ACC_PARTS": "2", "FLATGFA_PIECE_STEPS": "1024"}, {"FLATGFA_DENSE": "1"},
+        {"FLATGFA_ACC_PARTS": "2", "FLATGFA_PIECE_STEPS": "1024"}, {"FLATGFA_DENSE": "1", "FLATGFA_BIG_GROUPS": "1"}, {"FLATGFA_BIG_GROUPS": "1"}, {"FLATGFA_BIG_GROUPS": "0", "FLATGFA_PIECE_STEPS": "700"},
         {"FLATGFA_DENSE": "1", "FLATGFA_RANGE_SEGS": "65536", "FLATGFA_SHORT_MAX": "0"}]
 
 
@@ -96,7 +96,7 @@ def main():
         pools.paths, pools.steps, pools.segs = paths, steps, segs
         want_d, want_u = fo.seg_depth_with_uniq(pools)
         env = ENVS[case % len(ENVS)]
-        for k in ("FLATGFA_SHORT_MAX", "FLATGFA_BUCKET_CAP", "FLATGFA_PIECE_STEPS", "FLATGFA_DEPTH_PATH", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS", "FLATGFA_DENSE"):
+        for k in ("FLATGFA_SHORT_MAX", "FLATGFA_BUCKET_CAP", "FLATGFA_PIECE_STEPS", "FLATGFA_DEPTH_PATH", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS", "FLATGFA_DENSE", "FLATGFA_BIG_GROUPS"):
             os.environ.pop(k, None)
         os.environ.update(env)
         graph = dev.DeviceGraph(steps, pb, pe, S, seg_len, device="cuda:0")
