@@ -1368,12 +1368,26 @@ struct Claim {
     uint32_t old, mask, p, e, base, slot;
     bool act;
 };
-template <int WB>
+template <int WB, bool POINT = false>
 __device__ __forceinline__ Claim claim_begin(int *D, Pending &q, uint32_t *mybits, uint32_t slot, uint32_t hfirst, uint32_t rec, uint32_t dbg) {
     constexpr uint32_t kW = 1u << WB, kNW = kW / 32u;
     Claim c;
     const bool valid = rec != 0u;
     const uint32_t rel = rec & (kW - 1);
+    if (POINT) {  // one segment: one bit
+        c.e = rel;
+        if (valid) {
+            atomicAdd(&D[rel], 1);
+            atomicAdd(&D[rel + 1u], -1);
+        }
+        c.act = valid;
+        c.slot = slot;
+        c.base = rel & ~31u;
+        c.mask = 1u << (rel & 31u);
+        c.p = rel + 1u;
+        c.old = valid ? atomicOr(&mybits[slot * kNW + (rel >> 5)], c.mask) : 0u;
+        return c;
+    }
     c.e = rel + ((rec >> WB) & 1023u);  // last segment of the run
     if (valid && !(dbg & kDbgNoDepth)) {
         atomicAdd(&D[rel], 1);
@@ -1670,7 +1684,7 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
             }
             hdone = c.hl;
             const bool has = c.slot != kNoSlot;
-            return claim_begin<WB>(D, pq, mybits, has ? c.slot : 0u, c.hf, has ? loaded : 0u, A.dbg);
+            return claim_begin<WB, POINT>(D, pq, mybits, has ? c.slot : 0u, c.hf, has ? loaded : 0u, A.dbg);
         };
         Chunk c0 = prep();
         rec_request<0>(c0.src);
