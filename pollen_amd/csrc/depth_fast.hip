@@ -16,6 +16,9 @@
 //                 which tells pass 2 which records of a sub-bucket belong to which path.
 //                 A graph beyond 16 M segments is walked once per range of 16 M (k_scan<ranged>
 //                 clips every run to the range).
+//   k_scan_dense  (pass 1 for graphs with next to no runs)  every step is a record of length one;
+//                 the workgroup partitions tiles of 8192 steps by window in LDS, so that a window's
+//                 records leave as stretches of consecutive addresses instead of 64 scattered stores.
 //   k_scan_short  (pass 1 for paths of at most 2048 steps, and "medium" paths with few runs)
 //                 every wave walks whole paths on its own and claims the path's segments in a
 //                 per-wave hash set of bitset words; its records carry what they count for.
