@@ -314,6 +314,40 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
             if (!(st & 4u)) break;  // (an out-of-range id is reported by the query that meets it)
             (void)fast_plan_grow(&pl->fast);
         }
+        // More than a record for two steps: pass 1 by partition (k_scan_dense) may beat pass 1 by runs.
+        // The plan was sized for it (it makes the most records); now both are timed.
+        {
+            bool maybe = pl->fast.eligible && pl->fast.dense_maybe;
+            for (uint32_t r = 0; r < pl->fast.n_more; ++r) maybe = maybe && pl->fast.more[r].dense_maybe;
+            if (maybe) {
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                float best[2] = {1e30f, 1e30f};
+                bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+                const auto set_dense = [&](bool on) {
+                    pl->fast.dense = on;
+                    for (uint32_t r = 0; r < pl->fast.n_more; ++r) pl->fast.more[r].dense = on;
+                };
+                for (int rep = 0; rep < 3 && ok; ++rep) {
+                    for (int which = 0; which < 2 && ok; ++which) {
+                        set_dense(which != 0);
+                        ok = hipEventRecord(e0, nullptr) == hipSuccess;
+                        const int rc = fast_seg_depth(pl->fast, pl->g, tmp, tmp + g->n_segs, pl->status, nullptr);
+                        float ms = 0;
+                        ok = ok && rc == FLATGFA_OK && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+                             hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+                        if (ok && rep) best[which] = std::min(best[which], ms);
+                    }
+                }
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+                (void)hipMemset(pl->status, 0, 4);
+                set_dense(ok && best[1] < best[0]);
+                if (getenv("FLATGFA_TIMING")) fprintf(stderr, "plan: pass 1 by runs %.1f us, by partition %.1f us\n", best[0] * 1e3, best[1] * 1e3);
+            } else if (pl->fast.eligible && pl->fast.dense_maybe) {  // (ranges that disagree: by runs)
+                pl->fast.dense = false;
+                for (uint32_t r = 0; r < pl->fast.n_more; ++r) pl->fast.more[r].dense = pl->fast.more[r].dense && !pl->fast.more[r].dense_maybe;
+            }
+        }
         // Pass 2 can look, before it maps a step's 64 records to their items, whether the step lies
         // inside the item of the step before: a win where a path has hundreds of records per window
         // (paths along the graph: -10 %; ids without runs: -35 %), a few instructions lost where it

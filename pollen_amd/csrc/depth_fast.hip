@@ -2411,9 +2411,18 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             FAST_TRY(e);
             for (const uint4 &it : items) item_steps += it.y - it.x;
             // more than three records for four steps: not worth looking for runs (k_scan_dense)
-            fp->dense = !fp->dbg && runs64 * 4 > item_steps * 3 && dense_lds_bytes(fp->nwp) + 64 <= kLdsLimit;
+            const bool can = !fp->dbg && dense_lds_bytes(fp->nwp) + 64 <= kLdsLimit;
+            // More than a record for two steps: k_scan_dense may be the better pass 1 -- when the
+            // ids jump about; steps that stay in one window make its LDS atomics queue on one
+            // address.  Sized for the dense form (one record per step is the most either makes),
+            // then timed both ways by the plan's creator.
+            fp->dense_maybe = can && runs64 * 2 > item_steps;
+            fp->dense = fp->dense_maybe;
         }
-        if (const char *f = getenv("FLATGFA_DENSE")) fp->dense = !fp->dbg && strtol(f, nullptr, 10) != 0 && dense_lds_bytes(fp->nwp) + 64 <= kLdsLimit;  // tests, measurements
+        if (const char *f = getenv("FLATGFA_DENSE")) {  // tests, measurements
+            fp->dense = !fp->dbg && strtol(f, nullptr, 10) != 0 && dense_lds_bytes(fp->nwp) + 64 <= kLdsLimit;
+            fp->dense_maybe = false;
+        }
     }
     if (!short_items.empty()) {
         FAST_TRY(hipMalloc(&fp->short_items, short_items.size() * sizeof(uint4)));

@@ -19,6 +19,7 @@ struct FastPlan {
     uint32_t n_more = 0;
     uint32_t n_cus = 256;
     bool big_groups = false;   // pass 2 looks for steps that lie inside one item (worth it when a path has hundreds of records per window; the plan's creator times both)
+    bool dense_maybe = false;  // between one and nine records for ten steps: the plan's creator times k_scan_dense against k_scan
     bool dense = false;        // nearly every step starts a run: pass 1 partitions the steps themselves (k_scan_dense)
     uint32_t acc_parts = 1;  // workgroups per window in pass 2 (small graphs: fewer windows than CUs)
     uint32_t n_slots = 0;      // sub-buckets per window = persistent workgroups of pass 1
