@@ -52,6 +52,8 @@ WORKLOADS = {
     "cfgL-4paths": (1_000_000, 4, 25_000_000, "pangenome"),   # fewer paths than pass 2 has waves per window
     "cfgL-medium": (1_000_000, 10_000, 10_000, "pangenome"),  # paths of ten blocks each
     "cfgL-32k": (1_000_000, 3125, 32_000, "pangenome"),       # mid-length paths
+    "chrom-10k": (1_000_000, 10_000, 10_000, "chromosome"),   # ten thousand contigs of ten blocks each, half of them downwards
+    "chrom-1k": (1_000_000, 100_000, 1000, "chromosome"),     # a hundred thousand short ones
     "cfgL-100kseg": (100_000, 1000, 100_000, "pangenome"),    # deep coverage of a small graph: 25 windows
     "cfgL-4Mseg": (4_000_000, 1000, 100_000, "pangenome"),
     "cfgL-16Mseg": (16_000_000, 1000, 100_000, "pangenome"),

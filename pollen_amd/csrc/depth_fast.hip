@@ -96,6 +96,7 @@ constexpr uint32_t kDbgNoStore = 1, kDbgNoTiles = 8, kDbgHotLoads = 16, kDbgTime
 #define FGFA_SKIP(bit) (DBG && (A.dbg & (bit)))
 
 struct ScanArgs {
+    const uint32_t *path_begin, *path_end;  // set when `steps` is the reversed copy: a handed-back path is walked from the graph's own steps
     uint32_t seg_base, n_total, ranged;  // ranged: this walk keeps what falls into [seg_base, seg_base + n_segs) of the graph's n_total segments
     uint32_t *zero_a, *zero_b;  // k_scan clears these vectors of n_segs counts first (pass 2 adds to them when windows are shared); or null
     const uint32_t *steps;
@@ -293,7 +294,10 @@ struct Wave {
     int lane;
 };
 
-constexpr uint32_t kQCap = 320;  // 63 left over + up to 256 from four steps of every lane
+#ifndef FGFA_QCAP
+#define FGFA_QCAP 416
+#endif
+constexpr uint32_t kQCap = FGFA_QCAP;  // at least 63 left over + up to 256 from four steps of every lane; a short path has at most kQCap - 16 runs, hence bitset words: its 512-entry hash set must not fill up
 constexpr uint32_t kPCap = 96;   // parked claims (two words each): 31 left over + up to 64 from one chunk
 
 __device__ __forceinline__ uint32_t clamp_id(const ScanArgs &A, uint32_t id) {
@@ -716,7 +720,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
             if (handed_back) {                                                                          \
                 if (lane == 0) {                                                                        \
                     const uint32_t k = atomicAdd(A.work_counter, 1u);                                   \
-                    if (k < A.max_back) A.items[A.n_items + k] = make_uint4(cur.b, cur.e, kNoSlot, A.short_items[cur.item].w); \
+                    const uint32_t hp = A.short_items[cur.item].w;                                      \
+                    if (k < A.max_back) A.items[A.n_items + k] = A.path_begin ? make_uint4(A.path_begin[hp], A.path_end[hp], kNoSlot, hp) : make_uint4(cur.b, cur.e, kNoSlot, hp); \
                     else atomicOr(A.status, kStOverflow);                                               \
                 }                                                                                       \
                 handed_back = false;                                                                    \
@@ -1934,23 +1939,42 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
 // each path has.  One workgroup per path at a time.
 __global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__ steps, const uint32_t *__restrict__ pb,
                                                      const uint32_t *__restrict__ pe, uint32_t n_paths,
-                                                     uint32_t *__restrict__ runs) {
-    __shared__ uint32_t total;
+                                                     uint32_t *__restrict__ runs, uint32_t *__restrict__ runs_down) {
+    __shared__ uint32_t total, total_down;
     for (uint32_t p = blockIdx.x; p < n_paths; p += gridDim.x) {
-        if (threadIdx.x == 0) total = 0;
+        if (threadIdx.x == 0) total = total_down = 0;
         __syncthreads();
         const uint64_t b = pb[p], e = pe[p];
-        uint32_t mine = 0;
+        uint32_t mine = 0, down = 0;  // (down: the runs the path has when it is read backwards)
         for (uint64_t i = b + threadIdx.x; i < e; i += 256) {
-            const uint32_t id = steps[i] >> 1;
-            const bool start = i == b || id != (steps[i - 1] >> 1) + 1u || (id & 31u) == 0u;
-            mine += start ? 1u : 0u;
+            const uint32_t id = steps[i] >> 1, before = i == b ? 0u : steps[i - 1] >> 1;
+            mine += (i == b || id != before + 1u || (id & 31u) == 0u) ? 1u : 0u;
+            down += (i == b || id + 1u != before || (before & 31u) == 0u) ? 1u : 0u;
         }
-        for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&total, mine);
+        for (int off = 32; off > 0; off >>= 1) {
+            mine += __shfl_down(mine, off, 64);
+            down += __shfl_down(down, off, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&total, mine);
+            atomicAdd(&total_down, down);
+        }
         __syncthreads();
-        if (threadIdx.x == 0) runs[p] = total;
+        if (threadIdx.x == 0) {
+            runs[p] = total;
+            runs_down[p] = total_down;
+        }
         __syncthreads();
+    }
+}
+
+// Plan time: the steps of the listed paths (x = first step, y = one past the last, z = where the copy
+// starts) in reverse order.  One workgroup per path at a time.
+__global__ __launch_bounds__(256) void k_reverse_copy(const uint32_t *__restrict__ steps, const uint4 *__restrict__ list, uint32_t n,
+                                                      uint32_t *__restrict__ out) {
+    for (uint32_t j = blockIdx.x; j < n; j += gridDim.x) {
+        const uint4 d = list[j];
+        for (uint32_t i = threadIdx.x; i < d.y - d.x; i += 256) out[d.z + i] = steps[d.y - 1u - i];
     }
 }
 
@@ -2194,31 +2218,62 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // Which kernel walks a path depends on how many runs it has: short paths must fit the run queue,
     // paths with at most kMediumRuns runs are walked by single waves too, eight per CU, each with a
     // bigger hash set (k_scan_short's medium variant).  The counts come from a one-off kernel.
-    std::vector<uint32_t> runs;
+    std::vector<uint32_t> runs, runs_down;
     if (short_max) {
         uint32_t *d_runs = nullptr;
-        FAST_TRY(hipMalloc(&d_runs, (size_t)g.n_paths * 4));
+        FAST_TRY(hipMalloc(&d_runs, (size_t)g.n_paths * 8));
         hipLaunchKernelGGL(k_count_runs, dim3(std::min<uint32_t>(g.n_paths, fp->n_cus * 8u)), dim3(256), 0, nullptr, g.steps,
-                           g.path_begin, g.path_end, g.n_paths, d_runs);
+                           g.path_begin, g.path_end, g.n_paths, d_runs, d_runs + g.n_paths);
         runs.resize(g.n_paths);
-        const hipError_t e = hipMemcpy(runs.data(), d_runs, (size_t)g.n_paths * 4, hipMemcpyDeviceToHost);
+        runs_down.resize(g.n_paths);
+        hipError_t e = hipMemcpy(runs.data(), d_runs, (size_t)g.n_paths * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(runs_down.data(), d_runs + g.n_paths, (size_t)g.n_paths * 4, hipMemcpyDeviceToHost);
         (void)hipFree(d_runs);
         FAST_TRY(e);
     }
     const bool short_any = getenv("FLATGFA_SHORT_ANY") != nullptr;  // tests: let k_scan_short find out and hand back
-    std::vector<uint4> items, short_items, medium_items, whole;
+    const bool no_rev = getenv("FLATGFA_NO_REVERSED_COPIES") != nullptr;  // (measurements)
+    // A wave-per-path kernel only knows runs that go up.  A path that walks the ids downwards (a
+    // contig on the reverse strand) has far fewer runs when it is read backwards, and the order of a
+    // path's steps does not matter to the counts: such a path is walked from a reversed copy of its
+    // steps, made here once (rev_steps; every copy starts at a multiple of 16).
+    std::vector<uint4> items, short_items, medium_items, short_rev, medium_rev, whole, rev_list;
+    uint64_t rev_len = 0;
     for (uint32_t p = 0; p < g.n_paths; ++p) {
         const uint64_t b = hb[p], e = he[p], n = e - b;
         if (n == 0) continue;
         const bool in_reach = ((e + 15) & ~15ull) <= g.n_steps;  // the last block must not read past the step array
-        // a short path's runs (plus a few block-closing and placeholder ones) must fit the run queue
-        if (n <= short_max && in_reach && (runs[p] + 16 <= kQCap || short_any)) {
+        const bool down = short_max && !no_rev && runs_down[p] < runs[p] && rev_len + n + 2048 < 0xFFFFFFFFull;
+        const uint32_t rn = short_max ? (down ? runs_down[p] : runs[p]) : 0u;
+        const bool is_short = n <= short_max && (down || in_reach) && (rn + 16 <= kQCap || short_any);
+        const bool is_medium = !is_short && short_max && (down || in_reach) && rn <= kMediumRuns;
+        if ((is_short || is_medium) && down) {
+            const uint32_t at = (uint32_t)rev_len;
+            rev_list.push_back(make_uint4((uint32_t)b, (uint32_t)e, at, p));
+            (is_short ? short_rev : medium_rev).push_back(make_uint4(at, at + (uint32_t)n, kNoSlot, p));
+            rev_len += (n + 15) & ~15ull;
+        } else if (is_short) {
             short_items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
-        } else if (short_max && in_reach && runs[p] <= kMediumRuns) {
+        } else if (is_medium) {
             medium_items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
         } else {
             whole.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
         }
+    }
+    if (!rev_list.empty()) {
+        fp->n_rev_steps = (uint32_t)(rev_len + 1024);  // (a block is read whole)
+        FAST_TRY(hipMalloc(&fp->rev_steps, (size_t)fp->n_rev_steps * 4));
+        FAST_TRY(hipMemset(fp->rev_steps, 0, (size_t)fp->n_rev_steps * 4));
+        uint4 *d_list = nullptr;
+        FAST_TRY(hipMalloc(&d_list, rev_list.size() * sizeof(uint4)));
+        hipError_t e = hipMemcpy(d_list, rev_list.data(), rev_list.size() * sizeof(uint4), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_reverse_copy, dim3(std::min<uint32_t>((uint32_t)rev_list.size(), fp->n_cus * 8u)), dim3(256), 0, nullptr,
+                               g.steps, d_list, (uint32_t)rev_list.size(), fp->rev_steps);
+            e = hipDeviceSynchronize();
+        }
+        (void)hipFree(d_list);
+        FAST_TRY(e);
     }
     // k_scan's work items: whole paths, except that a path longer than `piece` steps is cut into
     // equal pieces, so that graphs with few long paths still fill the chip.  The workgroups take the
@@ -2267,6 +2322,12 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     std::stable_sort(items.begin(), items.end(), longer);
     std::stable_sort(short_items.begin(), short_items.end(), longer);
     std::stable_sort(medium_items.begin(), medium_items.end(), longer);
+    std::stable_sort(short_rev.begin(), short_rev.end(), longer);
+    std::stable_sort(medium_rev.begin(), medium_rev.end(), longer);
+    fp->n_short_rev = (uint32_t)short_rev.size();
+    fp->n_medium_rev = (uint32_t)medium_rev.size();
+    short_items.insert(short_items.end(), short_rev.begin(), short_rev.end());      // (the reversed ones behind the others)
+    medium_items.insert(medium_items.end(), medium_rev.begin(), medium_rev.end());
     fp->n_items = (uint32_t)items.size();
     fp->n_short = (uint32_t)short_items.size();
     fp->n_medium = (uint32_t)medium_items.size();
@@ -2527,7 +2588,7 @@ void fast_plan_destroy(FastPlan *fp) {
     delete[] fp->more;
     for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot, (void *)fp->perm,
                     (void *)fp->elist, (void *)fp->wave_off, (void *)fp->fat_off, (void *)fp->fat_woff, (void *)fp->items, (void *)fp->short_items,
-                    (void *)fp->medium_items, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part})
+                    (void *)fp->medium_items, (void *)fp->rev_steps, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part})
         if (p) (void)hipFree(p);
     *fp = FastPlan();
 }
@@ -2546,6 +2607,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     const uint32_t grid = has_pre ? fp.n_slots : std::min<uint32_t>(fp.n_items, fp.n_slots);
     ScanArgs sa;
     sa.zero_a = sa.zero_b = nullptr;
+    sa.path_begin = sa.path_end = nullptr;
     sa.steps = g.steps;
     sa.n_steps = g.n_steps;
     sa.items = reinterpret_cast<uint4 *>(fp.items);
@@ -2580,21 +2642,35 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
                fp.work_counter, fp.max_back, depth_out, uniq_out, status, fp.dbg,
                reinterpret_cast<const uint4 *>(fp.items), g.seg_len, ps ? reinterpret_cast<ulonglong2 *>(fp.psum_part) : nullptr,
                fp.fat_off, fp.fat_woff, fp.acc_parts};
-    if (fp.n_short) {
-        if (hipMemsetAsync(fp.work_counter, 0, 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
-        const uint32_t sgrid = std::min<uint32_t>((fp.n_short + kWaves - 1) / kWaves, fp.n_slots);
-        ProfScope pscope(uniq_out ? "k_scan_short<uniq>" : "k_scan_short<depth>", stream);
-        if (uniq_out) hipLaunchKernelGGL(k_walk_short<true>, dim3(sgrid), dim3(kThreads), fp.lds_bytes_short, stream, sa);
-        else hipLaunchKernelGGL(k_walk_short<false>, dim3(sgrid), dim3(kThreads), fp.lds_bytes_short, stream, sa);
-    }
-    if (fp.n_medium) {
-        ScanArgs sm = sa;
-        sm.short_items = reinterpret_cast<const uint4 *>(fp.medium_items);
-        sm.n_short = fp.n_medium;
-        const uint32_t mgrid = std::min<uint32_t>((fp.n_medium + kMediumWaves - 1) / kMediumWaves, fp.n_slots);
-        ProfScope pscope(uniq_out ? "k_scan_medium<uniq>" : "k_scan_medium<depth>", stream);
-        if (uniq_out) hipLaunchKernelGGL(k_walk_medium<true>, dim3(mgrid), dim3(kMediumWaves * 64), fp.lds_bytes_medium, stream, sm);
-        else hipLaunchKernelGGL(k_walk_medium<false>, dim3(mgrid), dim3(kMediumWaves * 64), fp.lds_bytes_medium, stream, sm);
+    // The wave-per-path kernels: the paths read from the graph's steps, then those read from their
+    // reversed copies (a handed-back one is walked by k_scan from the graph's own steps).
+    if (fp.n_short && hipMemsetAsync(fp.work_counter, 0, 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
+    for (int medium = 0; medium < 2; ++medium) {
+        const uint32_t n_all = medium ? fp.n_medium : fp.n_short, n_rev = medium ? fp.n_medium_rev : fp.n_short_rev;
+        const uint4 *list = reinterpret_cast<const uint4 *>(medium ? fp.medium_items : fp.short_items);
+        for (int rev = 0; rev < 2; ++rev) {
+            const uint32_t n = rev ? n_rev : n_all - n_rev;
+            if (!n) continue;
+            ScanArgs sk = sa;
+            sk.short_items = list + (rev ? n_all - n_rev : 0u);
+            sk.n_short = n;
+            if (rev) {
+                sk.steps = fp.rev_steps;
+                sk.n_steps = fp.n_rev_steps;
+                sk.path_begin = g.path_begin;
+                sk.path_end = g.path_end;
+            }
+            const uint32_t per_wg = medium ? kMediumWaves : kWaves;
+            const uint32_t kgrid = std::min<uint32_t>((n + per_wg - 1) / per_wg, fp.n_slots);
+            ProfScope pscope(medium ? (uniq_out ? "k_scan_medium<uniq>" : "k_scan_medium<depth>") : (uniq_out ? "k_scan_short<uniq>" : "k_scan_short<depth>"), stream);
+            if (medium) {
+                if (uniq_out) hipLaunchKernelGGL(k_walk_medium<true>, dim3(kgrid), dim3(kMediumWaves * 64), fp.lds_bytes_medium, stream, sk);
+                else hipLaunchKernelGGL(k_walk_medium<false>, dim3(kgrid), dim3(kMediumWaves * 64), fp.lds_bytes_medium, stream, sk);
+            } else {
+                if (uniq_out) hipLaunchKernelGGL(k_walk_short<true>, dim3(kgrid), dim3(kThreads), fp.lds_bytes_short, stream, sk);
+                else hipLaunchKernelGGL(k_walk_short<false>, dim3(kgrid), dim3(kThreads), fp.lds_bytes_short, stream, sk);
+            }
+        }
     }
     if (grid) {
         if (fp.acc_parts > 1) {

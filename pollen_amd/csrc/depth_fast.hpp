@@ -45,11 +45,15 @@ struct FastPlan {
                                    // with room for the short paths k_scan_short hands back
     uint32_t n_items = 0;
     uint32_t max_back = 0;
-    void *short_items = nullptr;   // uint4[n_short] paths every wave walks on its own (k_scan_short)
-    uint32_t n_short = 0;
+    void *short_items = nullptr;   // uint4[n_short] paths every wave walks on its own (k_scan_short): first those read from the graph's
+                                   // steps, then n_short_rev paths that walk the ids downwards, read from rev_steps (their
+                                   // steps in reverse order: a wave-per-path kernel only knows runs that go up)
+    uint32_t n_short = 0, n_short_rev = 0;
+    uint32_t *rev_steps = nullptr; // the reversed copies, every path at a multiple of 16
+    uint32_t n_rev_steps = 0;
     uint32_t lds_bytes_short = 0;
     void *medium_items = nullptr;  // uint4[n_medium] longer paths with few enough runs for a 2048-entry hash set
-    uint32_t n_medium = 0;
+    uint32_t n_medium = 0, n_medium_rev = 0;  // (laid out like short_items)
     uint32_t lds_bytes_medium = 0;
     uint32_t *work_counter = nullptr;  // how many short paths were handed back in this call
     void *psum_part = nullptr;         // ulonglong2[n_win * dstride] per-window path sums of k_scan's items (on first use)
