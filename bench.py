@@ -54,6 +54,7 @@ WORKLOADS = {
     "cfgL-32k": (1_000_000, 3125, 32_000, "pangenome"),       # mid-length paths
     "chrom-10k": (1_000_000, 10_000, 10_000, "chromosome"),   # ten thousand contigs of ten blocks each, half of them downwards
     "chrom-1k": (1_000_000, 100_000, 1000, "chromosome"),     # a hundred thousand short ones
+    "tiny-paths": (1_000_000, 1_000_000, 100, "pangenome"),   # a million paths of a hundred steps
     "cfgL-100kseg": (100_000, 1000, 100_000, "pangenome"),    # deep coverage of a small graph: 25 windows
     "cfgL-4Mseg": (4_000_000, 1000, 100_000, "pangenome"),
     "cfgL-16Mseg": (16_000_000, 1000, 100_000, "pangenome"),
