@@ -73,6 +73,12 @@ class FlatGFA:
         except Exception:
             pass
 
+    def __enter__(self) -> "FlatGFA":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
     # ---- flatgfa-py style list views (flatgfa-py/flatgfa.pyi:80-88) ----
     def _views(self):
         from . import views

@@ -1,134 +1,224 @@
-"""The reference's Python-binding tests (flatgfa-py/test/test_flatgfa.py), restated against the
-ctypes mirror: same fixture (tiny.gfa = tests/golden/ref_tiny.gfa), same assertions."""
+"""pollen_amd/views.py (the list-like segments / paths / links views over the C ABI, API shape of
+flatgfa-py/flatgfa.pyi:4-93) checked against a text model of the same file.
+
+Every expectation is derived in the test from the fixture's own GFA lines: `TextModel` splits the
+file into its S / P / L records, and each view has to agree with the record it stands for -- over
+every well-formed graph under tests/golden/, not one hand-picked file."""
 import os
 
 import pytest
 
-import pollen_amd as flatgfa
-from conftest import GOLDEN
-
-TEST_GFA = os.path.join(GOLDEN, "ref_tiny.gfa")
+import pollen_amd as pa
+from conftest import GOLDEN, fixture_id, golden_gfas
 
 
-@pytest.fixture
-def gfa():
-    with open(TEST_GFA, "rb") as f:
-        return flatgfa.parse_bytes(f.read())
+class TextModel:
+    """The S / P / L lines of a GFA file, in file order, as plain Python values."""
+
+    def __init__(self, text: str):
+        self.seg_lines, self.path_lines, self.link_lines = [], [], []
+        for line in text.splitlines():
+            kind = line[:1]
+            if kind == "S":
+                self.seg_lines.append(line)
+            elif kind == "P":
+                self.path_lines.append(line)
+            elif kind == "L":
+                self.link_lines.append(line)
+        self.segs = [(int(f[1]), f[2].encode()) for f in (ln.split("\t") for ln in self.seg_lines)]
+        self.paths = []
+        for f in (ln.split("\t") for ln in self.path_lines):
+            steps = [(int(s[:-1]), s[-1] == "+") for s in f[2].split(",")] if f[2] else []
+            self.paths.append((f[1], steps))
+        self.links = [((int(f[1]), f[2] == "+"), (int(f[3]), f[4] == "+")) for f in (ln.split("\t") for ln in self.link_lines)]
 
 
-def test_segs(gfa):
-    assert len(gfa.segments) == 4
-    seg = gfa.segments[0]
-    assert seg.name == 1
-    assert seg.sequence() == b"CAAATAAG"
-    assert len(seg) == 8
-    seg = list(gfa.segments)[2]
-    assert seg.name == 3
-    assert str(seg) == "S\t3\tTTG"
+# Two fixtures exist to pin quirks of the reference's printer (it writes an insertion where it read a
+# deletion, and normalises a file whose lines are out of order): their text does not survive a round
+# trip by design, tests/test_host.py checks them against the oracle instead.
+NOT_ROUND_TRIP = {"edge_names_loops", "ref_handmade_no-test-flip4"}
 
 
-def test_segs_find(gfa):
-    seg = gfa.segments.find(3)
-    assert seg.id == 2
-    assert seg.sequence() == b"TTG"
-    assert gfa.segments.find(99) is None
+def _views_fixtures():
+    return [p for p in golden_gfas() if fixture_id(p) not in NOT_ROUND_TRIP]
 
 
-def test_paths(gfa):
-    assert len(gfa.paths) == 2
-    assert len(list(gfa.paths)) == 2
-    path = gfa.paths[0]
-    assert path.name == "one"
-    assert str(path) == "P\tone\t1+,2+,4-\t*"
+@pytest.fixture(params=_views_fixtures(), ids=fixture_id)
+def pair(request):
+    with open(request.param, "rb") as f:
+        raw = f.read()
+    g = pa.parse_bytes(raw)
+    yield g, TextModel(raw.decode()), raw
+    g.close()
 
 
-def test_paths_find(gfa):
-    path = gfa.paths.find("two")
-    assert path.id == 1
-    assert path.name == "two"
-    assert gfa.paths.find("three") is None
+def handle_tuple(h):
+    return (h.segment.name, h.is_forward)
 
 
-def test_path_steps(gfa):
-    path = gfa.paths[1]
-    assert len(path) == 4
-    assert len(list(path)) == 4
-    step = path[0]
-    assert step.segment.name == 1
-    assert step.is_forward
-    assert str(step) == "1+"
+# ------------------------------------------------------------------ the three list views ---
+
+def test_lists_have_the_files_lengths(pair):
+    g, m, _ = pair
+    assert (len(g.segments), len(g.paths), len(g.links)) == (len(m.segs), len(m.paths), len(m.links))
+    assert [s.id for s in g.segments] == list(range(len(m.segs)))
+    assert [p.id for p in g.paths] == list(range(len(m.paths)))
 
 
-def test_links(gfa):
-    assert len(gfa.links) == 4
-    assert len(list(gfa.links)) == 4
-    link = gfa.links[1]
-    assert link.from_.segment.name == 2
-    assert link.from_.is_forward
-    assert link.to.segment.name == 4
-    assert not link.to.is_forward
-    assert str(link) == "L\t2\t+\t4\t-\t0M"
+def test_segment_views_match_their_lines(pair):
+    g, m, _ = pair
+    for seg, (name, seq), line in zip(g.segments, m.segs, m.seg_lines):
+        assert seg.name == name
+        assert seg.sequence() == seq and len(seg) == len(seq)
+        assert str(seg) == line
 
 
-def test_gfa_str(gfa):
-    with open(TEST_GFA, "r") as f:
-        assert str(gfa) == f.read()
+def test_path_views_match_their_lines(pair):
+    g, m, _ = pair
+    for path, (name, steps), line in zip(g.paths, m.paths, m.path_lines):
+        assert path.name == name
+        assert len(path) == len(steps)
+        assert [handle_tuple(h) for h in path] == steps
+        assert ",".join(str(h) for h in path) == line.split("\t")[2]
+        assert str(path) == line
 
 
-def test_read_write_gfa(gfa, tmp_path):
-    gfa_path = str(tmp_path / "tiny.gfa")
-    gfa.write_gfa(gfa_path)
-    with open(TEST_GFA, "rb") as orig_f, open(gfa_path, "rb") as written_f:
-        assert orig_f.read() == written_f.read()
-    new_gfa = flatgfa.parse(gfa_path)
-    assert len(new_gfa.segments) == len(gfa.segments)
+def test_link_views_match_their_lines(pair):
+    g, m, _ = pair
+    for link, (frm, to), line in zip(g.links, m.links, m.link_lines):
+        assert handle_tuple(link.from_) == frm and handle_tuple(link.to) == to
+        assert str(link) == line
 
 
-def test_read_write_flatgfa(gfa, tmp_path):
-    flatgfa_path = str(tmp_path / "tiny.flatgfa")
-    gfa.write_flatgfa(flatgfa_path)
-    new_gfa = flatgfa.load(flatgfa_path)
-    assert len(new_gfa.segments) == len(gfa.segments)
-    assert str(new_gfa) == str(gfa)
+def test_indexing_negative_and_out_of_range(pair):
+    g, m, _ = pair
+    for view, n in ((g.segments, len(m.segs)), (g.paths, len(m.paths)), (g.links, len(m.links))):
+        if n:
+            assert view[-1] == view[n - 1]
+            assert view[0] == next(iter(view))
+        with pytest.raises(IndexError):
+            view[n]
+        with pytest.raises(IndexError):
+            view[-n - 1]
 
 
-def test_eq(gfa):
-    assert gfa.segments[0] == gfa.segments[0]
-    assert gfa.segments[0] != gfa.segments[1]
-    assert gfa.paths[0] == gfa.paths[0]
-    assert gfa.paths[0] != gfa.paths[1]
-    assert gfa.links[0] == gfa.links[0]
-    assert gfa.links[0] != gfa.links[1]
-    assert gfa.links[1].from_ == gfa.links[2].from_
-    assert gfa.links[1].from_ != gfa.links[1].to
+def test_slices_are_views_of_the_same_items(pair):
+    g, m, _ = pair
+    for view in (g.segments, g.paths, g.links):
+        n = len(view)
+        for a, b in ((0, n), (1, n), (0, max(n - 1, 0)), (1, 3), (2, 100), (n, n + 5)):
+            sub = view[a:b]
+            want = list(range(n))[a:b]
+            assert len(sub) == len(want)
+            assert [x.id for x in sub] == want
+            if want:
+                assert sub[0] == view[want[0]] and sub[-1] == view[want[-1]]
+                assert len(sub[1:]) == len(want) - 1       # a slice of a slice
+        with pytest.raises(ValueError):
+            view[::2]
+    for path, (_, steps) in zip(g.paths, m.paths):
+        tail = path[1:]
+        assert [handle_tuple(h) for h in tail] == steps[1:]
+        assert len(path[len(steps):]) == 0
+        if len(steps) > 1:
+            assert tail[0] == path[1]
 
 
-def test_hash(gfa):
-    d = {gfa.segments[0]: "foo", gfa.paths[0]: "bar", gfa.links[0]: "baz", gfa.links[1].from_: "qux"}
-    assert d[gfa.segments[0]] == "foo"
-    assert d[gfa.paths[0]] == "bar"
-    assert d[gfa.links[0]] == "baz"
-    assert d[gfa.links[1].from_] == "qux"
+def test_find_returns_the_first_match_or_none(pair):
+    g, m, _ = pair
+    for idx, (name, _) in enumerate(m.segs):
+        first = next(i for i, (n, _) in enumerate(m.segs) if n == name)
+        hit = g.segments.find(name)
+        assert hit is not None and hit.id == first and hit.name == name
+        assert (first == idx) == (hit == g.segments[idx])
+    assert g.segments.find(max((n for n, _ in m.segs), default=0) + 1) is None
+    for name, _ in m.paths:
+        first = next(i for i, (n, _) in enumerate(m.paths) if n == name)
+        assert g.paths.find(name).id == first
+        assert g.paths.find(name.encode()).id == first       # bytes are accepted as well
+    assert g.paths.find("no such path \x00") is None
 
 
-def test_slice(gfa):
-    assert len(gfa.segments[1:3]) == 2
-    assert len(gfa.segments[2:]) == len(gfa.segments) - 2
-    assert gfa.segments[1:3][0].name == gfa.segments[1].name
-    assert len(gfa.paths[1:]) == 1
-    assert len(gfa.links[2:100]) == 2
-    assert len(list(gfa.paths[:1])) == 1
-    path = gfa.paths[0]
-    assert len(path[2:]) == len(path) - 2
-    assert path[2:][0] == path[2]
-    assert len(list(path[2:])) == len(path) - 2
+# ------------------------------------------------------------------ identity of the items ---
+
+def test_equality_is_by_position_handles_by_value(pair):
+    g, m, _ = pair
+    for view in (g.segments, g.paths, g.links):
+        items = list(view)
+        for i, a in enumerate(items):
+            for j, b in enumerate(items):
+                assert (a == b) == (i == j)
+                if i == j:
+                    assert hash(a) == hash(b)
+        assert len(set(items)) == len(items)
+    # a handle has no position: two steps on the same oriented segment are the same handle
+    seen = {}
+    for path in g.paths:
+        for h in path:
+            seen.setdefault(h, handle_tuple(h))
+            assert seen[h] == handle_tuple(h)
+    assert len(seen) == len({st for _, steps in m.paths for st in steps})
+    # items of different kinds (or graphs) never compare equal, whatever their index
+    if len(g.segments) and len(g.paths):
+        assert g.segments[0] != g.paths[0]
+    with pa.parse_bytes(pair[2]) as other:
+        if len(g.segments):
+            assert other.segments[0] != g.segments[0]
+            assert other.segments[0].name == g.segments[0].name
 
 
-def test_depth_example_loop_equals_seg_depth_text(gfa):
-    # flatgfa-py/examples/depth.py: the reference computes depth with a Python loop over the views
-    from collections import Counter
-    depths = Counter()
-    for path in gfa.paths:
-        for step in path:
-            depths[step.segment.id] += 1
-    assert [depths[s.id] for s in gfa.segments] == [2, 2, 1, 2]
+def test_items_work_as_dictionary_keys(pair):
+    g, _, _ = pair
+    table = {}
+    for view in (g.segments, g.paths, g.links):
+        for x in view:
+            table[x] = str(x)
+    for view in (g.segments, g.paths, g.links):
+        for i in range(len(view)):
+            assert table[view[i]] == str(view[i])     # a fresh view object finds the old key
+
+
+# ------------------------------------------------------------------ whole-graph text and files ---
+
+def test_str_of_the_graph_is_the_file(pair):
+    g, _, raw = pair
+    assert str(g) == raw.decode()
+
+
+def test_written_files_read_back_the_same(pair, tmp_path):
+    g, m, raw = pair
+    text_path, bin_path = str(tmp_path / "out.gfa"), str(tmp_path / "out.flatgfa")
+    g.write_gfa(text_path)
+    with open(text_path, "rb") as f:
+        assert f.read() == raw
+    g.write_flatgfa(bin_path)
+    for again in (pa.parse(text_path), pa.load(bin_path)):
+        with again:
+            assert str(again) == str(g)
+            assert [str(p) for p in again.paths] == m.path_lines
+            assert [s.sequence() for s in again.segments] == [seq for _, seq in m.segs]
+
+
+def test_a_python_loop_over_the_views_counts_node_depth(pair):
+    # What a binding user without a depth op would write (cf. flatgfa-py/examples/depth.py); the
+    # expected counts come from the text model, not from the views.
+    g, m, _ = pair
+    want = {}
+    for _, steps in m.paths:
+        for name, _ in steps:
+            want[name] = want.get(name, 0) + 1
+    got = [0] * len(g.segments)
+    for path in g.paths:
+        for h in path:
+            got[h.seg_id] += 1
+    assert got == [want.get(name, 0) for name, _ in m.segs]
+
+
+def test_tiny_gfa_known_values():
+    # flatgfa-py/test/tiny.gfa (committed here as ref_tiny.gfa): a few literal anchors, so that a
+    # bug shared by the views and the text model cannot hide
+    with open(os.path.join(GOLDEN, "ref_tiny.gfa"), "rb") as f, pa.parse_bytes(f.read()) as g:
+        assert g.segments.find(3).sequence() == b"TTG"
+        assert str(g.paths.find("one")) == "P\tone\t1+,2+,4-\t*"
+        assert [str(h) for h in g.paths[1]] == ["1+", "2+", "3+", "4-"]
+        assert str(g.links[1]) == "L\t2\t+\t4\t-\t0M"
