@@ -352,7 +352,7 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
         // inside the item of the step before: a win where a path has hundreds of records per window
         // (paths along the graph: -10 %; ids without runs: -35 %), a few instructions lost where it
         // has a dozen (+4 %).  Timed on this graph, both ways.
-        if (pl->fast.eligible && !getenv("FLATGFA_BIG_GROUPS")) {
+        if (pl->fast.eligible && !pl->fast.tagged && !getenv("FLATGFA_BIG_GROUPS")) {  // (a tagged plan walks sub-buckets, not items)
             hipEvent_t e0 = nullptr, e1 = nullptr;
             float best[2] = {1e30f, 1e30f};
             bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
@@ -385,7 +385,7 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
         // (or any of the knobs that shape the bucketed path) skips the comparison.
         bool shaped = force != nullptr;
         for (const char *k : {"FLATGFA_PIECE_STEPS", "FLATGFA_SHORT_MAX", "FLATGFA_SHORT_ANY", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS",
-                              "FLATGFA_DEBUG_SKIP", "FLATGFA_WB", "FLATGFA_DENSE"})
+                              "FLATGFA_DEBUG_SKIP", "FLATGFA_WB", "FLATGFA_DENSE", "FLATGFA_TAGGED"})
             shaped = shaped || getenv(k) != nullptr;
         if (pl->fast.eligible && !shaped && g->n_steps <= (8u << 20)) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -581,6 +581,10 @@ extern "C" int flatgfa_dev_status(flatgfa_dev_plan_t *pl, void *stream_) {
         if (st & 1u) {
             set_error("a step refers to a segment id (or a query to a path id) that is out of range");
             return FLATGFA_ERR_BOUNDS;
+        }
+        if (st & 8u) {  // (depth_fast.hip: kStInternal)
+            set_error("node depth: internal error (the records of pass 1 were not in the order pass 2 relies on)");
+            return FLATGFA_ERR_HIP;
         }
         if (!(st & 4u)) return FLATGFA_OK;
         // The last node-depth call ran out of sub-bucket room, so its outputs are incomplete: run

@@ -63,7 +63,7 @@ constexpr int kAccThreads = 1024;
 constexpr uint32_t kAccWaves = kAccThreads / 64;
 constexpr uint32_t kLdsLimit = 160 * 1024;
 // status word bits (flatgfa_dev_status)
-constexpr uint32_t kStBounds = 1u, kStDebug = 2u, kStOverflow = 4u;
+constexpr uint32_t kStBounds = 1u, kStDebug = 2u, kStOverflow = 4u, kStInternal = 8u;  // (8: an invariant between the two passes did not hold -- a bug, reported as an error rather than as counts)
 
 // ---- the wave-per-path kernels (k_scan_short): windows of 4096 segments, at most 256 of them ----
 constexpr uint32_t kRunBits = 11;  // a queued run is (start id << 11) | (len - 1)
@@ -84,6 +84,24 @@ constexpr int kShortHash = 9;              // per-wave hash set of 512 (bitset w
 constexpr int kMediumHash = 11, kMediumWaves = 8;
 constexpr uint32_t kMediumRuns = 1500;
 constexpr uint32_t kMaxHandBack = 4096;    // short paths k_scan_short may hand back to k_scan per call
+
+// ---- tagged records ----
+// A record of k_scan is (window-relative first segment) | (length - 1) << wb.  In a *tagged* call it
+// also says whose it is, from bit 23 up: pass 2 then needs no directory of which records of a
+// sub-bucket belong to which item, and k_scan no cursor snapshot (hence no turnaround) per item.
+//   private tag  = the item's ordinal among its workgroup's items (a whole path): its records lie in
+//                  ONE sub-bucket per window, and its "seen" bitset is one of the kTagSlots private
+//                  bitsets of the pass-2 wave that walks that sub-bucket, slot = tag mod kTagSlots.
+//                  k_scan guarantees that all records of tag t precede all records of tag T in a
+//                  sub-bucket whenever T - t >= kTagSlots (a wave may only emit for item rr once
+//                  every wave has left item rr - kTagSlots), so a slot is free when its next owner
+//                  shows up;
+//   shared tag   = kTagCount - 1 - (ordinal of a path that is cut into pieces): the pieces are walked
+//                  by different workgroups, their records lie in many sub-buckets, and all waves of
+//                  pass 2 claim in ONE bitset per such path (LDS ORs are atomic across waves).
+constexpr uint32_t kTagShift = 23, kTagCount = 1u << (32 - kTagShift);
+constexpr uint32_t kTagSlots = 4;
+constexpr uint32_t kMaxShared = 128;      // bitsets of split paths pass 2 has LDS for (4096-segment windows)
 
 // ---- k_scan ----
 constexpr uint32_t kMaxWin = 2048;        // windows per launch (LDS cursor table)
@@ -123,6 +141,7 @@ struct ScanArgs {
     uint32_t sink;       // n_win * stride
     uint32_t *status;
     uint32_t dbg;
+    uint32_t tagged;     // records carry their item's tag (see kTagShift); k_scan_dense reads this, k_scan is a build of its own
 };
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long m) {
@@ -721,7 +740,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
                 if (lane == 0) {                                                                        \
                     const uint32_t k = atomicAdd(A.work_counter, 1u);                                   \
                     const uint32_t hp = A.short_items[cur.item].w;                                      \
-                    if (k < A.max_back) A.items[A.n_items + k] = A.path_begin ? make_uint4(A.path_begin[hp], A.path_end[hp], kNoSlot, hp) : make_uint4(cur.b, cur.e, kNoSlot, hp); \
+                    if (k < A.max_back) A.items[A.n_items + k] = A.path_begin ? make_uint4(A.path_begin[hp], A.path_end[hp], 0u, hp) : make_uint4(cur.b, cur.e, 0u, hp); \
                     else atomicOr(A.status, kStOverflow);                                               \
                 }                                                                                       \
                 handed_back = false;                                                                    \
@@ -760,6 +779,7 @@ constexpr auto k_walk_medium = k_scan_short<UNIQ, kMediumWaves, kMediumHash, fal
 
 struct RWave {
     uint32_t dir;  // +1 / -1 (as unsigned): which way the current item's runs go (uniform; the queue never holds two items)
+    uint32_t tagc; // what every record of the current item carries besides its range: 1 << 24, or the item's tag << kTagShift
     uint2 *q;
     uint32_t fill;
     uint32_t vm[3];
@@ -826,7 +846,9 @@ constexpr int kModePlain = 0, kModeDbg = 1, kModeRanged = 2;
 #define FGFA_WIDE 4
 #endif
 constexpr int kWide = FGFA_WIDE;  // chunks of 64 queue entries k_scan emits side by side
-constexpr uint32_t kCtlNext = 0, kCtlArrive = 2, kCtlEpoch = 4, kCtlWords = 8;
+// (sixteen cells each for the block counters and the arrival counters, indexed by the item's ordinal
+// mod 16 in a tagged call -- waves may be kTagSlots items apart there -- and mod 2 otherwise)
+constexpr uint32_t kCtlNext = 0, kCtlArrive = 16, kCtlEpoch = 32, kCtlWords = 40;
 
 __device__ __forceinline__ uint32_t epoch_now(uint32_t *ctl) {
     return __hip_atomic_load(ctl + kCtlEpoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -884,13 +906,13 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const uint32_t l1 = cross[k] ? wmask - rel[k] : lenm1[k];
-        ovf |= put<DBG>(A, w, mine, valid[k], pos[k], win[k], rel[k] | (l1 << wb) | (1u << 24));
+        ovf |= put<DBG>(A, w, mine, valid[k], pos[k], win[k], rel[k] | (l1 << wb) | w.tagc);
     }
     if (__builtin_amdgcn_ballot_w64(any_cross)) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t pos2 = cross[k] ? atomicAdd(&bcur[win[k] + 1u], 1u) : 0u;
-            ovf |= put<DBG>(A, w, mine, cross[k], pos2, win[k] + 1u, ((lenm1[k] - (wmask - rel[k]) - 1u) << wb) | (1u << 24));
+            ovf |= put<DBG>(A, w, mine, cross[k], pos2, win[k] + 1u, ((lenm1[k] - (wmask - rel[k]) - 1u) << wb) | w.tagc);
         }
     }
     flag_if_any(A, ovf, kStOverflow);
@@ -949,7 +971,8 @@ __device__ __forceinline__ void tile_narrow_raw(const ScanArgs &A, RWave &w, uin
 struct Item {
     uint64_t b, e, t0, tail;
     uint32_t nblk, nl_last;
-    uint32_t dir;      // +1, or -1 for an item marked as running down the segment ids (items[].z == 1)
+    uint32_t dir;      // +1, or -1 for an item marked as running down the segment ids (items[].z & 1)
+    uint32_t shared;   // items[].z >> 1: 0, or 1 + the ordinal of the split path this item is a piece of
     const uint4 *src;  // this lane's first 16 bytes of block 0
 };
 
@@ -966,9 +989,11 @@ __device__ __forceinline__ Item make_item(const ScanArgs &A, bool have, uint4 d,
     it.nblk = 0;
     it.nl_last = 64;
     it.dir = 1u;
+    it.shared = 0u;
     it.src = nullptr;
     if (have) {
-        it.dir = d.z == 1u ? ~0u : 1u;
+        it.dir = (d.z & 1u) ? ~0u : 1u;
+        it.shared = d.z >> 1;
         it.b = d.x;
         it.e = d.y;
         const uint64_t up = (it.b + 15) & ~(uint64_t)15;
@@ -995,7 +1020,7 @@ __device__ __forceinline__ Item make_item(const ScanArgs &A, bool have, uint4 d,
 // emit, the oldest entries are emitted first, one chunk at a time; a block that queues a lot is
 // followed by a wide drain.
 template <int MODE>
-__device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *bcur, uint32_t *mine, uint32_t *ctl, uint32_t rr,
+__device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *bcur, uint32_t *mine, uint32_t *ctl, uint32_t need,
                                          uint32_t (&a)[16], const uint32_t (&pj)[16], uint32_t nsteps) {
     constexpr bool DBG = MODE == kModeDbg;
     unsigned long long m[16], act[4];
@@ -1028,10 +1053,10 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
         w.fill = 0;
     } else if (w.fill >= 65u || w.fill + total + 2u > kQ2) {
         if (!w.epoch_ok) {
-            if (epoch_now(ctl) >= rr) {
+            if (epoch_now(ctl) >= need) {
                 w.epoch_ok = true;
             } else if (w.fill + total + 2u > kQ2) {
-                while (epoch_now(ctl) < rr) __builtin_amdgcn_s_sleep(2);
+                while (epoch_now(ctl) < need) __builtin_amdgcn_s_sleep(2);
                 w.epoch_ok = true;
             }
             tmark<DBG>(A, w, 1);
@@ -1058,20 +1083,21 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
     // steps -- lost 15 %: their waves more often find the item before them not wrapped up yet.)
     // (the diagnostic build keeps cycle counters in registers and has room for one chunk at a time only)
     if (kWide > 1 && !FGFA_SKIP(kDbgNoEmit) && w.fill >= 64u * (DBG ? 1 : kWide) + 1u) {
-        if (!w.epoch_ok && epoch_now(ctl) >= rr) w.epoch_ok = true;
+        if (!w.epoch_ok && epoch_now(ctl) >= need) w.epoch_ok = true;
         tmark<DBG>(A, w, 1);
         if (w.epoch_ok) drain_raw<MODE, (DBG ? 1 : kWide)>(A, w, bcur, mine, false);
         tmark<DBG>(A, w, 3);
     }
 }
 
-template <int MODE>
+template <int MODE, bool TAGGED>
 __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     constexpr bool DBG = MODE == kModeDbg;
+    constexpr uint32_t kRing = TAGGED ? 15u : 1u;  // which cell of the control rings an item uses: its ordinal & kRing
     extern __shared__ uint32_t lds[];
     // layout: [bcur: nwp][snap: nwp][control words][run queues: kWaves * kQ2 entries of 8 bytes]
     uint32_t *bcur = lds;
-    uint32_t *snap = lds + A.nwp;  // the cursors when the current item started
+    uint32_t *snap = lds + A.nwp;  // the cursors when the current item started (not kept in a tagged call)
     uint32_t *ctl = lds + 2u * A.nwp;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the span math on the scalar unit
@@ -1094,10 +1120,10 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     for (uint32_t i = threadIdx.x; i < A.nwp; i += kThreads) {
         const uint32_t c = i < A.n_win ? A.counts[(size_t)i * A.n_slots + blockIdx.x] : 0u;
         bcur[i] = c;
-        snap[i] = c;
+        if (!TAGGED) snap[i] = c;
         if (A.has_pre && i < A.n_win) A.counts0[(size_t)i * A.n_slots + blockIdx.x] = c;
     }
-    if (threadIdx.x < kCtlWords) ctl[threadIdx.x] = threadIdx.x < 2 ? 4u * kWaves : 0u;
+    if (threadIdx.x < kCtlWords) ctl[threadIdx.x] = threadIdx.x < kCtlArrive ? 4u * kWaves : 0u;
     // block-relative positions of this lane's sixteen steps; opaque, so that they stay in registers
     uint32_t pj[16];
 #pragma unroll
@@ -1115,8 +1141,13 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     uint32_t job = item_of(0, blockIdx.x, gridDim.x);
     Item it = make_item(A, job < n_items, job < n_items ? A.items[job] : make_uint4(0u, 0u, 0u, 0u), lane);
     // where pass 2 looks for the item: fetched with its descriptor, long before it is needed
-    uint32_t place = job < A.n_items ? A.perm[job] : job | 0x80000000u;
+    uint32_t place = (TAGGED || job >= A.n_items) ? job | 0x80000000u : A.perm[job];
+    // Records of item rr may be appended once `need` items of this workgroup are complete: the item
+    // before it (its cursor snapshot is taken then), or -- tagged -- the one kTagSlots before it.
+    uint32_t need = 0;
     w.dir = __builtin_amdgcn_readfirstlane(it.dir);
+#define FGFA_ITEM_TAG() (TAGGED ? __builtin_amdgcn_readfirstlane(it.shared ? kTagCount - it.shared : rr) << kTagShift : 1u << 24)
+    w.tagc = FGFA_ITEM_TAG();
     uint32_t blk[3];  // the block each landing set holds (or will hold next)
     uint32_t resv;    // the block this wave takes after those
     // (a partial block is read whole: make_item has made sure that stays inside the step array)
@@ -1143,9 +1174,9 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         blk[SET] = resv;  /* taken one block ago, so that the LDS round trip is off this path */ \
         if (blk[SET] < it.nblk) load_block_coal<SET>(w, FGFA_BLOCK_PTR(blk[SET]));            \
         uint32_t got = 0;                                                                     \
-        if (lane == 0) got = atomicAdd(&ctl[kCtlNext + (rr & 1u)], 1u);                       \
+        if (lane == 0) got = atomicAdd(&ctl[kCtlNext + (rr & kRing)], 1u);                    \
         if (!FGFA_SKIP(kDbgNoTiles)) {                                                        \
-            block16r<MODE>(A, w, bcur, mine, ctl, rr, a, pj, mine_now + 1 == it.nblk ? 16u * it.nl_last : 1024u); \
+            block16r<MODE>(A, w, bcur, mine, ctl, need, a, pj, mine_now + 1 == it.nblk ? 16u * it.nl_last : 1024u); \
         } else if (a[0] == 0x3FFFFFFFu) {                                                     \
             atomicOr(A.status, kStDebug);                                                     \
         }                                                                                     \
@@ -1156,13 +1187,13 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     while (job < n_items) {
         const uint32_t next_job = item_of(rr + 1u, blockIdx.x, gridDim.x);
         const uint4 next_item = next_job < n_items ? A.items[next_job] : make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t next_place = next_job < A.n_items ? A.perm[next_job] : next_job | 0x80000000u;
+        const uint32_t next_place = (TAGGED || next_job >= A.n_items) ? next_job | 0x80000000u : A.perm[next_job];
         // the few steps outside the blocks are walked on their own, by the first and the last wave
         if (wave == 0 && it.t0 > it.b) tile_narrow_raw(A, w, it.b, (uint32_t)(it.t0 - it.b));
         if (wave == kWaves - 1) {
             for (uint64_t t = it.tail; t < it.e; t += 64) {  // fewer than 16 steps, but for a block left out by make_item
                 if (w.fill + 66u > kQ2) {
-                    while (epoch_now(ctl) < rr) __builtin_amdgcn_s_sleep(2);
+                    while (epoch_now(ctl) < need) __builtin_amdgcn_s_sleep(2);
                     w.epoch_ok = true;
                     drain_raw<MODE>(A, w, bcur, mine, false);
                 }
@@ -1176,10 +1207,11 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             FGFA_BLOCK(2)
         }
         // Records of this item may only be appended once every wave has left the item before it
-        // (its cursor snapshot is taken then); a wave that got ahead has been queueing until now.
+        // (its cursor snapshot is taken then; tagged: the item kTagSlots before it); a wave that got
+        // ahead has been queueing until now.
         tmark<DBG>(A, w, 4);
         if (!w.epoch_ok) {
-            while (epoch_now(ctl) < rr) __builtin_amdgcn_s_sleep(2);
+            while (epoch_now(ctl) < need) __builtin_amdgcn_s_sleep(2);
             w.epoch_ok = true;
         }
         tmark<DBG>(A, w, 1);
@@ -1193,27 +1225,32 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         w.dir = __builtin_amdgcn_readfirstlane(it.dir);  // the queue is empty here
         FGFA_PRELOAD();
         // The last wave to leave the item snapshots the cursors: dir[window][item] = the item's
-        // stretch of this workgroup's sub-bucket, which is how pass 2 tells the paths apart.
+        // stretch of this workgroup's sub-bucket, which is how pass 2 tells the paths apart --
+        // in a tagged call the records say so themselves, and the last wave only counts the item off.
         uint32_t old = 0;
-        if (lane == 0) old = __hip_atomic_fetch_add(&ctl[kCtlArrive + (rr & 1u)], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0) old = __hip_atomic_fetch_add(&ctl[kCtlArrive + (rr & kRing)], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
         old = __builtin_amdgcn_readfirstlane(old);
         if (old == kWaves - 1u) {
-            // (pass 2 finds the item at its place in ITS walk order: one coalesced read per 64 items there)
-            const uint32_t at = __builtin_amdgcn_readfirstlane(pe & 0x7FFFFFFFu);
-            for (uint32_t i = lane; i < A.n_win; i += 64) {
-                const uint32_t c = bcur[i];
-                A.dir[(size_t)i * A.dstride + at] = make_uint2(snap[i], c);
-                snap[i] = c;
+            if (!TAGGED) {
+                // (pass 2 finds the item at its place in ITS walk order: one coalesced read per 64 items there)
+                const uint32_t at = __builtin_amdgcn_readfirstlane(pe & 0x7FFFFFFFu);
+                for (uint32_t i = lane; i < A.n_win; i += 64) {
+                    const uint32_t c = bcur[i];
+                    A.dir[(size_t)i * A.dstride + at] = make_uint2(snap[i], c);
+                    snap[i] = c;
+                }
+                if (lane == 0) A.islot[at] = blockIdx.x | (pe & 0x80000000u);
             }
             if (lane == 0) {
-                A.islot[at] = blockIdx.x | (pe & 0x80000000u);
-                ctl[kCtlArrive + (rr & 1u)] = 0u;
-                ctl[kCtlNext + (rr & 1u)] = 4u * kWaves;  // for the item after the next one
+                ctl[kCtlArrive + (rr & kRing)] = 0u;
+                ctl[kCtlNext + (rr & kRing)] = 4u * kWaves;  // for the next item that uses these cells (no wave is there yet)
             }
-            __hip_atomic_store(ctl + kCtlEpoch, rr + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(ctl + kCtlEpoch, rr + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (items complete in order)
         }
         rr += 1u;
-        w.epoch_ok = false;
+        w.tagc = FGFA_ITEM_TAG();
+        need = TAGGED ? (rr >= kTagSlots ? rr - (kTagSlots - 1u) : 0u) : rr;
+        w.epoch_ok = TAGGED && epoch_now(ctl) >= need;
         tmark<DBG>(A, w, 5);
     }
     if (DBG && (A.dbg & kDbgTime) && lane == 0) {
@@ -1223,6 +1260,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
 #undef FGFA_PRELOAD
 #undef FGFA_BLOCK
 #undef FGFA_BLOCK_PTR
+#undef FGFA_ITEM_TAG
     // publish how many records this workgroup left in each window's sub-bucket
     __syncthreads();
     for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads)
@@ -1260,6 +1298,35 @@ struct AccArgs {
     const uint32_t *fat_off;   // [parts + 1] which of these paths workgroup blockIdx.y walks
     const uint32_t *fat_woff;  // [n_fat][kAccWaves + 1] which stretch of elist each wave walks of the path's items
     uint32_t parts;  // workgroups per window (blockIdx.y): each walks its share of the paths / sub-buckets and ADDS its counts to the (zeroed) outputs
+    uint32_t n_shared;  // tagged calls: the split paths, whose bitsets all waves of the workgroup share (tags kTagCount - n_shared .. kTagCount - 1)
+    uint32_t *tprof;    // FLATGFA_ACC_TIME (diagnostic): sixteen words per wave, see AccTimer
+};
+
+// FLATGFA_ACC_TIME: charge the time since the last mark to phase `ph` of this wave; the wave's
+// sixteen words (eight phase times in 10 ns units, eight event counts) are written once, at the end
+struct AccTimer {
+    uint32_t *buf;
+    unsigned long long last;
+    uint32_t acc[16];
+    __device__ __forceinline__ void start(uint32_t *b) {
+        buf = b;
+        for (int k = 0; k < 16; ++k) acc[k] = 0;
+        if (buf) last = __builtin_amdgcn_s_memrealtime();
+    }
+    __device__ __forceinline__ void mark(int ph) {
+        if (!buf) return;
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        acc[ph] += (uint32_t)(now - last);
+        last = now;
+    }
+    __device__ __forceinline__ void count(int what, uint32_t n = 1u) {
+        if (buf) acc[8 + what] += n;
+    }
+    __device__ __forceinline__ void finish() {
+        if (!buf || (threadIdx.x & 63)) return;
+        uint32_t *o = buf + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kAccWaves + (threadIdx.x >> 6)) * 16;
+        for (int k = 0; k < 16; ++k) o[k] = acc[k];
+    }
 };
 
 // Pass 2 keeps two difference arrays over the window in LDS: D for depth and R for revisits (steps
@@ -1270,7 +1337,7 @@ struct AccArgs {
 template <bool UNIQ, int WB>
 __device__ __forceinline__ void apply_record(int *D, int *R, uint32_t rec) {
     constexpr uint32_t kW = 1u << WB;
-    const uint32_t rel = rec & (kW - 1), end = rel + ((rec >> WB) & 2047u) + 1;  // end <= window size; that cell is a sink
+    const uint32_t rel = rec & (kW - 1), end = rel + ((rec >> WB) & ((1u << (kTagShift - WB)) - 1u)) + 1;  // (whatever lies below a tag; k_scan_short's lengths have eleven bits) end <= window size; that cell is a sink
     if (UNIQ) {
         const int d = (int)((rec >> 24) & 1u), rv = d - (int)((rec >> 25) & 1u);
         if (d) {
@@ -1298,7 +1365,7 @@ __device__ __forceinline__ void apply_record(int *D, int *R, uint32_t rec) {
 constexpr uint32_t kPend = 96;      // entries per list: fewer than kPendRun parked + up to 64 from one step
 constexpr uint32_t kPendRun = 32;   // a list is worked off while it holds at least this many
 struct Pending {
-    uint32_t *m;   // [kPend] rest of a record: first unclaimed segment | last segment << 13 | bitset slot << 26
+    uint32_t *m;   // [kPend] rest of a record: first unclaimed segment | last segment << PB | bitset slot << 2 PB (PB = 13; in a tagged call log2 of the window, which leaves eight bits for the slot at 4096 segments)
     uint2 *r;      // [kPend] {window-relative first segment of a bitset word, its revisited bits}
     uint32_t mcnt, rcnt;
     uint32_t moldest;  // ordinal (mod 256) of the path of the oldest entry on m
@@ -1328,19 +1395,19 @@ __device__ __forceinline__ void park_revisit(Pending &q, bool e, uint32_t base, 
     q.rcnt = __builtin_amdgcn_readfirstlane(q.rcnt + (uint32_t)__builtin_popcountll(mk));
 }
 // the newest (up to) 64 parked records: one more word each
-template <int WB>
+template <int WB, int PB = 13>
 __device__ __forceinline__ void run_rest(Pending &q, uint32_t *mybits, uint32_t dbg) {
-    constexpr uint32_t kNW = (1u << WB) / 32u;
+    constexpr uint32_t kNW = (1u << WB) / 32u, kPM = (1u << PB) - 1u;
     const uint32_t n = __builtin_amdgcn_readfirstlane(min(q.mcnt, 64u));
     q.mcnt = __builtin_amdgcn_readfirstlane(q.mcnt - n);
     const bool act = (uint32_t)q.lane < n;
     const uint32_t v = act ? q.m[q.mcnt + q.lane] : 0u;
     asm volatile("" ::: "memory");  // the slots read here are written again below, by other lanes
-    uint32_t p = v & 0x1FFFu, base;
-    const uint32_t e = (v >> 13) & 0x1FFFu;
-    uint32_t rv = claim_word(mybits + (v >> 26) * kNW, act, p, e, base);
+    uint32_t p = v & kPM, base;
+    const uint32_t e = (v >> PB) & kPM;
+    uint32_t rv = claim_word(mybits + (v >> (2 * PB)) * kNW, act, p, e, base);
     if (dbg & kDbgNoRevisit) rv = 0;
-    park_rest(q, act && p <= e, (v & ~0x1FFFu) | p);
+    park_rest(q, act && p <= e, (v & ~kPM) | p);
     park_revisit(q, rv != 0u, base, rv);
 }
 // the newest (up to) 64 parked words: one stretch of revisited segments each
@@ -1360,11 +1427,11 @@ __device__ __forceinline__ void run_revisits(Pending &q, int *R) {
     }
     park_revisit(q, rv != 0u, v.x, rv);
 }
-template <int WB>
+template <int WB, int PB = 13>
 __device__ __forceinline__ void run_pending(Pending &q, int *R, uint32_t *mybits, uint32_t dbg, uint32_t at_least) {
     while (q.mcnt >= at_least || q.rcnt >= at_least) {
         if (q.rcnt >= at_least) run_revisits(q, R);
-        else run_rest<WB>(q, mybits, dbg);
+        else run_rest<WB, PB>(q, mybits, dbg);
         if (at_least == 1u && q.mcnt == 0u && q.rcnt == 0u) break;
     }
 }
@@ -1377,10 +1444,9 @@ struct Claim {
     bool act;
 };
 template <int WB, bool POINT = false>
-__device__ __forceinline__ Claim claim_begin(int *D, Pending &q, uint32_t *mybits, uint32_t slot, uint32_t hfirst, uint32_t rec, uint32_t dbg) {
+__device__ __forceinline__ Claim claim_begin(int *D, Pending &q, uint32_t *mybits, uint32_t slot, uint32_t hfirst, uint32_t rec, bool valid, uint32_t dbg) {
     constexpr uint32_t kW = 1u << WB, kNW = kW / 32u;
     Claim c;
-    const bool valid = rec != 0u;
     const uint32_t rel = rec & (kW - 1);
     if (POINT) {  // one segment: one bit
         c.e = rel;
@@ -1411,7 +1477,7 @@ __device__ __forceinline__ Claim claim_begin(int *D, Pending &q, uint32_t *mybit
     if (q.mcnt == 0u) q.moldest = __builtin_amdgcn_readfirstlane(hfirst);
     return c;
 }
-template <int WB, bool POINT = false>
+template <int WB, bool POINT = false, int PB = 13>
 __device__ __forceinline__ void claim_end(int *R, Pending &q, uint32_t *mybits, const Claim &c, uint32_t dbg) {
     uint32_t rv = c.act ? (c.mask & c.old) : 0u;
     if (dbg & kDbgNoRevisit) rv = 0;
@@ -1422,9 +1488,9 @@ __device__ __forceinline__ void claim_end(int *R, Pending &q, uint32_t *mybits, 
         }
         return;
     }
-    park_rest(q, c.act && c.p <= c.e, c.p | (c.e << 13) | (c.slot << 26));
+    park_rest(q, c.act && c.p <= c.e, c.p | (c.e << PB) | (c.slot << (2 * PB)));
     park_revisit(q, rv != 0u, c.base, rv);
-    run_pending<WB>(q, R, mybits, dbg, kPendRun);
+    run_pending<WB, PB>(q, R, mybits, dbg, kPendRun);
 }
 
 // inclusive prefix sum of N*1024 values held N per thread by 1024 threads (v[] holds this thread's
@@ -1692,7 +1758,7 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
             }
             hdone = c.hl;
             const bool has = c.slot != kNoSlot;
-            return claim_begin<WB, POINT>(D, pq, mybits, has ? c.slot : 0u, c.hf, has ? loaded : 0u, A.dbg);
+            return claim_begin<WB, POINT>(D, pq, mybits, has ? c.slot : 0u, c.hf, loaded, has && loaded != 0u, A.dbg);
         };
         Chunk c0 = prep();
         rec_request<0>(c0.src);
@@ -1718,6 +1784,240 @@ __device__ __forceinline__ void apply_groups(const AccArgs &A, int *D, int *R, u
 #undef FGFA_ACC_STEP
     }
     run_pending<WB>(pq, R, mybits, A.dbg, 1u);
+}
+
+// minimum / maximum across the wave, uniform
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(~0u, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(~0u, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(~0u, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(~0u, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(~0u, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false));
+    x = min(x, (uint32_t)__builtin_amdgcn_update_dpp(~0u, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) { return __builtin_amdgcn_readlane(wave_scan_max(x), 63); }
+
+// The tagged walk's record requests: as rec_request / rec_take, but the address is a wave-uniform
+// pointer (an SGPR pair) plus the lane's own four bytes -- nothing to compute per lane and step.
+template <int K>
+__device__ __forceinline__ void rec_request_s(const uint32_t *p, uint32_t lane4) {
+    if (K == 0) asm volatile("global_load_dword v120, %0, %1" ::"v"(lane4), "s"(p) : "memory", "v120");
+    else if (K == 1) asm volatile("global_load_dword v121, %0, %1" ::"v"(lane4), "s"(p) : "memory", "v121");
+    else asm volatile("global_load_dword v122, %0, %1" ::"v"(lane4), "s"(p) : "memory", "v122");
+}
+
+// What one step does with its 64 records once each lane knows its path's bitset (sb: the bitset's
+// LDS byte address; vm: the lanes that hold a record): +1/-1 into D, the run's bits ORed into
+// the bitset one word at a time -- the first word by all lanes, further words by the lanes that
+// have any (a run of ten segments crosses a word boundary one time in three) -- and every stretch
+// of bits that were already set a +1/-1 pair into R (adding the lowest set bit carries through
+// its stretch; a word rarely has two).  Hand-written: as hipcc renders the same C++ a step costs
+// 100 vector and 120 scalar instructions, and a CU issues one of each per cycle for its sixteen
+// waves -- the walk was bound by instruction issue, scalar before vector (FLATGFA_ACC_SKIP
+// ablations).  This is 19 + 2 vector instructions for the first word, 12 per turn of the
+// revisit loop, 8 per further word, and a dozen scalar ones.  Nothing is parked, so a bitset can
+// change hands at any step.
+template <int WB>
+__device__ __forceinline__ void claim_step(uint32_t rec, uint32_t sb, unsigned long long vm, uint32_t dbase, uint32_t rbase,
+                                           uint32_t one, uint32_t mone) {
+    constexpr uint32_t kRelMask = (1u << WB) - 1u, kBaseMask = kRelMask & ~31u;
+    uint32_t n, a, w, tt, m, k, mask, base, old, rv, low, sum, f, g;
+    unsigned long long sv, s2;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[vm]\n\t"
+        "v_and_b32 %[a], %[relmask], %[rec]\n\t"              // the run's first segment, window-relative
+        "v_bfe_u32 %[n], %[rec], %[wb], 10\n\t"               // its length - 1
+        "v_lshl_add_u32 %[a], %[a], 2, %[dbase]\n\t"
+        "ds_add_u32 %[a], %[one]\n\t"                         // D[first] += 1
+        "v_lshl_add_u32 %[a], %[n], 2, %[a]\n\t"
+        "ds_add_u32 %[a], %[mone] offset:4\n\t"               // D[last + 1] -= 1
+        "v_bfe_u32 %[w], %[rec], 5, %[wb5]\n\t"               // the first segment's word in the bitset
+        "v_lshl_add_u32 %[w], %[w], 2, %[sb]\n\t"
+        "v_and_b32 %[k], 31, %[rec]\n\t"                      // its bit in that word
+        "v_add_u32 %[tt], %[k], %[n]\n\t"                     // the last segment's bit, counted from bit 0 of the first word
+        "v_min_u32 %[m], 31, %[tt]\n\t"
+        "v_sub_u32 %[m], 31, %[m]\n\t"
+        "v_lshrrev_b32 %[m], %[m], -1\n\t"
+        "v_lshlrev_b32 %[k], %[k], -1\n\t"
+        "v_and_b32 %[mask], %[m], %[k]\n\t"
+        "v_and_b32 %[base], %[basemask], %[rec]\n\t"
+        "v_lshl_add_u32 %[base], %[base], 2, %[rbase]\n\t"    // R's cell of the word's first segment
+        "1:\n\t"
+        "ds_or_rtn_b32 %[old], %[w], %[mask]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_and_b32 %[rv], %[old], %[mask]\n\t"                // the segments this path had already visited
+        "v_cmp_ne_u32 vcc, 0, %[rv]\n\t"
+        "s_cbranch_vccz 3f\n\t"
+        "s_mov_b64 %[s2], exec\n\t"
+        "2:\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "v_sub_u32 %[low], 0, %[rv]\n\t"
+        "v_and_b32 %[low], %[rv], %[low]\n\t"                 // the lowest revisited segment
+        "v_add_u32 %[sum], %[rv], %[low]\n\t"                 // (the carry runs through its stretch)
+        "v_ffbl_b32 %[f], %[low]\n\t"
+        "v_ffbl_b32 %[g], %[sum]\n\t"
+        "v_min_u32 %[g], 32, %[g]\n\t"                        // (no bit left: the stretch ends with the word)
+        "v_lshl_add_u32 %[f], %[f], 2, %[base]\n\t"
+        "v_lshl_add_u32 %[g], %[g], 2, %[base]\n\t"
+        "ds_add_u32 %[f], %[one]\n\t"
+        "ds_add_u32 %[g], %[mone]\n\t"
+        "v_and_b32 %[rv], %[rv], %[sum]\n\t"
+        "v_cmp_ne_u32 vcc, 0, %[rv]\n\t"
+        "s_cbranch_vccnz 2b\n\t"
+        "s_mov_b64 exec, %[s2]\n\t"
+        "3:\n\t"
+        "v_cmp_lt_u32 vcc, 31, %[tt]\n\t"                     // the lanes whose run goes on into the next word
+        "s_cbranch_vccz 4f\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "v_subrev_u32 %[tt], 32, %[tt]\n\t"
+        "v_add_u32 %[w], 4, %[w]\n\t"
+        "v_add_u32 %[base], 0x80, %[base]\n\t"
+        "v_min_u32 %[m], 31, %[tt]\n\t"
+        "v_sub_u32 %[m], 31, %[m]\n\t"
+        "v_lshrrev_b32 %[mask], %[m], -1\n\t"
+        "s_branch 1b\n\t"
+        "4:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [n] "=&v"(n), [a] "=&v"(a), [w] "=&v"(w), [tt] "=&v"(tt), [m] "=&v"(m), [k] "=&v"(k), [mask] "=&v"(mask), [base] "=&v"(base),
+          [old] "=&v"(old), [rv] "=&v"(rv), [low] "=&v"(low), [sum] "=&v"(sum), [f] "=&v"(f), [g] "=&v"(g), [sv] "=&s"(sv), [s2] "=&s"(s2)
+        : [rec] "v"(rec), [sb] "v"(sb), [vm] "s"(vm), [dbase] "s"(dbase), [rbase] "s"(rbase), [one] "v"(one), [mone] "v"(mone),
+          [relmask] "i"(kRelMask), [basemask] "i"(kBaseMask), [wb] "i"(WB), [wb5] "i"(WB - 5)
+        : "vcc", "memory");
+}
+
+// Pass 2 of a tagged call: every record of k_scan says whose it is (see kTagShift), so a wave
+// walks whole sub-buckets, 64 consecutive records per step, three steps' records requested ahead
+// of their use, and needs no directory: nothing to fetch before the first record, no mapping of
+// records to items.  The waves of a workgroup take its sub-buckets from an LDS counter, one ahead
+// (the first is their own index), so that none is left with the heavy ones.
+// `bits` holds the workgroup's kAccWaves * kTagSlots private bitsets, then one per split path
+// (shared by all waves; cleared by the kernel).  A private slot changes hands when a tag beyond
+// the highest seen so far shows up (k_scan guarantees that the slot's previous owner, kTagSlots
+// items earlier, has no record behind that point), and when the wave opens its next sub-bucket.
+template <int WB, bool POINT>
+__device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, uint32_t *bits, const uint2 *scnt2, const uint32_t *wbase,
+                                             uint32_t *grab) {
+    constexpr uint32_t kW = 1u << WB, kNW = kW / 32u;
+    constexpr uint32_t kPriv = kAccWaves * kTagSlots;  // slot ids: the waves' private bitsets first, the shared ones behind
+    const int lane = threadIdx.x & 63;
+    const uint32_t lane4 = 4u * (uint32_t)lane;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t y16 = blockIdx.y * kAccWaves, nw = A.parts * kAccWaves;
+    const uint32_t shlo = kTagCount - A.n_shared;  // tags from here up name split paths
+    const uint32_t bits0 = lds_addr(bits);  // (LDS byte addresses)
+    const uint32_t dbase = lds_addr(D), rbase = lds_addr(R);
+    uint32_t one = 1u, mone = ~0u;  // (the LDS adds take their operand from a register)
+    asm volatile("" : "+v"(one), "+v"(mone));
+    // this workgroup's sub-buckets: the i-th is y16 + (i & 15) + (i >> 4) * nw, while that is below n_slots
+    const uint32_t imax = A.n_slots > y16 ? kAccWaves * ((A.n_slots - y16 + nw - 1u) / nw) : 0u;
+    const uint32_t *sp = wbase;  // (uniform) the next record of the open sub-bucket ...
+    uint32_t left = 0;           // ... and how many it has left
+    uint32_t cur_i = wv;
+    const auto open = [&](uint32_t i) {
+        const uint32_t s = y16 + (i & (kAccWaves - 1u)) + (i / kAccWaves) * nw;
+        left = 0;
+        if (i < imax && s < A.n_slots) {
+            const uint2 c = scnt2[s];  // {where k_scan's records start, where they end}
+            const uint32_t c0 = __builtin_amdgcn_readfirstlane(c.x), c1 = __builtin_amdgcn_readfirstlane(c.y);
+            sp = wbase + (size_t)s * A.cap + c0;
+            left = c1 > c0 ? c1 - c0 : 0u;
+        }
+    };
+    open(cur_i);
+    uint32_t nxt = 0;  // the sub-bucket after the open one (taken when that one was opened: the LDS round trip is long over when it is needed)
+    if (lane == 0) nxt = atomicAdd(grab, 1u);
+    // The next step of this wave's stream: up to 64 records of the open sub-bucket, or of the next one
+    // that has any.  Lanes beyond the last record read what lies behind it (the bucket array ends
+    // with a window nobody reads); a step behind the end of the stream is empty but still requests its load.
+#define FGFA_TAG_GEN(K, NV, FR)                                  \
+    do {                                                         \
+        FR = 0u;                                                 \
+        while (left == 0u && cur_i < imax) {                     \
+            cur_i = __builtin_amdgcn_readfirstlane(nxt);         \
+            if (lane == 0) nxt = atomicAdd(grab, 1u);            \
+            open(cur_i);                                         \
+            FR = 1u;                                             \
+        }                                                        \
+        NV = min(64u, left);                                     \
+        rec_request_s<K>(sp, lane4);                             \
+        sp += NV;                                                \
+        left -= NV;                                              \
+    } while (0)
+    int hmax = -1;  // (uniform) the highest private tag met in the open sub-bucket
+    uint32_t nv0, nv1, nv2, f0, f1, f2;
+    FGFA_TAG_GEN(0, nv0, f0);
+    FGFA_TAG_GEN(1, nv1, f1);
+    FGFA_TAG_GEN(2, nv2, f2);
+#define FGFA_TAG_STEP(K, NV, FR)                                                                                       \
+    if (NV == 0u) break;                                                                                               \
+    {                                                                                                                  \
+        const uint32_t rec = rec_take<K>();                                                                            \
+        const unsigned long long vm = NV >= 64u ? ~0ull : (1ull << NV) - 1ull;  /* the lanes that hold a record */     \
+        if (FR) hmax = -1;  /* the private slots start over with this sub-bucket */                                    \
+        FGFA_TAG_GEN(K, NV, FR);                                                                                       \
+        const uint32_t tag = rec >> kTagShift;                                                                         \
+        const unsigned long long shm = A.n_shared ? __builtin_amdgcn_ballot_w64(tag >= shlo) & vm : 0ull;              \
+        unsigned long long todo = vm;                                                                                  \
+        do {                                                                                                           \
+            unsigned long long act = todo;                                                                             \
+            /* tags beyond those met so far: their bitsets change hands */                                             \
+            unsigned long long newm = __builtin_amdgcn_ballot_w64((int)tag > hmax) & todo & ~shm;                      \
+            if (newm) {                                                                                                \
+                int hnew = hmax;                                                                                       \
+                for (unsigned long long m = newm; m;) {                                                                \
+                    const uint32_t t = __builtin_amdgcn_readlane(tag, (int)__builtin_ctzll(m));                        \
+                    hnew = max(hnew, (int)t);                                                                          \
+                    m &= ~__builtin_amdgcn_ballot_w64(tag == t);                                                       \
+                }                                                                                                      \
+                if (__builtin_amdgcn_ballot_w64((int)(tag + kTagSlots) <= hnew) & todo & ~shm) {                       \
+                    /* (rare) more items in one step than a wave has bitsets: the lanes before the first one */        \
+                    /* whose tag is kTagSlots beyond the lowest go first -- records of such tags lie in order */       \
+                    const bool pv = ((todo & ~shm) >> lane) & 1ull;                                                    \
+                    const uint32_t tmin = wave_min_u32(pv ? tag : ~0u);                                                \
+                    const unsigned long long beyond = __builtin_amdgcn_ballot_w64(pv && tag >= tmin + kTagSlots);      \
+                    if (beyond) act = todo & ((1ull << __builtin_ctzll(beyond)) - 1ull);                               \
+                    if ((int)(tmin + kTagSlots) <= hmax || !act) {  /* cannot happen: k_scan's gate */                 \
+                        atomicOr(A.status, kStInternal);                                                               \
+                        act = todo;                                                                                    \
+                    }                                                                                                  \
+                    hnew = max(hmax, (int)wave_max_u32(((act & ~shm) >> lane) & 1ull ? tag : 0u));                     \
+                }                                                                                                      \
+                for (int t = max(hmax + 1, hnew - (int)(kTagSlots - 1u)); t <= hnew; ++t) {                            \
+                    uint32_t *bs = bits + (wv * kTagSlots + ((uint32_t)t & (kTagSlots - 1u))) * kNW;                   \
+                    for (uint32_t i = lane; i < kNW / 2u; i += 64) reinterpret_cast<uint2 *>(bs)[i] = make_uint2(0u, 0u); \
+                }                                                                                                      \
+                hmax = hnew;                                                                                           \
+            }                                                                                                          \
+            /* each lane's bitset: its wave's slot tag mod kTagSlots, or its split path's */                           \
+            uint32_t slot = wv * kTagSlots + (tag & (kTagSlots - 1u));                                                 \
+            if (shm) slot = tag >= shlo ? kPriv + (kTagCount - 1u - tag) : slot;                                       \
+            if (POINT) {  /* every record is one segment (k_scan_dense) */                                             \
+                const uint32_t rel = rec & (kW - 1u), bit = 1u << (rel & 31u);                                         \
+                uint32_t old = 0;                                                                                      \
+                if ((act >> lane) & 1ull) {                                                                            \
+                    atomicAdd(&D[rel], 1);                                                                             \
+                    atomicAdd(&D[rel + 1u], -1);                                                                       \
+                    old = atomicOr(bits + slot * kNW + (rel >> 5), bit);                                               \
+                }                                                                                                      \
+                if (old & bit) {                                                                                       \
+                    atomicAdd(&R[rel], 1);                                                                             \
+                    atomicAdd(&R[rel + 1u], -1);                                                                       \
+                }                                                                                                      \
+            } else {                                                                                                   \
+                claim_step<WB>(rec, bits0 + (slot << (WB - 3)), act, dbase, rbase, one, mone);                         \
+            }                                                                                                          \
+            todo &= ~act;                                                                                              \
+        } while (todo);                                                                                                \
+    }
+    while (true) {
+        FGFA_TAG_STEP(0, nv0, f0)
+        FGFA_TAG_STEP(1, nv1, f1)
+        FGFA_TAG_STEP(2, nv2, f2)
+    }
+#undef FGFA_TAG_STEP
+#undef FGFA_TAG_GEN
 }
 
 // the sum of a 64-bit value over the wave, uniform, by DPP adds on its halves
@@ -1813,7 +2113,11 @@ __global__ __launch_bounds__(256) void k_path_reduce(const uint4 *__restrict__ i
     }
 }
 
-template <bool UNIQ, int WB, bool PSUM = false, bool POINT = false, bool BIG = false>
+// the "seen" bitsets of a tagged call: dynamic shared memory, (kAccWaves * kTagSlots + n_shared) * window / 8 bytes
+extern __shared__ __attribute__((aligned(16))) uint32_t tag_bits[];
+uint32_t tagged_lds_bytes(uint32_t wb, uint32_t n_shared) { return (kAccWaves * kTagSlots + n_shared) * ((1u << wb) / 8u); }
+
+template <bool UNIQ, int WB, bool PSUM = false, bool POINT = false, bool BIG = false, bool TAGGED = false>
 __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     constexpr uint32_t kW = 1u << WB;
     constexpr int kPer = kW / kAccThreads;  // cells per thread: 4 or 8
@@ -1822,17 +2126,21 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     __shared__ __attribute__((aligned(16))) int cells[(UNIQ ? 2 : 1) * (kW + 64)];
     __shared__ unsigned long long wave_tot[kAccWaves];
     __shared__ uint32_t scnt[kMaxSlots];
-    __shared__ __attribute__((aligned(16))) uint32_t bits[UNIQ ? kAccWaves * kSlots * (kW / 32) : 4];
-    __shared__ uint32_t marks[UNIQ ? kAccWaves * 64 : 4];
-    __shared__ __attribute__((aligned(8))) uint32_t pend[UNIQ ? kAccWaves * 3 * kPend : 4];
+    __shared__ __attribute__((aligned(8))) uint2 scnt2[TAGGED && UNIQ ? kMaxSlots : 1];  // tagged: where k_scan's records start and end in each sub-bucket
+    __shared__ __attribute__((aligned(16))) uint32_t bits[UNIQ && !TAGGED ? kAccWaves * kSlots * (kW / 32) : 4];
+    __shared__ uint32_t marks[UNIQ && !TAGGED ? kAccWaves * 64 : 4];
+    __shared__ __attribute__((aligned(8))) uint32_t pend[UNIQ && !TAGGED ? kAccWaves * 3 * kPend : 4];
+    __shared__ uint32_t grab;  // tagged: the next of the workgroup's sub-buckets nobody has taken yet
     __shared__ unsigned long long Lw[PSUM ? kW + 1 : 1], Ww[PSUM ? kW + 1 : 1];  // prefix sums of len and depth * len
     int *D = cells, *R = cells + (UNIQ ? kW + 64 : 0);
     const int tid = threadIdx.x, wave = tid >> 6;
+    AccTimer tm;
+    tm.start(A.tprof);
     const uint32_t win = blockIdx.x, w0 = win * kW;
     // this window's record counts, one per sub-bucket: staged in LDS, and zeroed in place so that
     // the scratch is clean for the next call.  With unique depth, k_scan's records are found
     // through the directory; the counts staged are those of the records that came before them.
-    const bool flat = !UNIQ || A.has_pre;
+    const bool flat = !UNIQ || A.has_pre;  // (without unique depth every record is applied as it is, tagged or not)
     const uint32_t nw = A.parts * kAccWaves;  // a window's sub-buckets are shared out to the waves of its A.parts workgroups
     // The first round of directory entries of this wave's items is requested right away: it is on
     // its way while the workgroup clears its arrays (a round trip of the twelve microseconds a
@@ -1840,7 +2148,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     const uint32_t vwave = __builtin_amdgcn_readfirstlane(blockIdx.y * kAccWaves + wave);
     uint32_t ge0 = 0, ge1 = 0, slf_first = 0;
     uint2 be_first = make_uint2(0u, 0u);
-    if (UNIQ) {
+    if (UNIQ && !TAGGED) {
         ge0 = __builtin_amdgcn_readfirstlane(A.wave_off[vwave]);
         ge1 = __builtin_amdgcn_readfirstlane(A.wave_off[vwave + 1]);
         const uint32_t nback = A.has_pre ? min(__builtin_amdgcn_readfirstlane(*A.work_counter), A.max_back) : 0u;
@@ -1857,15 +2165,28 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
         uint32_t *c = A.counts + (size_t)win * A.n_slots + sl;
         uint32_t v = *c;
         *c = 0u;
-        if (UNIQ && A.has_pre) v = A.counts0[(size_t)win * A.n_slots + sl];
+        if (TAGGED && UNIQ) {
+            const uint32_t c1 = min(v, A.cap);
+            v = A.has_pre ? A.counts0[(size_t)win * A.n_slots + sl] : 0u;
+            scnt2[sl] = make_uint2(min(v, A.cap), c1);
+        } else if (UNIQ && A.has_pre) {
+            v = A.counts0[(size_t)win * A.n_slots + sl];
+        }
         scnt[sl] = min(v, A.cap);
     }
+    if (tid == 0) grab = kAccWaves;
+    if (TAGGED && UNIQ)  // the split paths' bitsets (the private ones are cleared when they change hands)
+        for (uint32_t i = tid; i < A.n_shared * (kW / 32); i += kAccThreads) tag_bits[kAccWaves * kTagSlots * (kW / 32) + i] = 0u;
     const uint32_t nvalid = min(kW, A.n_segs - w0);
     for (uint32_t i = tid; i < (UNIQ ? 2u : 1u) * (kW + 64); i += kAccThreads) cells[i] = 0;
     __syncthreads();
     const uint32_t *wbase = A.buckets + (size_t)win * A.n_slots * A.cap;
+    tm.mark(0);
     if (flat) apply_flat<UNIQ, WB>(A, D, R, scnt, wbase);
-    if (UNIQ) {
+    tm.mark(1);
+    if (UNIQ && TAGGED) {
+        apply_tagged<WB, POINT>(A, D, R, tag_bits, scnt2, wbase, &grab);
+    } else if (UNIQ) {
         apply_groups<WB, false, POINT, BIG>(A, D, R, bits + wave * (kSlots * (kW / 32)), marks + wave * 64, pend + wave * (3 * kPend), wbase, win,
                                 ge0, ge1, true, be_first, slf_first);
         // the long paths, one after the other, all waves on each: the bitset is slot 1 of wave 0's
@@ -1878,7 +2199,9 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
                                    __builtin_amdgcn_readfirstlane(wo[0]), __builtin_amdgcn_readfirstlane(wo[1]));
         }
     }
+    tm.mark(2);
     __syncthreads();
+    tm.mark(3);
     const uint32_t i0 = kPer * tid;
     uint32_t d[kPer], u[kPer];
     if (UNIQ) {
@@ -1900,6 +2223,8 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
             store_n<kPer>(A.depth_out + w0, i0, nvalid, d);
             store_n<kPer>(A.uniq_out + w0, i0, nvalid, u);
         }
+        tm.mark(4);
+        tm.finish();
     } else {
         int v[kPer];
 #pragma unroll
@@ -2028,6 +2353,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_dense(const ScanArgs A) {
         if (job >= n_items) break;
         const uint4 d = A.items[job];
         const uint32_t place = job < A.n_items ? A.perm[job] : job | 0x80000000u;
+        const uint32_t tagc = A.tagged ? ((d.z >> 1) ? kTagCount - (d.z >> 1) : rr) << kTagShift : 1u << 24;  // (see kTagShift)
         // the next tile's steps are requested before this one is partitioned
         uint32_t nxt[kDensePer];
         const auto request = [&](uint64_t t0) {
@@ -2088,7 +2414,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_dense(const ScanArgs A) {
             for (uint32_t j = tid; j < total; j += kThreads) {
                 const uint32_t id = stage[j], wn = id >> wb;
                 const uint32_t pos = delta[wn] + j;
-                if (pos < A.cap) mine[(size_t)wn * A.stride + pos] = (id & wmask) | (1u << 24);
+                if (pos < A.cap) mine[(size_t)wn * A.stride + pos] = (id & wmask) | tagc;
                 else ovf = true;
             }
             lds_barrier();
@@ -2112,7 +2438,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_dense(const ScanArgs A) {
     for (uint32_t i = tid; i < A.n_win; i += kThreads) A.counts[(size_t)i * A.n_slots + blockIdx.x] = bcur[i];
 }
 
-// Plan time: which way each of k_scan's items runs through the segment ids.  items[j].z = 1 when
+// Plan time: which way each of k_scan's items runs through the segment ids.  Bit 0 of items[j].z = 1 when
 // more of its steps follow their predecessor downwards (id - 1) than upwards (id + 1), else 0.
 // One workgroup per item at a time.
 __global__ __launch_bounds__(256) void k_item_dirs(const uint32_t *__restrict__ steps, uint4 *__restrict__ items, uint32_t n_items,
@@ -2138,7 +2464,7 @@ __global__ __launch_bounds__(256) void k_item_dirs(const uint32_t *__restrict__ 
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            items[j].z = down > up ? 1u : 0u;
+            items[j].z = (items[j].z & ~1u) | (down > up ? 1u : 0u);
             atomicAdd(n_runs, (unsigned long long)(e - b) - max(up, down));  // the records k_scan will make of the item (but for window crossings)
         }
         __syncthreads();
@@ -2282,13 +2608,18 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // longest).  So the deal is played through on the host for a few piece sizes, every item charged
     // a few blocks' worth for its turnaround, and the size with the shortest longest hand is taken
     // (the largest such size: for 1000 paths of 100 k steps, no cutting at all).
-    const auto cut = [&](uint64_t piece, std::vector<uint4> *out) {
+    // (z: bit 0 = the item walks the ids downwards, set by k_item_dirs; from bit 1 up, 1 + the
+    // ordinal of the split path the item is a piece of, or 0 for a whole path)
+    const auto cut = [&](uint64_t piece, std::vector<uint4> *out) -> uint32_t {
+        uint32_t n_split = 0;
         for (const uint4 &w : whole) {
             const uint64_t b = w.x, n = (uint64_t)w.y - w.x;
             const uint32_t k = (uint32_t)((n + piece - 1) / piece);
+            const uint32_t z = k > 1 ? (++n_split) << 1 : 0u;
             for (uint32_t j = 0; j < k; ++j)
-                out->push_back(make_uint4((uint32_t)(b + n * j / k), (uint32_t)(b + n * (j + 1) / k), kNoSlot, w.w));
+                out->push_back(make_uint4((uint32_t)(b + n * j / k), (uint32_t)(b + n * (j + 1) / k), z, w.w));
         }
+        return n_split;
     };
     const auto longer = [](const uint4 &a, const uint4 &b) { return a.y - a.x > b.y - b.x; };
     uint64_t piece = 0;
@@ -2318,7 +2649,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             if (cand == 32768) break;
         }
     }
-    cut(piece ? piece : 32768, &items);
+    fp->n_shared = cut(piece ? piece : 32768, &items);
     std::stable_sort(items.begin(), items.end(), longer);
     std::stable_sort(short_items.begin(), short_items.end(), longer);
     std::stable_sort(medium_items.begin(), medium_items.end(), longer);
@@ -2345,6 +2676,17 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     fp->acc_parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({16, fp->n_cus / n_win, (g.n_steps / n_win + (32u << 10) - 1) >> 15}));  // a workgroup per 32 k steps: a wave's walk is a chain of dependent round trips, a microsecond per 64 records
     if (const char *f = getenv("FLATGFA_ACC_PARTS")) fp->acc_parts = std::max(1u, std::min(64u, (uint32_t)strtoul(f, nullptr, 10)));
     const uint32_t acc_waves = fp->acc_parts * kAccWaves;
+    // Tagged calls (records say whose they are; see kTagShift): every workgroup's items -- the handed-back
+    // ones included -- must have tags of their own next to the split paths', and pass 2 needs LDS for a
+    // bitset per split path (none to spare with 8192-segment windows; a window shared by several
+    // workgroups cannot share bitsets).  FLATGFA_TAGGED=0 keeps the directory (tests, measurements).
+    {
+        const uint32_t grid = (fp->n_short || fp->n_medium) ? fp->n_slots : std::min<uint32_t>(fp->n_items, fp->n_slots);
+        const uint64_t per_wg = grid ? ((uint64_t)fp->n_items + fp->max_back + grid - 1) / grid : 0;
+        const char *t = getenv("FLATGFA_TAGGED");
+        fp->tagged = !fp->dbg && !(t && t[0] == '0') && per_wg + fp->n_shared <= kTagCount &&
+                     fp->n_shared <= (wb <= 12 ? kMaxShared : 0u) && (fp->n_shared == 0 || fp->acc_parts == 1);
+    }
     // Pass 2 walks k_scan's items grouped by path (the pieces of a split path share a bitset),
     // each of its waves a contiguous stretch of the list: paths are dealt to the waves longest
     // first, each to the wave with the least steps so far.
@@ -2512,9 +2854,17 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipFuncSetAttribute((const void *)k_walk_medium<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     FAST_TRY(hipMalloc(&fp->work_counter, 256));
     FAST_TRY(hipMemset(fp->work_counter, 0, 256));
-    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModePlain>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeDbg>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeRanged>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModePlain, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModePlain, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeDbg, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeRanged, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeRanged, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    // pass 2 of a tagged call keeps its bitsets in dynamic shared memory (next to about 60 KB of static arrays, 93 KB with 8192-segment windows)
+    FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 11, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(11, kMaxShared)));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 13, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(13, 0)));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 13, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(13, 0)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     fp->eligible = true;
     return true;
@@ -2637,11 +2987,18 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     sa.sink = fp.n_win * stride;
     sa.status = status;
     sa.dbg = fp.dbg;
+    // Tagged: k_scan's records name their items, pass 2 walks whole sub-buckets.  Path sums ride on
+    // the directory walk (an item's records have to be found again once the window's depth is final).
+    const bool tagged = fp.tagged && !ps;
+    sa.tagged = tagged ? 1u : 0u;
     AccArgs aa{fp.n_range, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.counts0, has_pre ? 1u : 0u, fp.buckets,
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
                fp.work_counter, fp.max_back, depth_out, uniq_out, status, fp.dbg,
                reinterpret_cast<const uint4 *>(fp.items), g.seg_len, ps ? reinterpret_cast<ulonglong2 *>(fp.psum_part) : nullptr,
-               fp.fat_off, fp.fat_woff, fp.acc_parts};
+               fp.fat_off, fp.fat_woff, fp.acc_parts, tagged ? fp.n_shared : 0u, nullptr};
+    if (const char *sk = getenv("FLATGFA_ACC_SKIP")) aa.dbg = (uint32_t)strtoul(sk, nullptr, 10);  // (diagnostic: pass 2 without its revisit counts 128 / depth 256 / claims 64 / words behind the first 1024)
+    const size_t tprof_words = (size_t)fp.n_win * fp.acc_parts * kAccWaves * 16;
+    if (getenv("FLATGFA_ACC_TIME") && uniq_out && hipMalloc(&aa.tprof, tprof_words * 4) != hipSuccess) aa.tprof = nullptr;
     // The wave-per-path kernels: the paths read from the graph's steps, then those read from their
     // reversed copies (a handed-back one is walked by k_scan from the graph's own steps).
     if (fp.n_short && hipMemsetAsync(fp.work_counter, 0, 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
@@ -2679,9 +3036,11 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
         }
         ProfScope pscope(fp.dense ? "k_scan_dense" : "k_scan", stream);
         if (fp.dense) hipLaunchKernelGGL(k_scan_dense, dim3(grid), dim3(kThreads), dense_lds_bytes(fp.nwp), stream, sa);
-        else if (fp.dbg) hipLaunchKernelGGL(k_scan<kModeDbg>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
-        else if (sa.ranged) hipLaunchKernelGGL(k_scan<kModeRanged>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
-        else hipLaunchKernelGGL(k_scan<kModePlain>, dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
+        else if (fp.dbg) hipLaunchKernelGGL((k_scan<kModeDbg, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
+        else if (sa.ranged && tagged) hipLaunchKernelGGL((k_scan<kModeRanged, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
+        else if (sa.ranged) hipLaunchKernelGGL((k_scan<kModeRanged, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
+        else if (tagged) hipLaunchKernelGGL((k_scan<kModePlain, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
+        else hipLaunchKernelGGL((k_scan<kModePlain, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
     }
     if (fp.acc_parts > 1 && !grid) {  // the window's workgroups add to the outputs: cleared by k_scan, or here when it does not run
         ProfScope pscope("memset_outputs", stream);
@@ -2691,7 +3050,14 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     {
         ProfScope pscope(uniq_out ? "k_accum<uniq>" : (ps ? "k_accum<depth+paths>" : "k_accum<depth>"), stream);
         const dim3 agrid(fp.n_win, fp.acc_parts);
-        if (uniq_out) {
+        if (uniq_out && tagged) {
+            const uint32_t tl = tagged_lds_bytes(fp.wb, fp.n_shared);
+            if (fp.dense && fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12, false, true, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
+            else if (fp.dense && fp.wb == 13) hipLaunchKernelGGL((k_accum<true, 13, false, true, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
+            else if (fp.wb == 11) hipLaunchKernelGGL((k_accum<true, 11, false, false, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
+            else if (fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12, false, false, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
+            else hipLaunchKernelGGL((k_accum<true, 13, false, false, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
+        } else if (uniq_out) {
             // (k_scan_dense's records are single segments: the walk has nothing to park)
             const bool big = fp.big_groups;
             if (fp.dense && fp.wb == 12 && big) hipLaunchKernelGGL((k_accum<true, 12, false, true, true>), agrid, dim3(kAccThreads), 0, stream, aa);
@@ -2718,6 +3084,23 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     if (hipGetLastError() != hipSuccess) {
         set_error("fast_seg_depth: kernel launch failed");
         return FLATGFA_ERR_HIP;
+    }
+    if (aa.tprof) {  // diagnostic: where the waves of pass 2 spend their time
+        std::vector<uint32_t> raw(tprof_words);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(raw.data(), aa.tprof, tprof_words * 4, hipMemcpyDeviceToHost);
+        (void)hipFree(aa.tprof);
+        const size_t waves = tprof_words / 16;
+        double sum[16] = {}, mx[16] = {};
+        for (size_t w = 0; w < waves; ++w)
+            for (int k = 0; k < 16; ++k) {
+                sum[k] += raw[w * 16 + k];
+                mx[k] = std::max<double>(mx[k], raw[w * 16 + k]);
+            }
+        static const char *names[5] = {"setup", "flat", "walk", "barrier", "scan+store"};
+        fprintf(stderr, "k_accum%s per wave, us avg (max):", tagged ? " [tagged]" : "");
+        for (int k = 0; k < 5; ++k) fprintf(stderr, "  %s %.2f (%.2f)", names[k], sum[k] / waves / 100.0, mx[k] / 100.0);
+        fprintf(stderr, "  | per wave avg (max): steps %.1f (%.0f) rounds %.1f flushes %.1f (%.0f)\n", sum[8] / waves, mx[8], sum[9] / waves, sum[10] / waves, mx[10]);
     }
     if (fp.dbg & kDbgTime) {  // diagnostic: where the waves of k_scan spend their cycles
         unsigned long long acc[8] = {};

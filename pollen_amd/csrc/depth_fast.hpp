@@ -18,6 +18,8 @@ struct FastPlan {
     FastPlan *more = nullptr;
     uint32_t n_more = 0;
     uint32_t n_cus = 256;
+    bool tagged = false;       // k_scan's records can carry their item's tag: pass 2 then walks whole sub-buckets and needs no directory (depth_fast.hip: kTagShift)
+    uint32_t n_shared = 0;     // paths cut into pieces (their bitsets are shared by all waves of a pass-2 workgroup in a tagged call)
     bool big_groups = false;   // pass 2 looks for steps that lie inside one item (worth it when a path has hundreds of records per window; the plan's creator times both)
     bool dense_maybe = false;  // between one and nine records for ten steps: the plan's creator times k_scan_dense against k_scan
     bool dense = false;        // nearly every step starts a run: pass 1 partitions the steps themselves (k_scan_dense)

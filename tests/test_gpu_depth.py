@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
-@pytest.fixture(params=["auto", "bucketed", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3", "ranges", "dense"])
+@pytest.fixture(params=["auto", "bucketed", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3", "ranges", "dense",
+                        "untagged", "untagged_pieces", "untagged_noshort"])
 def device_path(request, monkeypatch):
     """Runs a test once per device path: the default (up to 8 M steps the plan times the bucketed
     path against the atomic kernels on the graph at hand and keeps the faster), the bucketed path
@@ -30,8 +31,12 @@ def device_path(request, monkeypatch):
     share their windows out), and the segments cut into ranges of 40960 with one walk of the
     steps per range (by default only graphs beyond 16 M segments are; more than 64 ranges: the
     atomic kernels), and pass 1 without run detection (k_scan_dense: every step a record,
-    partitioned by window in LDS; by default only for graphs with next to no runs).  The variables
-    are read when a graph becomes resident."""
+    partitioned by window in LDS; by default only for graphs with next to no runs).  All of those
+    run tagged where the plan allows it (records that name their item, pass 2 walking whole
+    sub-buckets; pieces of split paths claim in bitsets shared by a workgroup's waves); the
+    "untagged" paths keep the directory walk (what plans with more split paths than pass 2 has
+    bitsets for fall back to, and what path depth rides on).  The variables are read when a graph
+    becomes resident."""
     monkeypatch.delenv("FLATGFA_DEPTH_PATH", raising=False)
     monkeypatch.delenv("FLATGFA_BUCKET_CAP", raising=False)
     monkeypatch.delenv("FLATGFA_PIECE_STEPS", raising=False)
@@ -41,19 +46,23 @@ def device_path(request, monkeypatch):
     monkeypatch.delenv("FLATGFA_RANGE_SEGS", raising=False)
     monkeypatch.delenv("FLATGFA_DENSE", raising=False)
     monkeypatch.delenv("FLATGFA_BIG_GROUPS", raising=False)
+    monkeypatch.delenv("FLATGFA_TAGGED", raising=False)
+    if request.param.startswith("untagged"):
+        monkeypatch.setenv("FLATGFA_TAGGED", "0")
+        monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
     if request.param == "dense":
         monkeypatch.setenv("FLATGFA_DENSE", "1")
-    if request.param in ("dense", "pieces", "ranges"):  # pass 2's one-item shortcut on (elsewhere the plan times it)
+    if request.param in ("dense", "pieces", "ranges", "untagged_pieces"):  # pass 2's one-item shortcut on (elsewhere the plan times it)
         monkeypatch.setenv("FLATGFA_BIG_GROUPS", "1")
     if request.param == "ranges":
         monkeypatch.setenv("FLATGFA_RANGE_SEGS", "40960")
     if request.param == "parts3":
         monkeypatch.setenv("FLATGFA_ACC_PARTS", "3")
-    if request.param == "noshort":
+    if request.param in ("noshort", "untagged_noshort"):
         monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
     if request.param == "handback":  # short paths go to k_scan_short whatever their run count: it hands back what does not fit
         monkeypatch.setenv("FLATGFA_SHORT_ANY", "1")
-    if request.param == "pieces":   # every path longer than 512 steps is scanned as several pieces + k_merge
+    if request.param in ("pieces", "untagged_pieces"):   # every path longer than 512 steps is scanned as several pieces + k_merge
         monkeypatch.setenv("FLATGFA_PIECE_STEPS", "512")
     if request.param == "bucketed":
         monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
