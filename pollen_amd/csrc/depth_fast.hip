@@ -1833,6 +1833,9 @@ __device__ __forceinline__ void claim_step(uint32_t rec, uint32_t sb, unsigned l
         "ds_add_u32 %[a], %[one]\n\t"                         // D[first] += 1
         "v_lshl_add_u32 %[a], %[n], 2, %[a]\n\t"
         "ds_add_u32 %[a], %[mone] offset:4\n\t"               // D[last + 1] -= 1
+#if FGFA_TAG_ABLATE & 4
+        "s_branch 4f\n\t"
+#endif
         "v_bfe_u32 %[w], %[rec], 5, %[wb5]\n\t"               // the first segment's word in the bitset
         "v_lshl_add_u32 %[w], %[w], 2, %[sb]\n\t"
         "v_and_b32 %[k], 31, %[rec]\n\t"                      // its bit in that word
@@ -1847,6 +1850,9 @@ __device__ __forceinline__ void claim_step(uint32_t rec, uint32_t sb, unsigned l
         "1:\n\t"
         "ds_or_rtn_b32 %[old], %[w], %[mask]\n\t"
         "s_waitcnt lgkmcnt(0)\n\t"
+#if FGFA_TAG_ABLATE & 8
+        "s_branch 4f\n\t"
+#endif
         "v_and_b32 %[rv], %[old], %[mask]\n\t"                // the segments this path had already visited
         "v_cmp_ne_u32 vcc, 0, %[rv]\n\t"
         "s_cbranch_vccz 3f\n\t"
@@ -1868,6 +1874,9 @@ __device__ __forceinline__ void claim_step(uint32_t rec, uint32_t sb, unsigned l
         "s_cbranch_vccnz 2b\n\t"
         "s_mov_b64 exec, %[s2]\n\t"
         "3:\n\t"
+#if FGFA_TAG_ABLATE & 16
+        "s_branch 4f\n\t"
+#endif
         "v_cmp_lt_u32 vcc, 31, %[tt]\n\t"                     // the lanes whose run goes on into the next word
         "s_cbranch_vccz 4f\n\t"
         "s_mov_b64 exec, vcc\n\t"
@@ -1896,7 +1905,15 @@ __device__ __forceinline__ void claim_step(uint32_t rec, uint32_t sb, unsigned l
 // (shared by all waves; cleared by the kernel).  A private slot changes hands when a tag beyond
 // the highest seen so far shows up (k_scan guarantees that the slot's previous owner, kTagSlots
 // items earlier, has no record behind that point), and when the wave opens its next sub-bucket.
-template <int WB, bool POINT>
+// The walk is bound by instruction issue -- a CU issues one scalar and one vector instruction per
+// cycle for all its sixteen waves -- so the common step is kept short: the tags of a step are
+// nearly always between the highest met so far and the tag of the step's last record, and then
+// the hand-over is a couple of compares; anything else (items interleaved by waves that ran ahead,
+// more items in a step than a wave has bitsets) takes the general route below it.
+#ifndef FGFA_TAG_ABLATE
+#define FGFA_TAG_ABLATE 0  /* measurements only (results are then wrong): 1 = no claims, 2 = no bitset hand-overs, 4 = claims stop behind the depth updates, 8 = behind the first word's OR, 16 = no further words */
+#endif
+template <int WB, bool POINT, bool SHARED>
 __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, uint32_t *bits, const uint2 *scnt2, const uint32_t *wbase,
                                              uint32_t *grab) {
     constexpr uint32_t kW = 1u << WB, kNW = kW / 32u;
@@ -1906,7 +1923,7 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t y16 = blockIdx.y * kAccWaves, nw = A.parts * kAccWaves;
     const uint32_t shlo = kTagCount - A.n_shared;  // tags from here up name split paths
-    const uint32_t bits0 = lds_addr(bits);  // (LDS byte addresses)
+    const uint32_t bits0 = lds_addr(bits), priv_b = bits0 + ((wv * kTagSlots) << (WB - 3));  // (LDS byte addresses)
     const uint32_t dbase = lds_addr(D), rbase = lds_addr(R);
     uint32_t one = 1u, mone = ~0u;  // (the LDS adds take their operand from a register)
     asm volatile("" : "+v"(one), "+v"(mone));
@@ -1915,19 +1932,32 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
     const uint32_t *sp = wbase;  // (uniform) the next record of the open sub-bucket ...
     uint32_t left = 0;           // ... and how many it has left
     uint32_t cur_i = wv;
+    // (scnt2: {where k_scan's records start, counted from the window's first bucket; how many there are})
     const auto open = [&](uint32_t i) {
         const uint32_t s = y16 + (i & (kAccWaves - 1u)) + (i / kAccWaves) * nw;
         left = 0;
         if (i < imax && s < A.n_slots) {
-            const uint2 c = scnt2[s];  // {where k_scan's records start, where they end}
-            const uint32_t c0 = __builtin_amdgcn_readfirstlane(c.x), c1 = __builtin_amdgcn_readfirstlane(c.y);
-            sp = wbase + (size_t)s * A.cap + c0;
-            left = c1 > c0 ? c1 - c0 : 0u;
+            const uint2 c = scnt2[s];
+            sp = wbase + __builtin_amdgcn_readfirstlane(c.x);
+            left = __builtin_amdgcn_readfirstlane(c.y);
         }
     };
     open(cur_i);
-    uint32_t nxt = 0;  // the sub-bucket after the open one (taken when that one was opened: the LDS round trip is long over when it is needed)
-    if (lane == 0) nxt = atomicAdd(grab, 1u);
+    // The sub-bucket after the open one is taken when that one is opened: the LDS round trip is
+    // long over when it is needed.  (By hand: hipcc turns an atomicAdd by one lane into its wave-aggregated
+    // form, a dozen instructions.)
+    const uint32_t grab_a = lds_addr(grab);
+    uint32_t nxt = 0;
+#define FGFA_TAG_GRAB()                                                                                         \
+    do {                                                                                                        \
+        unsigned long long sv_;                                                                                 \
+        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1" \
+                     : "+v"(nxt), "=&s"(sv_)                                                                    \
+                     : "v"(grab_a), "v"(one)                                                                    \
+                     : "memory");                                                                               \
+    } while (0)
+#define FGFA_TAG_TAKEN(OUT) asm volatile("s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %0, %1" : "=s"(OUT) : "v"(nxt) : "memory")
+    FGFA_TAG_GRAB();
     // The next step of this wave's stream: up to 64 records of the open sub-bucket, or of the next one
     // that has any.  Lanes beyond the last record read what lies behind it (the bucket array ends
     // with a window nobody reads); a step behind the end of the stream is empty but still requests its load.
@@ -1935,8 +1965,8 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
     do {                                                         \
         FR = 0u;                                                 \
         while (left == 0u && cur_i < imax) {                     \
-            cur_i = __builtin_amdgcn_readfirstlane(nxt);         \
-            if (lane == 0) nxt = atomicAdd(grab, 1u);            \
+            FGFA_TAG_TAKEN(cur_i);                               \
+            FGFA_TAG_GRAB();                                     \
             open(cur_i);                                         \
             FR = 1u;                                             \
         }                                                        \
@@ -1946,6 +1976,32 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
         left -= NV;                                              \
     } while (0)
     int hmax = -1;  // (uniform) the highest private tag met in the open sub-bucket
+    const auto clear_slots = [&](int from, int to) {  // the bitsets of the tags from .. to change hands
+        for (int t = from; t <= to; ++t) {
+            uint32_t *bs = bits + (wv * kTagSlots + ((uint32_t)t & (kTagSlots - 1u))) * kNW;
+            for (uint32_t i = lane; i < kNW / 2u; i += 64) reinterpret_cast<uint2 *>(bs)[i] = make_uint2(0u, 0u);
+        }
+    };
+    const auto claim = [&](uint32_t rec, uint32_t tag, unsigned long long act, bool any_shared) {
+        // each lane's bitset: its wave's slot tag mod kTagSlots, or its split path's
+        uint32_t sb = priv_b + ((tag & (kTagSlots - 1u)) << (WB - 3));
+        if (SHARED && any_shared) sb = tag >= shlo ? bits0 + ((kPriv + kTagCount - 1u - tag) << (WB - 3)) : sb;
+        if (POINT) {  // every record is one segment (k_scan_dense)
+            const uint32_t rel = rec & (kW - 1u), bit = 1u << (rel & 31u);
+            uint32_t old = 0;
+            if ((act >> lane) & 1ull) {
+                atomicAdd(&D[rel], 1);
+                atomicAdd(&D[rel + 1u], -1);
+                old = atomicOr(bits + ((sb - bits0) >> 2) + (rel >> 5), bit);
+            }
+            if (old & bit) {
+                atomicAdd(&R[rel], 1);
+                atomicAdd(&R[rel + 1u], -1);
+            }
+        } else if (!(FGFA_TAG_ABLATE & 1)) {
+            claim_step<WB>(rec, sb, act, dbase, rbase, one, mone);
+        }
+    };
     uint32_t nv0, nv1, nv2, f0, f1, f2;
     FGFA_TAG_GEN(0, nv0, f0);
     FGFA_TAG_GEN(1, nv1, f1);
@@ -1955,26 +2011,33 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
     {                                                                                                                  \
         const uint32_t rec = rec_take<K>();                                                                            \
         const unsigned long long vm = NV >= 64u ? ~0ull : (1ull << NV) - 1ull;  /* the lanes that hold a record */     \
+        const uint32_t last = NV - 1u;                                                                                 \
         if (FR) hmax = -1;  /* the private slots start over with this sub-bucket */                                    \
         FGFA_TAG_GEN(K, NV, FR);                                                                                       \
         const uint32_t tag = rec >> kTagShift;                                                                         \
-        const unsigned long long shm = A.n_shared ? __builtin_amdgcn_ballot_w64(tag >= shlo) & vm : 0ull;              \
-        unsigned long long todo = vm;                                                                                  \
-        do {                                                                                                           \
-            unsigned long long act = todo;                                                                             \
-            /* tags beyond those met so far: their bitsets change hands */                                             \
-            unsigned long long newm = __builtin_amdgcn_ballot_w64((int)tag > hmax) & todo & ~shm;                      \
-            if (newm) {                                                                                                \
-                int hnew = hmax;                                                                                       \
-                for (unsigned long long m = newm; m;) {                                                                \
-                    const uint32_t t = __builtin_amdgcn_readlane(tag, (int)__builtin_ctzll(m));                        \
-                    hnew = max(hnew, (int)t);                                                                          \
-                    m &= ~__builtin_amdgcn_ballot_w64(tag == t);                                                       \
-                }                                                                                                      \
-                if (__builtin_amdgcn_ballot_w64((int)(tag + kTagSlots) <= hnew) & todo & ~shm) {                       \
-                    /* (rare) more items in one step than a wave has bitsets: the lanes before the first one */        \
-                    /* whose tag is kTagSlots beyond the lowest go first -- records of such tags lie in order */       \
-                    const bool pv = ((todo & ~shm) >> lane) & 1ull;                                                    \
+        const unsigned long long shm = SHARED ? __builtin_amdgcn_ballot_w64(tag >= shlo) & vm : 0ull;                  \
+        const unsigned long long pvm = vm & ~shm;  /* the lanes whose tag names an item of their own */                \
+        bool general = false;                                                                                          \
+        if (!(FGFA_TAG_ABLATE & 2) && (__builtin_amdgcn_ballot_w64((uint32_t)hmax - tag >= kTagSlots) & pvm)) {        \
+            /* tags beyond those met so far (or, which cannot be, kTagSlots behind): their bitsets change hands. */     \
+            /* The last record's tag is the highest unless waves that ran ahead have interleaved the items */          \
+            const int c = (int)__builtin_amdgcn_readlane(tag, (int)last);                                              \
+            general = !((pvm >> last) & 1ull) || (__builtin_amdgcn_ballot_w64((int)tag > c || (int)(tag + kTagSlots) <= c) & pvm); \
+            if (!general) {                                                                                            \
+                clear_slots(max(hmax + 1, c - (int)(kTagSlots - 1u)), c);                                              \
+                hmax = c;                                                                                              \
+            }                                                                                                          \
+        }                                                                                                              \
+        if (!general) {                                                                                                \
+            claim(rec, tag, vm, shm != 0ull);                                                                          \
+        } else {                                                                                                       \
+            unsigned long long todo = vm;                                                                              \
+            do {                                                                                                       \
+                unsigned long long act = todo;                                                                         \
+                const bool pv = ((todo & pvm) >> lane) & 1ull;                                                         \
+                if (todo & pvm) {                                                                                      \
+                    /* the lanes before the first one whose tag is kTagSlots beyond the lowest go first: */            \
+                    /* records of such tags lie in order */                                                            \
                     const uint32_t tmin = wave_min_u32(pv ? tag : ~0u);                                                \
                     const unsigned long long beyond = __builtin_amdgcn_ballot_w64(pv && tag >= tmin + kTagSlots);      \
                     if (beyond) act = todo & ((1ull << __builtin_ctzll(beyond)) - 1ull);                               \
@@ -1982,34 +2045,14 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
                         atomicOr(A.status, kStInternal);                                                               \
                         act = todo;                                                                                    \
                     }                                                                                                  \
-                    hnew = max(hmax, (int)wave_max_u32(((act & ~shm) >> lane) & 1ull ? tag : 0u));                     \
+                    const int hnew = max(hmax, (int)wave_max_u32(((act & pvm) >> lane) & 1ull ? tag : 0u));            \
+                    clear_slots(max(hmax + 1, hnew - (int)(kTagSlots - 1u)), hnew);                                    \
+                    hmax = hnew;                                                                                       \
                 }                                                                                                      \
-                for (int t = max(hmax + 1, hnew - (int)(kTagSlots - 1u)); t <= hnew; ++t) {                            \
-                    uint32_t *bs = bits + (wv * kTagSlots + ((uint32_t)t & (kTagSlots - 1u))) * kNW;                   \
-                    for (uint32_t i = lane; i < kNW / 2u; i += 64) reinterpret_cast<uint2 *>(bs)[i] = make_uint2(0u, 0u); \
-                }                                                                                                      \
-                hmax = hnew;                                                                                           \
-            }                                                                                                          \
-            /* each lane's bitset: its wave's slot tag mod kTagSlots, or its split path's */                           \
-            uint32_t slot = wv * kTagSlots + (tag & (kTagSlots - 1u));                                                 \
-            if (shm) slot = tag >= shlo ? kPriv + (kTagCount - 1u - tag) : slot;                                       \
-            if (POINT) {  /* every record is one segment (k_scan_dense) */                                             \
-                const uint32_t rel = rec & (kW - 1u), bit = 1u << (rel & 31u);                                         \
-                uint32_t old = 0;                                                                                      \
-                if ((act >> lane) & 1ull) {                                                                            \
-                    atomicAdd(&D[rel], 1);                                                                             \
-                    atomicAdd(&D[rel + 1u], -1);                                                                       \
-                    old = atomicOr(bits + slot * kNW + (rel >> 5), bit);                                               \
-                }                                                                                                      \
-                if (old & bit) {                                                                                       \
-                    atomicAdd(&R[rel], 1);                                                                             \
-                    atomicAdd(&R[rel + 1u], -1);                                                                       \
-                }                                                                                                      \
-            } else {                                                                                                   \
-                claim_step<WB>(rec, bits0 + (slot << (WB - 3)), act, dbase, rbase, one, mone);                         \
-            }                                                                                                          \
-            todo &= ~act;                                                                                              \
-        } while (todo);                                                                                                \
+                claim(rec, tag, act, shm != 0ull);                                                                     \
+                todo &= ~act;                                                                                          \
+            } while (todo);                                                                                            \
+        }                                                                                                              \
     }
     while (true) {
         FGFA_TAG_STEP(0, nv0, f0)
@@ -2018,6 +2061,8 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
     }
 #undef FGFA_TAG_STEP
 #undef FGFA_TAG_GEN
+#undef FGFA_TAG_GRAB
+#undef FGFA_TAG_TAKEN
 }
 
 // the sum of a 64-bit value over the wave, uniform, by DPP adds on its halves
@@ -2167,8 +2212,8 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
         *c = 0u;
         if (TAGGED && UNIQ) {
             const uint32_t c1 = min(v, A.cap);
-            v = A.has_pre ? A.counts0[(size_t)win * A.n_slots + sl] : 0u;
-            scnt2[sl] = make_uint2(min(v, A.cap), c1);
+            v = min(A.has_pre ? A.counts0[(size_t)win * A.n_slots + sl] : 0u, c1);
+            scnt2[sl] = make_uint2(sl * A.cap + v, c1 - v);  // k_scan's records: where they start in the window's buckets, how many
         } else if (UNIQ && A.has_pre) {
             v = A.counts0[(size_t)win * A.n_slots + sl];
         }
@@ -2185,7 +2230,8 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     if (flat) apply_flat<UNIQ, WB>(A, D, R, scnt, wbase);
     tm.mark(1);
     if (UNIQ && TAGGED) {
-        apply_tagged<WB, POINT>(A, D, R, tag_bits, scnt2, wbase, &grab);
+        if (A.n_shared) apply_tagged<WB, POINT, true>(A, D, R, tag_bits, scnt2, wbase, &grab);
+        else apply_tagged<WB, POINT, false>(A, D, R, tag_bits, scnt2, wbase, &grab);
     } else if (UNIQ) {
         apply_groups<WB, false, POINT, BIG>(A, D, R, bits + wave * (kSlots * (kW / 32)), marks + wave * 64, pend + wave * (3 * kPend), wbase, win,
                                 ge0, ge1, true, be_first, slf_first);
