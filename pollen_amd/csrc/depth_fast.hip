@@ -142,6 +142,7 @@ struct ScanArgs {
     uint32_t *status;
     uint32_t dbg;
     uint32_t tagged;     // records carry their item's tag (see kTagShift); k_scan_dense reads this, k_scan is a build of its own
+    unsigned long long *tprof;  // FLATGFA_SCAN_TIME (diagnostic): per workgroup, when it started, when it ended, when each of its waves ran out of work (10 ns units)
 };
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long m) {
@@ -848,7 +849,10 @@ constexpr int kModePlain = 0, kModeDbg = 1, kModeRanged = 2;
 constexpr int kWide = FGFA_WIDE;  // chunks of 64 queue entries k_scan emits side by side
 // (sixteen cells each for the block counters and the arrival counters, indexed by the item's ordinal
 // mod 16 in a tagged call -- waves may be kTagSlots items apart there -- and mod 2 otherwise)
-constexpr uint32_t kCtlNext = 0, kCtlArrive = 16, kCtlEpoch = 32, kCtlWords = 40;
+constexpr uint32_t kCtlNext = 0, kCtlArrive = 16, kCtlEpoch = 32, kCtlJobs = 40, kCtlWords = 56;
+// A tagged call deals the items out as the workgroups get to them (an item's tag is its ordinal in
+// its workgroup, whatever the item): ctl[kCtlJobs + (r & 15)] is the workgroup's r-th item, or one of
+constexpr uint32_t kJobEmpty = 0xFFFFFFFFu, kJobPending = 0xFFFFFFFEu;  // nobody has asked yet / a wave is fetching it
 
 __device__ __forceinline__ uint32_t epoch_now(uint32_t *ctl) {
     return __hip_atomic_load(ctl + kCtlEpoch, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1102,6 +1106,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the span math on the scalar unit
     uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;  // this workgroup's sub-bucket of window 0
+    if (TAGGED && MODE == kModePlain && A.tprof && threadIdx.x == 0) A.tprof[(2 + kWaves) * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     RWave w;
     w.q = reinterpret_cast<uint2 *>(lds + 2u * A.nwp + kCtlWords) + (uint32_t)wave * kQ2;
     w.fill = 0;
@@ -1123,7 +1128,8 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         if (!TAGGED) snap[i] = c;
         if (A.has_pre && i < A.n_win) A.counts0[(size_t)i * A.n_slots + blockIdx.x] = c;
     }
-    if (threadIdx.x < kCtlWords) ctl[threadIdx.x] = threadIdx.x < kCtlArrive ? 4u * kWaves : 0u;
+    if (threadIdx.x < kCtlWords)
+        ctl[threadIdx.x] = threadIdx.x < kCtlArrive ? 4u * kWaves : threadIdx.x < kCtlJobs ? 0u : threadIdx.x == kCtlJobs + 1u ? gridDim.x + blockIdx.x : kJobEmpty;
     // block-relative positions of this lane's sixteen steps; opaque, so that they stay in registers
     uint32_t pj[16];
 #pragma unroll
@@ -1138,7 +1144,12 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     // The first blocks of an item are requested while the previous item is being wrapped up, and
     // its descriptor while the previous item is being walked.
     uint32_t rr = 0;  // this workgroup's items so far
-    uint32_t job = item_of(0, blockIdx.x, gridDim.x);
+    // Which items a workgroup walks: untagged, the r-th is fixed (item_of: pass 2 finds it through the
+    // directory anyway); tagged, the first two are (its own index, and that plus the number of
+    // workgroups) and the rest come off a global counter, longest first, as the workgroups get to
+    // them -- the slower ones take fewer.  A wave asks two items ahead, so that the answer and the
+    // item's descriptor are there long before they are needed.
+    uint32_t job = TAGGED ? blockIdx.x : item_of(0, blockIdx.x, gridDim.x);
     Item it = make_item(A, job < n_items, job < n_items ? A.items[job] : make_uint4(0u, 0u, 0u, 0u), lane);
     // where pass 2 looks for the item: fetched with its descriptor, long before it is needed
     uint32_t place = (TAGGED || job >= A.n_items) ? job | 0x80000000u : A.perm[job];
@@ -1152,12 +1163,16 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     uint32_t resv;    // the block this wave takes after those
     // (a partial block is read whole: make_item has made sure that stays inside the step array)
 #define FGFA_BLOCK_PTR(j) (it.src + (size_t)(j) * 256)
+    // (An item's first 64 blocks are its waves' own: wave w takes blocks j, j + 16, j + 32 and j + 48,
+    // j = w less the blocks of the items before, mod 16 -- items of ten blocks would otherwise leave
+    // the same six waves without work every time.)
+    uint32_t rot = 0;
 #define FGFA_PRELOAD()                                                      \
     do {                                                                    \
-        blk[0] = (uint32_t)wave;                                            \
-        blk[1] = (uint32_t)wave + kWaves;                                   \
-        blk[2] = (uint32_t)wave + 2u * kWaves;                              \
-        resv = (uint32_t)wave + 3u * kWaves;                                \
+        blk[0] = ((uint32_t)wave - rot) & (kWaves - 1u);                    \
+        blk[1] = blk[0] + kWaves;                                           \
+        blk[2] = blk[0] + 2u * kWaves;                                      \
+        resv = blk[0] + 3u * kWaves;                                        \
         if (blk[0] < it.nblk) load_block_coal<0>(w, FGFA_BLOCK_PTR(blk[0])); \
         if (blk[1] < it.nblk) load_block_coal<1>(w, FGFA_BLOCK_PTR(blk[1])); \
         if (blk[2] < it.nblk) load_block_coal<2>(w, FGFA_BLOCK_PTR(blk[2])); \
@@ -1185,7 +1200,23 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     FGFA_PRELOAD();
 
     while (job < n_items) {
-        const uint32_t next_job = item_of(rr + 1u, blockIdx.x, gridDim.x);
+        uint32_t next_job;
+        if (TAGGED) {
+            uint32_t *ahead = &ctl[kCtlJobs + ((rr + 2u) & 15u)];
+            uint32_t st = 0;
+            if (lane == 0) st = atomicCAS(ahead, kJobEmpty, kJobPending);  // who fetches the item after the next?
+            do {
+                next_job = __hip_atomic_load(&ctl[kCtlJobs + ((rr + 1u) & 15u)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } while (next_job >= kJobPending);  // (asked for an item ago: it is there, but for items of a handful of steps)
+            if ((uint32_t)__builtin_amdgcn_readfirstlane(st) == kJobEmpty) {
+                uint32_t got = 0;
+                if (lane == 0) got = atomicAdd(A.work_counter + 1, 1u);
+                got = min(__builtin_amdgcn_readfirstlane(got) + 2u * gridDim.x, kJobPending - 1u);
+                if (lane == 0) __hip_atomic_store(ahead, got, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+            next_job = item_of(rr + 1u, blockIdx.x, gridDim.x);
+        }
         const uint4 next_item = next_job < n_items ? A.items[next_job] : make_uint4(0u, 0u, 0u, 0u);
         const uint32_t next_place = (TAGGED || next_job >= A.n_items) ? next_job | 0x80000000u : A.perm[next_job];
         // the few steps outside the blocks are walked on their own, by the first and the last wave
@@ -1221,6 +1252,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         const uint32_t pe = place;
         place = next_place;
         job = next_job;
+        rot = (rot + it.nblk) & (kWaves - 1u);
         it = make_item(A, job < n_items, next_item, lane);
         w.dir = __builtin_amdgcn_readfirstlane(it.dir);  // the queue is empty here
         FGFA_PRELOAD();
@@ -1244,6 +1276,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             if (lane == 0) {
                 ctl[kCtlArrive + (rr & kRing)] = 0u;
                 ctl[kCtlNext + (rr & kRing)] = 4u * kWaves;  // for the next item that uses these cells (no wave is there yet)
+                if (TAGGED) ctl[kCtlJobs + (rr & 15u)] = kJobEmpty;
             }
             __hip_atomic_store(ctl + kCtlEpoch, rr + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (items complete in order)
         }
@@ -1262,9 +1295,18 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
 #undef FGFA_BLOCK_PTR
 #undef FGFA_ITEM_TAG
     // publish how many records this workgroup left in each window's sub-bucket
+    if (TAGGED && MODE == kModePlain && A.tprof && lane == 0) A.tprof[(2 + kWaves) * blockIdx.x + 2 + wave] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads)
         A.counts[(size_t)wdw * A.n_slots + blockIdx.x] = bcur[wdw];
+    if (TAGGED && threadIdx.x == 0) {  // the last workgroup out leaves the item counter clean for the next call
+        const uint32_t out = atomicAdd(A.work_counter + 2, 1u);
+        if (out == gridDim.x - 1u) {
+            A.work_counter[1] = 0u;
+            A.work_counter[2] = 0u;
+        }
+    }
+    if (TAGGED && MODE == kModePlain && A.tprof && threadIdx.x == 0) A.tprof[(2 + kWaves) * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ------------------------------------------------------------------ pass 2 ---
@@ -3037,6 +3079,8 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     // the directory walk (an item's records have to be found again once the window's depth is final).
     const bool tagged = fp.tagged && !ps;
     sa.tagged = tagged ? 1u : 0u;
+    sa.tprof = nullptr;
+    if (getenv("FLATGFA_SCAN_TIME") && hipMalloc(&sa.tprof, (2 + kWaves) * 8 * (size_t)fp.n_slots) == hipSuccess) (void)hipMemset(sa.tprof, 0, (2 + kWaves) * 8 * (size_t)fp.n_slots);
     AccArgs aa{fp.n_range, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.counts0, has_pre ? 1u : 0u, fp.buckets,
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
                fp.work_counter, fp.max_back, depth_out, uniq_out, status, fp.dbg,
@@ -3130,6 +3174,30 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     if (hipGetLastError() != hipSuccess) {
         set_error("fast_seg_depth: kernel launch failed");
         return FLATGFA_ERR_HIP;
+    }
+    if (sa.tprof) {  // diagnostic: when the workgroups of k_scan start, when their first wave runs out of work, when they end
+        constexpr size_t kRow = 2 + kWaves;
+        std::vector<unsigned long long> raw(kRow * (size_t)fp.n_slots);
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(raw.data(), sa.tprof, raw.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(sa.tprof);
+        unsigned long long t0 = ~0ull;
+        for (uint32_t i = 0; i < grid; ++i) t0 = std::min(t0, raw[kRow * i]);
+        std::vector<double> st, fw, lw, en;
+        for (uint32_t i = 0; i < grid; ++i) {
+            st.push_back((raw[kRow * i] - t0) / 100.0);
+            en.push_back((raw[kRow * i + 1] - t0) / 100.0);
+            unsigned long long a = ~0ull, b = 0;
+            for (size_t k = 0; k < kWaves; ++k) {
+                a = std::min(a, raw[kRow * i + 2 + k]);
+                b = std::max(b, raw[kRow * i + 2 + k]);
+            }
+            fw.push_back((a - t0) / 100.0);
+            lw.push_back((b - t0) / 100.0);
+        }
+        const auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
+        fprintf(stderr, "k_scan%s workgroups (us since the first one started): start p50 %.1f max %.1f | first wave out of work p5 %.1f p50 %.1f p95 %.1f | last wave p5 %.1f p50 %.1f p95 %.1f max %.1f | end p50 %.1f max %.1f\n",
+                tagged ? " [tagged]" : "", pct(st, 0.5), pct(st, 1.0), pct(fw, 0.05), pct(fw, 0.5), pct(fw, 0.95), pct(lw, 0.05), pct(lw, 0.5), pct(lw, 0.95), pct(lw, 1.0), pct(en, 0.5), pct(en, 1.0));
     }
     if (aa.tprof) {  // diagnostic: where the waves of pass 2 spend their time
         std::vector<uint32_t> raw(tprof_words);
