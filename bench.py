@@ -98,6 +98,10 @@ def main():
     ap.add_argument("--rotate", type=int, default=3,
                     help="N = 1 extras: also time the loop cycling this many resident graph images (seeds 1..K), "
                          "so that no step finds its steps in the 256 MiB Infinity Cache; 0 = skip")
+    ap.add_argument("--host", default="torch", choices=["torch", "c"],
+                    help="who shards and reduces for N > 1: torch.distributed (one rank per GPU, RCCL through torch's nccl backend), or "
+                         "the C ABI (flatgfa_sharded_*: rank 0 alone drives all N devices, RCCL inside libflatgfa.so; the other ranks only "
+                         "keep the launcher's barrier)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -110,6 +114,9 @@ def main():
     import pollen_amd as pa
     from pollen_amd import device as dev
     from pollen_amd.sharded import ShardedDepth, local_slice, shard_paths
+
+    if args.host == "c":
+        return main_host_c(args, torch, dist, pa, dev)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -498,6 +505,93 @@ def main():
             line["speedup_vs_cpu_1core"] = round(value / cpu["value"], 2)
         print(json.dumps(line), flush=True)
 
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_host_c(args, torch, dist, pa, dev):
+    """--host c: BASELINE.json configs[3] through the C ABI alone.  One process (rank 0) holds the
+    graph and a flatgfa_sharded_t over all N devices: shards cut by libflatgfa.so, per-device plans
+    and streams, ncclCommInitAll + ncclAllReduce inside the library.  A step = flatgfa_sharded_enqueue
+    (local kernels + collective on every shard's stream); the timed region ends with
+    flatgfa_sharded_sync.  Under torch.distributed.run the other ranks only take part in the barriers."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world not in (1, args.gpus):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)  # (barriers only: the data path is rank 0's)
+    S, P, L, model = WORKLOADS[args.workload]
+    N = P * L
+    line = None
+    if rank == 0:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+        one_dev = os.environ.get("FLATGFA_BENCH_ONE_DEVICE") == "1"
+        devices = [0] * args.gpus if one_dev else list(range(args.gpus))
+        g = pa.synth(1, S, P, L, model, False)
+        sh = pa.ShardedFlatGFA(g, args.gpus, devices=devices)
+        lay = sh.layout()
+        for _ in range(max(args.warmup, 1)):
+            sh.enqueue(True)
+        sh.sync()
+        verified = None
+        if not args.no_verify:
+            from oracle import flatgfa_oracle as fo
+            pools = fo.Pools(**{n: g.pool(n) for n in fo.POOL_ORDER})
+            want_d, want_u = fo.seg_depth_with_uniq(pools)
+            verified = True
+            for i in range(args.gpus):  # every shard holds the reduced vectors
+                d, u = sh.fetch(i)
+                verified = verified and bool((d == want_d).all() and (u == want_u).all())
+            if not verified:
+                raise SystemExit("HIP result differs from the oracle: refusing to report a number")
+        dev.profile_enable(False)
+        dev.profile_read()
+        sh.sync()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            sh.enqueue(True)
+        sh.sync()
+        elapsed = time.perf_counter() - t0
+        # kernel durations of a few more steps, outside the timed region (the event records are process-wide)
+        dev.profile_enable(True)
+        for _ in range(3):
+            sh.enqueue(True)
+        sh.sync()
+        dev.profile_enable(False)
+        per = {}
+        for name, ms in dev.profile_read():
+            per.setdefault(name, []).append(ms)
+        kern = {k: round(float(np.mean(v)), 5) for k, v in per.items()}
+        dom = max(kern, key=lambda k: kern[k]) if kern else None
+        N_local = max(x["step_end"] - x["step_begin"] for x in lay)
+        roofline = None
+        if dom:
+            B_dom = kernel_bytes(dom, N_local, P // max(args.gpus, 1), S, 2)
+            ach = B_dom / (kern[dom] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "kernel_avg_ms": kern[dom], "algorithmic_bytes": B_dom,
+                        "kernels_avg_ms": kern, "kernel_timing": "HIP events around each launch of three steps after the timed region, all shards"}
+        line = {
+            "metric": f"path-steps/sec on `depth` ({S / 1e6:g}M seg / {N / 1e6:g}M step GFA)" + ("; bit-exact vs flatgfa CPU" if verified else ""),
+            "value": round(N * args.steps / elapsed, 1), "unit": "path-steps/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: seg_depth_with_uniq on synth(seed=1, S={S}, P={P}, L={L}, model={model})",
+                       "segments": S, "steps_per_job_step": N, "host": "c",
+                       "sharding": f"flatgfa_sharded_* (C ABI, one process): {args.gpus} shards on devices {devices}, "
+                                   f"{lay[0]['split_paths']} paths cut, exchange by " + ("RCCL ncclAllReduce inside libflatgfa.so" if lay[0]["rccl"] else "device-side adds (shards share a device)"),
+                       "shards": [{k: x[k] for k in ("device", "step_begin", "step_end", "pieces")} for x in lay]},
+            "bit_exact_vs_oracle": verified, "roofline": roofline, "cpu_baseline": None, "commit": git_head(),
+        }
+        sh.close()
+    if world > 1:
+        dist.barrier()
+    if line is not None:
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -151,6 +151,48 @@ int flatgfa_bed_depth_table(flatgfa_t gfa, const uint8_t *bed, size_t bed_len, c
 /* format_float (ops/depth.rs:192-197); returns bytes written (no NUL). */
 int flatgfa_format_float(double x, int digits, char *out, int cap);
 
+/* ---- one graph sharded over the GPUs of a node by ONE process ----
+ * The reference has no counterpart (it is single-threaded, flatgfa/src/ops/depth.rs:15-39); the
+ * semantics are those of the functions above, the sharding is invisible in the results.
+ * The graph's steps are cut into n_shards contiguous stretches of near-equal size -- at path
+ * boundaries where one lies within an eighth of a shard's share of the even cut, inside a path
+ * where none does (fewer paths than shards; a path longer than a shard's share) -- and shard i is
+ * made resident on HIP device devices[i] (NULL: shard i on device i mod the device count), with a
+ * depth plan, a stream and a host thread of its own.  A query is the local HIP kernels on every
+ * shard, ONE all-reduce of the fused [depth | uniq | per-cut-path touch] u32 vector over RCCL
+ * (ncclAllReduce, ncclUint32, ncclSum; communicators from ncclCommInitAll), and a fix-up of
+ * unique depth for the paths that were cut (depth.rs:30-34 counts a path once per segment however
+ * many of its pieces touch it).  librccl.so is loaded on the first create with more than one
+ * shard.  Devices may repeat: shards that share a device exchange by device-side adds instead (so
+ * does FLATGFA_SHARD_NO_RCCL).  The handle borrows `gfa`, which must outlive it.
+ * flags: */
+enum {
+    FLATGFA_SHARD_WHOLE_PATHS = 1, /* never cut inside a path (shards may then be uneven, or empty) */
+    FLATGFA_SHARD_NO_RCCL = 2      /* exchange by peer copies and device-side adds */
+};
+typedef struct flatgfa_sharded flatgfa_sharded_t;
+flatgfa_sharded_t *flatgfa_sharded_create(flatgfa_t gfa, const int *devices, int n_shards, unsigned flags);
+void flatgfa_sharded_free(flatgfa_sharded_t *sh);
+/* What shard `shard` holds (any out pointer may be NULL): its device, its stretch of the steps
+ * pool, the first path it has steps of, how many paths or pieces of paths it walks, how many paths
+ * the whole handle cuts, and whether the exchange is RCCL's. */
+int flatgfa_sharded_layout(flatgfa_sharded_t *sh, int shard, int *device, uint64_t *step_begin, uint64_t *step_end,
+                           uint32_t *first_path, uint32_t *n_pieces, uint32_t *n_split_paths, int *uses_rccl);
+/* seg_depth_with_uniq (depth.rs:15-39) / seg_depth (:45-56) over all shards: results as
+ * flatgfa_seg_depth's. */
+int flatgfa_sharded_seg_depth(flatgfa_sharded_t *sh, uint64_t *depth_out, uint64_t *uniq_out);
+/* path_depth (depth.rs:88-131) for the given path ids: every shard measures its paths (and
+ * pieces) against the reduced node depth; the host adds the pieces of a cut path up and divides. */
+int flatgfa_sharded_path_depth(flatgfa_sharded_t *sh, const uint32_t *path_ids, uint32_t n_ids, uint64_t *length_out,
+                               double *mean_depth_out);
+/* The same query in three steps, for callers that time it or overlap it with other work:
+ * enqueue (local kernels + collective on every shard's stream; returns without waiting), sync
+ * (waits for every shard; FLATGFA_ERR_BOUNDS as flatgfa_dev_status), fetch (the reduced vectors
+ * as held by shard `shard` -- every shard holds them). */
+int flatgfa_sharded_enqueue(flatgfa_sharded_t *sh, int with_uniq);
+int flatgfa_sharded_sync(flatgfa_sharded_t *sh);
+int flatgfa_sharded_fetch(flatgfa_sharded_t *sh, int shard, uint64_t *depth_out, uint64_t *uniq_out);
+
 /* ------------------------------------------------------------------------ */
 /* Part 3 -- device-level entry points (caller-owned HBM buffers)           */
 /* ------------------------------------------------------------------------ */

@@ -6,8 +6,8 @@ include/flatgfa.h, `device` the device-level surface on caller-owned HBM buffers
 the multi-GPU path sharding.  All depth arithmetic runs in hand-written HIP kernels
 (pollen_amd/csrc/depth_device.hip); the package has no CPU fallback.
 """
-from .flatgfa import (FlatGFA, FlatGFAError, device_count, format_float, load, parse, parse_bytes,
+from .flatgfa import (SHARD_NO_RCCL, SHARD_WHOLE_PATHS, FlatGFA, FlatGFAError, ShardedFlatGFA, device_count, format_float, load, parse, parse_bytes,
                       parse_stream_bytes, synth)
 
-__all__ = ["FlatGFA", "FlatGFAError", "device_count", "format_float", "load", "parse", "parse_bytes",
+__all__ = ["SHARD_NO_RCCL", "SHARD_WHOLE_PATHS", "ShardedFlatGFA", "FlatGFA", "FlatGFAError", "device_count", "format_float", "load", "parse", "parse_bytes",
            "parse_stream_bytes", "synth"]

@@ -62,6 +62,15 @@ SIGNATURES = {
     "flatgfa_interval_depth": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_uint64, c_void_p]),
     "flatgfa_window_depth_table": (c_int, [c_void_p, c_uint32, c_uint64, POINTER(c_void_p), POINTER(c_size_t)]),
     "flatgfa_bed_depth_table": (c_int, [c_void_p, c_char_p, c_size_t, POINTER(c_void_p), POINTER(c_size_t)]),
+    "flatgfa_sharded_create": (c_void_p, [c_void_p, c_void_p, c_int, ctypes.c_uint]),
+    "flatgfa_sharded_free": (None, [c_void_p]),
+    "flatgfa_sharded_layout": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint32),
+                                       POINTER(c_uint32), POINTER(c_uint32), POINTER(c_int)]),
+    "flatgfa_sharded_seg_depth": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "flatgfa_sharded_path_depth": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_void_p]),
+    "flatgfa_sharded_enqueue": (c_int, [c_void_p, c_int]),
+    "flatgfa_sharded_sync": (c_int, [c_void_p]),
+    "flatgfa_sharded_fetch": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "flatgfa_dev_path_depth_all": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flatgfa_dev_path_overlaps": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_void_p]),
     "flatgfa_dev_plan_create": (c_void_p, [POINTER(flatgfa_dev_graph_t), c_void_p, c_void_p]),

@@ -63,6 +63,9 @@ static bool steps_name_segments(CStore *cs) {
     return cs->steps_ok == 1;
 }
 
+// (sharded.hip reads the pools of a handle)
+const fgfa::View &flatgfa_capi_view(flatgfa_t gfa) { return gfa->view; }
+
 #define CAPI_HIP(expr)                                                                      \
     do {                                                                                    \
         hipError_t _e = (expr);                                                             \

@@ -298,6 +298,93 @@ class FlatGFA:
         return _take_text(p, n)
 
 
+SHARD_WHOLE_PATHS = 1  # FLATGFA_SHARD_WHOLE_PATHS
+SHARD_NO_RCCL = 2      # FLATGFA_SHARD_NO_RCCL
+
+
+class ShardedFlatGFA:
+    """One graph sharded over the GPUs of a node by this process (`flatgfa_sharded_t`): the local
+    kernels on every shard, one RCCL all-reduce of the fused [depth | uniq] vector, results as the
+    single-device calls give them.  `devices[i]` is shard i's HIP device (default: shard i on
+    device i mod the device count); devices may repeat (shards that share one exchange by
+    device-side adds)."""
+
+    def __init__(self, graph: FlatGFA, n_shards: int, devices: Optional[Sequence[int]] = None, flags: int = 0):
+        self.graph = graph  # the handle borrows the graph
+        self.n_shards = int(n_shards)
+        arr = None
+        if devices is not None:
+            if len(devices) != self.n_shards:
+                raise ValueError("one device per shard")
+            arr = (ctypes.c_int * self.n_shards)(*[int(d) for d in devices])
+        self._h = ctypes.c_void_p(_lib.lib().flatgfa_sharded_create(graph._h, arr, self.n_shards, int(flags)))
+        if not self._h.value:
+            raise FlatGFAError(f"flatgfa_sharded_create: {_lib.last_error()}")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().flatgfa_sharded_free(self._h)
+            self._h = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self) -> "ShardedFlatGFA":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
+    def layout(self) -> List[dict]:
+        """Per shard: its device, its stretch of the steps pool, the first path it walks, how many
+        paths or pieces it walks; plus how many paths the handle cuts and whether RCCL carries the exchange."""
+        out = []
+        for i in range(self.n_shards):
+            dev, uses = ctypes.c_int(), ctypes.c_int()
+            b, e = ctypes.c_uint64(), ctypes.c_uint64()
+            fp, npc, nsp = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+            _check(_lib.lib().flatgfa_sharded_layout(self._h, i, ctypes.byref(dev), ctypes.byref(b), ctypes.byref(e), ctypes.byref(fp),
+                                                     ctypes.byref(npc), ctypes.byref(nsp), ctypes.byref(uses)), "sharded_layout")
+            out.append({"device": dev.value, "step_begin": b.value, "step_end": e.value, "first_path": fp.value,
+                        "pieces": npc.value, "split_paths": nsp.value, "rccl": bool(uses.value)})
+        return out
+
+    def seg_depth_with_uniq(self) -> Tuple[np.ndarray, np.ndarray]:
+        S = self.graph.segment_count
+        d, u = np.zeros(S, dtype=np.uint64), np.zeros(S, dtype=np.uint64)
+        _check(_lib.lib().flatgfa_sharded_seg_depth(self._h, d.ctypes.data, u.ctypes.data), "sharded_seg_depth")
+        return d, u
+
+    def seg_depth(self) -> np.ndarray:
+        d = np.zeros(self.graph.segment_count, dtype=np.uint64)
+        _check(_lib.lib().flatgfa_sharded_seg_depth(self._h, d.ctypes.data, None), "sharded_seg_depth")
+        return d
+
+    def path_depth(self, path_ids: Optional[Iterable[int]] = None) -> Tuple[np.ndarray, np.ndarray]:
+        ids = np.arange(self.graph.path_count, dtype=np.uint32) if path_ids is None else np.asarray(list(path_ids), dtype=np.uint32)
+        ln, mean = np.zeros(len(ids), dtype=np.uint64), np.zeros(len(ids), dtype=np.float64)
+        _check(_lib.lib().flatgfa_sharded_path_depth(self._h, ids.ctypes.data if len(ids) else None, len(ids),
+                                                     ln.ctypes.data if len(ids) else None, mean.ctypes.data if len(ids) else None),
+               "sharded_path_depth")
+        return ln, mean
+
+    def enqueue(self, with_uniq: bool = True) -> None:
+        _check(_lib.lib().flatgfa_sharded_enqueue(self._h, 1 if with_uniq else 0), "sharded_enqueue")
+
+    def sync(self) -> None:
+        _check(_lib.lib().flatgfa_sharded_sync(self._h), "sharded_sync")
+
+    def fetch(self, shard: int = 0, with_uniq: bool = True):
+        S = self.graph.segment_count
+        d = np.zeros(S, dtype=np.uint64)
+        u = np.zeros(S, dtype=np.uint64) if with_uniq else None
+        _check(_lib.lib().flatgfa_sharded_fetch(self._h, int(shard), d.ctypes.data, u.ctypes.data if with_uniq else None), "sharded_fetch")
+        return (d, u) if with_uniq else d
+
+
 def parse(filename: Union[str, os.PathLike]) -> FlatGFA:
     """Parse a GFA text file (flatgfa_parse, flatgfa-c/src/lib.rs:63)."""
     return FlatGFA(_lib.lib().flatgfa_parse(os.fsencode(filename)))

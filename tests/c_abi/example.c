@@ -1,7 +1,8 @@
 /* A C consumer of libflatgfa.so, the way a user of the reference's flatgfa-c would write one
  * (flatgfa-c/example/example.c shows the reference's own): parse a GFA file, walk every path and
  * every step through the C ABI of include/flatgfa.h Part 1, then -- unless "--no-depth" is given --
- * ask for node depth through Part 2 and print the `fgfa depth -d` table.
+ * ask for node depth through Part 2, print the `fgfa depth -d` table, and ask again with the
+ * graph sharded two ways (flatgfa_sharded_*).
  *
  *   cc -Iinclude tests/c_abi/example.c -Lpollen_amd/lib -lflatgfa -Wl,-rpath,$PWD/pollen_amd/lib -o example
  *   ./example graph.gfa [--no-depth]
@@ -63,8 +64,29 @@ int main(int argc, char **argv) {
         for (uint32_t i = 0; i < n_segs; ++i) total += depth[i];
         printf("total depth %" PRIu64 "\n", total);
         flatgfa_free_text(text);
+        /* the same query with the graph sharded over two shards by this process (here both on device 0;
+         * on a node with several GPUs: flatgfa_sharded_create(g, NULL, n_gpus, 0) and RCCL carries the reduce) */
+        const int devices[2] = {0, 0};
+        flatgfa_sharded_t *sh = flatgfa_sharded_create(g, devices, 2, 0);
+        if (!sh) {
+            fprintf(stderr, "flatgfa_sharded_create: %s\n", flatgfa_last_error());
+            return 1;
+        }
+        uint64_t *depth2 = calloc(n_segs ? n_segs : 1, sizeof *depth2), *uniq2 = calloc(n_segs ? n_segs : 1, sizeof *uniq2);
+        if (flatgfa_sharded_seg_depth(sh, depth2, uniq2) != FLATGFA_OK) {
+            fprintf(stderr, "flatgfa_sharded_seg_depth: %s\n", flatgfa_last_error());
+            return 1;
+        }
+        uint32_t n_cut = 0;
+        flatgfa_sharded_layout(sh, 0, NULL, NULL, NULL, NULL, NULL, &n_cut, NULL);
+        const int same = memcmp(depth, depth2, n_segs * sizeof *depth) == 0 && memcmp(uniq, uniq2, n_segs * sizeof *uniq) == 0;
+        printf("sharded two ways: %s\n", same ? "same vectors" : "DIFFERENT");
+        flatgfa_sharded_free(sh);
+        free(depth2);
+        free(uniq2);
         free(depth);
         free(uniq);
+        if (!same) return 1;
     }
     flatgfa_free(g);
     flatgfa_free(NULL); /* null-safe, lib.rs:72-76 */

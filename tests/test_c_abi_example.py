@@ -51,5 +51,5 @@ def test_c_example_node_depth(tmp_path):
     r = subprocess.run([exe, gfa], capture_output=True)
     assert r.returncode == 0, r.stderr
     d, _ = fo.seg_depth_with_uniq(pools)
-    want = expected_walk(pools).encode() + open(gfa[:-4] + ".depth.tsv", "rb").read() + f"total depth {int(d.sum())}\n".encode()
+    want = expected_walk(pools).encode() + open(gfa[:-4] + ".depth.tsv", "rb").read() + f"total depth {int(d.sum())}\nsharded two ways: same vectors\n".encode()
     assert r.stdout == want

@@ -134,3 +134,28 @@ def test_bench_multirank_control_flow_on_one_gpu(scaling):
     assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["bit_exact_vs_oracle"] is True
     assert line["config"]["steps_per_job_step"] == (1_000_000 if scaling == "strong" else 2_000_000)
     assert line["allreduce_ms"] > 0 and line["roofline"]["kernel"]
+
+
+@pytest.mark.gpu
+def test_bench_host_c_two_shards_on_one_gpu():
+    """bench.py --host c under the launcher: rank 0 alone drives both shards through
+    flatgfa_sharded_* (here on one device, so the exchange is the device-side add; on a node it is
+    RCCL inside the library), rank 1 only keeps the barriers.  bench.py checks every shard's
+    reduced vectors against the oracle before it prints a line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FLATGFA_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--workload", "cfgS", "--host", "c"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["bit_exact_vs_oracle"] is True
+    assert line["config"]["host"] == "c" and len(line["config"]["shards"]) == 2
+    assert sum(x["step_end"] - x["step_begin"] for x in line["config"]["shards"]) == 1_000_000
