@@ -272,6 +272,7 @@ def main():
                                    "achieved": round(whole, 2) if whole else None,
                                    "frac": round(whole / HBM_PEAK_GBS, 5) if whole else None},
                     "kernels_avg_ms": {k: round(v, 5) for k, v in kern_avg_ms.items()},
+                    "plan_choice": plan.describe(),
                     "kernel_timing": f"HIP events around each launch on steps 0, {EVENT_EVERY}, {2 * EVENT_EVERY}, ... "
                                      f"of the timed region ({n_timed_steps} of {args.steps} steps)"}
         # An event pair also contains the launch itself; what it reads around a kernel of k_scan's

@@ -263,8 +263,14 @@ int flatgfa_dev_path_overlaps(flatgfa_dev_plan_t *plan, const uint32_t *query_id
  * graph when they are created; should a node-depth call nevertheless have run out of scratch room
  * (the step values changed behind the plan's back), this call runs it again on a larger plan
  * before it returns, into the same output buffers -- which therefore must not have been
- * modified in between. */
+ * modified in between.  Only the last call can be completed that way: if several node-depth calls
+ * were enqueued since the last status and one of them ran out of room, this returns
+ * FLATGFA_ERR_HIP (call status after every call where step values may change behind a plan). */
 int flatgfa_dev_status(flatgfa_dev_plan_t *plan, void *stream);
+
+/* Which kernels this plan's calls run -- the choices made when it was created, some of them by
+ * timing on the graph -- as a line of `key=value` words; returns the bytes written (NUL excluded). */
+int flatgfa_dev_plan_describe(flatgfa_dev_plan_t *plan, char *out, int cap);
 
 /* Kernel-level timing for bench.py: when enabled, every kernel the library launches is bracketed
  * by HIP events on its own stream; flatgfa_dev_profile_read synchronizes and returns, for up to

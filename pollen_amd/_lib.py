@@ -75,6 +75,7 @@ SIGNATURES = {
     "flatgfa_dev_path_overlaps": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_void_p]),
     "flatgfa_dev_plan_create": (c_void_p, [POINTER(flatgfa_dev_graph_t), c_void_p, c_void_p]),
     "flatgfa_dev_plan_destroy": (None, [c_void_p]),
+    "flatgfa_dev_plan_describe": (c_int, [c_void_p, c_char_p, c_int]),
     "flatgfa_dev_seg_depth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "flatgfa_dev_path_sums": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flatgfa_dev_status": (c_int, [c_void_p, c_void_p]),

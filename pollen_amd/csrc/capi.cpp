@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <memory>
 #include <sys/mman.h>
+#include <unistd.h>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -36,6 +37,7 @@ struct CStore {
     uint32_t *d_small = nullptr;  // one allocation behind the five arrays below
     uint32_t *d_path_begin = nullptr, *d_path_end = nullptr, *d_seg_len = nullptr;
     uint32_t *d_depth = nullptr, *d_uniq = nullptr;
+    uint64_t *d_sums = nullptr;  // [2 * paths] scratch of flatgfa_path_depth (inside d_small)
     std::vector<uint32_t> h_path_begin, h_path_end;
     flatgfa_dev_plan_t *plan = nullptr;
     hipStream_t stream = nullptr;
@@ -43,7 +45,7 @@ struct CStore {
     std::vector<uint32_t> sub_ids;
     flatgfa_dev_plan_t *sub_plan = nullptr;
     uint32_t *d_sub_spans = nullptr;  // the subset's begin[] then end[]
-    int steps_ok = -1;  // -1 = not checked yet: do all step handles name a segment? (host-side walks index by them)
+    std::atomic<int> steps_ok{-1};  // -1 = not checked yet: do all step handles name a segment? (host-side walks index by them)
 
     ~CStore() {
         if (plan) flatgfa_dev_plan_destroy(plan);
@@ -261,8 +263,9 @@ static hipError_t upload(void *dst, const void *src, size_t bytes, hipStream_t s
                     if (e == hipSuccess) {
 #ifdef MADV_POPULATE_READ
                         {   // a freshly mapped file: let the kernel map the chunk's pages in one go instead of
-                            // taking a fault per page inside the memcpy (fails harmlessly on anonymous memory)
-                            const uintptr_t a0 = ((uintptr_t)src + off) & ~(uintptr_t)4095;
+                            // taking a fault per page inside the memcpy (on anonymous memory it only maps what the copy would touch anyway)
+                            static const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+                            const uintptr_t a0 = ((uintptr_t)src + off) & ~(page - 1);
                             (void)madvise((void *)a0, ((uintptr_t)src + off + len) - a0, MADV_POPULATE_READ);
                         }
 #endif
@@ -325,7 +328,7 @@ static int ensure_device(CStore *cs, int device) {
     struct Image {
         hipStream_t stream = nullptr;
         uint32_t *steps = nullptr, *small = nullptr;
-        uint32_t *pb = nullptr, *pe = nullptr, *seg_len = nullptr, *depth = nullptr, *uniq = nullptr;  // inside `small`
+        uint32_t *pb = nullptr, *pe = nullptr, *seg_len = nullptr, *depth = nullptr, *uniq = nullptr, *sums = nullptr;  // inside `small`
         flatgfa_dev_plan_t *plan = nullptr;
         bool keep = false;
         ~Image() {
@@ -356,13 +359,14 @@ static int ensure_device(CStore *cs, int device) {
     }
     tick("steps: hipMalloc + upload");
     if (P || S) {
-        CAPI_HIP(hipMalloc(&im.small, (2 * Pa + 3 * Sa) * 4));
+        CAPI_HIP(hipMalloc(&im.small, (2 * Pa + 3 * Sa + 4 * Pa) * 4));  // (the last 4 * Pa words: two u64 sums per path)
         CAPI_HIP(hipMemcpy(im.small, host.data(), host.size() * 4, hipMemcpyHostToDevice));
         im.pb = im.small;
         im.pe = im.small + Pa;
         im.seg_len = im.small + 2 * Pa;
         im.depth = im.seg_len + Sa;
         im.uniq = im.depth + Sa;
+        im.sums = im.uniq + Sa;  // (256-byte aligned: every sub-array is)
     }
     flatgfa_dev_graph_t g{im.steps, (uint64_t)N, im.pb, im.pe, (uint32_t)P, (uint32_t)S, im.seg_len};
     tick("paths, segments, outputs");
@@ -379,6 +383,7 @@ static int ensure_device(CStore *cs, int device) {
     cs->d_seg_len = im.seg_len;
     cs->d_depth = im.depth;
     cs->d_uniq = im.uniq;
+    cs->d_sums = reinterpret_cast<uint64_t *>(im.sums);
     cs->h_path_begin.assign(h_pb, h_pb + P);
     cs->h_path_end.assign(h_pe, h_pe + P);
     cs->plan = im.plan;
@@ -434,13 +439,11 @@ int flatgfa_path_depth(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, 
     if (rc) return rc;
     const size_t P = gfa->view.paths.len;
     if (n_ids == 0 || P == 0) return run_seg_depth(gfa, false);
-    uint64_t *d_sums = nullptr;
-    CAPI_HIP(hipMalloc(&d_sums, P * 16));
+    uint64_t *d_sums = gfa->d_sums;  // (the handle's own: a hipMalloc per call cost five times the kernels it bracketed)
     std::vector<uint64_t> sums(P * 2);
     rc = flatgfa_dev_path_depth_all(gfa->plan, gfa->d_depth, d_sums, d_sums + P, gfa->stream);
     if (!rc) rc = flatgfa_dev_status(gfa->plan, gfa->stream);
     if (!rc && hipMemcpy(sums.data(), d_sums, P * 16, hipMemcpyDeviceToHost) != hipSuccess) rc = FLATGFA_ERR_HIP;
-    (void)hipFree(d_sums);
     if (rc) return rc;
     for (uint32_t k = 0; k < n_ids; ++k) {
         const uint64_t ln = sums[path_ids[k]], ws = sums[P + path_ids[k]];

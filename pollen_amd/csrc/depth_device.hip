@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -225,17 +226,19 @@ struct flatgfa_dev_plan {
     uint32_t *overlap_bits = nullptr;  // per-path coarse handle bitmaps (built on first overlap query)
     uint32_t *overlap_qbits = nullptr; // exact handle bitsets of the queries of the last overlap call (scratch)
     size_t overlap_qbytes = 0;
+    bool overlap_qall = false;         // the exact bitsets are those of all paths, in path order (else: of the last call's queries)
     uint2 *len_depth = nullptr;        // (seg_len, depth) table of the last path_sums call (built on first use)
     // the outputs of the last node-depth call through the bucketed path: flatgfa_dev_status
     // completes that call if its records did not fit the sub-buckets
     uint32_t *last_depth = nullptr, *last_uniq = nullptr;
     uint64_t *last_len = nullptr, *last_weighted = nullptr;  // (a path_depth_all call)
     bool last_fast = false;
+    uint32_t calls_since_status = 0;   // node-depth calls enqueued since the last flatgfa_dev_status: only the last can be completed there
     uint32_t *all_ids = nullptr;       // 0..n_paths-1 (path_depth_all without the bucketed path)
 };
 
 extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int n_cus, uint32_t **coarse_cache,
-                                              uint32_t **qbits_cache, size_t *qbits_bytes, const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out,
+                                              uint32_t **qbits_cache, size_t *qbits_bytes, bool *qbits_all, const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out,
                                               uint32_t *status, hipStream_t stream);
 
 #define HIP_TRY(expr, fail_stmt)                                                            \
@@ -317,8 +320,11 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
         // More than a record for two steps: pass 1 by partition (k_scan_dense) may beat pass 1 by runs.
         // The plan was sized for it (it makes the most records); now both are timed.
         {
-            bool maybe = pl->fast.eligible && pl->fast.dense_maybe;
-            for (uint32_t r = 0; r < pl->fast.n_more; ++r) maybe = maybe && pl->fast.more[r].dense_maybe;
+            bool maybe = pl->fast.eligible && pl->fast.dense_maybe, any_maybe = maybe;  // all ranges / some range
+            for (uint32_t r = 0; r < pl->fast.n_more; ++r) {
+                maybe = maybe && pl->fast.more[r].dense_maybe;
+                any_maybe = any_maybe || (pl->fast.eligible && pl->fast.more[r].dense_maybe);
+            }
             if (maybe) {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 float best[2] = {1e30f, 1e30f};
@@ -343,8 +349,8 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
                 (void)hipMemset(pl->status, 0, 4);
                 set_dense(ok && best[1] < best[0]);
                 if (getenv("FLATGFA_TIMING")) fprintf(stderr, "plan: pass 1 by runs %.1f us, by partition %.1f us\n", best[0] * 1e3, best[1] * 1e3);
-            } else if (pl->fast.eligible && pl->fast.dense_maybe) {  // (ranges that disagree: by runs)
-                pl->fast.dense = false;
+            } else if (any_maybe) {  // (ranges that disagree: all of them by runs, nothing left at an untimed default)
+                pl->fast.dense = pl->fast.dense && !pl->fast.dense_maybe;
                 for (uint32_t r = 0; r < pl->fast.n_more; ++r) pl->fast.more[r].dense = pl->fast.more[r].dense && !pl->fast.more[r].dense_maybe;
             }
         }
@@ -460,6 +466,7 @@ extern "C" int flatgfa_dev_seg_depth(flatgfa_dev_plan_t *pl, uint32_t *depth_out
     pl->last_depth = depth_out;
     pl->last_uniq = uniq_out;
     pl->last_len = pl->last_weighted = nullptr;
+    pl->calls_since_status += 1;
     if (pl->fast.eligible) {
         return fast_seg_depth(pl->fast, g, depth_out, uniq_out, pl->status, stream);
     }
@@ -556,13 +563,14 @@ extern "C" int flatgfa_dev_path_depth_all(flatgfa_dev_plan_t *pl, uint32_t *dept
     pl->last_uniq = nullptr;
     pl->last_len = length_out;
     pl->last_weighted = weighted_out;
+    pl->calls_since_status += 1;
     return path_depth_all_enqueue(pl, depth_out, length_out, weighted_out, (hipStream_t)stream_, true);
 }
 
 extern "C" int flatgfa_dev_path_overlaps(flatgfa_dev_plan_t *pl, const uint32_t *query_ids, uint32_t n_q,
                                          uint8_t *touch_out, void *stream_) {
     if (!pl || (n_q && (!query_ids || !touch_out))) { set_error("dev_path_overlaps: NULL argument"); return FLATGFA_ERR_ARG; }
-    return flatgfa_dev_path_overlaps_impl(&pl->g, pl->n_cus, &pl->overlap_bits, &pl->overlap_qbits, &pl->overlap_qbytes,
+    return flatgfa_dev_path_overlaps_impl(&pl->g, pl->n_cus, &pl->overlap_bits, &pl->overlap_qbits, &pl->overlap_qbytes, &pl->overlap_qall,
                                           query_ids, n_q, touch_out, pl->status,
                                           (hipStream_t)stream_);
 }
@@ -576,6 +584,8 @@ extern "C" int flatgfa_dev_status(flatgfa_dev_plan_t *pl, void *stream_) {
         uint32_t st = 0;
         HIP_TRY(hipMemcpyAsync(&st, pl->status, 4, hipMemcpyDeviceToHost, stream), return FLATGFA_ERR_HIP);
         HIP_TRY(hipStreamSynchronize(stream), return FLATGFA_ERR_HIP);
+        const uint32_t n_calls = pl->calls_since_status;
+        if (attempt == 0) pl->calls_since_status = 0;
         if (!st) return FLATGFA_OK;
         HIP_TRY(hipMemsetAsync(pl->status, 0, 4, stream), return FLATGFA_ERR_HIP);
         if (st & 1u) {
@@ -586,7 +596,14 @@ extern "C" int flatgfa_dev_status(flatgfa_dev_plan_t *pl, void *stream_) {
             set_error("node depth: internal error (the records of pass 1 were not in the order pass 2 relies on)");
             return FLATGFA_ERR_HIP;
         }
-        if (!(st & 4u)) return FLATGFA_OK;
+        if (!(st & (4u | 16u))) return FLATGFA_OK;
+        if (attempt == 0 && n_calls > 1) {
+            // Several calls were enqueued since the last status and (at least) one of them ran out of
+            // scratch room: which one is not recorded, and only the last one's outputs are known here.
+            set_error("node depth: a call ran out of scratch room (the steps changed behind the plan?) and " + std::to_string(n_calls) +
+                      " calls were enqueued since the last flatgfa_dev_status: call it after every call to have such a call completed");
+            return FLATGFA_ERR_HIP;
+        }
         // The last node-depth call ran out of sub-bucket room, so its outputs are incomplete: run
         // it again with four times the room, or -- when the plan cannot grow -- through the
         // atomic kernels.  The scratch cleans itself in pass 2, whatever was dropped.
@@ -595,13 +612,34 @@ extern "C" int flatgfa_dev_status(flatgfa_dev_plan_t *pl, void *stream_) {
             return FLATGFA_ERR_HIP;
         }
         int rc;
-        const bool grown = fast_plan_grow(&pl->fast);
+        const bool grown = !(st & 16u) && fast_plan_grow(&pl->fast);  // (a full hand-back list is not a matter of bucket room)
+        if (st & 16u) pl->fast.eligible = false;  // (later calls take the atomic kernels right away)
         if (!grown) pl->last_fast = false;
         if (pl->last_len) rc = path_depth_all_enqueue(pl, pl->last_depth, pl->last_len, pl->last_weighted, stream, grown);
         else if (grown) rc = fast_seg_depth(pl->fast, pl->g, pl->last_depth, pl->last_uniq, pl->status, stream);
         else rc = atomic_seg_depth(pl, pl->last_depth, pl->last_uniq, stream);
         if (rc) return rc;
     }
+}
+
+// Which kernels a plan's calls run: the choices made (some of them by timing) when it was created.
+extern "C" int flatgfa_dev_plan_describe(flatgfa_dev_plan_t *pl, char *out, int cap) {
+    if (!pl || !out || cap <= 0) return 0;
+    const FastPlan &f = pl->fast;
+    std::string s;
+    if (!f.eligible) {
+        s = "path=atomic (k_depth_scan / k_depth_uniq_path)";
+    } else {
+        s = "path=bucketed pass1=" + std::string(f.dense ? "k_scan_dense" : "k_scan") + (f.n_short ? "+k_scan_short" : "") + (f.n_medium ? "+k_scan_medium" : "") +
+            " pass2=" + (f.tagged ? (f.n_shared ? "tagged(shared bitsets)" : "tagged") : (f.big_groups ? "directory(one-item shortcut)" : "directory")) +
+            " windows=" + std::to_string(f.n_win) + "x" + std::to_string(1u << f.wb) + " ranges=" + std::to_string(f.n_more + 1) +
+            " workgroups_per_window=" + std::to_string(f.acc_parts) + " items=" + std::to_string(f.n_items) + " split_paths=" + std::to_string(f.n_shared) +
+            " short_paths=" + std::to_string(f.n_short) + " medium_paths=" + std::to_string(f.n_medium) + " bucket_cap=" + std::to_string(f.cap);
+    }
+    const int n = (int)std::min<size_t>(s.size(), (size_t)cap - 1);
+    memcpy(out, s.data(), (size_t)n);
+    out[n] = 0;
+    return n;
 }
 
 extern "C" void flatgfa_dev_profile_enable(int on) {

@@ -63,7 +63,7 @@ constexpr int kAccThreads = 1024;
 constexpr uint32_t kAccWaves = kAccThreads / 64;
 constexpr uint32_t kLdsLimit = 160 * 1024;
 // status word bits (flatgfa_dev_status)
-constexpr uint32_t kStBounds = 1u, kStDebug = 2u, kStOverflow = 4u, kStInternal = 8u;  // (8: an invariant between the two passes did not hold -- a bug, reported as an error rather than as counts)
+constexpr uint32_t kStBounds = 1u, kStDebug = 2u, kStOverflow = 4u, kStInternal = 8u, kStBackOverflow = 16u;  // (16: more short paths handed back than the list holds: larger buckets would not help, the atomic kernels complete the call)  // (8: an invariant between the two passes did not hold -- a bug, reported as an error rather than as counts)
 
 // ---- the wave-per-path kernels (k_scan_short): windows of 4096 segments, at most 256 of them ----
 constexpr uint32_t kRunBits = 11;  // a queued run is (start id << 11) | (len - 1)
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
                     const uint32_t k = atomicAdd(A.work_counter, 1u);                                   \
                     const uint32_t hp = A.short_items[cur.item].w;                                      \
                     if (k < A.max_back) A.items[A.n_items + k] = A.path_begin ? make_uint4(A.path_begin[hp], A.path_end[hp], 0u, hp) : make_uint4(cur.b, cur.e, 0u, hp); \
-                    else atomicOr(A.status, kStOverflow);                                               \
+                    else atomicOr(A.status, kStBackOverflow);                                           \
                 }                                                                                       \
                 handed_back = false;                                                                    \
             } else {                                                                                    \
@@ -847,11 +847,13 @@ constexpr int kModePlain = 0, kModeDbg = 1, kModeRanged = 2;
 #define FGFA_WIDE 4
 #endif
 constexpr int kWide = FGFA_WIDE;  // chunks of 64 queue entries k_scan emits side by side
-// (sixteen cells each for the block counters and the arrival counters, indexed by the item's ordinal
-// mod 16 in a tagged call -- waves may be kTagSlots items apart there -- and mod 2 otherwise)
-constexpr uint32_t kCtlNext = 0, kCtlArrive = 16, kCtlEpoch = 32, kCtlJobs = 40, kCtlWords = 56;
+// (kCtlRing cells each for the block counters, the arrival counters and the items, indexed by the
+// item's ordinal mod kCtlRing in a tagged call -- a wave with records to append may be kTagSlots items
+// ahead of the slowest there, one without any kIdleAhead -- and mod 2 otherwise)
+constexpr uint32_t kCtlRing = 32, kIdleAhead = 20;
+constexpr uint32_t kCtlNext = 0, kCtlArrive = kCtlRing, kCtlEpoch = 2 * kCtlRing, kCtlJobs = 2 * kCtlRing + 8, kCtlWords = 3 * kCtlRing + 8;
 // A tagged call deals the items out as the workgroups get to them (an item's tag is its ordinal in
-// its workgroup, whatever the item): ctl[kCtlJobs + (r & 15)] is the workgroup's r-th item, or one of
+// its workgroup, whatever the item): ctl[kCtlJobs + (r mod kCtlRing)] is the workgroup's r-th item, or one of
 constexpr uint32_t kJobEmpty = 0xFFFFFFFFu, kJobPending = 0xFFFFFFFEu;  // nobody has asked yet / a wave is fetching it
 
 __device__ __forceinline__ uint32_t epoch_now(uint32_t *ctl) {
@@ -1097,7 +1099,7 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
 template <int MODE, bool TAGGED>
 __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     constexpr bool DBG = MODE == kModeDbg;
-    constexpr uint32_t kRing = TAGGED ? 15u : 1u;  // which cell of the control rings an item uses: its ordinal & kRing
+    constexpr uint32_t kRing = TAGGED ? kCtlRing - 1u : 1u;  // which cell of the control rings an item uses: its ordinal & kRing
     extern __shared__ uint32_t lds[];
     // layout: [bcur: nwp][snap: nwp][control words][run queues: kWaves * kQ2 entries of 8 bytes]
     uint32_t *bcur = lds;
@@ -1202,11 +1204,11 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     while (job < n_items) {
         uint32_t next_job;
         if (TAGGED) {
-            uint32_t *ahead = &ctl[kCtlJobs + ((rr + 2u) & 15u)];
+            uint32_t *ahead = &ctl[kCtlJobs + ((rr + 2u) & kRing)];
             uint32_t st = 0;
             if (lane == 0) st = atomicCAS(ahead, kJobEmpty, kJobPending);  // who fetches the item after the next?
             do {
-                next_job = __hip_atomic_load(&ctl[kCtlJobs + ((rr + 1u) & 15u)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                next_job = __hip_atomic_load(&ctl[kCtlJobs + ((rr + 1u) & kRing)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             } while (next_job >= kJobPending);  // (asked for an item ago: it is there, but for items of a handful of steps)
             if ((uint32_t)__builtin_amdgcn_readfirstlane(st) == kJobEmpty) {
                 uint32_t got = 0;
@@ -1240,13 +1242,19 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         // Records of this item may only be appended once every wave has left the item before it
         // (its cursor snapshot is taken then; tagged: the item kTagSlots before it); a wave that got
         // ahead has been queueing until now.
+        // (In a tagged call a wave that has queued nothing -- the item had no block for it -- has
+        // nothing to wait for: it goes on, up to kIdleAhead items ahead of the slowest.)
         tmark<DBG>(A, w, 4);
-        if (!w.epoch_ok) {
-            while (epoch_now(ctl) < need) __builtin_amdgcn_s_sleep(2);
-            w.epoch_ok = true;
+        if (TAGGED && w.fill == 0u) {
+            while (rr >= kIdleAhead && epoch_now(ctl) + kIdleAhead <= rr) __builtin_amdgcn_s_sleep(2);
+        } else {
+            if (!w.epoch_ok) {
+                while (epoch_now(ctl) < need) __builtin_amdgcn_s_sleep(2);
+                w.epoch_ok = true;
+            }
+            tmark<DBG>(A, w, 1);
+            drain_raw<MODE, (DBG ? 1 : kWide)>(A, w, bcur, mine, true);
         }
-        tmark<DBG>(A, w, 1);
-        drain_raw<MODE, (DBG ? 1 : kWide)>(A, w, bcur, mine, true);
         tmark<DBG>(A, w, 3);
         // This wave is done with the item: it requests its first two blocks of the next one right away.
         const uint32_t pe = place;
@@ -1276,7 +1284,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             if (lane == 0) {
                 ctl[kCtlArrive + (rr & kRing)] = 0u;
                 ctl[kCtlNext + (rr & kRing)] = 4u * kWaves;  // for the next item that uses these cells (no wave is there yet)
-                if (TAGGED) ctl[kCtlJobs + (rr & 15u)] = kJobEmpty;
+                if (TAGGED) ctl[kCtlJobs + (rr & kRing)] = kJobEmpty;
             }
             __hip_atomic_store(ctl + kCtlEpoch, rr + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (items complete in order)
         }
@@ -2868,7 +2876,9 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // sub-buckets; real graphs need a fraction of that (runs), skewed ones more, so the
     // capacity starts at the even share of N records + 25% and grows on demand (fast_plan_grow).
     const uint64_t slots = (uint64_t)n_win * fp->n_slots;
-    uint64_t cap = (g.n_steps + slots - 1) / slots;
+    uint64_t walked = 0;  // (the steps the paths span, not the pool: a plan over a few paths of a large graph needs little)
+    for (uint32_t p = 0; p < g.n_paths; ++p) walked += he[p] - hb[p];
+    uint64_t cap = (std::min<uint64_t>(g.n_steps, walked) + slots - 1) / slots;
     if (ranged) cap = (uint64_t)((double)cap * n_range / g.n_segs) + 1;  // a range sees its share of the runs
     cap = cap + cap / 4 + 256;
     if (const char *forced = getenv("FLATGFA_BUCKET_CAP")) {  // tests: force the overflow route

@@ -183,7 +183,7 @@ using namespace fgfa_dev;
 // `coarse_cache`: the per-path coarse bitmaps, built on the first call and kept with the plan.
 // `qbits_cache` / `qbits_bytes`: scratch for the queries' exact bitsets, grown on demand, kept too.
 extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int n_cus, uint32_t **coarse_cache,
-                                              uint32_t **qbits_cache, size_t *qbits_bytes, const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out,
+                                              uint32_t **qbits_cache, size_t *qbits_bytes, bool *qbits_all, const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out,
                                               uint32_t *status, hipStream_t stream) {
     if (n_q == 0 || g->n_paths == 0) return FLATGFA_OK;
     const uint32_t words = (((g->n_segs + 31u) / 32u) + 3u) & ~3u;
@@ -219,7 +219,10 @@ extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int 
     if (const char *f = getenv("FLATGFA_OVERLAP_DENSE_MAX")) dense_max = strtoull(f, nullptr, 10);  // tests: 0 = query bitsets only
     const bool all_paths = (uint64_t)g->n_paths * per_query <= dense_max;
     const uint32_t batch = all_paths ? g->n_paths : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_q, (1ull << 30) / per_query));
+    // (what the cache holds is recorded, not inferred from its size: bitsets of every path in path
+    // order, or those of the last call's queries in query order)
     bool build_all = false;
+    if (*qbits_bytes >= (size_t)batch * per_query && all_paths && !*qbits_all) build_all = true;  // big enough, but laid out by query
     if (*qbits_bytes < (size_t)batch * per_query) {
         if (*qbits_cache) {
             (void)hipStreamSynchronize(stream);  // an earlier call on this plan may still be reading it
@@ -234,6 +237,7 @@ extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int 
         *qbits_bytes = (size_t)batch * per_query;
         build_all = all_paths;
     }
+    *qbits_all = all_paths;
     uint32_t *qbits = *qbits_cache;
     const uint32_t lds = std::min(words, kBitsWinWords) * 4u;
     (void)hipFuncSetAttribute((const void *)k_handle_bits, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -261,10 +265,11 @@ extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int 
         if (hipGetLastError() != hipSuccess) {
             set_error("path overlaps: kernel launch failed");
             rc = FLATGFA_ERR_HIP;
-            if (build_all) {  // never keep bitsets that were not built
+            if (all_paths) {  // never keep bitsets that may not have been built
                 (void)hipFree(*qbits_cache);
                 *qbits_cache = nullptr;
                 *qbits_bytes = 0;
+                *qbits_all = false;
             }
         }
     }

@@ -139,6 +139,12 @@ class DepthPlan:
                                                         touch_out.data_ptr() if touch_out.numel() else None,
                                                         self._stream()), "dev_path_overlaps")
 
+    def describe(self) -> str:
+        """Which kernels this plan's calls run (the choices made, some by timing, when it was created)."""
+        buf = ctypes.create_string_buffer(512)
+        _lib.lib().flatgfa_dev_plan_describe(self._p, buf, 512)
+        return buf.value.decode()
+
     def status(self) -> None:
         """Synchronize the current stream and raise if a kernel saw an out-of-range id."""
         with _torch().cuda.device(self.graph.device):
