@@ -2,25 +2,27 @@
 # Produces the committed profile summaries for one round (run via gpurun from the repo root):
 #   tools/profile_round.sh r01
 # Writes gpurun_out/profiles/<tag>_*; copy them into profiles/ afterwards.
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/profiles; mkdir -p $OUT; cd $R
 CMD="bench.py --steps 20 --warmup 3"
 # 1. the bench line itself (all workloads; cfgL is the headline)
-for w in cfgL cfgL-uniform cfgL-chrom cfgL-short cfgL-fewlong cfgL-4paths cfgL-medium cfgL-32k cfgL-100kseg cfgL-4Mseg cfgL-16Mseg cfgL-64Mseg cfgM cfgS; do
+for w in cfgL cfgL-uniform cfgL-chrom cfgL-short cfgL-fewlong cfgL-4paths cfgL-medium cfgL-32k chrom-10k chrom-1k tiny-paths cfgL-100kseg cfgL-4Mseg cfgL-16Mseg cfgL-64Mseg cfgM cfgS; do
   python3 bench.py --steps 20 --warmup 3 --workload $w 2>/dev/null | tail -1 > $OUT/${TAG}_bench_$w.json
 done
 # 2. kernel trace + stats of the same command (csv)
 rm -rf $OUT/_trace; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_trace -o t -- python3 $CMD --no-cpu-baseline --no-extras > $OUT/_trace.log 2>&1
 f=$(find $OUT/_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_rocprofv3_kernel_stats.csv
-# 3. PMC passes (separate runs; --kernel-trace only, as gpurun requires)
+# 3. PMC passes (separate runs; --kernel-trace only, as gpurun requires): the headline workload, and the shapes next to it
+for wl in cfgL cfgL-chrom cfgL-short; do
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE"; do
   tag=$(echo $set | cut -d' ' -f1)
   rm -rf $OUT/_pmc_$tag
-  rocprofv3 --kernel-trace --pmc $set -d $OUT/_pmc_$tag -o p -- python3 $CMD --no-cpu-baseline --no-verify --no-extras > $OUT/_pmc_$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set -d $OUT/_pmc_$tag -o p -- python3 $CMD --workload $wl --no-cpu-baseline --no-verify --no-extras > $OUT/_pmc_$tag.log 2>&1
 done
-python3 - <<PY > $OUT/${TAG}_pmc_summary.txt
-import sqlite3,glob,re
+[ $wl = cfgL ] && SUMMARY=$OUT/${TAG}_pmc_summary.txt || SUMMARY=$OUT/${TAG}_pmc_$wl.txt
+WL=$wl python3 - <<PY > $SUMMARY
+import sqlite3,glob,re,os
 def short(k):
     m=re.search(r"(k_\w+)(<[^>]*>)?\(",k)
     if not m: return k[:40]
@@ -28,7 +30,7 @@ def short(k):
     if n=="k_accum": return n+("<uniq>" if t.startswith("<true") else "<depth>")
     if n=="k_scan": return n
     return n+t
-print("# rocprofv3 --pmc, averages per dispatch over the bench run (python3 $CMD); FETCH_SIZE/WRITE_SIZE in KB")
+print("# rocprofv3 --pmc, averages per dispatch over the bench run (python3 $CMD --workload %s); FETCH_SIZE/WRITE_SIZE in KB" % os.environ["WL"])
 print("# (gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -- MI355X_MICROARCH.md; double it)")
 for d in sorted(glob.glob("$OUT/_pmc_*/**/*.db", recursive=True)):
     db=sqlite3.connect(d)
@@ -36,6 +38,9 @@ for d in sorted(glob.glob("$OUT/_pmc_*/**/*.db", recursive=True)):
         if 'fgfa_dev' in k:
             print("%-22s %-22s %18.1f  dispatches=%d" % (short(k), c, v, n))
 PY
+[ $wl = cfgL ] && for t in FETCH_SIZE WRITE_SIZE; do rm -rf $OUT/_keep_$t; cp -r $OUT/_pmc_$t $OUT/_keep_$t; done
+done
+for t in FETCH_SIZE WRITE_SIZE; do rm -rf $OUT/_pmc_$t; mv $OUT/_keep_$t $OUT/_pmc_$t; done
 # 4. per-kernel HBM traffic (what bench.py quotes as roofline.traffic)
 python3 - <<PY > $OUT/latest_traffic.json
 import sqlite3,glob,json,re
