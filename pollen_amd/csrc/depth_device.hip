@@ -35,7 +35,37 @@ static std::mutex g_prof_mu;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 
+// events belong to the device that was current when they were created: a pool per device
+static std::vector<std::vector<hipEvent_t>> g_event_pool;
+static std::vector<hipEvent_t> &pool_of_current_device() {  // (g_prof_mu held)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if ((size_t)dev >= g_event_pool.size()) g_event_pool.resize((size_t)dev + 1);
+    return g_event_pool[(size_t)dev];
+}
+
 bool prof_enabled() { return g_prof_on; }
+hipEvent_t prof_event_get() {
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        std::vector<hipEvent_t> &pool = pool_of_current_device();
+        if (!pool.empty()) {
+            hipEvent_t e = pool.back();
+            pool.pop_back();
+            return e;
+        }
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void prof_event_put(hipEvent_t e) {
+    if (!e) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::vector<hipEvent_t> &pool = pool_of_current_device();
+    if (pool.size() < 256) pool.push_back(e);
+    else (void)hipEventDestroy(e);
+}
 void prof_push(const ProfRec &r) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back(r);
@@ -650,6 +680,7 @@ extern "C" void flatgfa_dev_profile_enable(int on) {
 extern "C" int flatgfa_dev_profile_read(const char **names, float *ms, int cap) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     int n = 0;
+    std::vector<std::pair<int, hipEvent_t>> done;
     for (auto &r : g_prof) {
         (void)hipEventSynchronize(r.b);
         float t = 0.f;
@@ -659,10 +690,16 @@ extern "C" int flatgfa_dev_profile_read(const char **names, float *ms, int cap) 
             ms[n] = t;
             ++n;
         }
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        done.push_back({r.device, r.a});
+        done.push_back({r.device, r.b});
     }
     g_prof.clear();
+    for (const auto &de : done) {  // (back to their device's pool: events are reused, not created per kernel)
+        if ((size_t)de.first >= g_event_pool.size()) g_event_pool.resize((size_t)de.first + 1);
+        std::vector<hipEvent_t> &pool = g_event_pool[(size_t)de.first];
+        if (pool.size() < 256) pool.push_back(de.second);
+        else (void)hipEventDestroy(de.second);
+    }
     return n;
 }
 

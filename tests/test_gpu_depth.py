@@ -429,3 +429,44 @@ def test_device_path_depth_all_matches_two_walks(device_path):
     want_ws = np.array([(want_d[ids_all[b:e]].astype(np.uint64) * lens[ids_all[b:e]]).sum() for b, e in zip(nb, ne)], dtype=np.uint64)
     assert (ln.cpu().numpy().view(np.uint64) == want_ln).all() and (ws.cpu().numpy().view(np.uint64) == want_ws).all()
     plan.close()
+
+
+@pytest.mark.parametrize("n_paths,steps", [(6000, 7), (900, 150), (40, 9000)])
+def test_tagged_walk_many_items_per_step(n_paths, steps, monkeypatch):
+    """Pass 2 of a tagged call keeps four bitsets per wave.  With every path an item of k_scan and a
+    handful of steps per path, one 64-record step of a sub-bucket spans dozens of items (the
+    general route: rounds of four tags, lowest first), and the waves of pass 1 run items ahead of
+    each other (its gate: four for a wave with records to append).  All paths crowd into a few
+    windows, revisit each other's segments and their own."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")       # every path is an item of k_scan
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.delenv("FLATGFA_TAGGED", raising=False)
+    rng = np.random.default_rng(n_paths)
+    S = 3 * 4096 + 100
+    walks = []
+    for p in range(n_paths):
+        start = int(rng.integers(0, S))
+        jumps = rng.choice([1, 1, 1, 1, 2, -1, -3, 5, 4096, -4000], size=steps)
+        ids = (start + np.cumsum(jumps)) % S
+        walks.append(ids.astype(np.uint32))
+    lens = np.array([len(x) for x in walks], dtype=np.uint32)
+    stp = (np.concatenate(walks) << 1) | rng.integers(0, 2, size=int(lens.sum())).astype(np.uint32)
+    pe = np.cumsum(lens).astype(np.uint32)
+    pb = (pe - lens).astype(np.uint32)
+    paths = np.zeros(len(lens), dtype=fo.PATH_DT)
+    paths["steps_start"], paths["steps_end"] = pb, pe
+    pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
+    pools.paths, pools.steps, pools.segs = paths, stp, np.zeros(S, dtype=fo.SEG_DT)
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    plan = DepthPlan(DeviceGraph(stp, pb, pe, S))
+    assert "pass2=tagged" in plan.describe()
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    for _ in range(3):
+        plan.seg_depth(d, u)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == want_d).all()
+        assert (u.cpu().numpy().view(np.uint32) == want_u).all()
+    plan.close()
