@@ -91,6 +91,13 @@ flatgfa_t flatgfa_parse_stream_bytes(const uint8_t *data, size_t len);
 flatgfa_t flatgfa_load(const char *flatgfa_filename);
 /* file::dump (flatgfa/src/file.rs:290; cli/main.rs:197-201). */
 int flatgfa_write_flatgfa(flatgfa_t gfa, const char *filename);
+/* The preallocated ("in-place") container of `fgfa -m -p FACTOR -o OUT [-I GFA]`
+ * (cli/main.rs:216-248, file.rs:255-272): every pool's region is `capacity` items long, `len` of
+ * them in use.  With the GFA text the graph was parsed from, the capacities are the reference's
+ * estimates from it (parse.rs:176-216, file.rs:136-158); with gfa_text == NULL, file.rs:117-132's
+ * guess from `factor`.  FLATGFA_ERR_BOUNDS where a pool does not fit its capacity (the reference's
+ * fixed-capacity store panics there).  flatgfa_load reads such files as it reads any other. */
+int flatgfa_write_flatgfa_prealloc(flatgfa_t gfa, const char *filename, const uint8_t *gfa_text, size_t text_len, uint32_t factor);
 /* GFA text (flatgfa/src/print.rs:99-153).  *text is malloc'd; release with flatgfa_free_text. */
 int flatgfa_print_gfa(flatgfa_t gfa, char **text, size_t *len);
 void flatgfa_free_text(char *text);

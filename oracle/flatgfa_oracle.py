@@ -360,6 +360,58 @@ def dump_flatgfa(p: Pools) -> bytes:
     return b"".join(toc + body)
 
 
+def estimate_toc(buf: bytes) -> List[int]:
+    """parse.rs:176-216 + Toc::estimate (file.rs:136-158): capacities of the eleven pools, in file
+    order, from a scan of the GFA text's line types and lengths."""
+    segs = links = paths = header_bytes = seg_bytes = path_bytes = 0
+    rest = buf
+    while rest:
+        marker = rest[0:1]
+        nl = rest.find(b"\n")
+        nxt = nl if nl >= 0 else len(rest) + 1
+        if marker == b"H":
+            header_bytes += nxt
+        elif marker == b"S":
+            segs += 1
+            seg_bytes += nxt
+        elif marker == b"L":
+            links += 1
+        elif marker == b"P":
+            paths += 1
+            path_bytes += nxt
+        else:
+            raise ParseError("unknown line type")
+        if nxt >= len(rest):
+            break
+        rest = rest[nxt + 1:]
+    return [header_bytes, segs, paths, links, path_bytes // 3, seg_bytes, (links + paths) * 2, links * 2 + paths * 4,
+            paths * 512, links * 16, segs + links + paths + 8]
+
+
+def guess_toc(factor: int) -> List[int]:
+    """Toc::guess, file.rs:117-132."""
+    f = factor
+    return [128, 32 * f * f, f, 32 * f * f, 1024 * f * f, 512 * f * f, 256 * f, 64 * f * f, 64 * f, 512 * f * f, 64 * f * f]
+
+
+def dump_flatgfa_prealloc(p: Pools, caps: List[int]) -> bytes:
+    """What prealloc_translate leaves in the file (cli/main.rs:216-248): file::init with the
+    estimated capacities (file.rs:255-272), the parse into the fixed-capacity store, then the
+    table of contents rewritten with the lengths reached (Toc::for_fixed_store, file.rs:100-114).
+    Every region is `capacity` items long; the bytes behind `len` items stay zero (a fresh file)."""
+    toc = [np.uint64(MAGIC).tobytes()]
+    body = []
+    for name, cap in zip(POOL_ORDER, caps):
+        a = getattr(p, name)
+        n = int(a.shape[0])
+        if n > cap:
+            raise ParseError(f"{name}: {n} entries do not fit a capacity of {cap}")  # (SliceVec push panics)
+        toc.append(np.array([n, cap], dtype="<u8").tobytes())
+        raw = np.ascontiguousarray(a).tobytes()
+        body.append(raw + bytes(cap * POOL_DTYPES[name].itemsize - len(raw)))
+    return b"".join(toc + body)
+
+
 def view_flatgfa(data: bytes) -> Pools:
     """file::view, file.rs:163-213.  `len` items are taken from each region of
     `capacity` items."""

@@ -200,6 +200,26 @@ int flatgfa_write_flatgfa(flatgfa_t gfa, const char *filename) {
     return FLATGFA_OK;
 }
 
+int flatgfa_write_flatgfa_prealloc(flatgfa_t gfa, const char *filename, const uint8_t *gfa_text, size_t text_len, uint32_t factor) {
+    if (!gfa || !filename || (text_len && !gfa_text)) { set_error("flatgfa_write_flatgfa_prealloc: NULL argument"); return FLATGFA_ERR_ARG; }
+    uint64_t cap[11];
+    std::string err;
+    if (gfa_text) {
+        if (!fgfa::estimate_toc(gfa_text, text_len, cap, &err)) { set_error(err); return FLATGFA_ERR_BOUNDS; }
+    } else {
+        fgfa::guess_toc(factor, cap);
+    }
+    size_t n = 0;
+    if (!fgfa::prealloc_file_size(gfa->view, cap, &n, &err)) { set_error(err); return FLATGFA_ERR_BOUNDS; }
+    std::vector<uint8_t> buf(n, 0);  // (a fresh mapped file reads as zeros behind what is written)
+    fgfa::dump_flatgfa_prealloc(gfa->view, cap, buf.data());
+    FILE *f = fopen(filename, "wb");
+    if (!f) { set_error(std::string("cannot create ") + filename); return FLATGFA_ERR_IO; }
+    const size_t w = fwrite(buf.data(), 1, n, f);
+    if (fclose(f) != 0 || w != n) { set_error(std::string("short write to ") + filename); return FLATGFA_ERR_IO; }
+    return FLATGFA_OK;
+}
+
 static int give_text(const std::string &s, char **text, size_t *len) {
     char *p = (char *)malloc(s.size() + 1);
     if (!p) { set_error("out of memory"); return FLATGFA_ERR_IO; }

@@ -52,7 +52,8 @@ static void write_all(const char *p, size_t n) {
 }
 
 int main(int argc, char **argv) {
-    const char *in_flat = nullptr, *in_gfa = nullptr, *out_flat = nullptr, *out_gfa = nullptr;
+    const char *in_flat = nullptr, *in_gfa = nullptr, *out_flat = nullptr, *out_gfa = nullptr, *prealloc = nullptr;
+    bool mutate = false;  // -m: with -o, write the preallocated container (cli/main.rs:88-96); with -i, open for mutation (read the same way here)
     int i = 1;
     for (; i < argc; ++i) {
         std::string a = argv[i];
@@ -64,14 +65,24 @@ int main(int argc, char **argv) {
         else if (a == "-I") need(&in_gfa);
         else if (a == "-o") need(&out_flat);
         else if (a == "-O") need(&out_gfa);
-        else if (a == "-m" || a == "-p") { fprintf(stderr, "fgfa: %s (in-place mutation) is out of scope\n", a.c_str()); return 2; }
+        else if (a == "-m") mutate = true;
+        else if (a == "-p") need(&prealloc);
         else break;
     }
     std::string cmd = i < argc ? argv[i++] : "";
 
     flatgfa_t g;
+    std::string gfa_text;  // (kept for -m -o: the capacities of the preallocated file are measured on it)
     if (in_flat) {
         g = flatgfa_load(in_flat);
+    } else if (in_gfa && mutate && out_flat) {
+        FILE *f = fopen(in_gfa, "rb");
+        if (!f) { fprintf(stderr, "fgfa: cannot open %s\n", in_gfa); return 1; }
+        char tmp[1 << 16];
+        size_t r;
+        while ((r = fread(tmp, 1, sizeof tmp, f)) > 0) gfa_text.append(tmp, r);
+        fclose(f);
+        g = flatgfa_parse_bytes((const uint8_t *)gfa_text.data(), gfa_text.size());
     } else if (in_gfa) {
         g = flatgfa_parse(in_gfa);
     } else {
@@ -85,7 +96,10 @@ int main(int argc, char **argv) {
 
     int rc = 0;
     if (cmd.empty()) {
-        if (out_flat) {
+        if (out_flat && mutate) {  // prealloc_translate (cli/main.rs:216-248): estimates from the text, or a guess for stdin
+            const uint32_t factor = prealloc ? (uint32_t)strtoul(prealloc, nullptr, 10) : 32u;
+            if (flatgfa_write_flatgfa_prealloc(g, out_flat, in_gfa ? (const uint8_t *)gfa_text.data() : nullptr, gfa_text.size(), factor)) rc = die("write");
+        } else if (out_flat) {
             if (flatgfa_write_flatgfa(g, out_flat)) rc = die("write");
         } else {
             char *text = nullptr;

@@ -552,6 +552,67 @@ void dump_flatgfa(const View &v, uint8_t *buf) {
     }
 }
 
+// The preallocated ("in-place") container of `fgfa -m -p N -o OUT [-I GFA]` (cli/main.rs:216-248):
+// every pool's region is `capacity` items long, of which `len` are in use; capacities come from
+// measurements of the GFA text (parse.rs:176-216 -> Toc::estimate, file.rs:136-158) or, with no
+// text to measure (stdin), from Toc::guess(factor) (file.rs:117-132).
+bool estimate_toc(const uint8_t *buf, size_t n, uint64_t cap[11], std::string *err) {
+    uint64_t segs = 0, links = 0, paths = 0, header_bytes = 0, seg_bytes = 0, path_bytes = 0;
+    size_t at = 0;
+    while (at < n) {
+        const uint8_t marker = buf[at];
+        const void *nl = memchr(buf + at, '\n', n - at);
+        const size_t rest = n - at;
+        const size_t next = nl ? (size_t)((const uint8_t *)nl - (buf + at)) : rest + 1;  // (memchr(..).unwrap_or(rest.len() + 1))
+        switch (marker) {
+            case 'H': header_bytes += next; break;
+            case 'S': segs += 1; seg_bytes += next; break;
+            case 'L': links += 1; break;
+            case 'P': paths += 1; path_bytes += next; break;
+            default: *err = "unknown line type"; return false;  // (the reference panics, parse.rs:205)
+        }
+        if (next >= rest) break;
+        at += next + 1;
+    }
+    const uint64_t c[11] = {header_bytes, segs, paths, links, path_bytes / 3, seg_bytes, (links + paths) * 2, links * 2 + paths * 4,
+                            paths * 512, links * 16, segs + links + paths + 8};
+    memcpy(cap, c, sizeof c);
+    return true;
+}
+
+void guess_toc(uint64_t f, uint64_t cap[11]) {
+    const uint64_t c[11] = {128, 32 * f * f, f, 32 * f * f, 1024 * f * f, 512 * f * f, 256 * f, 64 * f * f, 64 * f, 512 * f * f, 64 * f * f};
+    memcpy(cap, c, sizeof c);
+}
+
+bool prealloc_file_size(const View &v, const uint64_t cap[11], size_t *total, std::string *err) {
+    static const char *names[11] = {"header", "segs", "paths", "links", "steps", "seq_data", "overlaps", "alignment", "name_data", "optional_data", "line_order"};
+    unsigned __int128 t = sizeof(Toc);
+    for (int i = 0; i < 11; ++i) {
+        if (v.pool_len(i) > cap[i]) {  // (where the reference's fixed-capacity store panics on the push that does not fit)
+            *err = std::string("preallocated flatgfa: the ") + names[i] + " pool needs " + std::to_string(v.pool_len(i)) + " entries, the estimate allows " + std::to_string(cap[i]);
+            return false;
+        }
+        t += (unsigned __int128)cap[i] * kPoolElemSize[i];
+    }
+    if (t > (unsigned __int128)1 << 46) { *err = "preallocated flatgfa: file too large"; return false; }
+    *total = (size_t)t;
+    return true;
+}
+
+void dump_flatgfa_prealloc(const View &v, const uint64_t cap[11], uint8_t *buf) {  // buf: prealloc_file_size bytes, zeroed
+    Toc toc;
+    toc.magic = kMagic;
+    for (int i = 0; i < 11; ++i) toc.pool[i] = TocSize{v.pool_len(i), cap[i]};
+    memcpy(buf, &toc, sizeof toc);
+    size_t off = sizeof toc;
+    for (int i = 0; i < 11; ++i) {
+        const size_t bytes = v.pool_len(i) * kPoolElemSize[i];
+        if (bytes) memcpy(buf + off, v.pool_data(i), bytes);
+        off += cap[i] * kPoolElemSize[i];
+    }
+}
+
 // ------------------------------------------------------------ GFA printer ---
 
 static void put_u64(std::string *o, uint64_t v) {

@@ -136,6 +136,12 @@ bool view_flatgfa(const uint8_t *data, size_t n, View *out, std::string *err);
 // file::size / file::dump with Toc::full (file.rs:82-98, 290-313)
 size_t flatgfa_file_size(const View &v);
 void dump_flatgfa(const View &v, uint8_t *buf);
+// The preallocated container (`fgfa -m -p`): capacities as parse.rs:176-216 + file.rs:136-158
+// estimate them from a GFA text, or as file.rs:117-132 guesses them; the file with those capacities.
+bool estimate_toc(const uint8_t *buf, size_t n, uint64_t cap[11], std::string *err);
+void guess_toc(uint64_t factor, uint64_t cap[11]);
+bool prealloc_file_size(const View &v, const uint64_t cap[11], size_t *total, std::string *err);
+void dump_flatgfa_prealloc(const View &v, const uint64_t cap[11], uint8_t *buf);
 
 // print.rs:99-153 (preserved order when line_order is non-empty, else normalized)
 bool print_gfa(const View &v, std::string *out, std::string *err);

@@ -162,6 +162,12 @@ class FlatGFA:
     def write_flatgfa(self, filename: str) -> None:
         _check(_lib.lib().flatgfa_write_flatgfa(self._h, os.fsencode(filename)), "write_flatgfa")
 
+    def write_flatgfa_prealloc(self, filename: str, gfa_text: Optional[bytes] = None, factor: int = 32) -> None:
+        """The preallocated container of `fgfa -m -p FACTOR -o OUT [-I GFA]` (cli/main.rs:216-248):
+        capacities estimated from `gfa_text` (the text this graph was parsed from), or guessed from `factor`."""
+        _check(_lib.lib().flatgfa_write_flatgfa_prealloc(self._h, os.fsencode(filename), gfa_text, len(gfa_text) if gfa_text is not None else 0,
+                                                         int(factor)), "write_flatgfa_prealloc")
+
     def gfa_text(self) -> bytes:
         p, n = ctypes.c_void_p(), ctypes.c_size_t()
         _check(_lib.lib().flatgfa_print_gfa(self._h, ctypes.byref(p), ctypes.byref(n)), "print_gfa")

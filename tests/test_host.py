@@ -284,3 +284,74 @@ def test_cli_host_commands():
     assert "segs: 120" in run("-I", ex2, "toc", "-b").stdout.decode()
     r = run("-I", os.path.join(GOLDEN, "missing.gfa"), "paths")
     assert r.returncode != 0 and b"cannot open" in r.stderr
+
+
+# ---- the preallocated ("in-place") container: `fgfa -m -p N -o OUT [-I GFA]`, tests/turnt.toml:170-172 ----
+
+@pytest.mark.parametrize("gfa", golden_gfas(), ids=fixture_id)
+def test_prealloc_flatgfa_matches_oracle_and_round_trips(gfa, tmp_path):
+    """Third round-trip variant of the reference (flatgfa_file_inplace): the file written with
+    estimated capacities must be, byte for byte, what the restated prealloc_translate leaves
+    (estimates of parse.rs:176-216 / file.rs:136-158, `len` of every `capacity` in use, zeros
+    behind), and reading it back must print the same GFA as the graph it came from.  Where a pool
+    does not fit its estimate the reference panics: an error here, on both sides."""
+    text = open(gfa, "rb").read()
+    g = pa.parse_bytes(text)
+    pools = fo.parse_gfa(text)
+    out = str(tmp_path / "inplace.flatgfa")
+    try:
+        want = fo.dump_flatgfa_prealloc(pools, fo.estimate_toc(text))
+    except fo.ParseError:
+        with pytest.raises(pa.FlatGFAError) as ei:
+            g.write_flatgfa_prealloc(out, text)
+        assert ei.value.code == -2
+        return
+    g.write_flatgfa_prealloc(out, text)
+    got = open(out, "rb").read()
+    assert got == want
+    assert len(got) >= len(fo.dump_flatgfa(pools))  # capacities, not lengths, size the regions
+    back = pa.load(out)
+    assert str(back) == str(g)
+    for name in fo.POOL_ORDER:
+        assert back.pool(name).tobytes() == g.pool(name).tobytes(), name
+
+
+def test_prealloc_flatgfa_guessed_capacities_and_overflow(tmp_path):
+    text = open(os.path.join(GOLDEN, "ref_tiny.gfa"), "rb").read()
+    g = pa.parse_bytes(text)
+    pools = fo.parse_gfa(text)
+    out = str(tmp_path / "guess.flatgfa")
+    g.write_flatgfa_prealloc(out, None, factor=4)  # no text to measure (stdin in the reference): Toc::guess(4)
+    assert open(out, "rb").read() == fo.dump_flatgfa_prealloc(pools, fo.guess_toc(4))
+    assert str(pa.load(out)) == text.decode()
+    with pytest.raises(fo.ParseError):
+        fo.dump_flatgfa_prealloc(pools, fo.guess_toc(1))  # one path of capacity, two paths
+    with pytest.raises(pa.FlatGFAError) as ei:
+        g.write_flatgfa_prealloc(out, None, factor=1)
+    assert ei.value.code == -2 and "paths" in str(ei.value)
+    # estimates of known inputs (parse.rs:176-216 by hand): one H line of 10 bytes, 4 S lines, 2 P lines, 4 L lines
+    caps = fo.estimate_toc(text)
+    lines = text.split(b"\n")[:-1]
+    assert caps[1] == 4 and caps[2] == 2 and caps[3] == 4
+    assert caps[0] == len(lines[0]) and caps[4] == sum(len(ln) for ln in lines if ln[:1] == b"P") // 3
+    assert caps[5] == sum(len(ln) for ln in lines if ln[:1] == b"S") and caps[10] == 4 + 4 + 2 + 8
+    with pytest.raises(fo.ParseError):
+        fo.estimate_toc(b"S\t1\tA\n\nS\t2\tC\n")  # a blank line is an unknown line type (the reference panics)
+
+
+def test_cli_inplace_round_trip(tmp_path):
+    # tests/turnt.toml:170-172: fgfa -m -p 128 -o X -I f.gfa ; fgfa -m -i X  must print f.gfa
+    fgfa = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
+    for name in ("ref_tiny", "ref_ex2", "standin_k"):
+        gfa = os.path.join(GOLDEN, name + ".gfa")
+        out = str(tmp_path / (name + ".inplace.flatgfa"))
+        r = subprocess.run([fgfa, "-m", "-p", "128", "-o", out, "-I", gfa], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        r = subprocess.run([fgfa, "-m", "-i", out], capture_output=True)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout == open(gfa, "rb").read()
+        # from stdin there is no text to measure: the guess from -p sizes the file
+        r = subprocess.run([fgfa, "-m", "-p", "8", "-o", out], input=open(gfa, "rb").read(), capture_output=True)
+        assert r.returncode == 0, r.stderr
+        assert os.path.getsize(out) > 100_000
+        assert subprocess.run([fgfa, "-i", out], capture_output=True).stdout == open(gfa, "rb").read()
