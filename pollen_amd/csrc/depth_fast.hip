@@ -1350,6 +1350,8 @@ struct AccArgs {
     uint32_t parts;  // workgroups per window (blockIdx.y): each walks its share of the paths / sub-buckets and ADDS its counts to the (zeroed) outputs
     uint32_t n_shared;  // tagged calls: the split paths, whose bitsets all waves of the workgroup share (tags kTagCount - n_shared .. kTagCount - 1)
     uint32_t *tprof;    // FLATGFA_ACC_TIME (diagnostic): sixteen words per wave, see AccTimer
+    uint32_t *pair_part;  // k_accum_pair: [n_win][2][depth | revisits][window] the two workgroups' halves
+    uint32_t *pair_flag;  // k_accum_pair: [n_win] how many halves are there (zero between calls)
 };
 
 // FLATGFA_ACC_TIME: charge the time since the last mark to phase `ph` of this wave; the wave's
@@ -1593,9 +1595,8 @@ __device__ __forceinline__ void add_n(uint32_t *out, uint32_t i0, uint32_t nvali
 // Apply the records [0, scnt[slot]) of every sub-bucket of the window as they are (they say what
 // they count for).  Each wave takes sixteen sub-buckets per round and requests the first 64 x 16
 // bytes of every one before it applies any, so a round pays the memory latency once.
-template <bool UNIQ, int WB>
+template <bool UNIQ, int WB, int kPerRound = 16>
 __device__ __forceinline__ void apply_flat(const AccArgs &A, int *D, int *R, const uint32_t *scnt, const uint32_t *wbase) {
-    constexpr int kPerRound = 16;
     const int lane = threadIdx.x & 63;
     // wave-uniform: sub-bucket addressing stays scalar.  The waves of all of the window's workgroups share the sub-buckets out.
     const uint32_t uw = __builtin_amdgcn_readfirstlane(blockIdx.y * kAccWaves + (threadIdx.x >> 6)), nw = A.parts * kAccWaves;
@@ -1850,6 +1851,21 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) { return __builtin_
 
 // The tagged walk's record requests: as rec_request / rec_take, but the address is a wave-uniform
 // pointer (an SGPR pair) plus the lane's own four bytes -- nothing to compute per lane and step.
+// (the build with two workgroups per CU has 64 registers: its landing registers are v61 .. v63)
+template <int K>
+__device__ __forceinline__ void rec_request_lo(const uint32_t *p, uint32_t lane4) {
+    if (K == 0) asm volatile("global_load_dword v61, %0, %1" ::"v"(lane4), "s"(p) : "memory", "v61");
+    else if (K == 1) asm volatile("global_load_dword v62, %0, %1" ::"v"(lane4), "s"(p) : "memory", "v62");
+    else asm volatile("global_load_dword v63, %0, %1" ::"v"(lane4), "s"(p) : "memory", "v63");
+}
+template <int K>
+__device__ __forceinline__ uint32_t rec_take_lo() {
+    uint32_t r;
+    if (K == 0) asm volatile("s_waitcnt vmcnt(2)\n\tv_mov_b32 %0, v61" : "=v"(r)::"memory");
+    else if (K == 1) asm volatile("s_waitcnt vmcnt(2)\n\tv_mov_b32 %0, v62" : "=v"(r)::"memory");
+    else asm volatile("s_waitcnt vmcnt(2)\n\tv_mov_b32 %0, v63" : "=v"(r)::"memory");
+    return r;
+}
 template <int K>
 __device__ __forceinline__ void rec_request_s(const uint32_t *p, uint32_t lane4) {
     if (K == 0) asm volatile("global_load_dword v120, %0, %1" ::"v"(lane4), "s"(p) : "memory", "v120");
@@ -1963,7 +1979,7 @@ __device__ __forceinline__ void claim_step(uint32_t rec, uint32_t sb, unsigned l
 #ifndef FGFA_TAG_ABLATE
 #define FGFA_TAG_ABLATE 0  /* measurements only (results are then wrong): 1 = no claims, 2 = no bitset hand-overs, 4 = claims stop behind the depth updates, 8 = behind the first word's OR, 16 = no further words */
 #endif
-template <int WB, bool POINT, bool SHARED>
+template <int WB, bool POINT, bool SHARED, bool LOW = false>
 __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, uint32_t *bits, const uint2 *scnt2, const uint32_t *wbase,
                                              uint32_t *grab) {
     constexpr uint32_t kW = 1u << WB, kNW = kW / 32u;
@@ -2021,7 +2037,8 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
             FR = 1u;                                             \
         }                                                        \
         NV = min(64u, left);                                     \
-        rec_request_s<K>(sp, lane4);                             \
+        if (LOW) rec_request_lo<K>(sp, lane4);                   \
+        else rec_request_s<K>(sp, lane4);                        \
         sp += NV;                                                \
         left -= NV;                                              \
     } while (0)
@@ -2059,7 +2076,7 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
 #define FGFA_TAG_STEP(K, NV, FR)                                                                                       \
     if (NV == 0u) break;                                                                                               \
     {                                                                                                                  \
-        const uint32_t rec = rec_take<K>();                                                                            \
+        const uint32_t rec = LOW ? rec_take_lo<K>() : rec_take<K>();                                                   \
         const unsigned long long vm = NV >= 64u ? ~0ull : (1ull << NV) - 1ull;  /* the lanes that hold a record */     \
         const uint32_t last = NV - 1u;                                                                                 \
         if (FR) hmax = -1;  /* the private slots start over with this sub-bucket */                                    \
@@ -2212,8 +2229,13 @@ __global__ __launch_bounds__(256) void k_path_reduce(const uint4 *__restrict__ i
 extern __shared__ __attribute__((aligned(16))) uint32_t tag_bits[];
 uint32_t tagged_lds_bytes(uint32_t wb, uint32_t n_shared) { return (kAccWaves * kTagSlots + n_shared) * ((1u << wb) / 8u); }
 
-template <bool UNIQ, int WB, bool PSUM = false, bool POINT = false, bool BIG = false, bool TAGGED = false>
-__global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
+// PAIR (tagged, unique depth, no split paths): TWO workgroups per window, each with half of its
+// sub-buckets, and both resident on a CU (64 registers, under 80 KB of LDS): the walk issues about
+// one instruction per cycle and CU where two are possible, and eight waves per SIMD hide more of its
+// LDS round trips than four.  Both leave their partial vectors in scratch; the second one to
+// finish adds the other's to its own and writes the results.
+template <bool UNIQ, int WB, bool PSUM, bool POINT, bool BIG, bool TAGGED, bool PAIR>
+__device__ __forceinline__ void accum_body(const AccArgs &A) {
     constexpr uint32_t kW = 1u << WB;
     constexpr int kPer = kW / kAccThreads;  // cells per thread: 4 or 8
     constexpr uint32_t kSlots = WB <= 12 ? 8u : 4u;
@@ -2277,10 +2299,11 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
     __syncthreads();
     const uint32_t *wbase = A.buckets + (size_t)win * A.n_slots * A.cap;
     tm.mark(0);
-    if (flat) apply_flat<UNIQ, WB>(A, D, R, scnt, wbase);
+    if (flat) apply_flat<UNIQ, WB, (PAIR ? 4 : 16)>(A, D, R, scnt, wbase);
     tm.mark(1);
     if (UNIQ && TAGGED) {
-        if (A.n_shared) apply_tagged<WB, POINT, true>(A, D, R, tag_bits, scnt2, wbase, &grab);
+        if (PAIR) apply_tagged<WB, POINT, false, true>(A, D, R, tag_bits, scnt2, wbase, &grab);
+        else if (A.n_shared) apply_tagged<WB, POINT, true>(A, D, R, tag_bits, scnt2, wbase, &grab);
         else apply_tagged<WB, POINT, false>(A, D, R, tag_bits, scnt2, wbase, &grab);
     } else if (UNIQ) {
         apply_groups<WB, false, POINT, BIG>(A, D, R, bits + wave * (kSlots * (kW / 32)), marks + wave * 64, pend + wave * (3 * kPend), wbase, win,
@@ -2312,7 +2335,40 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
             d[k] = (uint32_t)v[k];
             u[k] = d[k] - (uint32_t)(v[k] >> 32);
         }
-        if (A.parts > 1) {
+        if (PAIR) {
+            // this workgroup's half: depth and revisits, in scratch; whoever finds the other half there adds it up
+            __shared__ uint32_t second;
+            uint32_t rv[kPer];
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) rv[k] = (uint32_t)(v[k] >> 32);
+            uint32_t *mine = A.pair_part + ((size_t)win * 2u + blockIdx.y) * (2u * kW);
+            const uint32_t *theirs = A.pair_part + ((size_t)win * 2u + (1u - blockIdx.y)) * (2u * kW);
+            // The two workgroups may sit on different XCDs, whose L2s do not see each other's lines within
+            // a kernel: the halves are written and read with device-scope accesses (they go through to
+            // memory), the writes are waited for, and only then is the half counted -- a release fence
+            // would write the whole L2 back instead (tried: 0.25 ms per launch).
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                __hip_atomic_store(mine + i0 + k, d[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mine + kW + i0 + k, rv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) second = __hip_atomic_fetch_add(&A.pair_flag[win], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (second) {
+#pragma unroll
+                for (int k = 0; k < kPer; ++k) {
+                    d[k] += __hip_atomic_load(theirs + i0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    rv[k] += __hip_atomic_load(theirs + kW + i0 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int k = 0; k < kPer; ++k) u[k] = d[k] - rv[k];
+                store_n<kPer>(A.depth_out + w0, i0, nvalid, d);
+                store_n<kPer>(A.uniq_out + w0, i0, nvalid, u);
+                if (tid == 0) __hip_atomic_store(&A.pair_flag[win], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (clean for the next call)
+            }
+        } else if (A.parts > 1) {
             add_n<kPer>(A.depth_out + w0, i0, nvalid, d);
             add_n<kPer>(A.uniq_out + w0, i0, nvalid, u);
         } else {
@@ -2354,6 +2410,15 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
             }
         }
     }
+}
+
+template <bool UNIQ, int WB, bool PSUM = false, bool POINT = false, bool BIG = false, bool TAGGED = false>
+__global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
+    accum_body<UNIQ, WB, PSUM, POINT, BIG, TAGGED, false>(A);
+}
+template <int WB, bool POINT>
+__global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_accum_pair(const AccArgs A) {
+    accum_body<true, WB, false, POINT, false, true, true>(A);
 }
 
 // Plan time: how many runs (as k_scan_short cuts them: +1 continuations, cut at multiples of 32)
@@ -2911,6 +2976,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             (void)hipFree(d_runs64);
             FAST_TRY(e);
             for (const uint4 &it : items) item_steps += it.y - it.x;
+            fp->est_records = runs64;
             // more than three records for four steps: not worth looking for runs (k_scan_dense)
             const bool can = !fp->dbg && dense_lds_bytes(fp->nwp) + 64 <= kLdsLimit;
             // More than a record for two steps: k_scan_dense may be the better pass 1 -- when the
@@ -2963,6 +3029,21 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 13, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(13, 0)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 13, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(13, 0)));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_accum_pair<12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, 0)));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_accum_pair<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, 0)));
+    // Two pass-2 workgroups per window (k_accum_pair): tagged plans without split paths whose windows
+    // do not fill the chip twice over anyway.  FLATGFA_ACC_PAIR=0|1 (measurements, tests).
+    // Worth it where a window has work enough to pay for a second workgroup's setup, scan and exchange:
+    // cfg-L (43 k records per window) is 7 % slower that way, the chromosome model (122 k) 4 % faster,
+    // ten thousand contigs 13 %.
+    const bool pair_ok = fp->tagged && fp->n_shared == 0 && wb == 12 && fp->acc_parts == 1 && n_win <= 2 * fp->n_cus;
+    fp->acc_pair = pair_ok && fp->est_records / n_win >= 65536;
+    if (const char *f = getenv("FLATGFA_ACC_PAIR")) fp->acc_pair = pair_ok && strtol(f, nullptr, 10) != 0;
+    if (fp->acc_pair) {
+        FAST_TRY(hipMalloc(&fp->pair_part, (size_t)n_win * 2 * 2 * (1u << wb) * 4));
+        FAST_TRY(hipMalloc(&fp->pair_flag, (size_t)n_win * 4));
+        FAST_TRY(hipMemset(fp->pair_flag, 0, (size_t)n_win * 4));
+    }
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     fp->eligible = true;
     return true;
@@ -3036,7 +3117,8 @@ void fast_plan_destroy(FastPlan *fp) {
     delete[] fp->more;
     for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot, (void *)fp->perm,
                     (void *)fp->elist, (void *)fp->wave_off, (void *)fp->fat_off, (void *)fp->fat_woff, (void *)fp->items, (void *)fp->short_items,
-                    (void *)fp->medium_items, (void *)fp->rev_steps, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part})
+                    (void *)fp->medium_items, (void *)fp->rev_steps, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part,
+                    (void *)fp->pair_part, (void *)fp->pair_flag})
         if (p) (void)hipFree(p);
     *fp = FastPlan();
 }
@@ -3095,7 +3177,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
                fp.work_counter, fp.max_back, depth_out, uniq_out, status, fp.dbg,
                reinterpret_cast<const uint4 *>(fp.items), g.seg_len, ps ? reinterpret_cast<ulonglong2 *>(fp.psum_part) : nullptr,
-               fp.fat_off, fp.fat_woff, fp.acc_parts, tagged ? fp.n_shared : 0u, nullptr};
+               fp.fat_off, fp.fat_woff, fp.acc_parts, tagged ? fp.n_shared : 0u, nullptr, fp.pair_part, fp.pair_flag};
     if (const char *sk = getenv("FLATGFA_ACC_SKIP")) aa.dbg = (uint32_t)strtoul(sk, nullptr, 10);  // (diagnostic: pass 2 without its revisit counts 128 / depth 256 / claims 64 / words behind the first 1024)
     const size_t tprof_words = (size_t)fp.n_win * fp.acc_parts * kAccWaves * 16;
     if (getenv("FLATGFA_ACC_TIME") && uniq_out && hipMalloc(&aa.tprof, tprof_words * 4) != hipSuccess) aa.tprof = nullptr;
@@ -3150,7 +3232,14 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     {
         ProfScope pscope(uniq_out ? "k_accum<uniq>" : (ps ? "k_accum<depth+paths>" : "k_accum<depth>"), stream);
         const dim3 agrid(fp.n_win, fp.acc_parts);
-        if (uniq_out && tagged) {
+        const bool pair = uniq_out && tagged && fp.acc_pair;
+        if (pair) {
+            aa.parts = 2;
+            const uint32_t tl = tagged_lds_bytes(fp.wb, 0);
+            const dim3 pgrid(fp.n_win, 2);
+            if (fp.dense) hipLaunchKernelGGL((k_accum_pair<12, true>), pgrid, dim3(kAccThreads), tl, stream, aa);
+            else hipLaunchKernelGGL((k_accum_pair<12, false>), pgrid, dim3(kAccThreads), tl, stream, aa);
+        } else if (uniq_out && tagged) {
             const uint32_t tl = tagged_lds_bytes(fp.wb, fp.n_shared);
             if (fp.dense && fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12, false, true, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
             else if (fp.dense && fp.wb == 13) hipLaunchKernelGGL((k_accum<true, 13, false, true, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);

@@ -24,6 +24,9 @@ struct FastPlan {
     bool dense_maybe = false;  // between one and nine records for ten steps: the plan's creator times k_scan_dense against k_scan
     bool dense = false;        // nearly every step starts a run: pass 1 partitions the steps themselves (k_scan_dense)
     uint32_t acc_parts = 1;  // workgroups per window in pass 2 (small graphs: fewer windows than CUs)
+    uint64_t est_records = 0;  // records k_scan will make of its items (counted when the plan is made)
+    bool acc_pair = false;     // tagged calls with unique depth run two workgroups per window, both resident on a CU (k_accum_pair)
+    uint32_t *pair_part = nullptr, *pair_flag = nullptr;  // their halves of the result vectors, and how many are there
     uint32_t n_slots = 0;      // sub-buckets per window = persistent workgroups of pass 1
     uint32_t n_win = 0;        // accumulation windows
     uint32_t wb = 12;          // log2 of the window size (4096 segments, 8192 beyond 4 M segments)

@@ -19,7 +19,7 @@ FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
 @pytest.fixture(params=["auto", "bucketed", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3", "ranges", "dense",
-                        "untagged", "untagged_pieces", "untagged_noshort"])
+                        "untagged", "untagged_pieces", "untagged_noshort", "pair"])
 def device_path(request, monkeypatch):
     """Runs a test once per device path: the default (up to 8 M steps the plan times the bucketed
     path against the atomic kernels on the graph at hand and keeps the faster), the bucketed path
@@ -47,6 +47,10 @@ def device_path(request, monkeypatch):
     monkeypatch.delenv("FLATGFA_DENSE", raising=False)
     monkeypatch.delenv("FLATGFA_BIG_GROUPS", raising=False)
     monkeypatch.delenv("FLATGFA_TAGGED", raising=False)
+    monkeypatch.delenv("FLATGFA_ACC_PAIR", raising=False)
+    if request.param == "pair":  # two pass-2 workgroups per window, exchanging their halves (by default only where a window has 64 k records)
+        monkeypatch.setenv("FLATGFA_ACC_PAIR", "1")
+        monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
     if request.param.startswith("untagged"):
         monkeypatch.setenv("FLATGFA_TAGGED", "0")
         monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")

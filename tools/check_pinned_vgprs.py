@@ -59,10 +59,10 @@ def main():
         if not s or s.startswith("."):
             continue
         if "k_accum" in func:  # pass 2: pinned record registers -- v120..v122 (rec_request / rec_take), and in the
-            # tagged builds (template argument list ends in Lb1E) the ring v112..v119 (ring_request / ring_take)
-            pins = set(range(112, 120)) if func.endswith("Lb1EEEvNS0_7AccArgsE") else {120, 121, 122}
+            # build with two workgroups per CU (k_accum_pair, 64 registers) v61..v63 (rec_request_lo / rec_take_lo)
+            pins = {61, 62, 63} if "k_accum_pair" in func else {120, 121, 122}  # (the build with 64 registers lands its records in v61..v63)
             if regs_of(s) & pins:
-                m = re.match(r"^global_load_dword v(\d+), v\[\d+:\d+\], off$", s)
+                m = re.match(r"^global_load_dword v(\d+), (v\[\d+:\d+\], off|v\d+, s\[\d+:\d+\])$", s)
                 t = re.match(r"^v_mov_b32(_e32)? v(\d+), v(\d+)$", s)
                 if m and int(m.group(1)) in pins:
                     n_acc_load += 1
@@ -96,7 +96,7 @@ def main():
     if bad:
         print("pinned-VGPR check FAILED:\n  " + "\n  ".join(bad[:20]))
         return 1
-    print(f"pinned-VGPR check ok: k_accum {n_acc_load} record loads, {n_acc_take} takes, nothing else touches v120..v122 (tagged builds: v112..v119); "
+    print(f"pinned-VGPR check ok: k_accum {n_acc_load} record loads, {n_acc_take} takes, nothing else touches v120..v122 (k_accum_pair: v61..v63); "
           f"k_scan {n_load} loads, {n_take} takes, nothing else touches v80..v127; "
           f"k_scan budgets {sorted(set(v for k, v in budgets.items() if 'k_scan' in k))}")
     return 0
