@@ -99,6 +99,13 @@ __global__ __launch_bounds__(256) void k_add_into(uint32_t *__restrict__ acc, co
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += gridDim.x * 256ull) acc[i] += x[i];
 }
 
+// The calling thread's current device is its own business: whatever the entry points switch to, they switch back.
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
 struct Piece {
     uint32_t path;    // the path this is (a piece of)
     uint32_t lb, le;  // its steps in the shard's slice
@@ -257,6 +264,7 @@ int run_all(flatgfa_sharded &h, int cmd) {
 // Shards that share a device (or a handle without RCCL): the sum on shard 0's device, handed back to all.
 int exchange_by_adds(flatgfa_sharded &h) {
     if (h.S == 0) return FLATGFA_OK;
+    DeviceGuard guard;
     const size_t cnt = vec_count(h, h.with_uniq);
     Shard &root = *h.sh[0];
     Shard &s = root;  // (for SH_HIP's error text)
@@ -266,13 +274,16 @@ int exchange_by_adds(flatgfa_sharded &h) {
     }
     SH_HIP(hipSetDevice(root.device));
     SH_HIP(hipMemcpyAsync(root.d_recv, root.d_send, cnt * 4, hipMemcpyDeviceToDevice, root.stream));
-    uint32_t *bounce = nullptr;
+    struct Bounce {  // (shards on other devices are copied here first)
+        uint32_t *p = nullptr;
+        ~Bounce() { if (p) (void)hipFree(p); }
+    } bounce;
     for (int i = 1; i < h.n; ++i) {
         const uint32_t *src = h.sh[i]->d_send;
         if (h.sh[i]->device != root.device) {
-            if (!bounce) SH_HIP(hipMalloc(&bounce, cnt * 4));
-            SH_HIP(hipMemcpyPeerAsync(bounce, root.device, src, h.sh[i]->device, cnt * 4, root.stream));
-            src = bounce;
+            if (!bounce.p) SH_HIP(hipMalloc(&bounce.p, cnt * 4));
+            SH_HIP(hipMemcpyPeerAsync(bounce.p, root.device, src, h.sh[i]->device, cnt * 4, root.stream));
+            src = bounce.p;
         }
         hipLaunchKernelGGL(k_add_into, dim3(2048), dim3(256), 0, root.stream, root.d_recv, src, cnt);
     }
@@ -283,7 +294,6 @@ int exchange_by_adds(flatgfa_sharded &h) {
     for (int i = 1; i < h.n; ++i)
         SH_HIP(hipMemcpyPeerAsync(h.sh[i]->d_recv, h.sh[i]->device, root.d_recv, root.device, cnt * 4, root.stream));
     SH_HIP(hipStreamSynchronize(root.stream));
-    if (bounce) (void)hipFree(bounce);
     return FLATGFA_OK;
 }
 
@@ -304,6 +314,7 @@ extern "C" {
 
 void flatgfa_sharded_free(flatgfa_sharded_t *h) {
     if (!h) return;
+    DeviceGuard guard;
     for (auto &s : h->sh) {
         if (s->th.joinable()) {
             {
@@ -338,6 +349,7 @@ flatgfa_sharded_t *flatgfa_sharded_create(flatgfa_t gfa, const int *devices, int
         set_error("no HIP device is visible; the depth queries have no CPU fallback");
         return nullptr;
     }
+    DeviceGuard guard;
     const fgfa::View &v = flatgfa_capi_view(gfa);
     if (v.steps.len > 0xFFFFFFFFull || v.segs.len > 0x80000000ull || v.paths.len > 0xFFFFFFFFull) {
         set_error("graph too large for 32-bit ids");
@@ -528,6 +540,7 @@ int flatgfa_sharded_fetch(flatgfa_sharded_t *h, int shard, uint64_t *depth_out, 
     if (uniq_out && !h->with_uniq) { set_error("flatgfa_sharded_fetch: the last call computed node depth only"); return FLATGFA_ERR_ARG; }
     Shard &s = *h->sh[shard];
     if (h->S == 0) return FLATGFA_OK;
+    DeviceGuard guard;
     std::vector<uint32_t> tmp((size_t)h->S * (uniq_out ? 2 : 1));
     if (hipSetDevice(s.device) != hipSuccess || hipMemcpy(tmp.data(), s.d_recv, tmp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
         set_error("flatgfa_sharded_fetch: device to host copy failed");
@@ -563,6 +576,7 @@ int flatgfa_sharded_path_depth(flatgfa_sharded_t *h, const uint32_t *path_ids, u
     if (!rc) rc = run_all(*h, kCmdPathSums);
     if (rc) return rc;
     std::vector<uint64_t> ln(h->P, 0), ws(h->P, 0);
+    DeviceGuard guard;
     for (auto &sp : h->sh) {
         Shard &s = *sp;
         const size_t np = s.pieces.size();
