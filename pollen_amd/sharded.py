@@ -7,6 +7,10 @@ all-reduce of the per-segment vector(s) combines them -- RCCL over xGMI under
 torch.distributed's "nccl" backend.  The message is only 4*S (or 8*S) bytes, so the collective
 is latency-bound and is issued once, on the fused [depth | uniq] buffer.
 
+This module never cuts a path (a graph with fewer paths than ranks leaves ranks idle): the C ABI's
+`flatgfa_sharded_*` (pollen_amd/csrc/sharded.hip; `pollen_amd.ShardedFlatGFA`) cuts inside a path
+where no path boundary is near the even cut, and fixes unique depth up for the cut paths.
+
 Nothing here computes depth on the host: `local_fn` is the HIP path in production
 (DepthPlan.seg_depth); tests inject a stand-in to exercise the partition + reduce logic on CPU
 under gloo.

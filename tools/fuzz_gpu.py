@@ -16,7 +16,10 @@ ENVS = [{}, {"FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0"}, {"FL
         {"FLATGFA_SHORT_MAX": "300"}, {"FLATGFA_DEPTH_PATH": "atomic"}, {"FLATGFA_ACC_PARTS": "5"},
         {"FLATGFA_RANGE_SEGS": "65536"}, {"FLATGFA_RANGE_SEGS": "40960", "FLATGFA_PIECE_STEPS": "2048"},
         {"FLATGFA_ACC_PARTS": "2", "FLATGFA_PIECE_STEPS": "1024"}, {"FLATGFA_DENSE": "1", "FLATGFA_BIG_GROUPS": "1"}, {"FLATGFA_BIG_GROUPS": "1"}, {"FLATGFA_BIG_GROUPS": "0", "FLATGFA_PIECE_STEPS": "700"},
-        {"FLATGFA_DENSE": "1", "FLATGFA_RANGE_SEGS": "65536", "FLATGFA_SHORT_MAX": "0"}]
+        {"FLATGFA_DENSE": "1", "FLATGFA_RANGE_SEGS": "65536", "FLATGFA_SHORT_MAX": "0"},
+        {"FLATGFA_TAGGED": "0"}, {"FLATGFA_TAGGED": "0", "FLATGFA_PIECE_STEPS": "900"}, {"FLATGFA_ACC_PAIR": "1", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_ACC_PAIR": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_PIECE_STEPS": "4096", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"}]
 
 
 def random_graph(rng):
@@ -96,7 +99,7 @@ def main():
         pools.paths, pools.steps, pools.segs = paths, steps, segs
         want_d, want_u = fo.seg_depth_with_uniq(pools)
         env = ENVS[case % len(ENVS)]
-        for k in ("FLATGFA_SHORT_MAX", "FLATGFA_BUCKET_CAP", "FLATGFA_PIECE_STEPS", "FLATGFA_DEPTH_PATH", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS", "FLATGFA_DENSE", "FLATGFA_BIG_GROUPS"):
+        for k in ("FLATGFA_SHORT_MAX", "FLATGFA_BUCKET_CAP", "FLATGFA_PIECE_STEPS", "FLATGFA_DEPTH_PATH", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS", "FLATGFA_DENSE", "FLATGFA_BIG_GROUPS", "FLATGFA_TAGGED", "FLATGFA_ACC_PAIR"):
             os.environ.pop(k, None)
         os.environ.update(env)
         graph = dev.DeviceGraph(steps, pb, pe, S, seg_len, device="cuda:0")
@@ -122,7 +125,7 @@ def main():
         gd, gu, gd2 = (t.cpu().numpy().view(np.uint32) for t in (d, u, d2))
         ok = (gd == want_d).all() and (gu == want_u).all() and (gd2 == want_d).all() \
             and (got_ln == want_ln).all() and got_mean.tobytes() == want_mean.tobytes()
-        print(f"case {case}: S={S} P={P} N={len(steps)} env={env} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+        print(f"case {case}: S={S} P={P} N={len(steps)} env={env} [{plan.describe()[:60]}] -> {'ok' if ok else 'MISMATCH'}", flush=True)
         if not ok:
             bad += 1
             print("   depth bad:", int((gd != want_d).sum()), "uniq bad:", int((gu != want_u).sum()), "depth-only bad:", int((gd2 != want_d).sum()))
