@@ -660,7 +660,10 @@ extern "C" int flatgfa_dev_plan_describe(flatgfa_dev_plan_t *pl, char *out, int 
     if (!f.eligible) {
         s = "path=atomic (k_depth_scan / k_depth_uniq_path)";
     } else {
-        s = "path=bucketed pass1=" + std::string(f.dense ? "k_scan_dense" : "k_scan") + (f.n_short ? "+k_scan_short" : "") + (f.n_medium ? "+k_scan_medium" : "") +
+        const bool alone = (f.n_short || f.n_medium) && f.n_items == 0 && f.exact_short;  // (k_scan's launch is left out)
+        s = "path=bucketed pass1=" + std::string(alone ? "" : f.dense ? "k_scan_dense+" : "k_scan+") + (f.n_short ? "k_scan_short+" : "") + (f.n_medium ? "k_scan_medium+" : "");
+        s.pop_back();
+        s += std::string("") +
             " pass2=" + (f.tagged ? (f.n_shared ? "tagged(shared bitsets)" : f.acc_pair ? "tagged(two workgroups per window)" : "tagged") : (f.big_groups ? "directory(one-item shortcut)" : "directory")) +
             " windows=" + std::to_string(f.n_win) + "x" + std::to_string(1u << f.wb) + " ranges=" + std::to_string(f.n_more + 1) +
             " workgroups_per_window=" + std::to_string(f.acc_parts) + " items=" + std::to_string(f.n_items) + " split_paths=" + std::to_string(f.n_shared) +

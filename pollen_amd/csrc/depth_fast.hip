@@ -2284,9 +2284,9 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
         *c = 0u;
         if (TAGGED && UNIQ) {
             const uint32_t c1 = min(v, A.cap);
-            v = min(A.has_pre ? A.counts0[(size_t)win * A.n_slots + sl] : 0u, c1);
+            v = min(A.has_pre == 1 ? A.counts0[(size_t)win * A.n_slots + sl] : A.has_pre ? v : 0u, c1);  // (2: k_scan did not run, all are earlier records)
             scnt2[sl] = make_uint2(sl * A.cap + v, c1 - v);  // k_scan's records: where they start in the window's buckets, how many
-        } else if (UNIQ && A.has_pre) {
+        } else if (UNIQ && A.has_pre == 1) {
             v = A.counts0[(size_t)win * A.n_slots + sl];
         }
         scnt[sl] = min(v, A.cap);
@@ -2825,6 +2825,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     fp->n_medium = (uint32_t)medium_items.size();
     if (items.empty() && short_items.empty() && medium_items.empty()) return true;
     fp->max_back = std::min<uint32_t>(fp->n_short, kMaxHandBack);
+    fp->exact_short = !short_any;  // the run counts the lists were made from are exact: nothing is handed back
     fp->dstride = fp->n_items + fp->max_back + 1;
     // The directory (one cursor pair per item and window) must stay small next to the steps.
     if ((uint64_t)fp->dstride * n_win * 8 > std::max<uint64_t>(64ull << 20, g.n_steps * 2)) {
@@ -3134,7 +3135,11 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     const bool has_pre = fp.n_short || fp.n_medium;
     // one persistent workgroup per CU; k_scan may be handed short paths back, so it gets a full grid when there are any
     // (and whenever the wave-per-path kernels ran: it saves their cursors for pass 2)
-    const uint32_t grid = has_pre ? fp.n_slots : std::min<uint32_t>(fp.n_items, fp.n_slots);
+    // -- unless it has no items of its own and nothing can come back (the run counts of the lists are
+    // exact): then the launch is left out, every record is one of the wave-per-path kernels', and a
+    // path that does not fit after all (steps changed behind the plan) raises kStBackOverflow.
+    const bool scan_skip = has_pre && fp.n_items == 0 && fp.exact_short && !fp.dbg && !getenv("FLATGFA_SCAN_ALWAYS");
+    const uint32_t grid = scan_skip ? 0u : has_pre ? fp.n_slots : std::min<uint32_t>(fp.n_items, fp.n_slots);
     ScanArgs sa;
     sa.zero_a = sa.zero_b = nullptr;
     sa.path_begin = sa.path_end = nullptr;
@@ -3153,7 +3158,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     sa.wb = fp.wb;
     sa.nwp = fp.nwp;
     sa.has_pre = has_pre ? 1u : 0u;
-    sa.max_back = fp.max_back;
+    sa.max_back = scan_skip ? 0u : fp.max_back;
     sa.work_counter = fp.work_counter;
     sa.counts = fp.counts;
     sa.counts0 = fp.counts0;
@@ -3173,9 +3178,9 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     sa.tagged = tagged ? 1u : 0u;
     sa.tprof = nullptr;
     if (getenv("FLATGFA_SCAN_TIME") && hipMalloc(&sa.tprof, (2 + kWaves) * 8 * (size_t)fp.n_slots) == hipSuccess) (void)hipMemset(sa.tprof, 0, (2 + kWaves) * 8 * (size_t)fp.n_slots);
-    AccArgs aa{fp.n_range, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.counts0, has_pre ? 1u : 0u, fp.buckets,
+    AccArgs aa{fp.n_range, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.counts0, scan_skip ? 2u : has_pre ? 1u : 0u, fp.buckets,
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
-               fp.work_counter, fp.max_back, depth_out, uniq_out, status, fp.dbg,
+               fp.work_counter, scan_skip ? 0u : fp.max_back, depth_out, uniq_out, status, fp.dbg,
                reinterpret_cast<const uint4 *>(fp.items), g.seg_len, ps ? reinterpret_cast<ulonglong2 *>(fp.psum_part) : nullptr,
                fp.fat_off, fp.fat_woff, fp.acc_parts, tagged ? fp.n_shared : 0u, nullptr, fp.pair_part, fp.pair_flag};
     if (const char *sk = getenv("FLATGFA_ACC_SKIP")) aa.dbg = (uint32_t)strtoul(sk, nullptr, 10);  // (diagnostic: pass 2 without its revisit counts 128 / depth 256 / claims 64 / words behind the first 1024)

@@ -50,6 +50,7 @@ struct FastPlan {
                                    // with room for the short paths k_scan_short hands back
     uint32_t n_items = 0;
     uint32_t max_back = 0;
+    bool exact_short = false;      // the wave-per-path lists hold only paths that fit: nothing is handed back to k_scan
     void *short_items = nullptr;   // uint4[n_short] paths every wave walks on its own (k_scan_short): first those read from the graph's
                                    // steps, then n_short_rev paths that walk the ids downwards, read from rev_steps (their
                                    // steps in reverse order: a wave-per-path kernel only knows runs that go up)

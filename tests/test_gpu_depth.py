@@ -474,3 +474,45 @@ def test_tagged_walk_many_items_per_step(n_paths, steps, monkeypatch):
         assert (d.cpu().numpy().view(np.uint32) == want_d).all()
         assert (u.cpu().numpy().view(np.uint32) == want_u).all()
     plan.close()
+
+
+@pytest.mark.parametrize("always", [False, True])
+@pytest.mark.parametrize("tagged", [True, False])
+def test_wave_per_path_kernels_alone(always, tagged, monkeypatch):
+    """When every path goes to the wave-per-path kernels, k_scan has nothing to walk and nothing can
+    be handed back to it (the lists are made from exact run counts): its launch is left out and
+    pass 2 takes every record as an earlier one.  FLATGFA_SCAN_ALWAYS keeps the launch (its
+    workgroups only save the cursors); both routes, with and without unique depth, several calls."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.delenv("FLATGFA_SHORT_MAX", raising=False)
+    monkeypatch.delenv("FLATGFA_SHORT_ANY", raising=False)
+    if always:
+        monkeypatch.setenv("FLATGFA_SCAN_ALWAYS", "1")
+    else:
+        monkeypatch.delenv("FLATGFA_SCAN_ALWAYS", raising=False)
+    if tagged:
+        monkeypatch.delenv("FLATGFA_TAGGED", raising=False)
+    else:
+        monkeypatch.setenv("FLATGFA_TAGGED", "0")
+    g = pa.synth(11, 50_000, 3000, 700, "pangenome", False)   # short paths only (k_scan_short)
+    g2 = pa.synth(12, 50_000, 300, 4000, "pangenome", False)   # more runs than a short path may have: the medium variant
+    g3 = pa.synth(13, 50_000, 900, 1500, "chromosome", False)  # half of them walked from reversed copies
+    for gr in (g, g2, g3):
+        steps, pb, pe, _ = gr.soa()
+        pools = pools_of(gr)
+        want_d, want_u = fo.seg_depth_with_uniq(pools)
+        S = gr.segment_count
+        plan = DepthPlan(DeviceGraph(steps, pb, pe, S))
+        if gr is g:
+            assert " items=0 " in plan.describe() and "pass1=k_scan_short " in plan.describe(), plan.describe()
+        d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        for k in range(4):
+            plan.seg_depth(d, u if k % 2 == 0 else None)
+            plan.status()
+            assert (d.cpu().numpy().view(np.uint32) == want_d).all()
+            if k % 2 == 0:
+                assert (u.cpu().numpy().view(np.uint32) == want_u).all()
+        plan.close()
