@@ -378,11 +378,13 @@ def main():
                 c1 = time.perf_counter()
                 g2.to_device(local_rank)
                 c2 = time.perf_counter()
+                h2d_ms, plan_ms = g2.residency_ms()
                 g2.seg_depth_with_uniq()
                 c3 = time.perf_counter()
                 text = g2.depth_table()
                 c4 = time.perf_counter()
                 runs.append({"load_ms": round((c1 - c0) * 1e3, 3), "h2d_and_plan_ms": round((c2 - c1) * 1e3, 3),
+                             "h2d_ms": round(h2d_ms, 3), "plan_ms": round(plan_ms, 3),
                              "first_query_ms": round((c3 - c2) * 1e3, 3), "table_ms": round((c4 - c3) * 1e3, 3),
                              "total_ms": round((c4 - c0) * 1e3, 3), "steps_per_s": round(N / (c4 - c0), 1)})
             extras["end_to_end"] = dict(runs[1], what=".flatgfa mmap -> H2D -> seg_depth_with_uniq (kernels + D2H + widen to u64) -> "

@@ -119,6 +119,10 @@ int flatgfa_device_count(void);
  * HBM of `device` and keep it resident until flatgfa_free.  Depth calls do this lazily on
  * device 0 if it has not been done. */
 int flatgfa_to_device(flatgfa_t gfa, int device);
+/* What that took on this handle, in milliseconds of host time: the host-to-device copies (SoA
+ * conversion and allocation included) and the creation of the depth plan (scratch, item lists,
+ * the timing of kernel variants).  An error before the graph is resident. */
+int flatgfa_residency_ms(flatgfa_t gfa, double *h2d_ms, double *plan_ms);
 
 /* seg_depth_with_uniq (ops/depth.rs:15-39) when uniq_out != NULL, seg_depth (depth.rs:45-56)
  * when it is NULL.  Outputs are indexed by segment id, one uint64_t (Rust usize) each. */

@@ -38,6 +38,7 @@ struct CStore {
     uint32_t *d_path_begin = nullptr, *d_path_end = nullptr, *d_seg_len = nullptr;
     uint32_t *d_depth = nullptr, *d_uniq = nullptr;
     uint64_t *d_sums = nullptr;  // [2 * paths] scratch of flatgfa_path_depth (inside d_small)
+    double h2d_ms = 0, plan_ms = 0;  // what becoming resident took: the copies, and the plan's creation (flatgfa_residency_ms)
     std::vector<uint32_t> h_path_begin, h_path_end;
     flatgfa_dev_plan_t *plan = nullptr;
     hipStream_t stream = nullptr;
@@ -249,60 +250,122 @@ int flatgfa_format_float(double x, int digits, char *out, int cap) {
 
 // ---- device residency ----
 
+// The pinned staging buffers are the process's own, made on first use and kept: allocating and
+// freeing eight of them per upload cost 2.9 + 3.8 ms of the 17 ms a cfg-L graph took to become
+// resident (FLATGFA_TIMING).  One upload at a time uses them.
+namespace {
+constexpr size_t kChunk = 8u << 20;
+constexpr int kMaxUploadThreads = 16;
+struct StagePool {
+    std::mutex mu;  // held for the whole of an upload
+    char *stage[2 * kMaxUploadThreads] = {};
+    hipEvent_t ev[2 * kMaxUploadThreads] = {};
+    int device = -1;
+    void release() {
+        for (int i = 0; i < 2 * kMaxUploadThreads; ++i) {
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            if (stage[i]) (void)hipHostFree(stage[i]);
+            ev[i] = nullptr;
+            stage[i] = nullptr;
+        }
+        device = -1;
+    }
+    hipError_t ensure(int dev, int n) {
+        if (device != dev) release();  // (events belong to a device)
+        device = dev;
+        for (int i = 0; i < n; ++i) {
+            if (!stage[i]) {
+                const hipError_t rc = hipHostMalloc((void **)&stage[i], kChunk, hipHostMallocDefault);
+                if (rc != hipSuccess) { stage[i] = nullptr; return rc; }
+            }
+            if (!ev[i]) {
+                const hipError_t rc = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+                if (rc != hipSuccess) { ev[i] = nullptr; return rc; }
+            }
+        }
+        return hipSuccess;
+    }
+};
+StagePool *stage_pool() {
+    static StagePool *p = new StagePool();  // never destroyed: the HIP runtime may be gone by the time static destructors run
+    return p;
+}
+}  // namespace
+
 // Host -> device copy of a large pageable (or file-mapped) region.  A plain hipMemcpy stages it
 // through the runtime's own pinned buffer on one thread (10-24 GB/s here, less when the source
-// is a mapped file that still has to be faulted in); four threads copying 8 MB chunks into their
-// own pinned buffers and queueing async copies reach the PCIe rate (~49 GB/s measured,
+// is a mapped file that still has to be faulted in); a few threads copying 8 MB chunks into
+// pinned buffers and queueing async copies reach the PCIe rate (~49 GB/s measured with four,
 // tools/h2d_test.hip; a freshly mapped file adds ~17 ms of first-touch page faults per 400 MB,
 // which pread() into the pinned buffers does not beat).  Small regions take the plain route.
 static hipError_t upload(void *dst, const void *src, size_t bytes, hipStream_t stream) {
-    constexpr size_t kChunk = 8u << 20;
-    constexpr int kThreads = 4;
+    static const int kThreads = [] {
+        const char *e = getenv("FLATGFA_UPLOAD_THREADS");
+        const int n = e ? atoi(e) : 4;
+        return n < 1 ? 1 : n > kMaxUploadThreads ? kMaxUploadThreads : n;
+    }();
+    const bool timing = getenv("FLATGFA_TIMING") != nullptr;
+    auto tick = [t = std::chrono::steady_clock::now(), timing](const char *what) mutable {
+        if (!timing) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "upload: %-31s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    };
     if (bytes < 4 * kChunk) return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
     int device = 0;
     hipError_t rc = hipGetDevice(&device);
     if (rc != hipSuccess) return rc;
-    char *stage[2 * kThreads] = {};
-    hipEvent_t ev[2 * kThreads] = {};
-    for (int i = 0; i < 2 * kThreads && rc == hipSuccess; ++i) {
-        rc = hipHostMalloc((void **)&stage[i], kChunk, hipHostMallocDefault);
-        if (rc == hipSuccess) rc = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
-    }
+    StagePool &pool = *stage_pool();
+    std::lock_guard<std::mutex> lk(pool.mu);
+    rc = pool.ensure(device, 2 * kThreads);
+    char **stage = pool.stage;
+    hipEvent_t *ev = pool.ev;
     std::atomic<int> failed{(int)rc};
+    tick("pinned buffers + events");
     if (rc == hipSuccess) {
         const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
         std::vector<std::thread> workers;
         for (int t = 0; t < kThreads; ++t)
             workers.emplace_back([&, t]() {
+                const auto w0 = std::chrono::steady_clock::now();
+                const auto since = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count(); };
                 if (hipSetDevice(device) != hipSuccess) { failed = (int)hipErrorInvalidDevice; return; }
+                const double t_dev = since();
+                const auto populate = [&](size_t off, size_t len) {
+#ifdef MADV_POPULATE_READ
+                    // a freshly mapped file: let the kernel map the chunk's pages in one go instead of taking a fault per
+                    // page inside the memcpy (on anonymous memory it only maps what the copy would touch anyway)
+                    static const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
+                    const uintptr_t a0 = ((uintptr_t)src + off) & ~(page - 1);
+                    (void)madvise((void *)a0, ((uintptr_t)src + off + len) - a0, MADV_POPULATE_READ);
+#else
+                    (void)off, (void)len;
+#endif
+                };
                 int round = 0;
                 for (size_t c = (size_t)t; c < n_chunks && !failed; c += kThreads, ++round) {
                     const int b = 2 * t + (round & 1);
+                    const double t_w = since();
                     hipError_t e = round >= 2 ? hipEventSynchronize(ev[b]) : hipSuccess;  // the buffer's previous copy is done
                     const size_t off = c * kChunk, len = std::min(kChunk, bytes - off);
+                    const double t_a = since();
                     if (e == hipSuccess) {
-#ifdef MADV_POPULATE_READ
-                        {   // a freshly mapped file: let the kernel map the chunk's pages in one go instead of
-                            // taking a fault per page inside the memcpy (on anonymous memory it only maps what the copy would touch anyway)
-                            static const uintptr_t page = (uintptr_t)sysconf(_SC_PAGESIZE);
-                            const uintptr_t a0 = ((uintptr_t)src + off) & ~(page - 1);
-                            (void)madvise((void *)a0, ((uintptr_t)src + off + len) - a0, MADV_POPULATE_READ);
-                        }
-#endif
+                        populate(off, len);
                         memcpy(stage[b], (const char *)src + off, len);
+                        const double t_b = since();
                         e = hipMemcpyAsync((char *)dst + off, stage[b], len, hipMemcpyHostToDevice, stream);
+                        if (timing && t == 0 && round < 3)
+                            fprintf(stderr, "upload: worker 0 chunk %2d at %6.2f ms (set device %.2f): waited %.2f, fault + stage %.2f, queue %.2f ms\n", round, t_w, t_dev, t_a - t_w, t_b - t_a, since() - t_b);
                     }
                     if (e == hipSuccess) e = hipEventRecord(ev[b], stream);
                     if (e != hipSuccess) failed = (int)e;
                 }
             });
         for (auto &w : workers) w.join();
+        tick("workers: fault in, stage, queue");
         const hipError_t e = hipStreamSynchronize(stream);
         if (e != hipSuccess && !failed) failed = (int)e;
-    }
-    for (int i = 0; i < 2 * kThreads; ++i) {
-        if (ev[i]) (void)hipEventDestroy(ev[i]);
-        if (stage[i]) (void)hipHostFree(stage[i]);
+        tick("copies drained");
     }
     return (hipError_t)failed.load();
 }
@@ -327,7 +390,8 @@ static int ensure_device(CStore *cs, int device) {
         return FLATGFA_ERR_TOO_LARGE;
     }
     const bool timing = getenv("FLATGFA_TIMING") != nullptr;  // diagnostic: where making a graph resident spends its time
-    auto tick = [t = std::chrono::steady_clock::now(), timing](const char *what) mutable {
+    const auto t_enter = std::chrono::steady_clock::now();
+    auto tick = [t = t_enter, timing](const char *what) mutable {
         if (!timing) return;
         const auto n = std::chrono::steady_clock::now();
         fprintf(stderr, "to_device: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
@@ -375,9 +439,10 @@ static int ensure_device(CStore *cs, int device) {
     tick("span arrays on the host");
     if (N) {
         CAPI_HIP(hipMalloc(&im.steps, N * 4));
+        tick("steps: hipMalloc");
         CAPI_HIP(upload(im.steps, v.steps.data, N * 4, im.stream));
     }
-    tick("steps: hipMalloc + upload");
+    tick("steps: upload");
     if (P || S) {
         CAPI_HIP(hipMalloc(&im.small, (2 * Pa + 3 * Sa + 4 * Pa) * 4));  // (the last 4 * Pa words: two u64 sums per path)
         CAPI_HIP(hipMemcpy(im.small, host.data(), host.size() * 4, hipMemcpyHostToDevice));
@@ -390,10 +455,14 @@ static int ensure_device(CStore *cs, int device) {
     }
     flatgfa_dev_graph_t g{im.steps, (uint64_t)N, im.pb, im.pe, (uint32_t)P, (uint32_t)S, im.seg_len};
     tick("paths, segments, outputs");
+    const auto t_plan = std::chrono::steady_clock::now();
     im.plan = flatgfa_dev_plan_create(&g, h_pb, h_pe);
+    const auto t_done = std::chrono::steady_clock::now();
     tick("plan (scratch + item lists)");
     if (!im.plan) return FLATGFA_ERR_HIP;  // the spans were checked above: what is left is the HIP runtime (see flatgfa_last_error)
     im.keep = true;
+    cs->h2d_ms = std::chrono::duration<double, std::milli>(t_plan - t_enter).count();
+    cs->plan_ms = std::chrono::duration<double, std::milli>(t_done - t_plan).count();
     cs->device = device;
     cs->stream = im.stream;
     cs->d_steps = im.steps;
@@ -414,6 +483,15 @@ static int ensure_device(CStore *cs, int device) {
 int flatgfa_to_device(flatgfa_t gfa, int device) {
     if (!gfa) { set_error("flatgfa_to_device: NULL handle"); return FLATGFA_ERR_ARG; }
     return ensure_device(gfa, device);
+}
+
+int flatgfa_residency_ms(flatgfa_t gfa, double *h2d_ms, double *plan_ms) {
+    if (!gfa) { set_error("flatgfa_residency_ms: NULL handle"); return FLATGFA_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(gfa->dev_mu);
+    if (!gfa->on_device) { set_error("flatgfa_residency_ms: the graph is not resident"); return FLATGFA_ERR_ARG; }
+    if (h2d_ms) *h2d_ms = gfa->h2d_ms;
+    if (plan_ms) *plan_ms = gfa->plan_ms;
+    return FLATGFA_OK;
 }
 
 // Runs the node-depth kernels and leaves u32 results in cs->d_depth / cs->d_uniq.

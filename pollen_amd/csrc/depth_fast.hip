@@ -104,7 +104,8 @@ constexpr uint32_t kTagSlots = 4;
 constexpr uint32_t kMaxShared = 128;      // bitsets of split paths pass 2 has LDS for (4096-segment windows)
 
 // ---- k_scan ----
-constexpr uint32_t kMaxWin = 2048;        // windows per launch (LDS cursor table)
+constexpr uint32_t kMaxWin = 2048;        // windows per launch (LDS tables: the cursors and their snapshots per item)
+constexpr uint32_t kMaxWinTagged = 4096;  // ... of a plan whose calls are always tagged: k_scan keeps no snapshots then
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;  // queue entry that starts no run (terminates the one before it)
 constexpr uint32_t kQ2 = 64 + 1024 + 8;   // queue entries per wave: what is left over + one all-starts block
 
@@ -1101,16 +1102,17 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     constexpr bool DBG = MODE == kModeDbg;
     constexpr uint32_t kRing = TAGGED ? kCtlRing - 1u : 1u;  // which cell of the control rings an item uses: its ordinal & kRing
     extern __shared__ uint32_t lds[];
-    // layout: [bcur: nwp][snap: nwp][control words][run queues: kWaves * kQ2 entries of 8 bytes]
+    // layout: [bcur: nwp][snap: nwp, untagged only][control words][run queues: kWaves * kQ2 entries of 8 bytes]
+    constexpr uint32_t kTables = TAGGED ? 1u : 2u;
     uint32_t *bcur = lds;
     uint32_t *snap = lds + A.nwp;  // the cursors when the current item started (not kept in a tagged call)
-    uint32_t *ctl = lds + 2u * A.nwp;
+    uint32_t *ctl = lds + kTables * A.nwp;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the span math on the scalar unit
     uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;  // this workgroup's sub-bucket of window 0
     if (TAGGED && MODE == kModePlain && A.tprof && threadIdx.x == 0) A.tprof[(2 + kWaves) * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
     RWave w;
-    w.q = reinterpret_cast<uint2 *>(lds + 2u * A.nwp + kCtlWords) + (uint32_t)wave * kQ2;
+    w.q = reinterpret_cast<uint2 *>(lds + kTables * A.nwp + kCtlWords) + (uint32_t)wave * kQ2;
     w.fill = 0;
     w.vm[0] = w.vm[1] = w.vm[2] = 0;
     w.lane = lane;
@@ -1866,11 +1868,40 @@ __device__ __forceinline__ uint32_t rec_take_lo() {
     else asm volatile("s_waitcnt vmcnt(2)\n\tv_mov_b32 %0, v63" : "=v"(r)::"memory");
     return r;
 }
+#ifndef FGFA_TAG_DEPTH
+#define FGFA_TAG_DEPTH 3  /* steps the tagged walk requests ahead (3 .. 8): landing registers v(123 - depth) .. v122 */
+#endif
+constexpr int kTagDepth = FGFA_TAG_DEPTH;
+static_assert(kTagDepth >= 3 && kTagDepth <= 8, "FGFA_TAG_DEPTH");
 template <int K>
 __device__ __forceinline__ void rec_request_s(const uint32_t *p, uint32_t lane4) {
-    if (K == 0) asm volatile("global_load_dword v120, %0, %1" ::"v"(lane4), "s"(p) : "memory", "v120");
-    else if (K == 1) asm volatile("global_load_dword v121, %0, %1" ::"v"(lane4), "s"(p) : "memory", "v121");
-    else asm volatile("global_load_dword v122, %0, %1" ::"v"(lane4), "s"(p) : "memory", "v122");
+#define FGFA_REQ_S(REG) asm volatile("global_load_dword " REG ", %0, %1" ::"v"(lane4), "s"(p) : "memory", REG)
+    constexpr int kReg = 123 - kTagDepth + K;
+    if (kReg == 115) FGFA_REQ_S("v115");
+    else if (kReg == 116) FGFA_REQ_S("v116");
+    else if (kReg == 117) FGFA_REQ_S("v117");
+    else if (kReg == 118) FGFA_REQ_S("v118");
+    else if (kReg == 119) FGFA_REQ_S("v119");
+    else if (kReg == 120) FGFA_REQ_S("v120");
+    else if (kReg == 121) FGFA_REQ_S("v121");
+    else FGFA_REQ_S("v122");
+#undef FGFA_REQ_S
+}
+template <int K>
+__device__ __forceinline__ uint32_t rec_take_s() {  // (the kTagDepth - 1 younger requests are the only other vector-memory operations in flight)
+    uint32_t r;
+#define FGFA_TAKE_S(REG) asm volatile("s_waitcnt vmcnt(%1)\n\tv_mov_b32 %0, " REG : "=v"(r) : "n"(kTagDepth - 1) : "memory")
+    constexpr int kReg = 123 - kTagDepth + K;
+    if (kReg == 115) FGFA_TAKE_S("v115");
+    else if (kReg == 116) FGFA_TAKE_S("v116");
+    else if (kReg == 117) FGFA_TAKE_S("v117");
+    else if (kReg == 118) FGFA_TAKE_S("v118");
+    else if (kReg == 119) FGFA_TAKE_S("v119");
+    else if (kReg == 120) FGFA_TAKE_S("v120");
+    else if (kReg == 121) FGFA_TAKE_S("v121");
+    else FGFA_TAKE_S("v122");
+#undef FGFA_TAKE_S
+    return r;
 }
 
 // What one step does with its 64 records once each lane knows its path's bitset (sb: the bitset's
@@ -2069,14 +2100,20 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
             claim_step<WB>(rec, sb, act, dbase, rbase, one, mone);
         }
     };
-    uint32_t nv0, nv1, nv2, f0, f1, f2;
+    constexpr int kDepth = LOW ? 3 : kTagDepth;
+    uint32_t nv0 = 0, nv1 = 0, nv2 = 0, nv3 = 0, nv4 = 0, nv5 = 0, nv6 = 0, nv7 = 0, f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0, f6 = 0, f7 = 0;
     FGFA_TAG_GEN(0, nv0, f0);
     FGFA_TAG_GEN(1, nv1, f1);
     FGFA_TAG_GEN(2, nv2, f2);
+    if (kDepth > 3) FGFA_TAG_GEN((kDepth > 3 ? 3 : 0), nv3, f3);
+    if (kDepth > 4) FGFA_TAG_GEN((kDepth > 4 ? 4 : 0), nv4, f4);
+    if (kDepth > 5) FGFA_TAG_GEN((kDepth > 5 ? 5 : 0), nv5, f5);
+    if (kDepth > 6) FGFA_TAG_GEN((kDepth > 6 ? 6 : 0), nv6, f6);
+    if (kDepth > 7) FGFA_TAG_GEN((kDepth > 7 ? 7 : 0), nv7, f7);
 #define FGFA_TAG_STEP(K, NV, FR)                                                                                       \
     if (NV == 0u) break;                                                                                               \
     {                                                                                                                  \
-        const uint32_t rec = LOW ? rec_take_lo<K>() : rec_take<K>();                                                   \
+        const uint32_t rec = LOW ? rec_take_lo<K>() : rec_take_s<K>();                                                 \
         const unsigned long long vm = NV >= 64u ? ~0ull : (1ull << NV) - 1ull;  /* the lanes that hold a record */     \
         const uint32_t last = NV - 1u;                                                                                 \
         if (FR) hmax = -1;  /* the private slots start over with this sub-bucket */                                    \
@@ -2125,6 +2162,11 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
         FGFA_TAG_STEP(0, nv0, f0)
         FGFA_TAG_STEP(1, nv1, f1)
         FGFA_TAG_STEP(2, nv2, f2)
+        if (kDepth > 3) { FGFA_TAG_STEP((kDepth > 3 ? 3 : 0), nv3, f3) }
+        if (kDepth > 4) { FGFA_TAG_STEP((kDepth > 4 ? 4 : 0), nv4, f4) }
+        if (kDepth > 5) { FGFA_TAG_STEP((kDepth > 5 ? 5 : 0), nv5, f5) }
+        if (kDepth > 6) { FGFA_TAG_STEP((kDepth > 6 ? 6 : 0), nv6, f6) }
+        if (kDepth > 7) { FGFA_TAG_STEP((kDepth > 7 ? 7 : 0), nv7, f7) }
     }
 #undef FGFA_TAG_STEP
 #undef FGFA_TAG_GEN
@@ -2632,7 +2674,8 @@ __global__ __launch_bounds__(256) void k_item_dirs(const uint32_t *__restrict__ 
     }
 }
 
-uint32_t scan_lds_bytes(uint32_t nwp) { return (2u * nwp + kCtlWords + kWaves * kQ2 * 2u) * 4u; }
+// (a plan of at most kMaxWin windows may run either build of k_scan: sized for the untagged one)
+uint32_t scan_lds_bytes(uint32_t nwp, bool tagged_only = false) { return ((tagged_only ? 1u : 2u) * nwp + kCtlWords + kWaves * kQ2 * 2u) * 4u; }
 
 #define FAST_TRY(expr)                                                                      \
     do {                                                                                    \
@@ -2672,7 +2715,7 @@ int alloc_buckets(FastPlan *fp, uint64_t want_cap) {
 // The plan of one range of segments, [seg_base, seg_base + n_range): the whole graph, or one of
 // the ranges of a graph beyond 16 M segments.
 static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp, uint32_t seg_base,
-                         uint32_t n_range) {
+                         uint32_t n_range, uint32_t max_win) {
     *fp = FastPlan();
     fp->seg_base = seg_base;
     fp->n_range = n_range;
@@ -2682,7 +2725,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     uint32_t wb = g.n_segs <= 1024u * 4096u ? 12u : 13u;
     if (const char *f = getenv("FLATGFA_WB")) wb = (uint32_t)strtoul(f, nullptr, 10);
     const uint32_t n_win = (uint32_t)(((uint64_t)n_range + (1u << wb) - 1) >> wb);
-    if (n_win > kMaxWin) return true;
+    if (n_win > max_win) return true;
     hipDeviceProp_t prop;
     int dev = 0;
     FAST_TRY(hipGetDevice(&dev));
@@ -2693,7 +2736,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     fp->n_win = n_win;
     fp->wb = wb;
     fp->nwp = (n_win + 63u) & ~63u;
-    fp->lds_bytes_scan = scan_lds_bytes(fp->nwp);
+    fp->lds_bytes_scan = scan_lds_bytes(fp->nwp, n_win > kMaxWin);
     if (fp->lds_bytes_scan + 64 > kLdsLimit) return true;
     if (const char *d = getenv("FLATGFA_DEBUG_SKIP")) fp->dbg = (uint32_t)strtoul(d, nullptr, 10);
     if (fp->dbg && ranged) return true;  // the diagnostic build of k_scan has no registers left for ranges
@@ -2848,6 +2891,10 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         const char *t = getenv("FLATGFA_TAGGED");
         fp->tagged = !fp->dbg && !(t && t[0] == '0') && per_wg + fp->n_shared <= kTagCount &&
                      fp->n_shared <= (wb <= 12 ? kMaxShared : 0u) && (fp->n_shared == 0 || fp->acc_parts == 1);
+        if (!fp->tagged && n_win > kMaxWin) {  // so many windows only without cursor snapshots: the caller cuts smaller ranges
+            fast_plan_destroy(fp);
+            return true;
+        }
     }
     // Pass 2 walks k_scan's items grouped by path (the pieces of a split path share a bitset),
     // each of its waves a contiguous stretch of the list: paths are dealt to the waves longest
@@ -3054,31 +3101,38 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     *fp = FastPlan();
     if (g.n_segs == 0 || g.n_paths == 0 || g.n_steps == 0) return true;
     if ((reinterpret_cast<uintptr_t>(g.steps) & 15u) != 0) return true;  // 16-byte step loads
-    // One range while the graph fits 2048 windows of 8192 segments (16 M); beyond, ranges of equal
-    // size, each a walk of the steps per call (64 M segments / 100 M steps: four walks, 0.5 ms,
-    // against 7.4 ms for the atomic kernels).  FLATGFA_MAX_WINDOWS keeps the old cut-off (tests).
-    uint64_t max_range = (uint64_t)kMaxWin << 13;
-    if (const char *f = getenv("FLATGFA_RANGE_SEGS")) max_range = std::max<uint64_t>(8192, strtoull(f, nullptr, 10) & ~8191ull);  // tests
+    // One range while the graph fits 4096 windows of 8192 segments (32 M); beyond, ranges of equal
+    // size, each a walk of the steps per call (64 M segments / 100 M steps: two walks).  So many
+    // windows only for plans whose calls are tagged (k_scan then keeps one LDS table per window, not
+    // two); when a range cannot be (FLATGFA_TAGGED=0, more split paths than pass 2 has bitsets
+    // for), the ranges are cut again at 2048 windows.  FLATGFA_MAX_WINDOWS keeps the old cut-off (tests).
     if (const char *off = getenv("FLATGFA_MAX_WINDOWS")) {
         const uint32_t wb = g.n_segs <= 1024u * 4096u ? 12u : 13u;
         if ((((uint64_t)g.n_segs + (1u << wb) - 1) >> wb) > strtoul(off, nullptr, 10)) return true;
     }
-    const uint32_t n_ranges = (uint32_t)((g.n_segs + max_range - 1) / max_range);
-    if (n_ranges > 64) return true;
-    const uint32_t per = (uint32_t)((((uint64_t)g.n_segs + n_ranges - 1) / n_ranges + 8191) & ~8191ull);
-    if (!create_range(g, hb, he, fp, 0, std::min<uint32_t>(per, g.n_segs))) return false;
-    if (n_ranges == 1 || !fp->eligible) return true;
-    fp->more = new FastPlan[n_ranges - 1];
-    fp->n_more = n_ranges - 1;
-    bool ok = true, all = true;
-    for (uint32_t r = 1; r < n_ranges && ok; ++r) {
-        const uint32_t base = r * per;
-        ok = create_range(g, hb, he, &fp->more[r - 1], base, std::min<uint32_t>(per, g.n_segs - base));
-        all = all && fp->more[r - 1].eligible;
-    }
-    if (!ok || !all) {  // all ranges or none
-        fast_plan_destroy(fp);
-        return ok;
+    for (const uint32_t max_win : {kMaxWinTagged, kMaxWin}) {
+        uint64_t max_range = (uint64_t)max_win << 13;
+        if (const char *f = getenv("FLATGFA_RANGE_SEGS")) max_range = std::max<uint64_t>(8192, strtoull(f, nullptr, 10) & ~8191ull);  // tests
+        const uint32_t n_ranges = (uint32_t)((g.n_segs + max_range - 1) / max_range);
+        if (n_ranges > 64) return true;
+        const uint32_t per = (uint32_t)((((uint64_t)g.n_segs + n_ranges - 1) / n_ranges + 8191) & ~8191ull);
+        if (!create_range(g, hb, he, fp, 0, std::min<uint32_t>(per, g.n_segs), max_win)) return false;
+        bool all = fp->eligible;
+        if (all && n_ranges > 1) {
+            fp->more = new FastPlan[n_ranges - 1];
+            fp->n_more = n_ranges - 1;
+            for (uint32_t r = 1; r < n_ranges && all; ++r) {
+                const uint32_t base = r * per;
+                if (!create_range(g, hb, he, &fp->more[r - 1], base, std::min<uint32_t>(per, g.n_segs - base), max_win)) {
+                    fast_plan_destroy(fp);
+                    return false;
+                }
+                all = fp->more[r - 1].eligible;
+            }
+        }
+        if (all) return true;
+        fast_plan_destroy(fp);  // all ranges or none
+        if (((uint64_t)g.n_segs + 8191) / 8192 <= kMaxWin * (uint64_t)n_ranges) break;  // (the smaller cut-off would make the same ranges)
     }
     return true;
 }
@@ -3086,7 +3140,7 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
 // Scratch for path sums riding on seg_depth: one {sum len, sum depth * len} per (window, item).
 // False when that would be out of proportion (then the caller walks the steps a second time).
 bool fast_plan_want_path_sums(FastPlan *fp) {
-    if (!fp->eligible || fp->wb != 12 || fp->acc_parts > 1 || fp->n_more) return false;  // (the fused form needs a window's final depth in one workgroup)
+    if (!fp->eligible || fp->wb != 12 || fp->acc_parts > 1 || fp->n_more || fp->n_win > kMaxWin) return false;  // (the fused form needs a window's final depth in one workgroup, and the directory: k_scan's untagged build)
     if (fp->psum_part) return true;
     const uint64_t bytes = (uint64_t)fp->n_win * fp->dstride * 16;
     if (bytes > (256ull << 20)) return false;

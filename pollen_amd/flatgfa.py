@@ -184,6 +184,12 @@ class FlatGFA:
     def to_device(self, device: int = 0) -> None:
         _check(_lib.lib().flatgfa_to_device(self._h, device), "to_device")
 
+    def residency_ms(self) -> Tuple[float, float]:
+        """(host-to-device copies, plan creation) of to_device on this handle, milliseconds."""
+        h2d, plan = ctypes.c_double(0), ctypes.c_double(0)
+        _check(_lib.lib().flatgfa_residency_ms(self._h, ctypes.byref(h2d), ctypes.byref(plan)), "residency_ms")
+        return h2d.value, plan.value
+
     def seg_depth_with_uniq(self) -> Tuple[np.ndarray, np.ndarray]:
         """ops/depth.rs:15-39 -> (depths, uniq_depths), uint64, indexed by segment id."""
         S = self.segment_count

@@ -122,6 +122,30 @@ def test_known_answers():
     assert d.tolist() == [2, 0, 4, 2] and u.tolist() == [2, 0, 3, 2]
 
 
+def test_residency_timing_and_repeated_uploads(tmp_path):
+    """to_device keeps its pinned staging buffers for the next graph (large step arrays go up in
+    8 MB chunks from four threads): several graphs, in memory and file-mapped, one after the other
+    and interleaved, each with the right answer; residency_ms is an error before, two durations after."""
+    g0 = pa.parse(os.path.join(GOLDEN, "standin_note5.gfa"))
+    with pytest.raises(pa.FlatGFAError):
+        g0.residency_ms()
+    graphs = []
+    for seed, steps in ((3, 90_000), (4, 110_000), (5, 9_000)):   # 9, 11 and 0.9 M steps: the first two take the chunked route
+        g = pa.synth(seed, 60_000, 100, steps, "pangenome", True)
+        f = str(tmp_path / f"g{seed}.flatgfa")
+        g.write_flatgfa(f)
+        graphs += [g, pa.load(f)]
+    for g in graphs[::2] + graphs[1::2]:
+        g.to_device(0)
+        h2d, plan = g.residency_ms()
+        assert h2d > 0 and plan > 0
+    for g in graphs:
+        want_d, want_u = fo.seg_depth_with_uniq(pools_of(g))
+        d, u = g.seg_depth_with_uniq()
+        assert (d == want_d).all() and (u == want_u).all()
+        g.close()
+
+
 def test_cli_depth_is_byte_identical():
     for name in ("standin_note5", "ref_ex2", "edge_names_loops"):
         gfa = os.path.join(GOLDEN, name + ".gfa")
@@ -516,3 +540,35 @@ def test_wave_per_path_kernels_alone(always, tagged, monkeypatch):
             if k % 2 == 0:
                 assert (u.cpu().numpy().view(np.uint32) == want_u).all()
         plan.close()
+
+
+@pytest.mark.parametrize("tagged", [True, False])
+def test_more_windows_than_the_directory_allows(tagged, monkeypatch):
+    """A tagged plan may have 4096 windows per range (k_scan keeps one LDS table per window then,
+    not two); a plan that cannot be tagged is cut into ranges of at most 2048.  17 M segments:
+    2076 windows of 8192."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    for v in ("FLATGFA_RANGE_SEGS", "FLATGFA_MAX_WINDOWS", "FLATGFA_SHORT_MAX", "FLATGFA_WB", "FLATGFA_PIECE_STEPS"):
+        monkeypatch.delenv(v, raising=False)
+    if tagged:
+        monkeypatch.delenv("FLATGFA_TAGGED", raising=False)
+    else:
+        monkeypatch.setenv("FLATGFA_TAGGED", "0")
+    S = 17_000_000
+    g = pa.synth(21, S, 1000, 10_000, "pangenome", False)
+    steps, pb, pe, _ = g.soa()
+    want_d, want_u = fo.seg_depth_with_uniq(pools_of(g))
+    plan = DepthPlan(DeviceGraph(steps, pb, pe, S))
+    text = plan.describe()
+    assert ("windows=2076x8192 ranges=1" in text and "pass2=tagged" in text) if tagged else ("ranges=2" in text and "pass2=directory" in text), text
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    for k in range(3):
+        plan.seg_depth(d, u if k != 1 else None)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == want_d).all()
+        if k != 1:
+            assert (u.cpu().numpy().view(np.uint32) == want_u).all()
+    plan.close()

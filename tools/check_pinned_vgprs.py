@@ -41,9 +41,16 @@ def regs_of(text):
 def main():
     with tempfile.TemporaryDirectory() as td:
         asm = os.path.join(td, "depth_fast.s")
+        extra = os.environ.get("FGFA_CXXFLAGS", "").split()  # (the -D flags of a variant build, tools/tag_sweep.sh)
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                               SRC, "-o", asm], stderr=subprocess.DEVNULL)
+                               SRC, "-o", asm] + extra, stderr=subprocess.DEVNULL)
         lines = open(asm).read().splitlines()
+    # the tagged walk's depth: FGFA_TAG_DEPTH steps are requested ahead, into v(123 - depth) .. v122
+    depth = int(re.search(r"#define FGFA_TAG_DEPTH (\d+)", open(SRC).read()).group(1))
+    for f in extra:
+        if f.startswith("-DFGFA_TAG_DEPTH="):
+            depth = int(f.split("=")[1])
+    tagged_pins = set(range(123 - depth, 123))
     bad, n_load, n_take, func = [], 0, 0, "?"
     n_acc_load = n_acc_take = 0
     budgets = {}
@@ -60,7 +67,8 @@ def main():
             continue
         if "k_accum" in func:  # pass 2: pinned record registers -- v120..v122 (rec_request / rec_take), and in the
             # build with two workgroups per CU (k_accum_pair, 64 registers) v61..v63 (rec_request_lo / rec_take_lo)
-            pins = {61, 62, 63} if "k_accum_pair" in func else {120, 121, 122}  # (the build with 64 registers lands its records in v61..v63)
+            tagged = re.search(r"k_accumILb\dELi\d+ELb\dELb\dELb\dELb1EE", func) is not None  # (the last template argument)
+            pins = {61, 62, 63} if "k_accum_pair" in func else tagged_pins if tagged else {120, 121, 122}  # (the build with 64 registers lands its records in v61..v63)
             if regs_of(s) & pins:
                 m = re.match(r"^global_load_dword v(\d+), (v\[\d+:\d+\], off|v\d+, s\[\d+:\d+\])$", s)
                 t = re.match(r"^v_mov_b32(_e32)? v(\d+), v(\d+)$", s)
@@ -96,7 +104,7 @@ def main():
     if bad:
         print("pinned-VGPR check FAILED:\n  " + "\n  ".join(bad[:20]))
         return 1
-    print(f"pinned-VGPR check ok: k_accum {n_acc_load} record loads, {n_acc_take} takes, nothing else touches v120..v122 (k_accum_pair: v61..v63); "
+    print(f"pinned-VGPR check ok: k_accum {n_acc_load} record loads, {n_acc_take} takes, nothing else touches v120..v122 (tagged walk: v{123 - depth}..v122, k_accum_pair: v61..v63); "
           f"k_scan {n_load} loads, {n_take} takes, nothing else touches v80..v127; "
           f"k_scan budgets {sorted(set(v for k, v in budgets.items() if 'k_scan' in k))}")
     return 0
