@@ -548,19 +548,19 @@ extern "C" int flatgfa_dev_path_sums(flatgfa_dev_plan_t *pl, const uint32_t *pat
 static int path_depth_all_enqueue(flatgfa_dev_plan_t *pl, uint32_t *depth_out, uint64_t *length_out, uint64_t *weighted_out,
                                   hipStream_t stream, bool use_fast) {
     const flatgfa_dev_graph_t &g = pl->g;
-    {
-        ProfScope ps("memset_path_sums", stream);
-        HIP_TRY(hipMemsetAsync(length_out, 0, (size_t)g.n_paths * 8, stream), return FLATGFA_ERR_HIP);
-        HIP_TRY(hipMemsetAsync(weighted_out, 0, (size_t)g.n_paths * 8, stream), return FLATGFA_ERR_HIP);
-    }
     use_fast = use_fast && pl->fast.eligible;
     if (use_fast && fast_plan_want_path_sums(&pl->fast)) {
         // pass 2 adds up the paths k_scan walked; the wave-per-path kernels' paths take the gather kernel
-        const PathSums ps{length_out, weighted_out};
+        const PathSums ps{length_out, weighted_out, true};
         int rc = fast_seg_depth(pl->fast, g, depth_out, nullptr, pl->status, stream, &ps);
         if (rc) return rc;
         if (pl->fast.n_other) rc = path_sums_launch(pl, pl->fast.other_ids, pl->fast.n_other, depth_out, length_out, weighted_out, 1u, stream);
         return rc;
+    }
+    {
+        ProfScope ps("memset_path_sums", stream);
+        HIP_TRY(hipMemsetAsync(length_out, 0, (size_t)g.n_paths * 8, stream), return FLATGFA_ERR_HIP);
+        HIP_TRY(hipMemsetAsync(weighted_out, 0, (size_t)g.n_paths * 8, stream), return FLATGFA_ERR_HIP);
     }
     int rc = use_fast ? fast_seg_depth(pl->fast, g, depth_out, nullptr, pl->status, stream)
                       : atomic_seg_depth(pl, depth_out, nullptr, stream);

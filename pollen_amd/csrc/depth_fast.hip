@@ -118,6 +118,8 @@ struct ScanArgs {
     const uint32_t *path_begin, *path_end;  // set when `steps` is the reversed copy: a handed-back path is walked from the graph's own steps
     uint32_t seg_base, n_total, ranged;  // ranged: this walk keeps what falls into [seg_base, seg_base + n_segs) of the graph's n_total segments
     uint32_t *zero_a, *zero_b;  // k_scan clears these vectors of n_segs counts first (pass 2 adds to them when windows are shared); or null
+    unsigned long long *zero_c, *zero_d;  // ... and these two of n_zero64 sums (the paths' sums k_path_reduce adds to); or null
+    uint32_t n_zero64;
     const uint32_t *steps;
     uint4 *items;        // work items, longest first: {begin, end, -, path}; room behind the first n_items
                          // for the short paths k_scan_short hands back (counted in *work_counter)
@@ -1124,6 +1126,9 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             A.zero_a[i] = 0u;
             if (A.zero_b) A.zero_b[i] = 0u;
         }
+    }
+    if (A.zero_c) {  // path depth: two memset launches less per call
+        for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < A.n_zero64; i += gridDim.x * kThreads) A.zero_c[i] = A.zero_d[i] = 0ull;
     }
     // the cursors continue where k_scan_short (if it ran) left this workgroup's sub-buckets
     for (uint32_t i = threadIdx.x; i < A.nwp; i += kThreads) {
@@ -2538,6 +2543,9 @@ __global__ __launch_bounds__(kThreads) void k_scan_dense(const ScanArgs A) {
             if (A.zero_b) A.zero_b[i] = 0u;
         }
     }
+    if (A.zero_c) {
+        for (uint32_t i = blockIdx.x * kThreads + tid; i < A.n_zero64; i += gridDim.x * kThreads) A.zero_c[i] = A.zero_d[i] = 0ull;
+    }
     for (uint32_t i = tid; i < A.nwp; i += kThreads) {
         const uint32_t c = i < A.n_win ? A.counts[(size_t)i * A.n_slots + blockIdx.x] : 0u;
         bcur[i] = c;
@@ -3196,6 +3204,8 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     const uint32_t grid = scan_skip ? 0u : has_pre ? fp.n_slots : std::min<uint32_t>(fp.n_items, fp.n_slots);
     ScanArgs sa;
     sa.zero_a = sa.zero_b = nullptr;
+    sa.zero_c = sa.zero_d = nullptr;
+    sa.n_zero64 = 0;
     sa.path_begin = sa.path_end = nullptr;
     sa.steps = g.steps;
     sa.n_steps = g.n_steps;
@@ -3268,6 +3278,17 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
                 if (uniq_out) hipLaunchKernelGGL(k_walk_short<true>, dim3(kgrid), dim3(kThreads), fp.lds_bytes_short, stream, sk);
                 else hipLaunchKernelGGL(k_walk_short<false>, dim3(kgrid), dim3(kThreads), fp.lds_bytes_short, stream, sk);
             }
+        }
+    }
+    if (ps && ps->clear) {  // the sums k_path_reduce adds to start at zero: k_scan's first act, or two memsets when it does not run
+        if (grid) {
+            sa.zero_c = (unsigned long long *)ps->len_out;
+            sa.zero_d = (unsigned long long *)ps->weighted_out;
+            sa.n_zero64 = g.n_paths;
+        } else {
+            ProfScope pscope("memset_path_sums", stream);
+            if (hipMemsetAsync(ps->len_out, 0, (size_t)g.n_paths * 8, stream) != hipSuccess) return FLATGFA_ERR_HIP;
+            if (hipMemsetAsync(ps->weighted_out, 0, (size_t)g.n_paths * 8, stream) != hipSuccess) return FLATGFA_ERR_HIP;
         }
     }
     if (grid) {

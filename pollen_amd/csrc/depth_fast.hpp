@@ -78,7 +78,8 @@ bool fast_plan_grow(FastPlan *fp);
 // Per-path sums of measure_path (depth.rs:116-131), accumulated by pass 2 of a seg_depth call for
 // the paths k_scan walks (plan.other_ids lists the rest): u64[n_paths] each, zeroed by the caller.
 struct PathSums {
-    uint64_t *len_out, *weighted_out;
+    uint64_t *len_out, *weighted_out;  // one per path of the graph
+    bool clear = false;                // the call zeroes them first (inside k_scan where it runs)
 };
 // Allocates (once) the scratch `ps` needs; false = not possible for this plan.
 bool fast_plan_want_path_sums(FastPlan *fp);
