@@ -19,11 +19,13 @@ ENVS = [{}, {"FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0"}, {"FL
         {"FLATGFA_DENSE": "1", "FLATGFA_RANGE_SEGS": "65536", "FLATGFA_SHORT_MAX": "0"},
         {"FLATGFA_TAGGED": "0"}, {"FLATGFA_TAGGED": "0", "FLATGFA_PIECE_STEPS": "900"}, {"FLATGFA_ACC_PAIR": "1", "FLATGFA_DEPTH_PATH": "bucketed"},
         {"FLATGFA_ACC_PAIR": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
-        {"FLATGFA_PIECE_STEPS": "4096", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"}]
+        {"FLATGFA_PIECE_STEPS": "4096", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_SCAN_ALWAYS": "1", "FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_WB": "12", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_WB": "11", "FLATGFA_DEPTH_PATH": "bucketed"}]
 
 
 def random_graph(rng):
-    S = int(rng.choice([1, 7, 33, 1000, 5000, 70_000, 300_000, 1_100_000, 2_200_000]))
+    S = int(rng.choice([1, 7, 33, 1000, 5000, 70_000, 300_000, 1_100_000, 2_200_000, 9_000_000]))  # (the last with FLATGFA_WB=12: more windows than an untagged plan may have)
     kinds = rng.integers(0, 4)
     lens = []
     n_paths = int(rng.integers(1, 400))
@@ -99,7 +101,7 @@ def main():
         pools.paths, pools.steps, pools.segs = paths, steps, segs
         want_d, want_u = fo.seg_depth_with_uniq(pools)
         env = ENVS[case % len(ENVS)]
-        for k in ("FLATGFA_SHORT_MAX", "FLATGFA_BUCKET_CAP", "FLATGFA_PIECE_STEPS", "FLATGFA_DEPTH_PATH", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS", "FLATGFA_DENSE", "FLATGFA_BIG_GROUPS", "FLATGFA_TAGGED", "FLATGFA_ACC_PAIR"):
+        for k in ("FLATGFA_SHORT_MAX", "FLATGFA_BUCKET_CAP", "FLATGFA_PIECE_STEPS", "FLATGFA_DEPTH_PATH", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS", "FLATGFA_DENSE", "FLATGFA_BIG_GROUPS", "FLATGFA_TAGGED", "FLATGFA_ACC_PAIR", "FLATGFA_SCAN_ALWAYS", "FLATGFA_WB"):
             os.environ.pop(k, None)
         os.environ.update(env)
         graph = dev.DeviceGraph(steps, pb, pe, S, seg_len, device="cuda:0")
@@ -122,9 +124,20 @@ def main():
         want_ln, want_mean = fo.path_depth(pools, ids)
         got_ln = ln.cpu().numpy().view(np.uint64)
         got_mean = ws.cpu().numpy().view(np.uint64).astype(np.float64) / got_ln.astype(np.float64)
-        gd, gu, gd2 = (t.cpu().numpy().view(np.uint32) for t in (d, u, d2))
-        ok = (gd == want_d).all() and (gu == want_u).all() and (gd2 == want_d).all() \
-            and (got_ln == want_ln).all() and got_mean.tobytes() == want_mean.tobytes()
+        # ... and of all paths in the call that also counts node depth (`fgfa depth`); the outputs start as garbage
+        d3 = torch.full((S,), -7, dtype=torch.int32, device="cuda:0")
+        ln_all = torch.full((P,), 12345, dtype=torch.int64, device="cuda:0")
+        ws_all = torch.full((P,), -1, dtype=torch.int64, device="cuda:0")
+        for _ in range(2):
+            plan.path_depth_all(d3, ln_all, ws_all)
+            plan.status()
+        want_ln_all, want_mean_all = fo.path_depth(pools, np.arange(P, dtype=np.uint32))
+        got_ln_all = ln_all.cpu().numpy().view(np.uint64)
+        got_mean_all = ws_all.cpu().numpy().view(np.uint64).astype(np.float64) / got_ln_all.astype(np.float64)
+        gd, gu, gd2, gd3 = (t.cpu().numpy().view(np.uint32) for t in (d, u, d2, d3))
+        ok = (gd == want_d).all() and (gu == want_u).all() and (gd2 == want_d).all() and (gd3 == want_d).all() \
+            and (got_ln == want_ln).all() and got_mean.tobytes() == want_mean.tobytes() \
+            and (got_ln_all == want_ln_all).all() and got_mean_all.tobytes() == want_mean_all.tobytes()
         print(f"case {case}: S={S} P={P} N={len(steps)} env={env} [{plan.describe()[:60]}] -> {'ok' if ok else 'MISMATCH'}", flush=True)
         if not ok:
             bad += 1
