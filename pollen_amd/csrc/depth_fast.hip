@@ -854,7 +854,8 @@ constexpr int kWide = FGFA_WIDE;  // chunks of 64 queue entries k_scan emits sid
 // item's ordinal mod kCtlRing in a tagged call -- a wave with records to append may be kTagSlots items
 // ahead of the slowest there, one without any kIdleAhead -- and mod 2 otherwise)
 constexpr uint32_t kCtlRing = 32, kIdleAhead = 20;
-constexpr uint32_t kCtlNext = 0, kCtlArrive = kCtlRing, kCtlEpoch = 2 * kCtlRing, kCtlJobs = 2 * kCtlRing + 8, kCtlWords = 3 * kCtlRing + 8;
+constexpr uint32_t kCtlNext = 0, kCtlArrive = kCtlRing, kCtlEpoch = 2 * kCtlRing, kCtlJobs = 2 * kCtlRing + 8, kCtlDesc = 3 * kCtlRing + 8,
+                   kCtlWords = 7 * kCtlRing + 8;  // (kCtlDesc: four words per cell of the item ring -- the items' descriptors, tagged calls)
 // A tagged call deals the items out as the workgroups get to them (an item's tag is its ordinal in
 // its workgroup, whatever the item): ctl[kCtlJobs + (r mod kCtlRing)] is the workgroup's r-th item, or one of
 constexpr uint32_t kJobEmpty = 0xFFFFFFFFu, kJobPending = 0xFFFFFFFEu;  // nobody has asked yet / a wave is fetching it
@@ -990,6 +991,29 @@ struct Item {
 // queue: a returning global atomic per item sat on the critical path of every path.
 __device__ __forceinline__ uint32_t item_of(uint32_t round, uint32_t wg, uint32_t n_wg) {
     return round * n_wg + ((round & 1u) ? n_wg - 1u - wg : wg);
+}
+
+// An item's descriptor (and where pass 2 looks for it) is the same for all lanes: read through the
+// scalar cache.  As a vector load hipcc waited for it with vmcnt(0) on the spot -- which also waits
+// for every block the wave has in flight: a drained pipeline plus a round trip per item and wave
+// (nothing next to a 100 k-step item; with 10 k-step ones k_scan is 3.5 % faster this way).  The lists
+// are written before this kernel starts.
+#ifndef FGFA_ITEM_RING
+#define FGFA_ITEM_RING 1  /* 0: every wave reads its next item's descriptor from memory (measurements) */
+#endif
+#ifndef FGFA_ITEM_SLOAD
+#define FGFA_ITEM_SLOAD 1  /* 1: where a workgroup has more than eight items; 0 / 2: never / always (measurements) */
+#endif
+__device__ __forceinline__ uint4 sload_item(const uint4 *p) {
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t sload_u32(const uint32_t *p) {
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
 }
 
 __device__ __forceinline__ Item make_item(const ScanArgs &A, bool have, uint4 d, int lane) {
@@ -1139,6 +1163,8 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     }
     if (threadIdx.x < kCtlWords)
         ctl[threadIdx.x] = threadIdx.x < kCtlArrive ? 4u * kWaves : threadIdx.x < kCtlJobs ? 0u : threadIdx.x == kCtlJobs + 1u ? gridDim.x + blockIdx.x : kJobEmpty;
+    if (TAGGED && threadIdx.x >= kCtlDesc + 4u && threadIdx.x < kCtlDesc + 8u)  // the workgroup's second item is known from the start; its descriptor, if there is such an item (nobody looks otherwise)
+        ctl[threadIdx.x] = gridDim.x + blockIdx.x < A.n_items + A.max_back ? reinterpret_cast<const uint32_t *>(A.items + gridDim.x + blockIdx.x)[threadIdx.x - (kCtlDesc + 4u)] : 0u;
     // block-relative positions of this lane's sixteen steps; opaque, so that they stay in registers
     uint32_t pj[16];
 #pragma unroll
@@ -1153,6 +1179,10 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     // The first blocks of an item are requested while the previous item is being wrapped up, and
     // its descriptor while the previous item is being walked.
     uint32_t rr = 0;  // this workgroup's items so far
+    // (Few long items: reading the next item's descriptor from memory in every wave, which drains the
+    // wave's loads once per item, measures 1-1.5 % FASTER on cfg-L's k_scan than the LDS ring or the
+    // scalar read; with ten times as many items per workgroup those are 2-5 % faster.)
+    const bool many_items = n_items > 8u * gridDim.x;
     // Which items a workgroup walks: untagged, the r-th is fixed (item_of: pass 2 finds it through the
     // directory anyway); tagged, the first two are (its own index, and that plus the number of
     // workgroups) and the rest come off a global counter, longest first, as the workgroups get to
@@ -1221,16 +1251,35 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
                 uint32_t got = 0;
                 if (lane == 0) got = atomicAdd(A.work_counter + 1, 1u);
                 got = min(__builtin_amdgcn_readfirstlane(got) + 2u * gridDim.x, kJobPending - 1u);
+                // ... and its descriptor, for all the waves (each reading it from memory was a round trip per item and wave)
+                if (FGFA_ITEM_RING && many_items && got < n_items && lane < 4) ctl[kCtlDesc + 4u * ((rr + 2u) & kRing) + lane] = reinterpret_cast<const uint32_t *>(A.items + got)[lane];
                 if (lane == 0) __hip_atomic_store(ahead, got, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         } else {
             next_job = item_of(rr + 1u, blockIdx.x, gridDim.x);
         }
-        const uint4 next_item = next_job < n_items ? A.items[next_job] : make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t next_place = (TAGGED || next_job >= A.n_items) ? next_job | 0x80000000u : A.perm[next_job];
-        // the few steps outside the blocks are walked on their own, by the first and the last wave
-        if (wave == 0 && it.t0 > it.b) tile_narrow_raw(A, w, it.b, (uint32_t)(it.t0 - it.b));
-        if (wave == kWaves - 1) {
+        const uint32_t next_job_s = __builtin_amdgcn_readfirstlane(next_job);
+        uint4 next_item = make_uint4(0u, 0u, 0u, 0u);
+        uint32_t next_place = next_job_s | 0x80000000u;
+        if (TAGGED && FGFA_ITEM_RING && many_items) {
+            if (next_job_s < n_items) {
+                const uint32_t *dc = ctl + kCtlDesc + 4u * ((rr + 1u) & kRing);
+                next_item = make_uint4(dc[0], dc[1], dc[2], dc[3]);
+            }
+        } else if (!DBG && (FGFA_ITEM_SLOAD == 1 ? many_items : FGFA_ITEM_SLOAD != 0)) {  // (the diagnostic build has no registers to spare)
+            if (next_job_s < n_items) next_item = sload_item(A.items + next_job_s);
+            if (!TAGGED && next_job_s < A.n_items) next_place = sload_u32(A.perm + next_job_s);
+        } else {
+            if (next_job_s < n_items) next_item = A.items[next_job_s];
+            if (!TAGGED && next_job_s < A.n_items) next_place = A.perm[next_job_s];
+        }
+        // The few steps outside the blocks are walked on their own, by two waves that change with
+        // the item: their loads are plain ones, and the wait for them also waits for every block the
+        // wave has in flight -- with items of ten blocks the same two waves paid that for every block
+        // they took, and the others waited for them at the gate.
+        const uint32_t head_wave = TAGGED ? rr & (kWaves - 1u) : 0u, tail_wave = TAGGED ? (rr + kWaves / 2u) & (kWaves - 1u) : kWaves - 1u;
+        if ((uint32_t)wave == head_wave && it.t0 > it.b) tile_narrow_raw(A, w, it.b, (uint32_t)(it.t0 - it.b));
+        if ((uint32_t)wave == tail_wave) {
             for (uint64_t t = it.tail; t < it.e; t += 64) {  // fewer than 16 steps, but for a block left out by make_item
                 if (w.fill + 66u > kQ2) {
                     while (epoch_now(ctl) < need) __builtin_amdgcn_s_sleep(2);
