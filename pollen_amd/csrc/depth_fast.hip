@@ -644,18 +644,33 @@ struct ShortBlk {
     bool last, valid;  // last block of its path; there is a block at all
 };
 
-// The blocks of this wave's paths, in order.  The next path's descriptor is always requested one
-// path ahead of its use.
+// The blocks of this wave's paths, in order.  The descriptors of the wave's next 64 paths are read
+// with ONE load, a path per lane, and handed out by v_readlane: read one at a time -- even a path
+// ahead of its use -- hipcc waits for the load where it is issued, with vmcnt(0), which also waits
+// for the blocks in flight: a memory round trip and a drained pipeline per path, i.e. per block
+// where paths have a thousand steps.
 struct ShortStream {
     uint32_t gi, stride, b, e, pos, end, nb, ne;
+    uint32_t bx, by;  // (per lane) first and last step of the path lane * stride behind the batch's first
+    uint32_t bk;      // descriptors of the batch handed out so far
 };
-__device__ __forceinline__ void stream_fetch(const ScanArgs &A, ShortStream &g) {  // descriptor of path gi + stride
+__device__ __forceinline__ void stream_fetch(const ScanArgs &A, ShortStream &g, int lane) {  // descriptor of path gi + stride
     const uint32_t nx = g.gi + g.stride;
-    const uint4 d = nx < A.n_short && nx >= g.gi ? A.short_items[nx] : make_uint4(0u, 0u, 0u, 0u);
-    g.nb = d.x;
-    g.ne = d.y;
+    if (g.bk >= 64u) {
+        const uint64_t idx = (uint64_t)nx + (uint64_t)lane * g.stride;
+        uint2 d = make_uint2(0u, 0u);
+        if (nx >= g.gi && idx < A.n_short) d = *reinterpret_cast<const uint2 *>(A.short_items + idx);
+        asm volatile("" : "+v"(d.x), "+v"(d.y));  // (the wait for the load belongs here, once per batch: left pending, hipcc waits where the paths change, every time)
+        g.bx = d.x;
+        g.by = d.y;
+        g.bk = 0u;
+    }
+    const bool have = nx < A.n_short && nx >= g.gi;
+    g.nb = have ? (uint32_t)__builtin_amdgcn_readlane((int)g.bx, (int)g.bk) : 0u;
+    g.ne = have ? (uint32_t)__builtin_amdgcn_readlane((int)g.by, (int)g.bk) : 0u;
+    g.bk += 1u;
 }
-__device__ __forceinline__ ShortBlk stream_next(const ScanArgs &A, ShortStream &g) {
+__device__ __forceinline__ ShortBlk stream_next(const ScanArgs &A, ShortStream &g, int lane) {
     ShortBlk k;
     k.valid = g.gi < A.n_short;
     k.b = g.b;
@@ -672,7 +687,7 @@ __device__ __forceinline__ ShortBlk stream_next(const ScanArgs &A, ShortStream &
         g.e = g.ne;
         g.pos = g.b & ~15u;
         g.end = (g.e + 15u) & ~15u;
-        stream_fetch(A, g);
+        stream_fetch(A, g, lane);
     }
     return k;
 }
@@ -712,16 +727,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
         g.e = d.y;
         g.pos = g.b & ~15u;
         g.end = (g.e + 15u) & ~15u;
-        stream_fetch(A, g);
+        g.bx = g.by = 0u;
+        g.bk = 64u;
+        stream_fetch(A, g, lane);
     }
     ShortBlk slot[2];
     bool handed_back = false;  // the current path did not fit the run queue
     const uint4 *steps4 = reinterpret_cast<const uint4 *>(A.steps);
     // lanes beyond the last one holding steps re-read lane 0's chunk
 #define FGFA_SPTR(K) (steps4 + (size_t)(K).pos / 4 + ((uint32_t)lane < (K).nl ? lane * 4 : 0))
-    slot[0] = stream_next(A, g);
+    slot[0] = stream_next(A, g, lane);
     if (slot[0].valid) load_block_async<0>(w, FGFA_SPTR(slot[0]));
-    slot[1] = stream_next(A, g);
+    slot[1] = stream_next(A, g, lane);
     if (slot[1].valid) load_block_async<1>(w, FGFA_SPTR(slot[1]));
 #define FGFA_SBLOCK(SET)                                                                                \
     if (slot[SET].valid) {                                                                              \
@@ -729,7 +746,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
         uint32_t a[16];                                                                                 \
         take_block<SET>(a);                                                                             \
         const ShortBlk cur = slot[SET];                                                                 \
-        slot[SET] = stream_next(A, g);                                                                  \
+        slot[SET] = stream_next(A, g, lane);                                                            \
         if (slot[SET].valid) load_block_async<SET>(w, FGFA_SPTR(slot[SET]));                            \
         if (!handed_back) {                                                                             \
             const uint32_t lo = cur.b > cur.pos ? cur.b - cur.pos : 0u;                                 \
