@@ -90,7 +90,7 @@ def git_head():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfgL", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -201,9 +201,10 @@ def main():
 
     # ---- timed region: exactly K steps ----
     # Kernel durations come from HIP events recorded around each launch, inside this region, on
-    # every EVENT_EVERY-th step: the event records cost a few percent of a 0.19 ms step, and the
-    # value reported is the whole region's throughput.
-    EVENT_EVERY = 4
+    # every EVENT_EVERY-th step: a step with its four event records takes 0.20 ms where the others take
+    # 0.15 (the records are queue packets of their own, each with a completion signal), and the
+    # value reported is the whole region's throughput -- every fourth step cost it 8 %.
+    EVENT_EVERY = 10
 
     def timed_loop(run_step, n_steps, with_events):
         dev.profile_enable(False)

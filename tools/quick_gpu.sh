@@ -6,7 +6,7 @@ WLS=${WLS:-"cfgL cfgL-chrom chrom-10k cfgL-fewlong cfgL-32k cfgL-4paths cfgL-uni
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 if [ -z "$NO_TESTS" ]; then timeout 1500 python3 -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log; fi
 for w in $WLS; do
-  timeout 300 python3 bench.py --steps 20 --warmup 3 --workload $w --no-cpu-baseline --no-extras 2>$OUT/bench_$w.err | tail -1 > $OUT/bench_$w.json
+  timeout 300 python3 bench.py --steps 40 --warmup 3 --workload $w --no-cpu-baseline --no-extras 2>$OUT/bench_$w.err | tail -1 > $OUT/bench_$w.json
   python3 - $OUT/bench_$w.json $w <<'PY'
 import json,sys
 try:
