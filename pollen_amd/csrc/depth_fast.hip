@@ -2260,6 +2260,37 @@ __device__ __forceinline__ unsigned long long wave_total_u64(unsigned long long 
     return ((unsigned long long)__builtin_amdgcn_readlane((uint32_t)(x >> 32), 63) << 32) | __builtin_amdgcn_readlane((uint32_t)x, 63);
 }
 
+// Eight such sums at once: x[k] holds this lane's share of sum k; every lane returns the wave's
+// total of sum (lane & 7).  Three butterfly steps that halve the number of values a lane holds
+// (a lane keeps the sums whose index agrees with its own on bit j and passes the others to its
+// partner 2^j lanes away) and three that add what is left across the groups of eight: 18
+// instructions per sum where eight reductions of their own take 50.
+#define FGFA_DPP64(V, CTRL)                                                                                              \
+    (((unsigned long long)(uint32_t)__builtin_amdgcn_update_dpp(0u, (uint32_t)((V) >> 32), CTRL, 0xf, 0xf, true) << 32) | \
+     (uint32_t)__builtin_amdgcn_update_dpp(0u, (uint32_t)(V), CTRL, 0xf, 0xf, true))
+__device__ __forceinline__ unsigned long long wave_totals8_u64(const unsigned long long (&x)[8], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    unsigned long long y[4], z[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long keep = b0 ? x[2 * j + 1] : x[2 * j], send = b0 ? x[2 * j] : x[2 * j + 1];
+        y[j] = keep + FGFA_DPP64(send, 0xB1 /* quad_perm:[1,0,3,2] */);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const unsigned long long keep = b1 ? y[2 * j + 1] : y[2 * j], send = b1 ? y[2 * j] : y[2 * j + 1];
+        z[j] = keep + FGFA_DPP64(send, 0x4E /* quad_perm:[2,3,0,1] */);
+    }
+    const unsigned long long keep = b2 ? z[1] : z[0], send = b2 ? z[0] : z[1];
+    const unsigned long long up = FGFA_DPP64(send, 0x104 /* row_shl:4: from the lane four above */), dn = FGFA_DPP64(send, 0x114 /* row_shr:4: from four below */);
+    unsigned long long w = keep + (b2 ? dn : up);      // sum (lane & 7) over the lane's group of eight
+    w += FGFA_DPP64(w, 0x128 /* row_ror:8 */);        // ... over its row of sixteen
+    w += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(w >> 32), 16, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)w, 16, 64);
+    w += ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(w >> 32), 32, 64) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)w, 32, 64);
+    return w;
+}
+#undef FGFA_DPP64
+
 // measure_path (depth.rs:116-131) without a second walk of the steps: a record (first segment,
 // length) of path p contributes sum(len) and sum(depth * len) over its segments, which are two
 // differences of the window's prefix sums Lw / Ww (built in LDS once the window's depth is
@@ -2268,7 +2299,7 @@ __device__ __forceinline__ unsigned long long wave_total_u64(unsigned long long 
 // reduced across the wave and stored -- plain stores: an atomic per item would sit in the way of
 // the loads behind it until memory had acknowledged it -- and k_path_reduce adds the windows up.
 template <int WB>
-__device__ __forceinline__ void sum_groups(const AccArgs &A, const unsigned long long *Lw, const unsigned long long *Ww,
+__device__ __forceinline__ void sum_groups(const AccArgs &A, const ulonglong2 *LW,
                                            const uint32_t *wbase, uint32_t win, uint32_t e0, uint32_t e1) {
     constexpr uint32_t kW = 1u << WB;
     constexpr int kAhead = 8;
@@ -2276,8 +2307,9 @@ __device__ __forceinline__ void sum_groups(const AccArgs &A, const unsigned long
     ulonglong2 *part = A.psum_part + (size_t)win * A.dstride;
     const auto add = [&](uint32_t rec, unsigned long long &ls, unsigned long long &ws) {
         const uint32_t rel = rec & (kW - 1), e1x = rel + ((rec >> WB) & 1023u) + 1u;  // one past the run's last segment
-        ls += Lw[e1x] - Lw[rel];
-        ws += Ww[e1x] - Ww[rel];
+        const ulonglong2 hi = LW[e1x], lo = LW[rel];  // (both sums of a prefix side by side: two 16-byte LDS reads per record, not four of 8)
+        ls += hi.x - lo.x;
+        ws += hi.y - lo.y;
     };
     for (uint32_t mb = e0; mb < e1; mb += 64u) {
         const uint32_t cntE = min(64u, e1 - mb);
@@ -2297,19 +2329,21 @@ __device__ __forceinline__ void sum_groups(const AccArgs &A, const unsigned long
                 oo[k] = __builtin_amdgcn_readlane(off, i);
                 r[k] = wbase[oo[k] + ((uint32_t)lane < nn[k] ? (uint32_t)lane : 0u)];  // unconditional: a predicated load would be waited for on the spot
             }
+            unsigned long long ls[kAhead], ws[kAhead];  // this lane's share of each of the eight items' sums
 #pragma unroll
             for (int k = 0; k < kAhead; ++k) {
+                ls[k] = ws[k] = 0ull;
                 if (nn[k] == 0u) continue;
-                unsigned long long ls = 0, ws = 0;
-                if ((uint32_t)lane < nn[k]) add(r[k], ls, ws);
+                if ((uint32_t)lane < nn[k]) add(r[k], ls[k], ws[k]);
                 for (uint32_t c = 64u; c < nn[k]; c += 64u)
-                    if (c + (uint32_t)lane < nn[k]) add(wbase[oo[k] + c + lane], ls, ws);
-                ls = wave_total_u64(ls);  // by DPP: __shfl_down would go through LDS twelve times per value
-                ws = wave_total_u64(ws);
-                if ((uint32_t)lane == i0 + (uint32_t)k) {
-                    myL = ls;
-                    myW = ws;
-                }
+                    if (c + (uint32_t)lane < nn[k]) add(wbase[oo[k] + c + lane], ls[k], ws[k]);
+            }
+            // all eight reduced together (by DPP: __shfl_down would go through LDS twelve times per value);
+            // lane i0 + k -- i0 is a multiple of eight -- finds item k's totals in its own registers
+            const unsigned long long tl = wave_totals8_u64(ls, lane), tw = wave_totals8_u64(ws, lane);
+            if ((uint32_t)lane >= i0 && (uint32_t)lane < i0 + (uint32_t)kAhead) {
+                myL = tl;
+                myW = tw;
             }
         }
         if (have) part[at] = make_ulonglong2(myL, myW);
@@ -2361,7 +2395,7 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
     __shared__ uint32_t marks[UNIQ && !TAGGED ? kAccWaves * 64 : 4];
     __shared__ __attribute__((aligned(8))) uint32_t pend[UNIQ && !TAGGED ? kAccWaves * 3 * kPend : 4];
     __shared__ uint32_t grab;  // tagged: the next of the workgroup's sub-buckets nobody has taken yet
-    __shared__ unsigned long long Lw[PSUM ? kW + 1 : 1], Ww[PSUM ? kW + 1 : 1];  // prefix sums of len and depth * len
+    __shared__ __attribute__((aligned(16))) ulonglong2 LW[PSUM ? kW + 1 : 1];  // prefix sums of len and of depth * len, side by side
     int *D = cells, *R = cells + (UNIQ ? kW + 64 : 0);
     const int tid = threadIdx.x, wave = tid >> 6;
     AccTimer tm;
@@ -2511,15 +2545,14 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
             block_scan<unsigned long long, kPer>(wave_tot, w);
 #pragma unroll
             for (int k = 0; k < kPer; ++k) {
-                Lw[i0 + k + 1] = l[k];
-                Ww[i0 + k + 1] = w[k];
+                LW[i0 + k + 1] = make_ulonglong2(l[k], w[k]);
             }
-            if (tid == 0) Lw[0] = Ww[0] = 0ull;
+            if (tid == 0) LW[0] = make_ulonglong2(0ull, 0ull);
             __syncthreads();
-            sum_groups<WB>(A, Lw, Ww, wbase, win, __builtin_amdgcn_readfirstlane(A.wave_off[vwave]), __builtin_amdgcn_readfirstlane(A.wave_off[vwave + 1]));
+            sum_groups<WB>(A, LW, wbase, win, __builtin_amdgcn_readfirstlane(A.wave_off[vwave]), __builtin_amdgcn_readfirstlane(A.wave_off[vwave + 1]));
             for (uint32_t f = A.fat_off[blockIdx.y]; f < A.fat_off[blockIdx.y + 1]; ++f) {
                 const uint32_t *wo = A.fat_woff + (size_t)f * (kAccWaves + 1) + wave;
-                sum_groups<WB>(A, Lw, Ww, wbase, win, __builtin_amdgcn_readfirstlane(wo[0]), __builtin_amdgcn_readfirstlane(wo[1]));
+                sum_groups<WB>(A, LW, wbase, win, __builtin_amdgcn_readfirstlane(wo[0]), __builtin_amdgcn_readfirstlane(wo[1]));
             }
         }
     }
