@@ -61,6 +61,8 @@ WORKLOADS = {
     "16Mseg-tiny": (16_000_000, 10, 1000, "pangenome"),       # what a call costs when there is next to nothing to count
     "cfgL-64Mseg": (64_000_000, 1000, 100_000, "pangenome"),  # beyond the bucketed path's 16 M segments
     "cfgL-x16": (1_000_000, 16_000, 100_000, "pangenome"),    # 1.6 G steps = 6.4 GB of steps per GPU: the weak-scaling size
+    "x16-16Mseg": (16_000_000, 16_000, 100_000, "pangenome"),  # the same on a graph of 16 M segments: a hundred steps per segment, as whole-genome graphs have
+    "x16-16Mseg-chrom": (16_000_000, 16_000, 100_000, "chromosome"),  # ... with paths that run along the graph, as haplotypes do
     "cfgS": (10_000, 100, 10_000, "pangenome"),
     "cfgM": (100_000, 100, 100_000, "pangenome"),             # 10 M steps
 }

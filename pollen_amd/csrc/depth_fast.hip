@@ -140,8 +140,9 @@ struct ScanArgs {
     const uint32_t *perm;  // [n_items] item j's position in that order | first of its path << 31 (handed-back items keep their index)
     uint32_t dstride;
     uint32_t cap;
-    uint32_t stride;     // n_slots * cap: elements between consecutive windows (< 2^30 in total)
-    uint32_t sink;       // n_win * stride
+    uint32_t stride;     // n_slots * cap: elements between consecutive windows (< 2^24)
+    uint32_t sink;       // n_win * stride (meaningful while the bucket array holds fewer than 2^30 records)
+    uint32_t big;        // the bucket array holds 2^30 records or more: 64-bit offsets in put() (k_scan<kModeBig / kModeRangedBig>; k_scan_dense reads this)
     uint32_t *status;
     uint32_t dbg;
     uint32_t tagged;     // records carry their item's tag (see kTagShift); k_scan_dense reads this, k_scan is a build of its own
@@ -170,9 +171,20 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(
 // Store a record at slot `pos` of this workgroup's sub-bucket of window `win`.  Branch free:
 // lanes with nothing to store (or no room) write to the sink window.  Returns whether the record
 // did not fit (the call is then completed on a larger plan, see flatgfa_dev_status).
-template <bool DBG, typename W>
+template <bool DBG, bool BIG = false, typename W>
 __device__ __forceinline__ bool put(const ScanArgs &A, W &w, uint32_t *mine, bool e, uint32_t pos, uint32_t win, uint32_t rec) {
     const bool ok = e && pos < A.cap;
+    if (BIG) {
+        // A bucket array of 2^30 records or more (many windows times sub-buckets deep enough for the few
+        // workgroups that walk a window's paths, as on a whole-genome graph whose paths run along it):
+        // the offset takes 64 bits -- one quarter-rate multiply-add per chunk of 64 records.
+        const unsigned long long slot = (unsigned long long)(ok ? win : A.n_win) * A.stride + (ok ? pos : 0u);
+        mine[slot] = rec;
+        w.vm[0] += 1;  // exactly one store instruction, executed by the whole wave
+        w.vm[1] += 1;
+        w.vm[2] += 1;
+        return e && !ok;
+    }
     // The bucket array holds fewer than 2^30 records, so a 32-bit byte offset from a uniform base
     // suffices.  window * stride + pos as one full-rate 24-bit multiply-add (the plan keeps the
     // stride below 2^24; hipcc would otherwise pick the quarter-rate 64-bit mad).
@@ -862,7 +874,9 @@ __device__ __forceinline__ void tmark(const ScanArgs &A, RWave &w, int ph) {
 // next item nobody has taken yet (two cells, by item parity), how many waves have left the item
 // (two cells), and how many items are complete.
 // k_scan's builds: plain, diagnostic (FLATGFA_DEBUG_SKIP), ranged (one of several walks of a graph beyond 16 M segments)
-constexpr int kModePlain = 0, kModeDbg = 1, kModeRanged = 2;
+constexpr int kModePlain = 0, kModeDbg = 1, kModeRanged = 2, kModeBig = 3, kModeRangedBig = 4;  // (Big: builds of their own for bucket arrays of 2^30 records or more, see put())
+constexpr bool mode_ranged(int m) { return m == kModeRanged || m == kModeRangedBig; }
+constexpr bool mode_big(int m) { return m == kModeBig || m == kModeRangedBig; }
 #ifndef FGFA_WIDE
 #define FGFA_WIDE 4
 #endif
@@ -909,7 +923,7 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
         lenm1[k] = (s[k].y - e[k].y - 1u) & 1023u;
         valid[k] = valid[k] && e[k].x != kInvalid;
         uint32_t id = e[k].x - (lenm1[k] & down);  // a downward run is emitted from its low end
-        if (MODE == kModeRanged) {  // (uniform) the run's part inside this walk's range, if any; beyond the graph: the bounds check below
+        if (mode_ranged(MODE)) {  // (uniform) the run's part inside this walk's range, if any; beyond the graph: the bounds check below
             const uint32_t hi = id + lenm1[k];
             const bool outside = hi >= A.n_total;
             const uint32_t lo2 = max(id, A.seg_base), hi2 = min(hi, A.seg_base + A.n_segs - 1u);
@@ -933,13 +947,13 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const uint32_t l1 = cross[k] ? wmask - rel[k] : lenm1[k];
-        ovf |= put<DBG>(A, w, mine, valid[k], pos[k], win[k], rel[k] | (l1 << wb) | w.tagc);
+        ovf |= put<DBG, mode_big(MODE)>(A, w, mine, valid[k], pos[k], win[k], rel[k] | (l1 << wb) | w.tagc);
     }
     if (__builtin_amdgcn_ballot_w64(any_cross)) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t pos2 = cross[k] ? atomicAdd(&bcur[win[k] + 1u], 1u) : 0u;
-            ovf |= put<DBG>(A, w, mine, cross[k], pos2, win[k] + 1u, ((lenm1[k] - (wmask - rel[k]) - 1u) << wb) | w.tagc);
+            ovf |= put<DBG, mode_big(MODE)>(A, w, mine, cross[k], pos2, win[k] + 1u, ((lenm1[k] - (wmask - rel[k]) - 1u) << wb) | w.tagc);
         }
     }
     flag_if_any(A, ovf, kStOverflow);
@@ -2793,12 +2807,23 @@ uint32_t scan_lds_bytes(uint32_t nwp, bool tagged_only = false) { return ((tagge
         }                                                                                   \
     } while (0)
 
-// The bucket array: capacity per (window, sub-bucket), bounded by the 32-bit / 24-bit slot
-// arithmetic of put().
+// The bucket array: capacity per (window, sub-bucket), bounded by the 24-bit slot arithmetic of
+// put() and by memory: up to 2^30 records (4 GB) without asking; beyond -- a graph of many windows
+// whose paths run along it leaves most sub-buckets empty and needs the few others deep -- up to a
+// quarter of the device memory that is free, 64 GB at most (FLATGFA_BUCKET_GB; the diagnostic build
+// of k_scan keeps the 32-bit offsets).
 // Returns 1 when it is allocated, 0 when the capacity would be too small to be useful, -1 on a HIP error.
 int alloc_buckets(FastPlan *fp, uint64_t want_cap) {
     const uint64_t slots = (uint64_t)fp->n_win * fp->n_slots;
-    const uint64_t max_cap = ((1ull << 30) - 1) / ((uint64_t)(fp->n_win + 1) * fp->n_slots);
+    uint64_t max_cap = ((1ull << 30) - 1) / ((uint64_t)(fp->n_win + 1) * fp->n_slots);
+    if (want_cap > max_cap && !fp->dbg && fp->tagged && !fp->n_short && !fp->n_medium) {  // (k_scan's tagged builds only)
+        size_t free_b = 0, total_b = 0;
+        uint64_t budget = 64ull << 30;
+        if (const char *e = getenv("FLATGFA_BUCKET_GB")) budget = strtoull(e, nullptr, 10) << 30;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<uint64_t>(budget, (uint64_t)free_b / 4 + (fp->buckets ? (slots + fp->n_slots) * (uint64_t)fp->cap * 4 : 0));
+        else (void)hipGetLastError();
+        max_cap = std::max<uint64_t>(max_cap, budget / 4 / ((uint64_t)(fp->n_win + 1) * fp->n_slots));
+    }
     uint64_t cap = std::min(want_cap, max_cap);
     cap = std::min<uint64_t>(cap, ((1ull << 24) - 1) / fp->n_slots);  // window * (n_slots * cap) + pos is a 24-bit multiply
     cap &= cap >= 64 ? ~31ull : ~3ull;  // sub-buckets start on 128-byte lines: neighbours (other workgroups, other XCDs) never share one
@@ -3178,6 +3203,8 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeDbg, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeRanged, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeRanged, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeBig, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeRangedBig, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     // pass 2 of a tagged call keeps its bitsets in dynamic shared memory (next to about 60 KB of static arrays, 93 KB with 8192-segment windows)
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 11, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(11, kMaxShared)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
@@ -3248,6 +3275,7 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
 // False when that would be out of proportion (then the caller walks the steps a second time).
 bool fast_plan_want_path_sums(FastPlan *fp) {
     if (!fp->eligible || fp->wb != 12 || fp->acc_parts > 1 || fp->n_more || fp->n_win > kMaxWin) return false;  // (the fused form needs a window's final depth in one workgroup, and the directory: k_scan's untagged build)
+    if (((uint64_t)fp->n_win + 1) * fp->n_slots * fp->cap >= (1ull << 30)) return false;  // (... which knows 32-bit bucket offsets only)
     if (fp->psum_part) return true;
     const uint64_t bytes = (uint64_t)fp->n_win * fp->dstride * 16;
     if (bytes > (256ull << 20)) return false;
@@ -3333,6 +3361,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     sa.cap = fp.cap;
     sa.stride = stride;
     sa.sink = fp.n_win * stride;
+    sa.big = ((uint64_t)fp.n_win + 1) * stride >= (1ull << 30) ? 1u : 0u;
     sa.status = status;
     sa.dbg = fp.dbg;
     // Tagged: k_scan's records name their items, pass 2 walks whole sub-buckets.  Path sums ride on
@@ -3398,6 +3427,9 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
         ProfScope pscope(fp.dense ? "k_scan_dense" : "k_scan", stream);
         if (fp.dense) hipLaunchKernelGGL(k_scan_dense, dim3(grid), dim3(kThreads), dense_lds_bytes(fp.nwp), stream, sa);
         else if (fp.dbg) hipLaunchKernelGGL((k_scan<kModeDbg, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
+        else if (sa.big && !tagged) { set_error("fast_seg_depth: a bucket array this large needs a tagged call"); return FLATGFA_ERR_ARG; }
+        else if (sa.big && sa.ranged) hipLaunchKernelGGL((k_scan<kModeRangedBig, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
+        else if (sa.big) hipLaunchKernelGGL((k_scan<kModeBig, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
         else if (sa.ranged && tagged) hipLaunchKernelGGL((k_scan<kModeRanged, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
         else if (sa.ranged) hipLaunchKernelGGL((k_scan<kModeRanged, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
         else if (tagged) hipLaunchKernelGGL((k_scan<kModePlain, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);

@@ -572,3 +572,32 @@ def test_more_windows_than_the_directory_allows(tagged, monkeypatch):
         if k != 1:
             assert (u.cpu().numpy().view(np.uint32) == want_u).all()
     plan.close()
+
+
+@pytest.mark.parametrize("n_segs,ranges", [(17_000_000, 1), (34_000_000, 2)])
+def test_bucket_arrays_beyond_four_gigabytes(n_segs, ranges, monkeypatch):
+    """A plan whose (windows x sub-buckets x capacity) reaches 2^30 records addresses its buckets
+    with 64-bit offsets (builds of k_scan of their own, whole-graph and ranged): what a graph of
+    many windows whose paths run along it needs -- most sub-buckets empty, the others deep.  Forced
+    here with a capacity of 2048 on 2076 windows per range (4.4 GB of scratch each)."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.setenv("FLATGFA_BUCKET_CAP", "2048")
+    for v in ("FLATGFA_RANGE_SEGS", "FLATGFA_MAX_WINDOWS", "FLATGFA_SHORT_MAX", "FLATGFA_WB", "FLATGFA_PIECE_STEPS", "FLATGFA_TAGGED", "FLATGFA_BUCKET_GB"):
+        monkeypatch.delenv(v, raising=False)
+    g = pa.synth(23, n_segs, 1000, 10_000, "chromosome", False)
+    steps, pb, pe, _ = g.soa()
+    want_d, want_u = fo.seg_depth_with_uniq(pools_of(g))
+    plan = DepthPlan(DeviceGraph(steps, pb, pe, n_segs))
+    text = plan.describe()
+    assert f"x8192 ranges={ranges} " in text and "pass2=tagged" in text and "bucket_cap=2048" in text, text
+    d = torch.zeros(n_segs, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(n_segs, dtype=torch.int32, device="cuda:0")
+    for k in range(2):
+        plan.seg_depth(d, u if k == 0 else None)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == want_d).all()
+        if k == 0:
+            assert (u.cpu().numpy().view(np.uint32) == want_u).all()
+    plan.close()
