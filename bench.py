@@ -63,6 +63,7 @@ WORKLOADS = {
     "cfgL-x16": (1_000_000, 16_000, 100_000, "pangenome"),    # 1.6 G steps = 6.4 GB of steps per GPU: the weak-scaling size
     "x16-16Mseg": (16_000_000, 16_000, 100_000, "pangenome"),  # the same on a graph of 16 M segments: a hundred steps per segment, as whole-genome graphs have
     "x16-16Mseg-chrom": (16_000_000, 16_000, 100_000, "chromosome"),  # ... with paths that run along the graph, as haplotypes do
+    "x16-16Mseg-contigs": (16_000_000, 160_000, 10_000, "chromosome"),  # ... in contigs of ten thousand steps: more items per workgroup than a record's tag can name
     "cfgS": (10_000, 100, 10_000, "pangenome"),
     "cfgM": (100_000, 100, 100_000, "pangenome"),             # 10 M steps
 }
