@@ -421,7 +421,7 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
         // (or any of the knobs that shape the bucketed path) skips the comparison.
         bool shaped = force != nullptr;
         for (const char *k : {"FLATGFA_PIECE_STEPS", "FLATGFA_SHORT_MAX", "FLATGFA_SHORT_ANY", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS",
-                              "FLATGFA_DEBUG_SKIP", "FLATGFA_WB", "FLATGFA_DENSE", "FLATGFA_TAGGED"})
+                              "FLATGFA_DEBUG_SKIP", "FLATGFA_WB", "FLATGFA_DENSE", "FLATGFA_TAGGED", "FLATGFA_PATH_GROUPS"})
             shaped = shaped || getenv(k) != nullptr;
         if (pl->fast.eligible && !shaped && g->n_steps <= (8u << 20)) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -665,7 +665,8 @@ extern "C" int flatgfa_dev_plan_describe(flatgfa_dev_plan_t *pl, char *out, int 
         s.pop_back();
         s += std::string("") +
             " pass2=" + (f.tagged ? (f.n_shared ? "tagged(shared bitsets)" : f.acc_pair ? "tagged(two workgroups per window)" : "tagged") : (f.big_groups ? "directory(one-item shortcut)" : "directory")) +
-            " windows=" + std::to_string(f.n_win) + "x" + std::to_string(1u << f.wb) + " ranges=" + std::to_string(f.n_more + 1) +
+            " windows=" + std::to_string(f.n_win) + "x" + std::to_string(1u << f.wb) + " ranges=" + std::to_string((f.n_more + 1) / f.n_groups) +
+            (f.n_groups > 1 ? " path_groups=" + std::to_string(f.n_groups) : std::string()) +
             " workgroups_per_window=" + std::to_string(f.acc_parts) + " items=" + std::to_string(f.n_items) + " split_paths=" + std::to_string(f.n_shared) +
             " short_paths=" + std::to_string(f.n_short) + " medium_paths=" + std::to_string(f.n_medium) + " bucket_cap=" + std::to_string(f.cap);
     }

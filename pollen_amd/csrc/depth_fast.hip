@@ -1439,6 +1439,7 @@ struct AccArgs {
     uint32_t *tprof;    // FLATGFA_ACC_TIME (diagnostic): sixteen words per wave, see AccTimer
     uint32_t *pair_part;  // k_accum_pair: [n_win][2][depth | revisits][window] the two workgroups' halves
     uint32_t *pair_flag;  // k_accum_pair: [n_win] how many halves are there (zero between calls)
+    uint32_t accumulate;  // the outputs hold the counts of the paths walked before (another group of the same call): add to them
 };
 
 // FLATGFA_ACC_TIME: charge the time since the last mark to phase `ph` of this wave; the wave's
@@ -2525,11 +2526,16 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
                 }
 #pragma unroll
                 for (int k = 0; k < kPer; ++k) u[k] = d[k] - rv[k];
-                store_n<kPer>(A.depth_out + w0, i0, nvalid, d);
-                store_n<kPer>(A.uniq_out + w0, i0, nvalid, u);
+                if (A.accumulate) {
+                    add_n<kPer>(A.depth_out + w0, i0, nvalid, d);
+                    add_n<kPer>(A.uniq_out + w0, i0, nvalid, u);
+                } else {
+                    store_n<kPer>(A.depth_out + w0, i0, nvalid, d);
+                    store_n<kPer>(A.uniq_out + w0, i0, nvalid, u);
+                }
                 if (tid == 0) __hip_atomic_store(&A.pair_flag[win], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (clean for the next call)
             }
-        } else if (A.parts > 1) {
+        } else if (A.parts > 1 || A.accumulate) {
             add_n<kPer>(A.depth_out + w0, i0, nvalid, d);
             add_n<kPer>(A.uniq_out + w0, i0, nvalid, u);
         } else {
@@ -2545,7 +2551,7 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
         block_scan<int, kPer>(reinterpret_cast<int *>(wave_tot), v);
 #pragma unroll
         for (int k = 0; k < kPer; ++k) d[k] = (uint32_t)v[k];
-        if (!PSUM && A.parts > 1) add_n<kPer>(A.depth_out + w0, i0, nvalid, d);
+        if (!PSUM && (A.parts > 1 || A.accumulate)) add_n<kPer>(A.depth_out + w0, i0, nvalid, d);
         else store_n<kPer>(A.depth_out + w0, i0, nvalid, d);
         if (PSUM) {
             unsigned long long l[kPer], w[kPer];
@@ -3021,10 +3027,13 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         const uint32_t grid = (fp->n_short || fp->n_medium) ? fp->n_slots : std::min<uint32_t>(fp->n_items, fp->n_slots);
         const uint64_t per_wg = grid ? ((uint64_t)fp->n_items + fp->max_back + grid - 1) / grid : 0;
         const char *t = getenv("FLATGFA_TAGGED");
-        fp->tagged = !fp->dbg && !(t && t[0] == '0') && per_wg + fp->n_shared <= kTagCount &&
-                     fp->n_shared <= (wb <= 12 ? kMaxShared : 0u) && (fp->n_shared == 0 || fp->acc_parts == 1);
+        const bool taggable = !fp->dbg && !(t && t[0] == '0') && fp->n_shared <= (wb <= 12 ? kMaxShared : 0u) && (fp->n_shared == 0 || fp->acc_parts == 1);
+        fp->tagged = taggable && per_wg + fp->n_shared <= kTagCount;
+        fp->too_many_items = taggable && !fp->tagged && fp->acc_parts == 1 && !fp->n_short && !fp->n_medium;  // (fast_plan_create may walk the paths in groups)
         if (!fp->tagged && n_win > kMaxWin) {  // so many windows only without cursor snapshots: the caller cuts smaller ranges
+            const bool many = fp->too_many_items;
             fast_plan_destroy(fp);
+            fp->too_many_items = many;
             return true;
         }
     }
@@ -3231,6 +3240,48 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     return true;
 }
 
+// The plans of all segment ranges for one set of path spans, appended to `plans`.  *all: every one
+// of them is eligible; *many: one of them is kept from tagged calls by its number of items alone.
+static bool append_ranges(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, uint32_t max_win, std::vector<FastPlan> *plans,
+                          bool *all, bool *many) {
+    uint64_t max_range = (uint64_t)max_win << 13;
+    if (const char *f = getenv("FLATGFA_RANGE_SEGS")) max_range = std::max<uint64_t>(8192, strtoull(f, nullptr, 10) & ~8191ull);  // tests
+    const uint32_t n_ranges = (uint32_t)((g.n_segs + max_range - 1) / max_range);
+    if (n_ranges > 64) {
+        *all = false;
+        return true;
+    }
+    const uint32_t per = (uint32_t)((((uint64_t)g.n_segs + n_ranges - 1) / n_ranges + 8191) & ~8191ull);
+    for (uint32_t r = 0; r < n_ranges; ++r) {
+        const uint32_t base = r * per;
+        FastPlan q;
+        if (!create_range(g, hb, he, &q, base, std::min<uint32_t>(per, g.n_segs - base), max_win)) {
+            fast_plan_destroy(&q);
+            return false;
+        }
+        *many = *many || q.too_many_items;
+        plans->push_back(q);
+        if (!q.eligible) {  // all ranges or none
+            *all = false;
+            break;
+        }
+    }
+    return true;
+}
+
+static void destroy_plans(std::vector<FastPlan> *plans) {
+    for (FastPlan &q : *plans) fast_plan_destroy(&q);
+    plans->clear();
+}
+
+static void adopt_plans(std::vector<FastPlan> *plans, FastPlan *fp) {
+    *fp = (*plans)[0];
+    fp->n_more = (uint32_t)plans->size() - 1;
+    fp->more = fp->n_more ? new FastPlan[fp->n_more] : nullptr;
+    for (uint32_t r = 0; r < fp->n_more; ++r) fp->more[r] = (*plans)[r + 1];
+    plans->clear();
+}
+
 bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp) {
     *fp = FastPlan();
     if (g.n_segs == 0 || g.n_paths == 0 || g.n_steps == 0) return true;
@@ -3240,33 +3291,92 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     // windows only for plans whose calls are tagged (k_scan then keeps one LDS table per window, not
     // two); when a range cannot be (FLATGFA_TAGGED=0, more split paths than pass 2 has bitsets
     // for), the ranges are cut again at 2048 windows.  FLATGFA_MAX_WINDOWS keeps the old cut-off (tests).
+    //
+    // A record's tag has nine bits: a k_scan workgroup can name 512 items (less the split paths).
+    // When only that keeps a plan from being tagged -- 131 k paths or more on a graph too large for
+    // the wave-per-path kernels -- the PATHS are walked in groups, each with plans of its own over
+    // the same ranges: the first group's pass 2 stores its counts, the others' add theirs.  Every
+    // step is still read once per range.  (FLATGFA_PATH_GROUPS=0: never; n: at least n groups, tests.)
     if (const char *off = getenv("FLATGFA_MAX_WINDOWS")) {
         const uint32_t wb = g.n_segs <= 1024u * 4096u ? 12u : 13u;
         if ((((uint64_t)g.n_segs + (1u << wb) - 1) >> wb) > strtoul(off, nullptr, 10)) return true;
     }
+    uint32_t want_groups = 1;
+    bool groups_ok = true;
+    if (const char *e = getenv("FLATGFA_PATH_GROUPS")) {
+        want_groups = (uint32_t)strtoul(e, nullptr, 10);
+        groups_ok = want_groups != 0;
+        want_groups = std::max(1u, std::min(64u, want_groups));
+    }
+    std::vector<uint32_t> busy;  // the paths that have steps
+    for (uint32_t p = 0; p < g.n_paths; ++p)
+        if (he[p] > hb[p]) busy.push_back(p);
     for (const uint32_t max_win : {kMaxWinTagged, kMaxWin}) {
-        uint64_t max_range = (uint64_t)max_win << 13;
-        if (const char *f = getenv("FLATGFA_RANGE_SEGS")) max_range = std::max<uint64_t>(8192, strtoull(f, nullptr, 10) & ~8191ull);  // tests
-        const uint32_t n_ranges = (uint32_t)((g.n_segs + max_range - 1) / max_range);
-        if (n_ranges > 64) return true;
-        const uint32_t per = (uint32_t)((((uint64_t)g.n_segs + n_ranges - 1) / n_ranges + 8191) & ~8191ull);
-        if (!create_range(g, hb, he, fp, 0, std::min<uint32_t>(per, g.n_segs), max_win)) return false;
-        bool all = fp->eligible;
-        if (all && n_ranges > 1) {
-            fp->more = new FastPlan[n_ranges - 1];
-            fp->n_more = n_ranges - 1;
-            for (uint32_t r = 1; r < n_ranges && all; ++r) {
-                const uint32_t base = r * per;
-                if (!create_range(g, hb, he, &fp->more[r - 1], base, std::min<uint32_t>(per, g.n_segs - base), max_win)) {
-                    fast_plan_destroy(fp);
+        std::vector<FastPlan> plans;
+        bool all = true, many = false;
+        if (want_groups == 1) {
+            if (!append_ranges(g, hb, he, max_win, &plans, &all, &many)) {
+                destroy_plans(&plans);
+                return false;
+            }
+            if (all && !(many && groups_ok)) {
+                adopt_plans(&plans, fp);
+                return true;
+            }
+        } else {
+            many = true;
+        }
+        if (many && groups_ok && busy.size() >= 2) {
+            // an even share of the paths per group; more groups while some group still has too many items (long paths are cut into pieces)
+            uint32_t hint_items = (uint32_t)busy.size(), hint_slots = 256;
+            if (!plans.empty() && plans[0].n_slots) {
+                hint_slots = plans[0].n_slots;
+                hint_items = std::max<uint32_t>(hint_items, plans[0].n_items);
+            }
+            destroy_plans(&plans);
+            uint32_t n_groups = std::max<uint32_t>(want_groups, (uint32_t)((hint_items + 384ull * hint_slots - 1) / (384ull * hint_slots)));
+            for (; n_groups <= 64 && n_groups <= busy.size(); n_groups *= 2) {
+                bool g_all = true, g_many = false, hip_ok = true;
+                std::vector<uint32_t> hbk(g.n_paths), hek(g.n_paths);
+                for (uint32_t k = 0; k < n_groups && g_all && hip_ok; ++k) {
+                    const size_t lo = busy.size() * k / n_groups, hi = busy.size() * (k + 1) / n_groups;
+                    for (uint32_t p = 0; p < g.n_paths; ++p) hbk[p] = hek[p] = hb[p];  // (a path outside the group: no steps)
+                    for (size_t i = lo; i < hi; ++i) hek[busy[i]] = he[busy[i]];
+                    const size_t first = plans.size();
+                    hip_ok = append_ranges(g, hbk.data(), hek.data(), max_win, &plans, &g_all, &g_many);
+                    for (size_t i = first; i < plans.size(); ++i) {
+                        plans[i].accumulate = k > 0;
+                        g_all = g_all && plans[i].tagged;  // (a group is only worth it tagged)
+                    }
+                }
+                if (!hip_ok) {
+                    destroy_plans(&plans);
                     return false;
                 }
-                all = fp->more[r - 1].eligible;
+                if (g_all && !plans.empty()) {
+                    adopt_plans(&plans, fp);
+                    fp->n_groups = n_groups;
+                    return true;
+                }
+                destroy_plans(&plans);
+                if (!g_many) break;  // (something else stands in the way)
+            }
+            // no luck: the plan the whole path set gets
+            all = true;
+            many = false;
+            if (!append_ranges(g, hb, he, max_win, &plans, &all, &many)) {
+                destroy_plans(&plans);
+                return false;
+            }
+            if (all) {
+                adopt_plans(&plans, fp);
+                return true;
             }
         }
-        if (all) return true;
-        fast_plan_destroy(fp);  // all ranges or none
-        if (((uint64_t)g.n_segs + 8191) / 8192 <= kMaxWin * (uint64_t)n_ranges) break;  // (the smaller cut-off would make the same ranges)
+        destroy_plans(&plans);
+        const uint64_t max_range = getenv("FLATGFA_RANGE_SEGS") ? 0 : (uint64_t)max_win << 13;
+        const uint64_t n_ranges = max_range ? (g.n_segs + max_range - 1) / max_range : 1;
+        if (((uint64_t)g.n_segs + 8191) / 8192 <= kMaxWin * n_ranges) break;  // (the smaller cut-off would make the same ranges)
     }
     return true;
 }
@@ -3374,7 +3484,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
                fp.work_counter, scan_skip ? 0u : fp.max_back, depth_out, uniq_out, status, fp.dbg,
                reinterpret_cast<const uint4 *>(fp.items), g.seg_len, ps ? reinterpret_cast<ulonglong2 *>(fp.psum_part) : nullptr,
-               fp.fat_off, fp.fat_woff, fp.acc_parts, tagged ? fp.n_shared : 0u, nullptr, fp.pair_part, fp.pair_flag};
+               fp.fat_off, fp.fat_woff, fp.acc_parts, tagged ? fp.n_shared : 0u, nullptr, fp.pair_part, fp.pair_flag, fp.accumulate ? 1u : 0u};
     if (const char *sk = getenv("FLATGFA_ACC_SKIP")) aa.dbg = (uint32_t)strtoul(sk, nullptr, 10);  // (diagnostic: pass 2 without its revisit counts 128 / depth 256 / claims 64 / words behind the first 1024)
     const size_t tprof_words = (size_t)fp.n_win * fp.acc_parts * kAccWaves * 16;
     if (getenv("FLATGFA_ACC_TIME") && uniq_out && hipMalloc(&aa.tprof, tprof_words * 4) != hipSuccess) aa.tprof = nullptr;
@@ -3420,7 +3530,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
         }
     }
     if (grid) {
-        if (fp.acc_parts > 1) {
+        if (fp.acc_parts > 1 && !fp.accumulate) {  // (a later group of paths adds to what is there)
             sa.zero_a = depth_out;
             sa.zero_b = uniq_out;
         }
@@ -3435,7 +3545,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
         else if (tagged) hipLaunchKernelGGL((k_scan<kModePlain, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
         else hipLaunchKernelGGL((k_scan<kModePlain, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
     }
-    if (fp.acc_parts > 1 && !grid) {  // the window's workgroups add to the outputs: cleared by k_scan, or here when it does not run
+    if (fp.acc_parts > 1 && !grid && !fp.accumulate) {  // the window's workgroups add to the outputs: cleared by k_scan, or here when it does not run
         ProfScope pscope("memset_outputs", stream);
         if (hipMemsetAsync(depth_out, 0, (size_t)fp.n_range * 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
         if (uniq_out && hipMemsetAsync(uniq_out, 0, (size_t)fp.n_range * 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
