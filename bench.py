@@ -64,6 +64,8 @@ WORKLOADS = {
     "x16-16Mseg": (16_000_000, 16_000, 100_000, "pangenome"),  # the same on a graph of 16 M segments: a hundred steps per segment, as whole-genome graphs have
     "x16-16Mseg-chrom": (16_000_000, 16_000, 100_000, "chromosome"),  # ... with paths that run along the graph, as haplotypes do
     "x16-16Mseg-contigs": (16_000_000, 160_000, 10_000, "chromosome"),  # ... in contigs of ten thousand steps: more items per workgroup than a record's tag can name
+    "x16-16Mseg-fewlong": (16_000_000, 16, 100_000_000, "chromosome"),  # ... in sixteen paths of a hundred million steps (each wraps around the graph six times)
+    "chr-like": (16_000_000, 90, 10_000_000, "chromosome"),    # a chromosome graph as the HPRC ones are shaped: ninety haplotype paths of ten million steps each
     "cfgS": (10_000, 100, 10_000, "pangenome"),
     "cfgM": (100_000, 100, 100_000, "pangenome"),             # 10 M steps
 }

@@ -2853,7 +2853,7 @@ int alloc_buckets(FastPlan *fp, uint64_t want_cap) {
 // The plan of one range of segments, [seg_base, seg_base + n_range): the whole graph, or one of
 // the ranges of a graph beyond 16 M segments.
 static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp, uint32_t seg_base,
-                         uint32_t n_range, uint32_t max_win) {
+                         uint32_t n_range, uint32_t max_win, uint32_t force_wb) {
     *fp = FastPlan();
     fp->seg_base = seg_base;
     fp->n_range = n_range;
@@ -2861,6 +2861,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // Windows of 4096 segments up to 4 M segments, of 8192 beyond (pass 2 keeps a window's
     // difference array and per-path bitsets in LDS).
     uint32_t wb = g.n_segs <= 1024u * 4096u ? 12u : 13u;
+    if (force_wb) wb = force_wb;  // (fast_plan_create: 4096-segment windows on a larger graph, for the sake of its split paths)
     if (const char *f = getenv("FLATGFA_WB")) wb = (uint32_t)strtoul(f, nullptr, 10);
     const uint32_t n_win = (uint32_t)(((uint64_t)n_range + (1u << wb) - 1) >> wb);
     if (n_win > max_win) return true;
@@ -3027,13 +3028,19 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         const uint32_t grid = (fp->n_short || fp->n_medium) ? fp->n_slots : std::min<uint32_t>(fp->n_items, fp->n_slots);
         const uint64_t per_wg = grid ? ((uint64_t)fp->n_items + fp->max_back + grid - 1) / grid : 0;
         const char *t = getenv("FLATGFA_TAGGED");
-        const bool taggable = !fp->dbg && !(t && t[0] == '0') && fp->n_shared <= (wb <= 12 ? kMaxShared : 0u) && (fp->n_shared == 0 || fp->acc_parts == 1);
+        const uint32_t shared_cap = wb <= 12 ? kMaxShared : 0u;
+        const bool base_ok = !fp->dbg && !(t && t[0] == '0') && (fp->n_shared == 0 || fp->acc_parts == 1);
+        const bool taggable = base_ok && fp->n_shared <= shared_cap;
         fp->tagged = taggable && per_wg + fp->n_shared <= kTagCount;
-        fp->too_many_items = taggable && !fp->tagged && fp->acc_parts == 1 && !fp->n_short && !fp->n_medium;  // (fast_plan_create may walk the paths in groups)
+        // what fast_plan_create may do about a plan that is not: walk the paths in groups (fewer items, fewer
+        // split paths per group), or take 4096-segment windows (pass 2 then has LDS for split paths' bitsets)
+        fp->too_many_items = base_ok && !fp->tagged && fp->acc_parts == 1 && !fp->n_short && !fp->n_medium && (taggable || (wb <= 12 && fp->n_shared > shared_cap));
+        fp->want_wb12 = base_ok && !fp->tagged && wb == 13 && fp->n_shared > 0 && fp->acc_parts == 1;
         if (!fp->tagged && n_win > kMaxWin) {  // so many windows only without cursor snapshots: the caller cuts smaller ranges
-            const bool many = fp->too_many_items;
+            const bool many = fp->too_many_items, w12 = fp->want_wb12;
             fast_plan_destroy(fp);
             fp->too_many_items = many;
+            fp->want_wb12 = w12;
             return true;
         }
     }
@@ -3242,9 +3249,9 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
 
 // The plans of all segment ranges for one set of path spans, appended to `plans`.  *all: every one
 // of them is eligible; *many: one of them is kept from tagged calls by its number of items alone.
-static bool append_ranges(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, uint32_t max_win, std::vector<FastPlan> *plans,
-                          bool *all, bool *many) {
-    uint64_t max_range = (uint64_t)max_win << 13;
+static bool append_ranges(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, uint32_t max_win, uint32_t force_wb,
+                          std::vector<FastPlan> *plans, bool *all, bool *many, bool *want12 = nullptr) {
+    uint64_t max_range = (uint64_t)max_win << (force_wb ? force_wb : 13u);
     if (const char *f = getenv("FLATGFA_RANGE_SEGS")) max_range = std::max<uint64_t>(8192, strtoull(f, nullptr, 10) & ~8191ull);  // tests
     const uint32_t n_ranges = (uint32_t)((g.n_segs + max_range - 1) / max_range);
     if (n_ranges > 64) {
@@ -3255,11 +3262,12 @@ static bool append_ranges(const flatgfa_dev_graph_t &g, const uint32_t *hb, cons
     for (uint32_t r = 0; r < n_ranges; ++r) {
         const uint32_t base = r * per;
         FastPlan q;
-        if (!create_range(g, hb, he, &q, base, std::min<uint32_t>(per, g.n_segs - base), max_win)) {
+        if (!create_range(g, hb, he, &q, base, std::min<uint32_t>(per, g.n_segs - base), max_win, force_wb)) {
             fast_plan_destroy(&q);
             return false;
         }
         *many = *many || q.too_many_items;
+        if (want12) *want12 = *want12 || q.want_wb12;
         plans->push_back(q);
         if (!q.eligible) {  // all ranges or none
             *all = false;
@@ -3311,13 +3319,37 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
     std::vector<uint32_t> busy;  // the paths that have steps
     for (uint32_t p = 0; p < g.n_paths; ++p)
         if (he[p] > hb[p]) busy.push_back(p);
-    for (const uint32_t max_win : {kMaxWinTagged, kMaxWin}) {
+    // (max_win, force_wb) by preference: 4096 windows of the graph's own size; the same with 4096-segment
+    // windows when the split paths of a larger graph ask for them (their bitsets need the LDS that
+    // 8192-segment windows take: a graph of 16 M segments walked by ninety paths of ten million
+    // steps would otherwise have no tagged plan, nor -- its buckets beyond 2^30 records -- any);
+    // then 2048 windows, the untagged plans' limit.
+    struct Try {
+        uint32_t max_win, force_wb;
+    };
+    std::vector<Try> tries{{kMaxWinTagged, 0u}};
+    bool tried_wb12 = false;
+    for (size_t ti = 0; ti < tries.size(); ++ti) {
+        const uint32_t max_win = tries[ti].max_win, force_wb = tries[ti].force_wb;
         std::vector<FastPlan> plans;
-        bool all = true, many = false;
+        bool all = true, many = false, want12 = false;
         if (want_groups == 1) {
-            if (!append_ranges(g, hb, he, max_win, &plans, &all, &many)) {
+            if (!append_ranges(g, hb, he, max_win, force_wb, &plans, &all, &many, &want12)) {
                 destroy_plans(&plans);
                 return false;
+            }
+            bool all_tagged = all;
+            for (const FastPlan &q : plans) all_tagged = all_tagged && q.tagged;
+            if (want12 && !all_tagged && !force_wb && !tried_wb12 && !getenv("FLATGFA_WB") && !getenv("FLATGFA_RANGE_SEGS")) {
+                tried_wb12 = true;
+                tries.push_back({kMaxWinTagged, 12u});  // next; if that does not yield a tagged plan either, this try comes again
+                tries.push_back({max_win, 0u});
+                destroy_plans(&plans);
+                continue;
+            }
+            if (force_wb && !all_tagged && !many) {  // (the smaller windows were for tags' sake only)
+                destroy_plans(&plans);
+                continue;
             }
             if (all && !(many && groups_ok)) {
                 adopt_plans(&plans, fp);
@@ -3335,6 +3367,7 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
             }
             destroy_plans(&plans);
             uint32_t n_groups = std::max<uint32_t>(want_groups, (uint32_t)((hint_items + 384ull * hint_slots - 1) / (384ull * hint_slots)));
+            n_groups = std::max(n_groups, 2u);
             for (; n_groups <= 64 && n_groups <= busy.size(); n_groups *= 2) {
                 bool g_all = true, g_many = false, hip_ok = true;
                 std::vector<uint32_t> hbk(g.n_paths), hek(g.n_paths);
@@ -3343,7 +3376,7 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
                     for (uint32_t p = 0; p < g.n_paths; ++p) hbk[p] = hek[p] = hb[p];  // (a path outside the group: no steps)
                     for (size_t i = lo; i < hi; ++i) hek[busy[i]] = he[busy[i]];
                     const size_t first = plans.size();
-                    hip_ok = append_ranges(g, hbk.data(), hek.data(), max_win, &plans, &g_all, &g_many);
+                    hip_ok = append_ranges(g, hbk.data(), hek.data(), max_win, force_wb, &plans, &g_all, &g_many);
                     for (size_t i = first; i < plans.size(); ++i) {
                         plans[i].accumulate = k > 0;
                         g_all = g_all && plans[i].tagged;  // (a group is only worth it tagged)
@@ -3361,10 +3394,11 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
                 destroy_plans(&plans);
                 if (!g_many) break;  // (something else stands in the way)
             }
+            if (force_wb) continue;  // (the smaller windows were for tags' sake only)
             // no luck: the plan the whole path set gets
             all = true;
             many = false;
-            if (!append_ranges(g, hb, he, max_win, &plans, &all, &many)) {
+            if (!append_ranges(g, hb, he, max_win, force_wb, &plans, &all, &many)) {
                 destroy_plans(&plans);
                 return false;
             }
@@ -3374,9 +3408,11 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
             }
         }
         destroy_plans(&plans);
-        const uint64_t max_range = getenv("FLATGFA_RANGE_SEGS") ? 0 : (uint64_t)max_win << 13;
-        const uint64_t n_ranges = max_range ? (g.n_segs + max_range - 1) / max_range : 1;
-        if (((uint64_t)g.n_segs + 8191) / 8192 <= kMaxWin * n_ranges) break;  // (the smaller cut-off would make the same ranges)
+        if (ti + 1 == tries.size() && max_win == kMaxWinTagged && !force_wb) {
+            const uint64_t max_range = getenv("FLATGFA_RANGE_SEGS") ? 0 : (uint64_t)max_win << 13;
+            const uint64_t n_ranges = max_range ? (g.n_segs + max_range - 1) / max_range : 1;
+            if (((uint64_t)g.n_segs + 8191) / 8192 > kMaxWin * n_ranges) tries.push_back({kMaxWin, 0u});  // (else the smaller cut-off would make the same ranges)
+        }
     }
     return true;
 }

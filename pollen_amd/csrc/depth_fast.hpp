@@ -51,7 +51,8 @@ struct FastPlan {
     uint32_t n_items = 0;
     uint32_t max_back = 0;
     bool accumulate = false;       // a group of paths behind the first (see fast_plan_create): pass 2 adds to the outputs
-    bool too_many_items = false;   // create_range's verdict: only the number of items per k_scan workgroup stands between this range and a tagged plan
+    bool too_many_items = false;   // create_range's verdict: only the number of items (or of split paths) per k_scan workgroup stands between this range and a tagged plan
+    bool want_wb12 = false;        // ... or only the split paths' bitsets, for which pass 2 has LDS with 4096-segment windows
     uint32_t n_groups = 1;         // (of the first plan) path groups the ranges of `more` belong to
     bool exact_short = false;      // the wave-per-path lists hold only paths that fit: nothing is handed back to k_scan
     void *short_items = nullptr;   // uint4[n_short] paths every wave walks on its own (k_scan_short): first those read from the graph's
