@@ -66,6 +66,8 @@ WORKLOADS = {
     "x16-16Mseg-contigs": (16_000_000, 160_000, 10_000, "chromosome"),  # ... in contigs of ten thousand steps: more items per workgroup than a record's tag can name
     "x16-16Mseg-fewlong": (16_000_000, 16, 100_000_000, "chromosome"),  # ... in sixteen paths of a hundred million steps (each wraps around the graph six times)
     "chr-like": (16_000_000, 90, 10_000_000, "chromosome"),    # a chromosome graph as the HPRC ones are shaped: ninety haplotype paths of ten million steps each
+    "chr-like-40M": (40_000_000, 90, 20_000_000, "chromosome"),  # ... on forty million segments: beyond one range of 4096-segment windows
+    "chr-like-2k": (16_000_000, 2000, 500_000, "chromosome"),     # ... walked by two thousand paths of half a million steps
     "cfgS": (10_000, 100, 10_000, "pangenome"),
     "cfgM": (100_000, 100, 100_000, "pangenome"),             # 10 M steps
 }

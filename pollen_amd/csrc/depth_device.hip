@@ -347,6 +347,12 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
             if (!(st & 4u)) break;  // (an out-of-range id is reported by the query that meets it)
             (void)fast_plan_grow(&pl->fast);
         }
+        {   // ... and with headroom: k_scan deals its items to the workgroups as they come, so another call may
+            // fill a sub-bucket that was half full this time to the brim (see flatgfa_dev_status)
+            uint32_t fullest = 0;
+            if (hipMemcpy(&fullest, pl->status + 2, 4, hipMemcpyDeviceToHost) == hipSuccess && fullest && pl->fast.eligible) (void)fast_plan_grow(&pl->fast, true);
+            (void)hipMemset(pl->status, 0, 12);
+        }
         // More than a record for two steps: pass 1 by partition (k_scan_dense) may beat pass 1 by runs.
         // The plan was sized for it (it makes the most records); now both are timed.
         {
@@ -611,11 +617,20 @@ extern "C" int flatgfa_dev_status(flatgfa_dev_plan_t *pl, void *stream_) {
     if (!pl) return FLATGFA_ERR_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     for (int attempt = 0;; ++attempt) {
-        uint32_t st = 0;
-        HIP_TRY(hipMemcpyAsync(&st, pl->status, 4, hipMemcpyDeviceToHost, stream), return FLATGFA_ERR_HIP);
+        uint32_t st3[3] = {0, 0, 0};  // the flags; -; the fullest sub-bucket beyond half of the capacity
+        HIP_TRY(hipMemcpyAsync(st3, pl->status, 12, hipMemcpyDeviceToHost, stream), return FLATGFA_ERR_HIP);
         HIP_TRY(hipStreamSynchronize(stream), return FLATGFA_ERR_HIP);
+        const uint32_t st = st3[0];
         const uint32_t n_calls = pl->calls_since_status;
         if (attempt == 0) pl->calls_since_status = 0;
+        if (st3[2]) {
+            // A call filled a sub-bucket more than half: k_scan deals its items to the workgroups as they
+            // come, so a later call may fill it differently -- on a graph whose paths run along it,
+            // twice as much when two of a workgroup's items meet in a window.  Make room now (no call
+            // is in flight), not when a call enqueued among others has already run out.
+            HIP_TRY(hipMemsetAsync(pl->status + 2, 0, 4, stream), return FLATGFA_ERR_HIP);
+            if (!(st & (4u | 16u)) && pl->fast.eligible) (void)fast_plan_grow(&pl->fast, true);  // (a plan at its limit stays as it is)
+        }
         if (!st) return FLATGFA_OK;
         HIP_TRY(hipMemsetAsync(pl->status, 0, 4, stream), return FLATGFA_ERR_HIP);
         if (st & 1u) {
@@ -623,7 +638,10 @@ extern "C" int flatgfa_dev_status(flatgfa_dev_plan_t *pl, void *stream_) {
             return FLATGFA_ERR_BOUNDS;
         }
         if (st & 8u) {  // (depth_fast.hip: kStInternal)
-            set_error("node depth: internal error (the records of pass 1 were not in the order pass 2 relies on)");
+            char what[512] = "";
+            (void)flatgfa_dev_plan_describe(pl, what, (int)sizeof what);
+            set_error("node depth: internal error (the records of pass 1 were not in the order pass 2 relies on); status words " + std::to_string(st3[0]) + " " +
+                      std::to_string(st3[1]) + " " + std::to_string(st3[2]) + ", " + std::to_string(n_calls) + " call(s) since the last status; plan: " + what);
             return FLATGFA_ERR_HIP;
         }
         if (!(st & (4u | 16u))) return FLATGFA_OK;

@@ -2444,6 +2444,9 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
         uint32_t *c = A.counts + (size_t)win * A.n_slots + sl;
         uint32_t v = *c;
         *c = 0u;
+        // (a sub-bucket more than half full: flatgfa_dev_status makes room before a later call -- whose
+        // items k_scan may deal to other workgroups -- runs out of it)
+        if (v > (A.cap >> 1)) atomicMax(A.status + 2, v);
         if (TAGGED && UNIQ) {
             const uint32_t c1 = min(v, A.cap);
             v = min(A.has_pre == 1 ? A.counts0[(size_t)win * A.n_slots + sl] : A.has_pre ? v : 0u, c1);  // (2: k_scan did not run, all are earlier records)
@@ -2834,17 +2837,17 @@ int alloc_buckets(FastPlan *fp, uint64_t want_cap) {
     cap = std::min<uint64_t>(cap, ((1ull << 24) - 1) / fp->n_slots);  // window * (n_slots * cap) + pos is a 24-bit multiply
     cap &= cap >= 64 ? ~31ull : ~3ull;  // sub-buckets start on 128-byte lines: neighbours (other workgroups, other XCDs) never share one
     if (cap < 4) return 0;
-    if (fp->buckets) {
-        (void)hipFree(fp->buckets);
-        fp->buckets = nullptr;
-    }
-    fp->cap = (uint32_t)cap;
-    const hipError_t e = hipMalloc(&fp->buckets, (slots + fp->n_slots) * cap * 4);
+    if (fp->buckets && cap <= fp->cap) return 1;  // (at its limit: the array stays as it is)
+    uint32_t *fresh = nullptr;
+    const hipError_t e = hipMalloc(&fresh, (slots + fp->n_slots) * cap * 4);  // (the new one first: a plan that cannot grow keeps what it has)
     if (e != hipSuccess) {
+        (void)hipGetLastError();
         set_error(std::string("hipMalloc(buckets): ") + hipGetErrorString(e));
-        fp->buckets = nullptr;
-        return -1;
+        return fp->buckets ? 1 : -1;
     }
+    if (fp->buckets) (void)hipFree(fp->buckets);
+    fp->buckets = fresh;
+    fp->cap = (uint32_t)cap;
     return 1;
 }
 
@@ -3440,11 +3443,11 @@ static bool grow_range(FastPlan *fp) {
     return fp->cap > before;  // else the slot arithmetic allows no more
 }
 
-bool fast_plan_grow(FastPlan *fp) {
+bool fast_plan_grow(FastPlan *fp, bool ahead_of_need) {
     if (!fp->eligible || fp->cap_forced) return false;
     bool ok = grow_range(fp);
-    for (uint32_t r = 0; r < fp->n_more && ok; ++r) ok = grow_range(&fp->more[r]);  // (the status word does not say which range ran out)
-    if (!ok) fp->eligible = false;  // the atomic kernels take over
+    for (uint32_t r = 0; r < fp->n_more && (ok || ahead_of_need); ++r) ok = grow_range(&fp->more[r]) && ok;  // (the status word does not say which range ran out)
+    if (!ok && !ahead_of_need) fp->eligible = false;  // the atomic kernels take over
     return ok;
 }
 
