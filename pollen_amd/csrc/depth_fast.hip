@@ -3436,17 +3436,18 @@ bool fast_plan_want_path_sums(FastPlan *fp) {
     return true;
 }
 
-// After a call that ran out of sub-bucket room: four times the capacity, if that is possible.
-static bool grow_range(FastPlan *fp) {
+// After a call that ran out of sub-bucket room: four times the capacity, if that is possible (twice, ahead of need).
+static bool grow_range(FastPlan *fp, uint32_t factor) {
     const uint32_t before = fp->cap;
-    if (alloc_buckets(fp, (uint64_t)before * 4) <= 0) return false;
+    if (alloc_buckets(fp, (uint64_t)before * factor) <= 0) return false;
     return fp->cap > before;  // else the slot arithmetic allows no more
 }
 
 bool fast_plan_grow(FastPlan *fp, bool ahead_of_need) {
     if (!fp->eligible || fp->cap_forced) return false;
-    bool ok = grow_range(fp);
-    for (uint32_t r = 0; r < fp->n_more && (ok || ahead_of_need); ++r) ok = grow_range(&fp->more[r]) && ok;  // (the status word does not say which range ran out)
+    const uint32_t factor = ahead_of_need ? 2u : 4u;  // (ahead of need: what was more than half full is then at most half full)
+    bool ok = grow_range(fp, factor);
+    for (uint32_t r = 0; r < fp->n_more && (ok || ahead_of_need); ++r) ok = grow_range(&fp->more[r], factor) && ok;  // (the status word does not say which range ran out)
     if (!ok && !ahead_of_need) fp->eligible = false;  // the atomic kernels take over
     return ok;
 }
