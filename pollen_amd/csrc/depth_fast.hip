@@ -43,6 +43,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <queue>
 #include <cstdlib>
 #include <numeric>
 #include <string>
@@ -2993,6 +2994,31 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
                 piece = cand;
             }
             if (cand == 32768) break;
+        }
+        // Cutting has a price beyond the turnaround where pass 2 cannot give all split paths a bitset
+        // of their own kind -- none at all with 8192-segment windows, 128 with smaller ones: the plan
+        // then takes smaller windows, more ranges, or walks the paths in groups (fast_plan_create).  A
+        // graph of thousands of paths rarely needs its long ones cut: k_scan's workgroups take the
+        // items longest first as they get to them, and if whole paths dealt that way (to the least
+        // loaded workgroup each) leave the longest hand within a tenth of the best cut's, they stay whole.
+        if (piece && !getenv("FLATGFA_KEEP_CUTS")) {
+            std::vector<uint4> trial;
+            const uint32_t n_split = cut(piece, &trial);
+            if (n_split > (wb <= 12 ? kMaxShared : 0u)) {
+                std::vector<uint64_t> lens;
+                for (const uint4 &w : whole) lens.push_back((uint64_t)w.y - w.x);
+                std::sort(lens.begin(), lens.end(), std::greater<uint64_t>());
+                std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> hands;
+                for (uint32_t i = 0; i < fp->n_slots; ++i) hands.push(0);
+                uint64_t longest = 0;
+                for (const uint64_t n : lens) {
+                    const uint64_t h = hands.top() + n + kTurnaround;
+                    hands.pop();
+                    hands.push(h);
+                    longest = std::max(longest, h);
+                }
+                if (longest <= best + best / 10) piece = ~0ull >> 1;  // (longer than any path)
+            }
         }
     }
     fp->n_shared = cut(piece ? piece : 32768, &items);
