@@ -457,6 +457,11 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
         }
         (void)hipFree(tmp);
     }
+    // Everything above went through the null stream, which a caller's non-blocking stream does not
+    // wait for -- and a memset of device memory need not have happened when hipMemset returns: a
+    // plan without a trial call (no paths, say) could have its status words read, on the caller's
+    // stream, before they were cleared (seen once: a freed block's contents taken for status bits).
+    (void)hipStreamSynchronize(nullptr);
     return pl;
 }
 
