@@ -494,6 +494,7 @@ flatgfa_sharded_t *flatgfa_sharded_create(flatgfa_t gfa, const int *devices, int
         if (S) {
             CR_HIP(hipMalloc(&s.d_send, cnt * 4));
             CR_HIP(hipMemset(s.d_send, 0, cnt * 4));  // (the touch vectors of the split paths this shard holds no piece of stay zero)
+            CR_HIP(hipStreamSynchronize(nullptr));     // (the shard's own stream does not wait for the null stream)
             if (n_shards == 1 && !h->use_rccl) {
                 s.d_recv = s.d_send;
             } else {
