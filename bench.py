@@ -68,6 +68,8 @@ WORKLOADS = {
     "chr-like": (16_000_000, 90, 10_000_000, "chromosome"),    # a chromosome graph as the HPRC ones are shaped: ninety haplotype paths of ten million steps each
     "chr-like-40M": (40_000_000, 90, 20_000_000, "chromosome"),  # ... on forty million segments: beyond one range of 4096-segment windows
     "chr-like-2k": (16_000_000, 2000, 500_000, "chromosome"),     # ... walked by two thousand paths of half a million steps
+    "hap-16M": (16_000_000, 16_000, 100_000, "haplotype"),    # sixteen thousand haplotype walks of a hundred thousand steps that stay in their neighbourhood
+    "hap-chr": (16_000_000, 90, 10_000_000, "haplotype"),      # ninety of ten million steps
     "cfgS": (10_000, 100, 10_000, "pangenome"),
     "cfgM": (100_000, 100, 100_000, "pangenome"),             # 10 M steps
 }

@@ -102,7 +102,9 @@ int flatgfa_write_flatgfa_prealloc(flatgfa_t gfa, const char *filename, const ui
 int flatgfa_print_gfa(flatgfa_t gfa, char **text, size_t *len);
 void flatgfa_free_text(char *text);
 /* Deterministic synthetic graph; model 0 = pangenome walk, 1 = uniform,
- * 2 = chromosome (paths walk along the graph, every other one downwards). */
+ * 2 = chromosome (paths walk along the graph, every other one downwards; one step in a hundred
+ * jumps anywhere), 3 = haplotype (the same without those jumps: one step in 1600 skips up to 1087
+ * segments). */
 flatgfa_t flatgfa_synth(uint64_t seed, uint32_t n_segs, uint32_t n_paths, uint32_t steps_per_path, int model,
                         bool with_seq);
 

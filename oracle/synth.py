@@ -19,6 +19,8 @@ bit-for-bit.  This file is the readable definition:
                 chromosome (paths walk along the graph; odd paths downwards, handles flipped):
                            d = u<70: 1 | u<95: 2+(k&3) | u<99: 8+(k&63) | else: jump to j%S
                            even p: cur+d, odd p: cur-d (mod S); handle orientation bit ^= p&1
+                haplotype: as chromosome, but u>=99 does not jump anywhere: d = 1, or, when k & 0xF0 == 0
+                           (one step in 1600), d = 64 + (j & 1023) -- a structural variant, not another chromosome
                 cur %= S
   steps of path p occupy steps[p*L:(p+1)*L]  (contiguous, in order: parse.rs:149-159)
 """
@@ -50,7 +52,7 @@ def seg_lens(seed: int, S: int) -> np.ndarray:
 
 def steps(seed: int, S: int, P: int, L: int, model: str = "pangenome") -> np.ndarray:
     """Returns the flat u32 handle array, shape (P*L,)."""
-    assert model in ("pangenome", "uniform", "chromosome")
+    assert model in ("pangenome", "uniform", "chromosome", "haplotype")
     out = np.zeros((P, L), dtype=np.uint32)
     with np.errstate(over="ignore"):
         state = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) * GOLDEN + np.arange(P, dtype=np.uint64)
@@ -64,15 +66,17 @@ def steps(seed: int, S: int, P: int, L: int, model: str = "pangenome") -> np.nda
             j = r >> np.uint64(32)
             if model == "uniform":
                 cur = j % np.uint64(S)
-            elif model == "chromosome":
+            elif model in ("chromosome", "haplotype"):
                 odd = np.arange(P, dtype=np.uint64) & np.uint64(1)
                 out[:, t] ^= odd.astype(np.uint32)
                 u = (r >> np.uint64(8)) % np.uint64(100)
                 k = (r >> np.uint64(16)) & np.uint64(0xFF)
                 d = np.where(u < 70, np.uint64(1), np.where(u < 95, np.uint64(2) + (k & np.uint64(3)), np.uint64(8) + (k & np.uint64(63))))
+                if model == "haplotype":
+                    d = np.where(u >= 99, np.where((k & np.uint64(0xF0)) != 0, np.uint64(1), np.uint64(64) + (j & np.uint64(1023))), d)
                 d = d % np.uint64(S)
                 moved = np.where(odd == 1, cur + np.uint64(S) - d, cur + d) % np.uint64(S)
-                cur = np.where(u < 99, moved, j % np.uint64(S))
+                cur = moved if model == "haplotype" else np.where(u < 99, moved, j % np.uint64(S))
             else:
                 u = (r >> np.uint64(8)) % np.uint64(100)
                 k = (r >> np.uint64(16)) & np.uint64(0xFF)

@@ -180,7 +180,7 @@ void emit_overlap(const View &v, const uint32_t *query_ids, size_t n_q, const ui
                   std::string *out);
 
 // The synthetic-graph generator of SURVEY.md 8(d) (spec: oracle/synth.py).
-// model 0 = pangenome, 1 = uniform.
+// model 0 = pangenome, 1 = uniform, 2 = chromosome, 3 = haplotype (oracle/synth.py has the spec).
 void synth_store(uint64_t seed, uint32_t S, uint32_t P, uint32_t L, int model, bool with_seq, Store *out);
 
 // A read-only memory-mapped file (memfile.rs:7-10).

@@ -29,12 +29,13 @@ void walk(uint64_t seed, uint32_t S, uint32_t p, uint32_t L, int model, Handle *
         uint64_t j = r >> 32;
         if (model == 1) {
             cur = j % S;
-        } else if (model == 2) {  // chromosome: along the graph, odd paths downwards with flipped handles
+        } else if (model == 2 || model == 3) {  // chromosome: along the graph, odd paths downwards with flipped handles
             out[t].bits ^= p & 1u;
             uint64_t u = (r >> 8) % 100, k = (r >> 16) & 0xFF;
             uint64_t d = u < 70 ? 1 : u < 95 ? 2 + (k & 3) : 8 + (k & 63);
+            if (model == 3 && u >= 99) d = (k & 0xF0) ? 1 : 64 + (j & 1023);  // haplotype: no jumps anywhere; one step in 1600 skips up to 1087 segments (a structural variant, not another chromosome)
             d %= S;
-            cur = u < 99 ? ((p & 1u) ? cur + S - d : cur + d) % S : j % S;
+            cur = (u < 99 || model == 3) ? ((p & 1u) ? cur + S - d : cur + d) % S : j % S;
         } else {
             uint64_t u = (r >> 8) % 100, k = (r >> 16) & 0xFF;
             if (u < 90) cur += 1;

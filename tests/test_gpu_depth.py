@@ -287,7 +287,7 @@ def test_more_synthetic_graphs_match_slow_odgi_goldens(name, cfg, device_path):
     assert g.depth_table() == read(os.path.join(GOLDEN, name + ".depth.tsv"))
 
 
-@pytest.mark.parametrize("model", ["pangenome", "uniform", "chromosome"])
+@pytest.mark.parametrize("model", ["pangenome", "uniform", "chromosome", "haplotype"])
 def test_cfgL_full_size(model):
     # BASELINE.json configs[2]: 1M segments / 100M steps.  Checked against the oracle (a few
     # seconds of CPU) and through size-independent properties.

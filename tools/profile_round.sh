@@ -13,7 +13,7 @@ for w in cfgL cfgL-uniform cfgL-chrom cfgL-short cfgL-fewlong cfgL-4paths cfgL-m
   [ -s $OUT/${TAG}_bench_$w.json ] || timeout 600 python3 bench.py --steps 40 --warmup 3 --workload $w --no-extras 2>>$OUT/_bench_$w.err | tail -1 > $OUT/${TAG}_bench_$w.json
 done
 # 1b. chromosome-scale graphs (0.9 - 1.8 G steps; the secondary measurements are cfg-L's business)
-for w in chr-like chr-like-2k cfgL-x16 x16-16Mseg x16-16Mseg-chrom x16-16Mseg-contigs x16-16Mseg-fewlong chr-like-40M; do
+for w in chr-like chr-like-2k hap-16M hap-chr cfgL-x16 x16-16Mseg x16-16Mseg-chrom x16-16Mseg-contigs x16-16Mseg-fewlong chr-like-40M; do
   timeout 900 python3 bench.py --steps 10 --warmup 2 --workload $w --no-extras --no-cpu-baseline 2>$OUT/_bench_$w.err | tail -1 > $OUT/${TAG}_bench_$w.json
 done
 # 2. kernel trace + stats of the same command (csv)
