@@ -2775,6 +2775,12 @@ __global__ __launch_bounds__(kThreads) void k_scan_dense(const ScanArgs A) {
 // Plan time: which way each of k_scan's items runs through the segment ids.  Bit 0 of items[j].z = 1 when
 // more of its steps follow their predecessor downwards (id - 1) than upwards (id + 1), else 0.
 // One workgroup per item at a time.
+// the segment a path starts at (plan creation: paths of equal length are dealt out in this order)
+__global__ __launch_bounds__(256) void k_first_ids(const uint32_t *__restrict__ steps, const uint32_t *__restrict__ at, uint32_t n, uint32_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] = steps[at[i]] >> 1;
+}
+
 __global__ __launch_bounds__(256) void k_item_dirs(const uint32_t *__restrict__ steps, uint4 *__restrict__ items, uint32_t n_items,
                                                     unsigned long long *__restrict__ n_runs) {
     __shared__ uint32_t up, down;
@@ -2932,6 +2938,31 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         } else {
             whole.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
         }
+    }
+    // Paths of equal length -- the ties of the sort below -- are walked in the order of where they
+    // start: k_scan's workgroups take the items one after the other, so neighbours in the list go to
+    // different workgroups, and it is the paths that start near each other that meet in a window.  A
+    // sub-bucket then holds one path's records of its window, not those of the five or six that
+    // chance gave one workgroup (the capacity every sub-bucket gets is the fullest one's, §2).
+    if (whole.size() > 1 && !getenv("FLATGFA_KEEP_PATH_ORDER")) {
+        std::vector<uint32_t> at(whole.size()), first(whole.size(), 0u);
+        for (size_t i = 0; i < whole.size(); ++i) at[i] = whole[i].x;
+        uint32_t *d_at = nullptr;
+        FAST_TRY(hipMalloc(&d_at, whole.size() * 8));
+        hipError_t e = hipMemcpy(d_at, at.data(), whole.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_first_ids, dim3((uint32_t)((whole.size() + 255) / 256)), dim3(256), 0, nullptr, g.steps, d_at, (uint32_t)whole.size(),
+                               d_at + whole.size());
+            e = hipMemcpy(first.data(), d_at + whole.size(), whole.size() * 4, hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(d_at);
+        FAST_TRY(e);
+        std::vector<uint32_t> order(whole.size());
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return first[a] < first[b]; });
+        std::vector<uint4> sorted(whole.size());
+        for (size_t i = 0; i < whole.size(); ++i) sorted[i] = whole[order[i]];
+        whole.swap(sorted);
     }
     if (!rev_list.empty()) {
         fp->n_rev_steps = (uint32_t)(rev_len + 1024);  // (a block is read whole)
