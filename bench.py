@@ -209,11 +209,14 @@ def main():
                              "refusing to report a number")
 
     # ---- timed region: exactly K steps ----
-    # Kernel durations come from HIP events recorded around each launch, inside this region, on
-    # every EVENT_EVERY-th step: a step with its four event records takes 0.20 ms where the others take
-    # 0.15 (the records are queue packets of their own, each with a completion signal), and the
-    # value reported is the whole region's throughput -- every fourth step cost it 8 %.
-    EVENT_EVERY = 10
+    # Kernel durations come from HIP events recorded around each launch on the launch stream.  A step
+    # that carries its four event records takes 0.20 ms where the others take 0.15 (the records are
+    # queue packets of their own, each with a completion signal), and `value` is the whole region's
+    # throughput, so inside the region only every EVENT_EVERY-th step is sampled -- never step 0, the
+    # first launch behind a full sync -- and SAMPLE_STEPS more steps, every one of them sampled, follow
+    # right behind the region on the same stream (two unsampled steps first).  The roofline uses all of
+    # these warm samples; both groups are also reported on their own.
+    EVENT_EVERY, EVENT_AT, SAMPLE_STEPS = 10, 5, 16
 
     def timed_loop(run_step, n_steps, with_events):
         dev.profile_enable(False)
@@ -222,15 +225,26 @@ def main():
         t0 = time.perf_counter()
         for i in range(n_steps):
             if with_events:
-                dev.profile_enable(i % EVENT_EVERY == 0)
+                dev.profile_enable(i % EVENT_EVERY == EVENT_AT)
             run_step(i)
         sync_all()
         t1 = time.perf_counter()
         dev.profile_enable(False)
         return t1 - t0, dev.profile_read()
 
-    elapsed, kernels = timed_loop(lambda i: op.run(), args.steps, True)
-    n_timed_steps = len(range(0, args.steps, EVENT_EVERY))
+    elapsed, kernels_region = timed_loop(lambda i: op.run(), args.steps, True)
+    n_region_samples = len([i for i in range(args.steps) if i % EVENT_EVERY == EVENT_AT])
+    # the sampled pass behind the region
+    for _ in range(2):
+        op.run()
+    dev.profile_enable(True)
+    for _ in range(SAMPLE_STEPS):
+        op.run()
+    sync_all()
+    dev.profile_enable(False)
+    kernels_post = dev.profile_read()
+    kernels = kernels_region + kernels_post
+    n_timed_steps = n_region_samples + SAMPLE_STEPS
     plan.status()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
@@ -283,8 +297,19 @@ def main():
                                    "frac": round(whole / HBM_PEAK_GBS, 5) if whole else None},
                     "kernels_avg_ms": {k: round(v, 5) for k, v in kern_avg_ms.items()},
                     "plan_choice": plan.describe(),
-                    "kernel_timing": f"HIP events around each launch on steps 0, {EVENT_EVERY}, {2 * EVENT_EVERY}, ... "
-                                     f"of the timed region ({n_timed_steps} of {args.steps} steps)"}
+                    "kernel_timing": f"HIP events around each launch: steps {EVENT_AT}, {EVENT_AT + EVENT_EVERY}, ... of the timed region "
+                                     f"({n_region_samples} of {args.steps} steps; never step 0) plus {SAMPLE_STEPS} consecutive steps right "
+                                     "behind it on the same stream; `achieved` uses the mean over all of them"}
+        v = np.array(per[dom], dtype=np.float64)
+
+        def stats(x):
+            x = np.array(x, dtype=np.float64)
+            return {"n": int(len(x)), "mean_ms": round(float(x.mean()), 5), "median_ms": round(float(np.median(x)), 5),
+                    "min_ms": round(float(x.min()), 5), "max_ms": round(float(x.max()), 5)} if len(x) else {"n": 0}
+        roofline["samples"] = dict(stats(v), in_region=stats([ms for n_, ms in kernels_region if n_ == dom]),
+                                   behind_region=stats([ms for n_, ms in kernels_post if n_ == dom]),
+                                   frac_at_median=round(B_dom / (float(np.median(v)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5))
+        roofline["n"] = int(len(v))
         # An event pair also contains the launch itself; what it reads around a kernel of k_scan's
         # shape that does nothing is reported beside the kernel times, not subtracted from them
         # (rocprofv3's dispatch durations, profiles/, do not contain it).

@@ -11,7 +11,7 @@ from ctypes import (POINTER, c_bool, c_char_p, c_double, c_float, c_int, c_int64
                     c_void_p)
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libflatgfa.so")
+LIB_PATH = os.environ.get("FLATGFA_LIB") or os.path.join(PKG_DIR, "lib", "libflatgfa.so")  # (FLATGFA_LIB: a measurement build, tools/variants.sh)
 
 
 class flatgfa_string_t(ctypes.Structure):

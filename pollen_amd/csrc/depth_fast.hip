@@ -45,8 +45,11 @@
 #include <algorithm>
 #include <queue>
 #include <cstdlib>
+#include <cstring>
+#include <cstdio>
 #include <numeric>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "depth_fast.hpp"
@@ -147,6 +150,7 @@ struct ScanArgs {
     uint32_t *status;
     uint32_t dbg;
     uint32_t tagged;     // records carry their item's tag (see kTagShift); k_scan_dense reads this, k_scan is a build of its own
+    uint32_t tag_limit;  // tagged: how many items a workgroup may take (its private tags are 0 .. tag_limit - 1; the split paths' lie above)
     unsigned long long *tprof;  // FLATGFA_SCAN_TIME (diagnostic): per workgroup, when it started, when it ended, when each of its waves ran out of work (10 ns units)
 };
 
@@ -890,6 +894,7 @@ constexpr uint32_t kCtlNext = 0, kCtlArrive = kCtlRing, kCtlEpoch = 2 * kCtlRing
                    kCtlWords = 7 * kCtlRing + 8;  // (kCtlDesc: four words per cell of the item ring -- the items' descriptors, tagged calls)
 // A tagged call deals the items out as the workgroups get to them (an item's tag is its ordinal in
 // its workgroup, whatever the item): ctl[kCtlJobs + (r mod kCtlRing)] is the workgroup's r-th item, or one of
+constexpr size_t kTprofRow = 4 + kWaves;  // FLATGFA_SCAN_TIME: a workgroup's row of ScanArgs::tprof -- start, end, where it ran, its items, when each wave ran out of work
 constexpr uint32_t kJobEmpty = 0xFFFFFFFFu, kJobPending = 0xFFFFFFFEu;  // nobody has asked yet / a wave is fetching it
 
 __device__ __forceinline__ uint32_t epoch_now(uint32_t *ctl) {
@@ -1168,7 +1173,11 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the span math on the scalar unit
     uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;  // this workgroup's sub-bucket of window 0
-    if (TAGGED && MODE == kModePlain && A.tprof && threadIdx.x == 0) A.tprof[(2 + kWaves) * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (TAGGED && MODE == kModePlain && A.tprof && threadIdx.x == 0) {
+        A.tprof[kTprofRow * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+        // where it runs: HW_ID (wave, SIMD, CU, shader array and engine) and XCC_ID
+        A.tprof[kTprofRow * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
     RWave w;
     w.q = reinterpret_cast<uint2 *>(lds + kTables * A.nwp + kCtlWords) + (uint32_t)wave * kQ2;
     w.fill = 0;
@@ -1280,9 +1289,15 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
                 next_job = __hip_atomic_load(&ctl[kCtlJobs + ((rr + 1u) & kRing)], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             } while (next_job >= kJobPending);  // (asked for an item ago: it is there, but for items of a handful of steps)
             if ((uint32_t)__builtin_amdgcn_readfirstlane(st) == kJobEmpty) {
-                uint32_t got = 0;
-                if (lane == 0) got = atomicAdd(A.work_counter + 1, 1u);
-                got = min(__builtin_amdgcn_readfirstlane(got) + 2u * gridDim.x, kJobPending - 1u);
+                // (A workgroup has tag_limit private tags: its item of that ordinal would wrap into the split
+                // paths' tags, or onto a bitset slot still in use.  It takes no further item then -- the
+                // others do; should they all run out of tags, the last workgroup out reports it.)
+                uint32_t got = kJobPending - 1u - 2u * gridDim.x;
+                if (rr + 2u < A.tag_limit) {
+                    if (lane == 0) got = atomicAdd(A.work_counter + 1, 1u);
+                    got = __builtin_amdgcn_readfirstlane(got);
+                }
+                got = min(got + 2u * gridDim.x, kJobPending - 1u);
                 // ... and its descriptor, for all the waves (each reading it from memory was a round trip per item and wave)
                 if (FGFA_ITEM_RING && many_items && got < n_items && lane < 4) ctl[kCtlDesc + 4u * ((rr + 2u) & kRing) + lane] = reinterpret_cast<const uint32_t *>(A.items + got)[lane];
                 if (lane == 0) __hip_atomic_store(ahead, got, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1391,18 +1406,24 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
 #undef FGFA_BLOCK_PTR
 #undef FGFA_ITEM_TAG
     // publish how many records this workgroup left in each window's sub-bucket
-    if (TAGGED && MODE == kModePlain && A.tprof && lane == 0) A.tprof[(2 + kWaves) * blockIdx.x + 2 + wave] = __builtin_amdgcn_s_memrealtime();
+    if (TAGGED && MODE == kModePlain && A.tprof && lane == 0) A.tprof[kTprofRow * blockIdx.x + 4 + wave] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads)
         A.counts[(size_t)wdw * A.n_slots + blockIdx.x] = bcur[wdw];
     if (TAGGED && threadIdx.x == 0) {  // the last workgroup out leaves the item counter clean for the next call
         const uint32_t out = atomicAdd(A.work_counter + 2, 1u);
         if (out == gridDim.x - 1u) {
+            // items nobody took (every workgroup out of tags): the call is completed through the atomic kernels
+            const uint32_t taken = __hip_atomic_load(A.work_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((uint64_t)taken + 2ull * gridDim.x < n_items) atomicOr(A.status, kStBackOverflow);
             A.work_counter[1] = 0u;
             A.work_counter[2] = 0u;
         }
     }
-    if (TAGGED && MODE == kModePlain && A.tprof && threadIdx.x == 0) A.tprof[(2 + kWaves) * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if (TAGGED && MODE == kModePlain && A.tprof && threadIdx.x == 0) {
+        A.tprof[kTprofRow * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        A.tprof[kTprofRow * blockIdx.x + 3] = rr;  // the items it took
+    }
 }
 
 // ------------------------------------------------------------------ pass 2 ---
@@ -2261,6 +2282,356 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
 #undef FGFA_TAG_TAKEN
 }
 
+// ---- the tagged walk, K steps wide ----
+// A step of apply_tagged is a chain of short instructions around dependent LDS round trips (the
+// returning OR of every bitset word, then what its answer says about revisits), and a wave has
+// three of its kind as neighbours on its SIMD to hide them: the waves spend over 40 % of their time
+// in s_waitcnt.  Here a step takes K * 64 consecutive records of the open sub-bucket -- K registers per
+// lane, record 64 j + lane in register j -- and the K chains run side by side: one hand-over check
+// for all of them, the K ORs of a round issued back to back with ONE wait, the scalar bookkeeping
+// of a step (the stream, the counter of sub-buckets, the loop) paid once per K * 64 records.  A sub-bucket
+// of cfg-L holds 170 records: three steps before, one now (K = 3).  Claims are order-independent
+// (LDS atomics), so running the chains together changes nothing about the counts; a step whose
+// tags need the general route (more items than bitsets, items interleaved) is done register by
+// register with the one-wide logic.
+// Landing registers: three steps in flight, K registers each: v(123 - 3K) .. v122, step slot d's in
+// v(123 - 3K + d K) ...; the loads return in order, so slot d's are there once at most 2 K younger
+// ones are outstanding.
+// (a loop over 0 .. N - 1 whose index is a constant in the body: arrays indexed by it stay in registers)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+template <int K, int DS>
+__device__ __forceinline__ void wide_request(const uint32_t *p, uint32_t lane4) {
+#define FGFA_WREQ2(R0, R1) asm volatile("global_load_dword " R0 ", %0, %1\n\tglobal_load_dword " R1 ", %0, %1 offset:256" ::"v"(lane4), "s"(p) : "memory", R0, R1)
+#define FGFA_WREQ3(R0, R1, R2) asm volatile("global_load_dword " R0 ", %0, %1\n\tglobal_load_dword " R1 ", %0, %1 offset:256\n\tglobal_load_dword " R2 ", %0, %1 offset:512" ::"v"(lane4), "s"(p) : "memory", R0, R1, R2)
+    if (K == 2) {
+        if (DS == 0) FGFA_WREQ2("v117", "v118");
+        else if (DS == 1) FGFA_WREQ2("v119", "v120");
+        else FGFA_WREQ2("v121", "v122");
+    } else {
+        if (DS == 0) FGFA_WREQ3("v114", "v115", "v116");
+        else if (DS == 1) FGFA_WREQ3("v117", "v118", "v119");
+        else FGFA_WREQ3("v120", "v121", "v122");
+    }
+#undef FGFA_WREQ2
+#undef FGFA_WREQ3
+}
+template <int K, int DS>
+__device__ __forceinline__ void wide_take(uint32_t (&r)[K]) {
+#define FGFA_WTAKE2(R0, R1) asm volatile("s_waitcnt vmcnt(4)\n\tv_mov_b32 %0, " R0 "\n\tv_mov_b32 %1, " R1 : "=v"(r[0]), "=v"(r[1])::"memory")
+#define FGFA_WTAKE3(R0, R1, R2) asm volatile("s_waitcnt vmcnt(6)\n\tv_mov_b32 %0, " R0 "\n\tv_mov_b32 %1, " R1 "\n\tv_mov_b32 %2, " R2 : "=v"(r[0]), "=v"(r[1]), "=v"(r[K - 1])::"memory")
+    if (K == 2) {
+        if (DS == 0) FGFA_WTAKE2("v117", "v118");
+        else if (DS == 1) FGFA_WTAKE2("v119", "v120");
+        else FGFA_WTAKE2("v121", "v122");
+    } else {
+        if (DS == 0) FGFA_WTAKE3("v114", "v115", "v116");
+        else if (DS == 1) FGFA_WTAKE3("v117", "v118", "v119");
+        else FGFA_WTAKE3("v120", "v121", "v122");
+    }
+#undef FGFA_WTAKE2
+#undef FGFA_WTAKE3
+}
+
+// What claim_step does, for K registers of records at once (4096-segment windows).  Three kinds of
+// statements, exec restored at the end of each: the set-up of one register (+1 / -1 into D, the
+// first word's address, mask and R cell), a round's returning ORs for all registers with one wait,
+// and what one register's answer means (the revisited stretches into R; the lanes whose run goes on
+// into the next word, and that word's mask).
+struct WideLane {
+    uint32_t w, tt, mask, base;  // the bitset word's LDS address; the run's last bit counted from bit 0 of that word; the word's mask; R's cell of the word's first segment
+};
+__device__ __forceinline__ void wide_setup(WideLane &c, uint32_t rec, uint32_t sb, unsigned long long vm, uint32_t dbase, uint32_t rbase, uint32_t one, uint32_t mone) {
+    uint32_t a, n, k, m;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[vm]\n\t"
+        "v_and_b32 %[a], 0xfff, %[rec]\n\t"
+        "v_bfe_u32 %[n], %[rec], 12, 10\n\t"
+        "v_lshl_add_u32 %[a], %[a], 2, %[dbase]\n\t"
+        "ds_add_u32 %[a], %[one]\n\t"
+        "v_lshl_add_u32 %[a], %[n], 2, %[a]\n\t"
+        "ds_add_u32 %[a], %[mone] offset:4\n\t"
+        "v_bfe_u32 %[w], %[rec], 5, 7\n\t"
+        "v_lshl_add_u32 %[w], %[w], 2, %[sb]\n\t"
+        "v_and_b32 %[k], 31, %[rec]\n\t"
+        "v_add_u32 %[tt], %[k], %[n]\n\t"
+        "v_min_u32 %[m], 31, %[tt]\n\t"
+        "v_sub_u32 %[m], 31, %[m]\n\t"
+        "v_lshrrev_b32 %[m], %[m], -1\n\t"
+        "v_lshlrev_b32 %[k], %[k], -1\n\t"
+        "v_and_b32 %[mask], %[m], %[k]\n\t"
+        "v_and_b32 %[base], 0xfe0, %[rec]\n\t"
+        "v_lshl_add_u32 %[base], %[base], 2, %[rbase]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [a] "=&v"(a), [n] "=&v"(n), [k] "=&v"(k), [m] "=&v"(m), [w] "=&v"(c.w), [tt] "=&v"(c.tt), [mask] "=&v"(c.mask), [base] "=&v"(c.base), [sv] "=&s"(sv)
+        : [rec] "v"(rec), [sb] "v"(sb), [vm] "s"(vm), [dbase] "s"(dbase), [rbase] "s"(rbase), [one] "v"(one), [mone] "v"(mone)
+        : "memory");
+}
+template <int K>
+__device__ __forceinline__ void wide_or(const WideLane (&c)[K], const unsigned long long (&act)[K], uint32_t (&old)[K]) {
+    unsigned long long sv;
+    if (K == 2)
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_mov_b64 exec, %[a0]\n\tds_or_rtn_b32 %[o0], %[w0], %[m0]\n\t"
+            "s_mov_b64 exec, %[a1]\n\tds_or_rtn_b32 %[o1], %[w1], %[m1]\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : [o0] "=&v"(old[0]), [o1] "=&v"(old[1]), [sv] "=&s"(sv)
+            : [a0] "s"(act[0]), [a1] "s"(act[1]), [w0] "v"(c[0].w), [w1] "v"(c[1].w), [m0] "v"(c[0].mask), [m1] "v"(c[1].mask)
+            : "memory");
+    else
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_mov_b64 exec, %[a0]\n\tds_or_rtn_b32 %[o0], %[w0], %[m0]\n\t"
+            "s_mov_b64 exec, %[a1]\n\tds_or_rtn_b32 %[o1], %[w1], %[m1]\n\t"
+            "s_mov_b64 exec, %[a2]\n\tds_or_rtn_b32 %[o2], %[w2], %[m2]\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : [o0] "=&v"(old[0]), [o1] "=&v"(old[1]), [o2] "=&v"(old[K - 1]), [sv] "=&s"(sv)
+            : [a0] "s"(act[0]), [a1] "s"(act[1]), [a2] "s"(act[K - 1]), [w0] "v"(c[0].w), [w1] "v"(c[1].w), [w2] "v"(c[K - 1].w), [m0] "v"(c[0].mask),
+              [m1] "v"(c[1].mask), [m2] "v"(c[K - 1].mask)
+            : "memory");
+}
+// (act: in, the lanes that claimed a word this round; out, those whose run goes on into the next word)
+__device__ __forceinline__ void wide_after(WideLane &c, unsigned long long &act, uint32_t old, uint32_t one, uint32_t mone) {
+    uint32_t rv, low, sum, f, g;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[act]\n\t"
+        "v_and_b32 %[rv], %[old], %[mask]\n\t"                // the segments this path had already visited
+        "v_cmp_ne_u32 vcc, 0, %[rv]\n\t"
+        "s_cbranch_vccz 3f\n\t"
+        "2:\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "v_sub_u32 %[low], 0, %[rv]\n\t"
+        "v_and_b32 %[low], %[rv], %[low]\n\t"                 // the lowest revisited segment
+        "v_add_u32 %[sum], %[rv], %[low]\n\t"                 // (the carry runs through its stretch)
+        "v_ffbl_b32 %[f], %[low]\n\t"
+        "v_ffbl_b32 %[g], %[sum]\n\t"
+        "v_min_u32 %[g], 32, %[g]\n\t"                        // (no bit left: the stretch ends with the word)
+        "v_lshl_add_u32 %[f], %[f], 2, %[base]\n\t"
+        "v_lshl_add_u32 %[g], %[g], 2, %[base]\n\t"
+        "ds_add_u32 %[f], %[one]\n\t"
+        "ds_add_u32 %[g], %[mone]\n\t"
+        "v_and_b32 %[rv], %[rv], %[sum]\n\t"
+        "v_cmp_ne_u32 vcc, 0, %[rv]\n\t"
+        "s_cbranch_vccnz 2b\n\t"
+        "s_mov_b64 exec, %[act]\n\t"
+        "3:\n\t"
+        "v_cmp_lt_u32 vcc, 31, %[tt]\n\t"                     // the lanes whose run goes on into the next word
+        "s_mov_b64 %[act], vcc\n\t"
+        "s_cbranch_vccz 4f\n\t"
+        "s_mov_b64 exec, vcc\n\t"
+        "v_subrev_u32 %[tt], 32, %[tt]\n\t"
+        "v_add_u32 %[w], 4, %[w]\n\t"
+        "v_add_u32 %[base], 0x80, %[base]\n\t"
+        "v_min_u32 %[low], 31, %[tt]\n\t"
+        "v_sub_u32 %[low], 31, %[low]\n\t"
+        "v_lshrrev_b32 %[mask], %[low], -1\n\t"
+        "4:\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [act] "+s"(act), [w] "+v"(c.w), [tt] "+v"(c.tt), [mask] "+v"(c.mask), [base] "+v"(c.base), [rv] "=&v"(rv), [low] "=&v"(low), [sum] "=&v"(sum),
+          [f] "=&v"(f), [g] "=&v"(g), [sv] "=&s"(sv)
+        : [old] "v"(old), [one] "v"(one), [mone] "v"(mone)
+        : "vcc", "memory");
+}
+
+template <int WB, bool SHARED, int K>
+__device__ __forceinline__ void apply_tagged_wide(const AccArgs &A, int *D, int *R, uint32_t *bits, const uint2 *scnt2, const uint32_t *wbase,
+                                                  uint32_t *grab) {
+    static_assert(WB == 12 && (K == 2 || K == 3), "the wide walk's constants are those of 4096-segment windows");
+    constexpr uint32_t kW = 1u << WB, kNW = kW / 32u;
+    constexpr uint32_t kPriv = kAccWaves * kTagSlots;
+    const int lane = threadIdx.x & 63;
+    const uint32_t lane4 = 4u * (uint32_t)lane;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t y16 = blockIdx.y * kAccWaves, nw = A.parts * kAccWaves;
+    const uint32_t shlo = kTagCount - A.n_shared;
+    const uint32_t bits0 = lds_addr(bits), priv_b = bits0 + ((wv * kTagSlots) << (WB - 3));
+    const uint32_t dbase = lds_addr(D), rbase = lds_addr(R);
+    uint32_t one = 1u, mone = ~0u;
+    asm volatile("" : "+v"(one), "+v"(mone));
+    const uint32_t imax = A.n_slots > y16 ? kAccWaves * ((A.n_slots - y16 + nw - 1u) / nw) : 0u;
+    const uint32_t *sp = wbase;
+    uint32_t left = 0;
+    uint32_t cur_i = wv;
+    const auto open = [&](uint32_t i) {
+        const uint32_t s = y16 + (i & (kAccWaves - 1u)) + (i / kAccWaves) * nw;
+        left = 0;
+        if (i < imax && s < A.n_slots) {
+            const uint2 c = scnt2[s];
+            sp = wbase + __builtin_amdgcn_readfirstlane(c.x);
+            left = __builtin_amdgcn_readfirstlane(c.y);
+        }
+    };
+    open(cur_i);
+    const uint32_t grab_a = lds_addr(grab);
+    uint32_t nxt = 0;
+#define FGFA_TAG_GRAB()                                                                                         \
+    do {                                                                                                        \
+        unsigned long long sv_;                                                                                 \
+        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1" \
+                     : "+v"(nxt), "=&s"(sv_)                                                                    \
+                     : "v"(grab_a), "v"(one)                                                                    \
+                     : "memory");                                                                               \
+    } while (0)
+#define FGFA_TAG_TAKEN(OUT) asm volatile("s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %0, %1" : "=s"(OUT) : "v"(nxt) : "memory")
+    FGFA_TAG_GRAB();
+#define FGFA_WIDE_GEN(DS, NV, FR)                                \
+    do {                                                         \
+        FR = 0u;                                                 \
+        while (left == 0u && cur_i < imax) {                     \
+            FGFA_TAG_TAKEN(cur_i);                               \
+            FGFA_TAG_GRAB();                                     \
+            open(cur_i);                                         \
+            FR = 1u;                                             \
+        }                                                        \
+        NV = min(64u * K, left);                                 \
+        wide_request<K, DS>(sp, lane4);                          \
+        sp += NV;                                                \
+        left -= NV;                                              \
+    } while (0)
+    int hmax = -1;
+    const auto clear_slots = [&](int from, int to) {
+        for (int t = from; t <= to; ++t) {
+            uint32_t *bs = bits + (wv * kTagSlots + ((uint32_t)t & (kTagSlots - 1u))) * kNW;
+            for (uint32_t i = lane; i < kNW / 2u; i += 64) reinterpret_cast<uint2 *>(bs)[i] = make_uint2(0u, 0u);
+        }
+    };
+    const auto slot_of = [&](uint32_t tag, bool any_shared) {
+        uint32_t sb = priv_b + ((tag & (kTagSlots - 1u)) << (WB - 3));
+        if (SHARED && any_shared) sb = tag >= shlo ? bits0 + ((kPriv + kTagCount - 1u - tag) << (WB - 3)) : sb;
+        return sb;
+    };
+    // one register's 64 records by the one-wide logic (the general route included)
+    const auto step64 = [&](uint32_t rec, unsigned long long vm) {
+        const uint32_t tag = rec >> kTagShift;
+        const uint32_t last = 63u - (uint32_t)__builtin_clzll(vm);
+        const unsigned long long shm = SHARED ? __builtin_amdgcn_ballot_w64(tag >= shlo) & vm : 0ull;
+        const unsigned long long pvm = vm & ~shm;
+        bool general = false;
+        if (__builtin_amdgcn_ballot_w64((uint32_t)hmax - tag >= kTagSlots) & pvm) {
+            const int c = (int)__builtin_amdgcn_readlane(tag, (int)last);
+            general = !((pvm >> last) & 1ull) || (__builtin_amdgcn_ballot_w64((int)tag > c || (int)(tag + kTagSlots) <= c) & pvm);
+            if (!general) {
+                clear_slots(max(hmax + 1, c - (int)(kTagSlots - 1u)), c);
+                hmax = c;
+            }
+        }
+        if (!general) {
+            claim_step<WB>(rec, slot_of(tag, shm != 0ull), vm, dbase, rbase, one, mone);
+        } else {
+            unsigned long long todo = vm;
+            do {
+                unsigned long long act = todo;
+                const bool pv = ((todo & pvm) >> lane) & 1ull;
+                if (todo & pvm) {
+                    const uint32_t tmin = wave_min_u32(pv ? tag : ~0u);
+                    const unsigned long long beyond = __builtin_amdgcn_ballot_w64(pv && tag >= tmin + kTagSlots);
+                    if (beyond) act = todo & ((1ull << __builtin_ctzll(beyond)) - 1ull);
+                    if ((int)(tmin + kTagSlots) <= hmax || !act) {  // cannot happen: k_scan's gate
+                        atomicOr(A.status, kStInternal);
+                        act = todo;
+                    }
+                    const int hnew = max(hmax, (int)wave_max_u32(((act & pvm) >> lane) & 1ull ? tag : 0u));
+                    clear_slots(max(hmax + 1, hnew - (int)(kTagSlots - 1u)), hnew);
+                    hmax = hnew;
+                }
+                claim_step<WB>(rec, slot_of(tag, shm != 0ull), act, dbase, rbase, one, mone);
+                todo &= ~act;
+            } while (todo);
+        }
+    };
+    uint32_t nv0 = 0, nv1 = 0, nv2 = 0, f0 = 0, f1 = 0, f2 = 0;
+    FGFA_WIDE_GEN(0, nv0, f0);
+    FGFA_WIDE_GEN(1, nv1, f1);
+    FGFA_WIDE_GEN(2, nv2, f2);
+#define FGFA_WIDE_STEP(DS, NV, FR)                                                                                     \
+    if (NV == 0u) break;                                                                                               \
+    {                                                                                                                  \
+        uint32_t rec[K];                                                                                               \
+        wide_take<K, DS>(rec);                                                                                         \
+        const uint32_t nv = NV;                                                                                        \
+        if (FR) hmax = -1;  /* the private slots start over with this sub-bucket */                                    \
+        FGFA_WIDE_GEN(DS, NV, FR);                                                                                     \
+        unsigned long long vm[K], pvm[K], need = 0ull, shany = 0ull;                                                   \
+        uint32_t tag[K];                                                                                               \
+        static_for<K>([&](auto J) {                                                                                    \
+            constexpr int j = decltype(J)::value;                                                                      \
+            const uint32_t cnt = nv > 64u * (uint32_t)j ? min(64u, nv - 64u * (uint32_t)j) : 0u;                       \
+            vm[j] = cnt >= 64u ? ~0ull : (1ull << cnt) - 1ull;                                                         \
+            tag[j] = rec[j] >> kTagShift;                                                                              \
+            const unsigned long long shm = SHARED ? __builtin_amdgcn_ballot_w64(tag[j] >= shlo) & vm[j] : 0ull;        \
+            shany |= shm;                                                                                              \
+            pvm[j] = vm[j] & ~shm;                                                                                     \
+            need |= __builtin_amdgcn_ballot_w64((uint32_t)hmax - tag[j] >= kTagSlots) & pvm[j];                        \
+        });                                                                                                            \
+        bool general = false;                                                                                          \
+        if (need) {                                                                                                    \
+            /* the step's last record: its tag is the highest unless waves that ran ahead have interleaved the items */ \
+            const uint32_t li = nv - 1u, jl = li >> 6, ll = li & 63u;                                                  \
+            uint32_t tl = tag[0];                                                                                      \
+            unsigned long long pl = pvm[0];                                                                            \
+            if (jl == 1u) tl = tag[1], pl = pvm[1];                                                                    \
+            if (K > 2 && jl == 2u) tl = tag[K - 1], pl = pvm[K - 1];                                                   \
+            const int c = (int)__builtin_amdgcn_readlane(tl, (int)ll);                                                 \
+            unsigned long long out = 0ull;                                                                             \
+            static_for<K>([&](auto J) {                                                                                \
+                constexpr int j = decltype(J)::value;                                                                  \
+                out |= __builtin_amdgcn_ballot_w64((int)tag[j] > c || (int)(tag[j] + kTagSlots) <= c) & pvm[j];        \
+            });                                                                                                        \
+            general = !((pl >> ll) & 1ull) || out;                                                                     \
+            if (!general) {                                                                                            \
+                clear_slots(max(hmax + 1, c - (int)(kTagSlots - 1u)), c);                                              \
+                hmax = c;                                                                                              \
+            }                                                                                                          \
+        }                                                                                                              \
+        if (!general) {                                                                                                \
+            WideLane cl[K];                                                                                            \
+            unsigned long long act[K];                                                                                 \
+            static_for<K>([&](auto J) {                                                                                \
+                constexpr int j = decltype(J)::value;                                                                  \
+                wide_setup(cl[j], rec[j], slot_of(tag[j], shany != 0ull), vm[j], dbase, rbase, one, mone);             \
+                act[j] = vm[j];                                                                                        \
+            });                                                                                                        \
+            unsigned long long any;                                                                                    \
+            do {                                                                                                       \
+                uint32_t old[K];                                                                                       \
+                wide_or<K>(cl, act, old);                                                                              \
+                any = 0ull;                                                                                            \
+                static_for<K>([&](auto J) {                                                                            \
+                    constexpr int j = decltype(J)::value;                                                              \
+                    if (act[j]) wide_after(cl[j], act[j], old[j], one, mone);                                          \
+                    any |= act[j];                                                                                     \
+                });                                                                                                    \
+            } while (any);                                                                                             \
+        } else {                                                                                                       \
+            static_for<K>([&](auto J) {                                                                                \
+                constexpr int j = decltype(J)::value;                                                                  \
+                if (vm[j]) step64(rec[j], vm[j]);                                                                      \
+            });                                                                                                        \
+        }                                                                                                              \
+    }
+    while (true) {
+        FGFA_WIDE_STEP(0, nv0, f0)
+        FGFA_WIDE_STEP(1, nv1, f1)
+        FGFA_WIDE_STEP(2, nv2, f2)
+    }
+#undef FGFA_WIDE_STEP
+#undef FGFA_WIDE_GEN
+#undef FGFA_TAG_GRAB
+#undef FGFA_TAG_TAKEN
+}
+
 // the sum of a 64-bit value over the wave, uniform, by DPP adds on its halves
 __device__ __forceinline__ unsigned long long wave_total_u64(unsigned long long x) {
 #define FGFA_DPP_ADD64(CTRL, ROWMASK, BC)                                                                            \
@@ -2397,7 +2768,7 @@ uint32_t tagged_lds_bytes(uint32_t wb, uint32_t n_shared) { return (kAccWaves * 
 // one instruction per cycle and CU where two are possible, and eight waves per SIMD hide more of its
 // LDS round trips than four.  Both leave their partial vectors in scratch; the second one to
 // finish adds the other's to its own and writes the results.
-template <bool UNIQ, int WB, bool PSUM, bool POINT, bool BIG, bool TAGGED, bool PAIR>
+template <bool UNIQ, int WB, bool PSUM, bool POINT, bool BIG, bool TAGGED, bool PAIR, int WIDE = 1>
 __device__ __forceinline__ void accum_body(const AccArgs &A) {
     constexpr uint32_t kW = 1u << WB;
     constexpr int kPer = kW / kAccThreads;  // cells per thread: 4 or 8
@@ -2468,7 +2839,10 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
     if (flat) apply_flat<UNIQ, WB, (PAIR ? 4 : 16)>(A, D, R, scnt, wbase);
     tm.mark(1);
     if (UNIQ && TAGGED) {
-        if (PAIR) apply_tagged<WB, POINT, false, true>(A, D, R, tag_bits, scnt2, wbase, &grab);
+        if constexpr (WIDE > 1 && WB == 12 && !PAIR && !POINT) {
+            if (A.n_shared) apply_tagged_wide<WB, true, WIDE>(A, D, R, tag_bits, scnt2, wbase, &grab);
+            else apply_tagged_wide<WB, false, WIDE>(A, D, R, tag_bits, scnt2, wbase, &grab);
+        } else if (PAIR) apply_tagged<WB, POINT, false, true>(A, D, R, tag_bits, scnt2, wbase, &grab);
         else if (A.n_shared) apply_tagged<WB, POINT, true>(A, D, R, tag_bits, scnt2, wbase, &grab);
         else apply_tagged<WB, POINT, false>(A, D, R, tag_bits, scnt2, wbase, &grab);
     } else if (UNIQ) {
@@ -2582,9 +2956,9 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
     }
 }
 
-template <bool UNIQ, int WB, bool PSUM = false, bool POINT = false, bool BIG = false, bool TAGGED = false>
+template <bool UNIQ, int WB, bool PSUM = false, bool POINT = false, bool BIG = false, bool TAGGED = false, int WIDE = 1>
 __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
-    accum_body<UNIQ, WB, PSUM, POINT, BIG, TAGGED, false>(A);
+    accum_body<UNIQ, WB, PSUM, POINT, BIG, TAGGED, false, WIDE>(A);
 }
 template <int WB, bool POINT>
 __global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_accum_pair(const AccArgs A) {
@@ -2988,11 +3362,22 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // (the largest such size: for 1000 paths of 100 k steps, no cutting at all).
     // (z: bit 0 = the item walks the ids downwards, set by k_item_dirs; from bit 1 up, 1 + the
     // ordinal of the split path the item is a piece of, or 0 for a whole path)
+    // (FLATGFA_TAIL_PATHS=n, FLATGFA_TAIL_PIECES=k: the n shortest whole paths -- the ones k_scan's workgroups
+    // take last -- are cut into k pieces each, so that the deal ends on small items)
+    std::vector<uint32_t> tail_k(whole.size(), 1u);
+    if (const char *tp = getenv("FLATGFA_TAIL_PATHS")) {
+        const uint32_t n_tail = std::min<uint32_t>((uint32_t)strtoul(tp, nullptr, 10), (uint32_t)whole.size());
+        const uint32_t k_tail = getenv("FLATGFA_TAIL_PIECES") ? std::max(1u, (uint32_t)strtoul(getenv("FLATGFA_TAIL_PIECES"), nullptr, 10)) : 4u;
+        std::vector<uint32_t> order(whole.size());
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return whole[a].y - whole[a].x > whole[b].y - whole[b].x; });
+        for (uint32_t i = 0; i < n_tail; ++i) tail_k[order[whole.size() - 1 - i]] = k_tail;
+    }
     const auto cut = [&](uint64_t piece, std::vector<uint4> *out) -> uint32_t {
         uint32_t n_split = 0;
         for (const uint4 &w : whole) {
             const uint64_t b = w.x, n = (uint64_t)w.y - w.x;
-            const uint32_t k = (uint32_t)((n + piece - 1) / piece);
+            const uint32_t k = std::max((uint32_t)((n + piece - 1) / piece), n >= 4096 ? tail_k[(size_t)(&w - whole.data())] : 1u);
             const uint32_t z = k > 1 ? (++n_split) << 1 : 0u;
             for (uint32_t j = 0; j < k; ++j)
                 out->push_back(make_uint4((uint32_t)(b + n * j / k), (uint32_t)(b + n * (j + 1) / k), z, w.w));
@@ -3091,7 +3476,36 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         const uint32_t shared_cap = wb <= 12 ? kMaxShared : 0u;
         const bool base_ok = !fp->dbg && !(t && t[0] == '0') && (fp->n_shared == 0 || fp->acc_parts == 1);
         const bool taggable = base_ok && fp->n_shared <= shared_cap;
-        fp->tagged = taggable && per_wg + fp->n_shared <= kTagCount;
+        // A workgroup's private tags: what the split paths leave of the 512 (FLATGFA_TAG_LIMIT: fewer, tests).
+        // k_scan deals the items out as its workgroups get to them, so it is not the mean that has to
+        // fit but the most any workgroup takes: the deal is played through here (its first two items
+        // are fixed, every further one goes to whoever is done first), with some room to spare --
+        // a workgroup that does run out of tags stops taking items (k_scan) and the others go on.
+        uint32_t limit = fp->n_shared < kTagCount ? kTagCount - fp->n_shared : 0u;
+        if (const char *f = getenv("FLATGFA_TAG_LIMIT")) limit = std::min<uint32_t>(limit, std::max(2u, (uint32_t)strtoul(f, nullptr, 10)));
+        fp->tag_limit = limit;
+        uint64_t most = per_wg;
+        if (taggable && grid && per_wg <= limit && fp->n_items + fp->max_back > 2ull * grid && !getenv("FLATGFA_TAG_MEAN_ONLY")) {
+            constexpr uint64_t kTurn = 2048;  // steps' worth an item costs beyond its steps
+            std::priority_queue<std::pair<uint64_t, uint32_t>, std::vector<std::pair<uint64_t, uint32_t>>, std::greater<std::pair<uint64_t, uint32_t>>> hands;
+            std::vector<uint32_t> taken(grid, 0u);
+            for (uint32_t i = 0; i < grid; ++i) {
+                uint64_t h = 0;
+                for (uint32_t k = 0; k < 2; ++k)
+                    if (i + k * grid < fp->n_items) h += (uint64_t)(items[i + k * grid].y - items[i + k * grid].x) + kTurn, taken[i] += 1;
+                hands.push({h, i});
+            }
+            for (uint64_t j = 2ull * grid; j < (uint64_t)fp->n_items + fp->max_back; ++j) {
+                const uint64_t n = j < fp->n_items ? (uint64_t)(items[j].y - items[j].x) : kShortMax;
+                auto [h, i] = hands.top();
+                hands.pop();
+                taken[i] += 1;
+                hands.push({h + n + kTurn, i});
+            }
+            most = *std::max_element(taken.begin(), taken.end());
+            most += most / 4;  // (the workgroups do not run at one speed)
+        }
+        fp->tagged = taggable && per_wg <= limit && most <= limit;
         // what fast_plan_create may do about a plan that is not: walk the paths in groups (fewer items, fewer
         // split paths per group), or take 4096-segment windows (pass 2 then has LDS for split paths' bitsets)
         fp->too_many_items = base_ok && !fp->tagged && fp->acc_parts == 1 && !fp->n_short && !fp->n_medium && (taggable || (wb <= 12 && fp->n_shared > shared_cap));
@@ -3247,6 +3661,13 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             fp->dense_maybe = false;
         }
     }
+    if (!items.empty() && fp->tagged && short_items.empty() && medium_items.empty() && getenv("FLATGFA_ALTERNATE")) {
+        std::vector<uint4> back(items.size());
+        FAST_TRY(hipMemcpy(back.data(), fp->items, items.size() * sizeof(uint4), hipMemcpyDeviceToHost));  // (with the directions k_item_dirs found)
+        std::reverse(back.begin(), back.end());
+        FAST_TRY(hipMalloc(&fp->items_rev, (items.size() + 1) * sizeof(uint4)));
+        FAST_TRY(hipMemcpy(fp->items_rev, back.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    }
     if (!short_items.empty()) {
         FAST_TRY(hipMalloc(&fp->short_items, short_items.size() * sizeof(uint4)));
         FAST_TRY(hipMemcpy(fp->short_items, short_items.data(), short_items.size() * sizeof(uint4), hipMemcpyHostToDevice));
@@ -3285,6 +3706,8 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 11, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(11, kMaxShared)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, false, false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, false, false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 13, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(13, 0)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 13, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(13, 0)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum_pair<12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, 0)));
@@ -3297,6 +3720,9 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     const bool pair_ok = fp->tagged && fp->n_shared == 0 && wb == 12 && fp->acc_parts == 1 && n_win <= 2 * fp->n_cus;
     fp->acc_pair = pair_ok && fp->est_records / n_win >= 65536;
     if (const char *f = getenv("FLATGFA_ACC_PAIR")) fp->acc_pair = pair_ok && strtol(f, nullptr, 10) != 0;
+    // The tagged walk K steps wide (apply_tagged_wide; 4096-segment windows): FLATGFA_ACC_WIDE=1|2|3.
+    fp->acc_wide = 1;
+    if (const char *f = getenv("FLATGFA_ACC_WIDE")) fp->acc_wide = std::max(1u, std::min(3u, (uint32_t)strtoul(f, nullptr, 10)));
     if (fp->acc_pair) {
         FAST_TRY(hipMalloc(&fp->pair_part, (size_t)n_win * 2 * 2 * (1u << wb) * 4));
         FAST_TRY(hipMalloc(&fp->pair_flag, (size_t)n_win * 4));
@@ -3513,7 +3939,7 @@ void fast_plan_destroy(FastPlan *fp) {
     for (uint32_t r = 0; r < fp->n_more; ++r) fast_plan_destroy(&fp->more[r]);
     delete[] fp->more;
     for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot, (void *)fp->perm,
-                    (void *)fp->elist, (void *)fp->wave_off, (void *)fp->fat_off, (void *)fp->fat_woff, (void *)fp->items, (void *)fp->short_items,
+                    (void *)fp->elist, (void *)fp->wave_off, (void *)fp->fat_off, (void *)fp->fat_woff, (void *)fp->items, (void *)fp->items_rev, (void *)fp->short_items,
                     (void *)fp->medium_items, (void *)fp->rev_steps, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part,
                     (void *)fp->pair_part, (void *)fp->pair_flag})
         if (p) (void)hipFree(p);
@@ -3575,8 +4001,10 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     // the directory walk (an item's records have to be found again once the window's depth is final).
     const bool tagged = fp.tagged && !ps;
     sa.tagged = tagged ? 1u : 0u;
+    sa.tag_limit = std::max(2u, fp.tag_limit);
+    if (tagged && fp.items_rev && !fp.n_short && !fp.n_medium && !sa.ranged && ((fp.n_calls++) & 1u)) sa.items = reinterpret_cast<uint4 *>(fp.items_rev);
     sa.tprof = nullptr;
-    if (getenv("FLATGFA_SCAN_TIME") && hipMalloc(&sa.tprof, (2 + kWaves) * 8 * (size_t)fp.n_slots) == hipSuccess) (void)hipMemset(sa.tprof, 0, (2 + kWaves) * 8 * (size_t)fp.n_slots);
+    if (getenv("FLATGFA_SCAN_TIME") && hipMalloc(&sa.tprof, kTprofRow * 8 * (size_t)fp.n_slots) == hipSuccess) (void)hipMemset(sa.tprof, 0, kTprofRow * 8 * (size_t)fp.n_slots);
     AccArgs aa{fp.n_range, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.counts0, scan_skip ? 2u : has_pre ? 1u : 0u, fp.buckets,
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
                fp.work_counter, scan_skip ? 0u : fp.max_back, depth_out, uniq_out, status, fp.dbg,
@@ -3662,6 +4090,8 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
             if (fp.dense && fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12, false, true, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
             else if (fp.dense && fp.wb == 13) hipLaunchKernelGGL((k_accum<true, 13, false, true, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
             else if (fp.wb == 11) hipLaunchKernelGGL((k_accum<true, 11, false, false, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
+            else if (fp.wb == 12 && fp.acc_wide == 2) hipLaunchKernelGGL((k_accum<true, 12, false, false, false, true, 2>), agrid, dim3(kAccThreads), tl, stream, aa);
+            else if (fp.wb == 12 && fp.acc_wide == 3) hipLaunchKernelGGL((k_accum<true, 12, false, false, false, true, 3>), agrid, dim3(kAccThreads), tl, stream, aa);
             else if (fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12, false, false, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
             else hipLaunchKernelGGL((k_accum<true, 13, false, false, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
         } else if (uniq_out) {
@@ -3693,7 +4123,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
         return FLATGFA_ERR_HIP;
     }
     if (sa.tprof) {  // diagnostic: when the workgroups of k_scan start, when their first wave runs out of work, when they end
-        constexpr size_t kRow = 2 + kWaves;
+        constexpr size_t kRow = kTprofRow;
         std::vector<unsigned long long> raw(kRow * (size_t)fp.n_slots);
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(raw.data(), sa.tprof, raw.size() * 8, hipMemcpyDeviceToHost);
@@ -3706,8 +4136,8 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
             en.push_back((raw[kRow * i + 1] - t0) / 100.0);
             unsigned long long a = ~0ull, b = 0;
             for (size_t k = 0; k < kWaves; ++k) {
-                a = std::min(a, raw[kRow * i + 2 + k]);
-                b = std::max(b, raw[kRow * i + 2 + k]);
+                a = std::min(a, raw[kRow * i + 4 + k]);
+                b = std::max(b, raw[kRow * i + 4 + k]);
             }
             fw.push_back((a - t0) / 100.0);
             lw.push_back((b - t0) / 100.0);
@@ -3715,6 +4145,18 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
         const auto pct = [](std::vector<double> v, double q) { std::sort(v.begin(), v.end()); return v[(size_t)(q * (v.size() - 1))]; };
         fprintf(stderr, "k_scan%s workgroups (us since the first one started): start p50 %.1f max %.1f | first wave out of work p5 %.1f p50 %.1f p95 %.1f | last wave p5 %.1f p50 %.1f p95 %.1f max %.1f | end p50 %.1f max %.1f\n",
                 tagged ? " [tagged]" : "", pct(st, 0.5), pct(st, 1.0), pct(fw, 0.05), pct(fw, 0.5), pct(fw, 0.95), pct(lw, 0.05), pct(lw, 0.5), pct(lw, 0.95), pct(lw, 1.0), pct(en, 0.5), pct(en, 1.0));
+        // FLATGFA_SCAN_TIME=<file>: one line per workgroup and call -- call, workgroup, XCC, HW_ID, items, start, first / last wave out of work, end (us)
+        static int call_no = 0;
+        const char *where = getenv("FLATGFA_SCAN_TIME");
+        if (where && strchr(where, '/')) {
+            if (FILE *f = fopen(where, "a")) {
+                for (uint32_t i = 0; i < grid; ++i)
+                    fprintf(f, "%d,%u,%u,0x%08x,%u,%.2f,%.2f,%.2f,%.2f\n", call_no, i, (unsigned)(raw[kRow * i + 2] >> 32) & 15u, (unsigned)raw[kRow * i + 2],
+                            (unsigned)raw[kRow * i + 3], st[i], fw[i], lw[i], en[i]);
+                fclose(f);
+            }
+        }
+        call_no += 1;
     }
     if (aa.tprof) {  // diagnostic: where the waves of pass 2 spend their time
         std::vector<uint32_t> raw(tprof_words);

@@ -19,6 +19,7 @@ struct FastPlan {
     uint32_t n_more = 0;
     uint32_t n_cus = 256;
     bool tagged = false;       // k_scan's records can carry their item's tag: pass 2 then walks whole sub-buckets and needs no directory (depth_fast.hip: kTagShift)
+    uint32_t tag_limit = 0;    // tagged: items a k_scan workgroup may take (its private tags; at most 512 less the split paths; FLATGFA_TAG_LIMIT shrinks it for tests)
     uint32_t n_shared = 0;     // paths cut into pieces (their bitsets are shared by all waves of a pass-2 workgroup in a tagged call)
     bool big_groups = false;   // pass 2 looks for steps that lie inside one item (worth it when a path has hundreds of records per window; the plan's creator times both)
     bool dense_maybe = false;  // between one and nine records for ten steps: the plan's creator times k_scan_dense against k_scan
@@ -26,6 +27,7 @@ struct FastPlan {
     uint32_t acc_parts = 1;  // workgroups per window in pass 2 (small graphs: fewer windows than CUs)
     uint64_t est_records = 0;  // records k_scan will make of its items (counted when the plan is made)
     bool acc_pair = false;     // tagged calls with unique depth run two workgroups per window, both resident on a CU (k_accum_pair)
+    uint32_t acc_wide = 1;     // the tagged walk takes this many times 64 records per step (apply_tagged_wide)
     uint32_t *pair_part = nullptr, *pair_flag = nullptr;  // their halves of the result vectors, and how many are there
     uint32_t n_slots = 0;      // sub-buckets per window = persistent workgroups of pass 1
     uint32_t n_win = 0;        // accumulation windows
@@ -49,6 +51,8 @@ struct FastPlan {
     void *items = nullptr;         // uint4[n_items + max_back] whole paths and pieces of long paths, longest first,
                                    // with room for the short paths k_scan_short hands back
     uint32_t n_items = 0;
+    void *items_rev = nullptr;     // the same list back to front (see run_range: every other tagged call walks the items in this order)
+    mutable uint32_t n_calls = 0;  // tagged calls so far
     uint32_t max_back = 0;
     bool accumulate = false;       // a group of paths behind the first (see fast_plan_create): pass 2 adds to the outputs
     bool too_many_items = false;   // create_range's verdict: only the number of items (or of split paths) per k_scan workgroup stands between this range and a tagged plan

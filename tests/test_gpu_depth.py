@@ -605,3 +605,51 @@ def test_bucket_arrays_beyond_four_gigabytes(n_segs, ranges, monkeypatch):
         if k == 0:
             assert (u.cpu().numpy().view(np.uint32) == want_u).all()
     plan.close()
+
+
+@pytest.mark.parametrize("mode", ["kernel_bound", "plan_headroom"])
+def test_a_workgroup_never_takes_more_items_than_it_has_tags(mode, monkeypatch):
+    """A tagged k_scan deals its items to the workgroups as they get to them, and an item's private
+    tag is its ordinal in its workgroup: a few long whole paths keep some workgroups busy while the
+    others take the many tiny ones -- more of them than the mean a plan used to be accepted on.
+    FLATGFA_TAG_LIMIT shrinks the tag space so that a small graph gets there.  `kernel_bound`: the plan
+    is accepted on the mean alone (FLATGFA_TAG_MEAN_ONLY) and k_scan's workgroups stop taking items
+    at the limit; `plan_headroom`: the plan plays the deal through and walks the paths in groups (or
+    keeps the directory) instead.  Either way the counts are exact."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")       # every path is an item of k_scan
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    for v in ("FLATGFA_TAGGED", "FLATGFA_PATH_GROUPS", "FLATGFA_PIECE_STEPS"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("FLATGFA_PIECE_STEPS", "100000000")  # the long paths stay whole
+    monkeypatch.setenv("FLATGFA_TAG_LIMIT", "8")
+    if mode == "kernel_bound":
+        monkeypatch.setenv("FLATGFA_TAG_MEAN_ONLY", "1")
+    else:
+        monkeypatch.delenv("FLATGFA_TAG_MEAN_ONLY", raising=False)
+    S = 150_000
+    g = pa.synth(31, S, 10, 200_000, "pangenome", False)
+    steps, _, _, _ = g.soa()
+    # 200 long paths' worth of workgroups would be too many for a quick test: six long paths of 200 k
+    # steps, then 1600 paths of 500 steps (256 workgroups: 6.3 items each on average, limit 8)
+    lens = np.array([200_000] * 6 + [500] * 1600, dtype=np.uint32)
+    pe = np.cumsum(lens).astype(np.uint32)
+    pb = (pe - lens).astype(np.uint32)
+    paths = np.zeros(len(lens), dtype=fo.PATH_DT)
+    paths["steps_start"], paths["steps_end"] = pb, pe
+    pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
+    pools.paths, pools.steps, pools.segs = paths, steps, np.zeros(S, dtype=fo.SEG_DT)
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    plan = DepthPlan(DeviceGraph(steps, pb, pe, S))
+    text = plan.describe()
+    if mode == "kernel_bound":
+        assert "pass2=tagged" in text and "path_groups" not in text, text
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    for _ in range(4):
+        plan.seg_depth(d, u)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == want_d).all(), text
+        assert (u.cpu().numpy().view(np.uint32) == want_u).all(), text
+    plan.close()
