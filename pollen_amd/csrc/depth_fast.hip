@@ -49,7 +49,6 @@
 #include <cstdio>
 #include <numeric>
 #include <string>
-#include <type_traits>
 #include <vector>
 
 #include "depth_fast.hpp"
@@ -150,6 +149,8 @@ struct ScanArgs {
     uint32_t *status;
     uint32_t dbg;
     uint32_t tagged;     // records carry their item's tag (see kTagShift); k_scan_dense reads this, k_scan is a build of its own
+    uint32_t *taken;     // tagged: [n_slots] how many items each workgroup took (its private tags are 0 .. taken - 1): pass 2 clears all of a wave's
+                         // bitsets at once where a sub-bucket has no more tags than the wave has bitsets, and none changes hands inside it
     uint32_t tag_limit;  // tagged: how many items a workgroup may take (its private tags are 0 .. tag_limit - 1; the split paths' lie above)
     unsigned long long *tprof;  // FLATGFA_SCAN_TIME (diagnostic): per workgroup, when it started, when it ended, when each of its waves ran out of work (10 ns units)
 };
@@ -1411,6 +1412,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads)
         A.counts[(size_t)wdw * A.n_slots + blockIdx.x] = bcur[wdw];
     if (TAGGED && threadIdx.x == 0) {  // the last workgroup out leaves the item counter clean for the next call
+        A.taken[blockIdx.x] = rr;
         const uint32_t out = atomicAdd(A.work_counter + 2, 1u);
         if (out == gridDim.x - 1u) {
             // items nobody took (every workgroup out of tags): the call is completed through the atomic kernels
@@ -1462,6 +1464,7 @@ struct AccArgs {
     uint32_t *pair_part;  // k_accum_pair: [n_win][2][depth | revisits][window] the two workgroups' halves
     uint32_t *pair_flag;  // k_accum_pair: [n_win] how many halves are there (zero between calls)
     uint32_t accumulate;  // the outputs hold the counts of the paths walked before (another group of the same call): add to them
+    const uint32_t *taken;  // tagged: [n_slots] items each k_scan workgroup took (ScanArgs::taken)
 };
 
 // FLATGFA_ACC_TIME: charge the time since the last mark to phase `ph` of this wave; the wave's
@@ -2136,15 +2139,18 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
     const uint32_t imax = A.n_slots > y16 ? kAccWaves * ((A.n_slots - y16 + nw - 1u) / nw) : 0u;
     const uint32_t *sp = wbase;  // (uniform) the next record of the open sub-bucket ...
     uint32_t left = 0;           // ... and how many it has left
+    uint32_t plain = 0;          // ... and whether its private tags all have a bitset of their own (2) or not (0)
     uint32_t cur_i = wv;
-    // (scnt2: {where k_scan's records start, counted from the window's first bucket; how many there are})
+    // (scnt2: {where k_scan's records start, counted from the window's first bucket; how many there are | plain << 31})
     const auto open = [&](uint32_t i) {
         const uint32_t s = y16 + (i & (kAccWaves - 1u)) + (i / kAccWaves) * nw;
         left = 0;
         if (i < imax && s < A.n_slots) {
             const uint2 c = scnt2[s];
             sp = wbase + __builtin_amdgcn_readfirstlane(c.x);
-            left = __builtin_amdgcn_readfirstlane(c.y);
+            const uint32_t n = __builtin_amdgcn_readfirstlane(c.y);
+            left = n & 0x7FFFFFFFu;
+            plain = (n >> 31) << 1;
         }
     };
     open(cur_i);
@@ -2173,7 +2179,7 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
             FGFA_TAG_TAKEN(cur_i);                               \
             FGFA_TAG_GRAB();                                     \
             open(cur_i);                                         \
-            FR = 1u;                                             \
+            FR = 1u | plain;                                     \
         }                                                        \
         NV = min(64u, left);                                     \
         if (LOW) rec_request_lo<K>(sp, lane4);                   \
@@ -2181,7 +2187,7 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
         sp += NV;                                                \
         left -= NV;                                              \
     } while (0)
-    int hmax = -1;  // (uniform) the highest private tag met in the open sub-bucket
+    int hmax = -1;  // (uniform) the highest private tag met in the open sub-bucket (the wave's first one is walked the general way: nothing says it is new)
     const auto clear_slots = [&](int from, int to) {  // the bitsets of the tags from .. to change hands
         for (int t = from; t <= to; ++t) {
             uint32_t *bs = bits + (wv * kTagSlots + ((uint32_t)t & (kTagSlots - 1u))) * kNW;
@@ -2224,7 +2230,10 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
         const uint32_t rec = LOW ? rec_take_lo<K>() : rec_take_s<K>();                                                 \
         const unsigned long long vm = NV >= 64u ? ~0ull : (1ull << NV) - 1ull;  /* the lanes that hold a record */     \
         const uint32_t last = NV - 1u;                                                                                 \
-        if (FR) hmax = -1;  /* the private slots start over with this sub-bucket */                                    \
+        if (FR & 2u) {  /* a sub-bucket whose private tags each have a slot: all of them cleared here, none changes hands */ \
+            for (uint32_t i = lane; i < kTagSlots * kNW / 4u; i += 64) reinterpret_cast<uint4 *>(bits + wv * kTagSlots * kNW)[i] = make_uint4(0u, 0u, 0u, 0u); \
+            hmax = (int)kTagSlots - 1;                                                                                 \
+        } else if (FR) hmax = -1;  /* the private slots start over with this sub-bucket */                             \
         FGFA_TAG_GEN(K, NV, FR);                                                                                       \
         const uint32_t tag = rec >> kTagShift;                                                                         \
         const unsigned long long shm = SHARED ? __builtin_amdgcn_ballot_w64(tag >= shlo) & vm : 0ull;                  \
@@ -2278,356 +2287,6 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
     }
 #undef FGFA_TAG_STEP
 #undef FGFA_TAG_GEN
-#undef FGFA_TAG_GRAB
-#undef FGFA_TAG_TAKEN
-}
-
-// ---- the tagged walk, K steps wide ----
-// A step of apply_tagged is a chain of short instructions around dependent LDS round trips (the
-// returning OR of every bitset word, then what its answer says about revisits), and a wave has
-// three of its kind as neighbours on its SIMD to hide them: the waves spend over 40 % of their time
-// in s_waitcnt.  Here a step takes K * 64 consecutive records of the open sub-bucket -- K registers per
-// lane, record 64 j + lane in register j -- and the K chains run side by side: one hand-over check
-// for all of them, the K ORs of a round issued back to back with ONE wait, the scalar bookkeeping
-// of a step (the stream, the counter of sub-buckets, the loop) paid once per K * 64 records.  A sub-bucket
-// of cfg-L holds 170 records: three steps before, one now (K = 3).  Claims are order-independent
-// (LDS atomics), so running the chains together changes nothing about the counts; a step whose
-// tags need the general route (more items than bitsets, items interleaved) is done register by
-// register with the one-wide logic.
-// Landing registers: three steps in flight, K registers each: v(123 - 3K) .. v122, step slot d's in
-// v(123 - 3K + d K) ...; the loads return in order, so slot d's are there once at most 2 K younger
-// ones are outstanding.
-// (a loop over 0 .. N - 1 whose index is a constant in the body: arrays indexed by it stay in registers)
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
-template <int K, int DS>
-__device__ __forceinline__ void wide_request(const uint32_t *p, uint32_t lane4) {
-#define FGFA_WREQ2(R0, R1) asm volatile("global_load_dword " R0 ", %0, %1\n\tglobal_load_dword " R1 ", %0, %1 offset:256" ::"v"(lane4), "s"(p) : "memory", R0, R1)
-#define FGFA_WREQ3(R0, R1, R2) asm volatile("global_load_dword " R0 ", %0, %1\n\tglobal_load_dword " R1 ", %0, %1 offset:256\n\tglobal_load_dword " R2 ", %0, %1 offset:512" ::"v"(lane4), "s"(p) : "memory", R0, R1, R2)
-    if (K == 2) {
-        if (DS == 0) FGFA_WREQ2("v117", "v118");
-        else if (DS == 1) FGFA_WREQ2("v119", "v120");
-        else FGFA_WREQ2("v121", "v122");
-    } else {
-        if (DS == 0) FGFA_WREQ3("v114", "v115", "v116");
-        else if (DS == 1) FGFA_WREQ3("v117", "v118", "v119");
-        else FGFA_WREQ3("v120", "v121", "v122");
-    }
-#undef FGFA_WREQ2
-#undef FGFA_WREQ3
-}
-template <int K, int DS>
-__device__ __forceinline__ void wide_take(uint32_t (&r)[K]) {
-#define FGFA_WTAKE2(R0, R1) asm volatile("s_waitcnt vmcnt(4)\n\tv_mov_b32 %0, " R0 "\n\tv_mov_b32 %1, " R1 : "=v"(r[0]), "=v"(r[1])::"memory")
-#define FGFA_WTAKE3(R0, R1, R2) asm volatile("s_waitcnt vmcnt(6)\n\tv_mov_b32 %0, " R0 "\n\tv_mov_b32 %1, " R1 "\n\tv_mov_b32 %2, " R2 : "=v"(r[0]), "=v"(r[1]), "=v"(r[K - 1])::"memory")
-    if (K == 2) {
-        if (DS == 0) FGFA_WTAKE2("v117", "v118");
-        else if (DS == 1) FGFA_WTAKE2("v119", "v120");
-        else FGFA_WTAKE2("v121", "v122");
-    } else {
-        if (DS == 0) FGFA_WTAKE3("v114", "v115", "v116");
-        else if (DS == 1) FGFA_WTAKE3("v117", "v118", "v119");
-        else FGFA_WTAKE3("v120", "v121", "v122");
-    }
-#undef FGFA_WTAKE2
-#undef FGFA_WTAKE3
-}
-
-// What claim_step does, for K registers of records at once (4096-segment windows).  Three kinds of
-// statements, exec restored at the end of each: the set-up of one register (+1 / -1 into D, the
-// first word's address, mask and R cell), a round's returning ORs for all registers with one wait,
-// and what one register's answer means (the revisited stretches into R; the lanes whose run goes on
-// into the next word, and that word's mask).
-struct WideLane {
-    uint32_t w, tt, mask, base;  // the bitset word's LDS address; the run's last bit counted from bit 0 of that word; the word's mask; R's cell of the word's first segment
-};
-__device__ __forceinline__ void wide_setup(WideLane &c, uint32_t rec, uint32_t sb, unsigned long long vm, uint32_t dbase, uint32_t rbase, uint32_t one, uint32_t mone) {
-    uint32_t a, n, k, m;
-    unsigned long long sv;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b64 exec, %[vm]\n\t"
-        "v_and_b32 %[a], 0xfff, %[rec]\n\t"
-        "v_bfe_u32 %[n], %[rec], 12, 10\n\t"
-        "v_lshl_add_u32 %[a], %[a], 2, %[dbase]\n\t"
-        "ds_add_u32 %[a], %[one]\n\t"
-        "v_lshl_add_u32 %[a], %[n], 2, %[a]\n\t"
-        "ds_add_u32 %[a], %[mone] offset:4\n\t"
-        "v_bfe_u32 %[w], %[rec], 5, 7\n\t"
-        "v_lshl_add_u32 %[w], %[w], 2, %[sb]\n\t"
-        "v_and_b32 %[k], 31, %[rec]\n\t"
-        "v_add_u32 %[tt], %[k], %[n]\n\t"
-        "v_min_u32 %[m], 31, %[tt]\n\t"
-        "v_sub_u32 %[m], 31, %[m]\n\t"
-        "v_lshrrev_b32 %[m], %[m], -1\n\t"
-        "v_lshlrev_b32 %[k], %[k], -1\n\t"
-        "v_and_b32 %[mask], %[m], %[k]\n\t"
-        "v_and_b32 %[base], 0xfe0, %[rec]\n\t"
-        "v_lshl_add_u32 %[base], %[base], 2, %[rbase]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [a] "=&v"(a), [n] "=&v"(n), [k] "=&v"(k), [m] "=&v"(m), [w] "=&v"(c.w), [tt] "=&v"(c.tt), [mask] "=&v"(c.mask), [base] "=&v"(c.base), [sv] "=&s"(sv)
-        : [rec] "v"(rec), [sb] "v"(sb), [vm] "s"(vm), [dbase] "s"(dbase), [rbase] "s"(rbase), [one] "v"(one), [mone] "v"(mone)
-        : "memory");
-}
-template <int K>
-__device__ __forceinline__ void wide_or(const WideLane (&c)[K], const unsigned long long (&act)[K], uint32_t (&old)[K]) {
-    unsigned long long sv;
-    if (K == 2)
-        asm volatile(
-            "s_mov_b64 %[sv], exec\n\t"
-            "s_mov_b64 exec, %[a0]\n\tds_or_rtn_b32 %[o0], %[w0], %[m0]\n\t"
-            "s_mov_b64 exec, %[a1]\n\tds_or_rtn_b32 %[o1], %[w1], %[m1]\n\t"
-            "s_mov_b64 exec, %[sv]\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : [o0] "=&v"(old[0]), [o1] "=&v"(old[1]), [sv] "=&s"(sv)
-            : [a0] "s"(act[0]), [a1] "s"(act[1]), [w0] "v"(c[0].w), [w1] "v"(c[1].w), [m0] "v"(c[0].mask), [m1] "v"(c[1].mask)
-            : "memory");
-    else
-        asm volatile(
-            "s_mov_b64 %[sv], exec\n\t"
-            "s_mov_b64 exec, %[a0]\n\tds_or_rtn_b32 %[o0], %[w0], %[m0]\n\t"
-            "s_mov_b64 exec, %[a1]\n\tds_or_rtn_b32 %[o1], %[w1], %[m1]\n\t"
-            "s_mov_b64 exec, %[a2]\n\tds_or_rtn_b32 %[o2], %[w2], %[m2]\n\t"
-            "s_mov_b64 exec, %[sv]\n\t"
-            "s_waitcnt lgkmcnt(0)"
-            : [o0] "=&v"(old[0]), [o1] "=&v"(old[1]), [o2] "=&v"(old[K - 1]), [sv] "=&s"(sv)
-            : [a0] "s"(act[0]), [a1] "s"(act[1]), [a2] "s"(act[K - 1]), [w0] "v"(c[0].w), [w1] "v"(c[1].w), [w2] "v"(c[K - 1].w), [m0] "v"(c[0].mask),
-              [m1] "v"(c[1].mask), [m2] "v"(c[K - 1].mask)
-            : "memory");
-}
-// (act: in, the lanes that claimed a word this round; out, those whose run goes on into the next word)
-__device__ __forceinline__ void wide_after(WideLane &c, unsigned long long &act, uint32_t old, uint32_t one, uint32_t mone) {
-    uint32_t rv, low, sum, f, g;
-    unsigned long long sv;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b64 exec, %[act]\n\t"
-        "v_and_b32 %[rv], %[old], %[mask]\n\t"                // the segments this path had already visited
-        "v_cmp_ne_u32 vcc, 0, %[rv]\n\t"
-        "s_cbranch_vccz 3f\n\t"
-        "2:\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        "v_sub_u32 %[low], 0, %[rv]\n\t"
-        "v_and_b32 %[low], %[rv], %[low]\n\t"                 // the lowest revisited segment
-        "v_add_u32 %[sum], %[rv], %[low]\n\t"                 // (the carry runs through its stretch)
-        "v_ffbl_b32 %[f], %[low]\n\t"
-        "v_ffbl_b32 %[g], %[sum]\n\t"
-        "v_min_u32 %[g], 32, %[g]\n\t"                        // (no bit left: the stretch ends with the word)
-        "v_lshl_add_u32 %[f], %[f], 2, %[base]\n\t"
-        "v_lshl_add_u32 %[g], %[g], 2, %[base]\n\t"
-        "ds_add_u32 %[f], %[one]\n\t"
-        "ds_add_u32 %[g], %[mone]\n\t"
-        "v_and_b32 %[rv], %[rv], %[sum]\n\t"
-        "v_cmp_ne_u32 vcc, 0, %[rv]\n\t"
-        "s_cbranch_vccnz 2b\n\t"
-        "s_mov_b64 exec, %[act]\n\t"
-        "3:\n\t"
-        "v_cmp_lt_u32 vcc, 31, %[tt]\n\t"                     // the lanes whose run goes on into the next word
-        "s_mov_b64 %[act], vcc\n\t"
-        "s_cbranch_vccz 4f\n\t"
-        "s_mov_b64 exec, vcc\n\t"
-        "v_subrev_u32 %[tt], 32, %[tt]\n\t"
-        "v_add_u32 %[w], 4, %[w]\n\t"
-        "v_add_u32 %[base], 0x80, %[base]\n\t"
-        "v_min_u32 %[low], 31, %[tt]\n\t"
-        "v_sub_u32 %[low], 31, %[low]\n\t"
-        "v_lshrrev_b32 %[mask], %[low], -1\n\t"
-        "4:\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [act] "+s"(act), [w] "+v"(c.w), [tt] "+v"(c.tt), [mask] "+v"(c.mask), [base] "+v"(c.base), [rv] "=&v"(rv), [low] "=&v"(low), [sum] "=&v"(sum),
-          [f] "=&v"(f), [g] "=&v"(g), [sv] "=&s"(sv)
-        : [old] "v"(old), [one] "v"(one), [mone] "v"(mone)
-        : "vcc", "memory");
-}
-
-template <int WB, bool SHARED, int K>
-__device__ __forceinline__ void apply_tagged_wide(const AccArgs &A, int *D, int *R, uint32_t *bits, const uint2 *scnt2, const uint32_t *wbase,
-                                                  uint32_t *grab) {
-    static_assert(WB == 12 && (K == 2 || K == 3), "the wide walk's constants are those of 4096-segment windows");
-    constexpr uint32_t kW = 1u << WB, kNW = kW / 32u;
-    constexpr uint32_t kPriv = kAccWaves * kTagSlots;
-    const int lane = threadIdx.x & 63;
-    const uint32_t lane4 = 4u * (uint32_t)lane;
-    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t y16 = blockIdx.y * kAccWaves, nw = A.parts * kAccWaves;
-    const uint32_t shlo = kTagCount - A.n_shared;
-    const uint32_t bits0 = lds_addr(bits), priv_b = bits0 + ((wv * kTagSlots) << (WB - 3));
-    const uint32_t dbase = lds_addr(D), rbase = lds_addr(R);
-    uint32_t one = 1u, mone = ~0u;
-    asm volatile("" : "+v"(one), "+v"(mone));
-    const uint32_t imax = A.n_slots > y16 ? kAccWaves * ((A.n_slots - y16 + nw - 1u) / nw) : 0u;
-    const uint32_t *sp = wbase;
-    uint32_t left = 0;
-    uint32_t cur_i = wv;
-    const auto open = [&](uint32_t i) {
-        const uint32_t s = y16 + (i & (kAccWaves - 1u)) + (i / kAccWaves) * nw;
-        left = 0;
-        if (i < imax && s < A.n_slots) {
-            const uint2 c = scnt2[s];
-            sp = wbase + __builtin_amdgcn_readfirstlane(c.x);
-            left = __builtin_amdgcn_readfirstlane(c.y);
-        }
-    };
-    open(cur_i);
-    const uint32_t grab_a = lds_addr(grab);
-    uint32_t nxt = 0;
-#define FGFA_TAG_GRAB()                                                                                         \
-    do {                                                                                                        \
-        unsigned long long sv_;                                                                                 \
-        asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %2, %3\n\ts_mov_b64 exec, %1" \
-                     : "+v"(nxt), "=&s"(sv_)                                                                    \
-                     : "v"(grab_a), "v"(one)                                                                    \
-                     : "memory");                                                                               \
-    } while (0)
-#define FGFA_TAG_TAKEN(OUT) asm volatile("s_waitcnt lgkmcnt(0)\n\tv_readfirstlane_b32 %0, %1" : "=s"(OUT) : "v"(nxt) : "memory")
-    FGFA_TAG_GRAB();
-#define FGFA_WIDE_GEN(DS, NV, FR)                                \
-    do {                                                         \
-        FR = 0u;                                                 \
-        while (left == 0u && cur_i < imax) {                     \
-            FGFA_TAG_TAKEN(cur_i);                               \
-            FGFA_TAG_GRAB();                                     \
-            open(cur_i);                                         \
-            FR = 1u;                                             \
-        }                                                        \
-        NV = min(64u * K, left);                                 \
-        wide_request<K, DS>(sp, lane4);                          \
-        sp += NV;                                                \
-        left -= NV;                                              \
-    } while (0)
-    int hmax = -1;
-    const auto clear_slots = [&](int from, int to) {
-        for (int t = from; t <= to; ++t) {
-            uint32_t *bs = bits + (wv * kTagSlots + ((uint32_t)t & (kTagSlots - 1u))) * kNW;
-            for (uint32_t i = lane; i < kNW / 2u; i += 64) reinterpret_cast<uint2 *>(bs)[i] = make_uint2(0u, 0u);
-        }
-    };
-    const auto slot_of = [&](uint32_t tag, bool any_shared) {
-        uint32_t sb = priv_b + ((tag & (kTagSlots - 1u)) << (WB - 3));
-        if (SHARED && any_shared) sb = tag >= shlo ? bits0 + ((kPriv + kTagCount - 1u - tag) << (WB - 3)) : sb;
-        return sb;
-    };
-    // one register's 64 records by the one-wide logic (the general route included)
-    const auto step64 = [&](uint32_t rec, unsigned long long vm) {
-        const uint32_t tag = rec >> kTagShift;
-        const uint32_t last = 63u - (uint32_t)__builtin_clzll(vm);
-        const unsigned long long shm = SHARED ? __builtin_amdgcn_ballot_w64(tag >= shlo) & vm : 0ull;
-        const unsigned long long pvm = vm & ~shm;
-        bool general = false;
-        if (__builtin_amdgcn_ballot_w64((uint32_t)hmax - tag >= kTagSlots) & pvm) {
-            const int c = (int)__builtin_amdgcn_readlane(tag, (int)last);
-            general = !((pvm >> last) & 1ull) || (__builtin_amdgcn_ballot_w64((int)tag > c || (int)(tag + kTagSlots) <= c) & pvm);
-            if (!general) {
-                clear_slots(max(hmax + 1, c - (int)(kTagSlots - 1u)), c);
-                hmax = c;
-            }
-        }
-        if (!general) {
-            claim_step<WB>(rec, slot_of(tag, shm != 0ull), vm, dbase, rbase, one, mone);
-        } else {
-            unsigned long long todo = vm;
-            do {
-                unsigned long long act = todo;
-                const bool pv = ((todo & pvm) >> lane) & 1ull;
-                if (todo & pvm) {
-                    const uint32_t tmin = wave_min_u32(pv ? tag : ~0u);
-                    const unsigned long long beyond = __builtin_amdgcn_ballot_w64(pv && tag >= tmin + kTagSlots);
-                    if (beyond) act = todo & ((1ull << __builtin_ctzll(beyond)) - 1ull);
-                    if ((int)(tmin + kTagSlots) <= hmax || !act) {  // cannot happen: k_scan's gate
-                        atomicOr(A.status, kStInternal);
-                        act = todo;
-                    }
-                    const int hnew = max(hmax, (int)wave_max_u32(((act & pvm) >> lane) & 1ull ? tag : 0u));
-                    clear_slots(max(hmax + 1, hnew - (int)(kTagSlots - 1u)), hnew);
-                    hmax = hnew;
-                }
-                claim_step<WB>(rec, slot_of(tag, shm != 0ull), act, dbase, rbase, one, mone);
-                todo &= ~act;
-            } while (todo);
-        }
-    };
-    uint32_t nv0 = 0, nv1 = 0, nv2 = 0, f0 = 0, f1 = 0, f2 = 0;
-    FGFA_WIDE_GEN(0, nv0, f0);
-    FGFA_WIDE_GEN(1, nv1, f1);
-    FGFA_WIDE_GEN(2, nv2, f2);
-#define FGFA_WIDE_STEP(DS, NV, FR)                                                                                     \
-    if (NV == 0u) break;                                                                                               \
-    {                                                                                                                  \
-        uint32_t rec[K];                                                                                               \
-        wide_take<K, DS>(rec);                                                                                         \
-        const uint32_t nv = NV;                                                                                        \
-        if (FR) hmax = -1;  /* the private slots start over with this sub-bucket */                                    \
-        FGFA_WIDE_GEN(DS, NV, FR);                                                                                     \
-        unsigned long long vm[K], pvm[K], need = 0ull, shany = 0ull;                                                   \
-        uint32_t tag[K];                                                                                               \
-        static_for<K>([&](auto J) {                                                                                    \
-            constexpr int j = decltype(J)::value;                                                                      \
-            const uint32_t cnt = nv > 64u * (uint32_t)j ? min(64u, nv - 64u * (uint32_t)j) : 0u;                       \
-            vm[j] = cnt >= 64u ? ~0ull : (1ull << cnt) - 1ull;                                                         \
-            tag[j] = rec[j] >> kTagShift;                                                                              \
-            const unsigned long long shm = SHARED ? __builtin_amdgcn_ballot_w64(tag[j] >= shlo) & vm[j] : 0ull;        \
-            shany |= shm;                                                                                              \
-            pvm[j] = vm[j] & ~shm;                                                                                     \
-            need |= __builtin_amdgcn_ballot_w64((uint32_t)hmax - tag[j] >= kTagSlots) & pvm[j];                        \
-        });                                                                                                            \
-        bool general = false;                                                                                          \
-        if (need) {                                                                                                    \
-            /* the step's last record: its tag is the highest unless waves that ran ahead have interleaved the items */ \
-            const uint32_t li = nv - 1u, jl = li >> 6, ll = li & 63u;                                                  \
-            uint32_t tl = tag[0];                                                                                      \
-            unsigned long long pl = pvm[0];                                                                            \
-            if (jl == 1u) tl = tag[1], pl = pvm[1];                                                                    \
-            if (K > 2 && jl == 2u) tl = tag[K - 1], pl = pvm[K - 1];                                                   \
-            const int c = (int)__builtin_amdgcn_readlane(tl, (int)ll);                                                 \
-            unsigned long long out = 0ull;                                                                             \
-            static_for<K>([&](auto J) {                                                                                \
-                constexpr int j = decltype(J)::value;                                                                  \
-                out |= __builtin_amdgcn_ballot_w64((int)tag[j] > c || (int)(tag[j] + kTagSlots) <= c) & pvm[j];        \
-            });                                                                                                        \
-            general = !((pl >> ll) & 1ull) || out;                                                                     \
-            if (!general) {                                                                                            \
-                clear_slots(max(hmax + 1, c - (int)(kTagSlots - 1u)), c);                                              \
-                hmax = c;                                                                                              \
-            }                                                                                                          \
-        }                                                                                                              \
-        if (!general) {                                                                                                \
-            WideLane cl[K];                                                                                            \
-            unsigned long long act[K];                                                                                 \
-            static_for<K>([&](auto J) {                                                                                \
-                constexpr int j = decltype(J)::value;                                                                  \
-                wide_setup(cl[j], rec[j], slot_of(tag[j], shany != 0ull), vm[j], dbase, rbase, one, mone);             \
-                act[j] = vm[j];                                                                                        \
-            });                                                                                                        \
-            unsigned long long any;                                                                                    \
-            do {                                                                                                       \
-                uint32_t old[K];                                                                                       \
-                wide_or<K>(cl, act, old);                                                                              \
-                any = 0ull;                                                                                            \
-                static_for<K>([&](auto J) {                                                                            \
-                    constexpr int j = decltype(J)::value;                                                              \
-                    if (act[j]) wide_after(cl[j], act[j], old[j], one, mone);                                          \
-                    any |= act[j];                                                                                     \
-                });                                                                                                    \
-            } while (any);                                                                                             \
-        } else {                                                                                                       \
-            static_for<K>([&](auto J) {                                                                                \
-                constexpr int j = decltype(J)::value;                                                                  \
-                if (vm[j]) step64(rec[j], vm[j]);                                                                      \
-            });                                                                                                        \
-        }                                                                                                              \
-    }
-    while (true) {
-        FGFA_WIDE_STEP(0, nv0, f0)
-        FGFA_WIDE_STEP(1, nv1, f1)
-        FGFA_WIDE_STEP(2, nv2, f2)
-    }
-#undef FGFA_WIDE_STEP
-#undef FGFA_WIDE_GEN
 #undef FGFA_TAG_GRAB
 #undef FGFA_TAG_TAKEN
 }
@@ -2768,7 +2427,7 @@ uint32_t tagged_lds_bytes(uint32_t wb, uint32_t n_shared) { return (kAccWaves * 
 // one instruction per cycle and CU where two are possible, and eight waves per SIMD hide more of its
 // LDS round trips than four.  Both leave their partial vectors in scratch; the second one to
 // finish adds the other's to its own and writes the results.
-template <bool UNIQ, int WB, bool PSUM, bool POINT, bool BIG, bool TAGGED, bool PAIR, int WIDE = 1>
+template <bool UNIQ, int WB, bool PSUM, bool POINT, bool BIG, bool TAGGED, bool PAIR>
 __device__ __forceinline__ void accum_body(const AccArgs &A) {
     constexpr uint32_t kW = 1u << WB;
     constexpr int kPer = kW / kAccThreads;  // cells per thread: 4 or 8
@@ -2822,7 +2481,8 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
         if (TAGGED && UNIQ) {
             const uint32_t c1 = min(v, A.cap);
             v = min(A.has_pre == 1 ? A.counts0[(size_t)win * A.n_slots + sl] : A.has_pre ? v : 0u, c1);  // (2: k_scan did not run, all are earlier records)
-            scnt2[sl] = make_uint2(sl * A.cap + v, c1 - v);  // k_scan's records: where they start in the window's buckets, how many
+            // (bit 31 of the count: the sub-bucket's private tags are 0 .. kTagSlots - 1 at most, so no bitset changes hands inside it)
+            scnt2[sl] = make_uint2(sl * A.cap + v, (c1 - v) | (A.taken && A.taken[sl] <= kTagSlots ? 0x80000000u : 0u));  // k_scan's records: where they start in the window's buckets, how many
         } else if (UNIQ && A.has_pre == 1) {
             v = A.counts0[(size_t)win * A.n_slots + sl];
         }
@@ -2839,10 +2499,7 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
     if (flat) apply_flat<UNIQ, WB, (PAIR ? 4 : 16)>(A, D, R, scnt, wbase);
     tm.mark(1);
     if (UNIQ && TAGGED) {
-        if constexpr (WIDE > 1 && WB == 12 && !PAIR && !POINT) {
-            if (A.n_shared) apply_tagged_wide<WB, true, WIDE>(A, D, R, tag_bits, scnt2, wbase, &grab);
-            else apply_tagged_wide<WB, false, WIDE>(A, D, R, tag_bits, scnt2, wbase, &grab);
-        } else if (PAIR) apply_tagged<WB, POINT, false, true>(A, D, R, tag_bits, scnt2, wbase, &grab);
+        if (PAIR) apply_tagged<WB, POINT, false, true>(A, D, R, tag_bits, scnt2, wbase, &grab);
         else if (A.n_shared) apply_tagged<WB, POINT, true>(A, D, R, tag_bits, scnt2, wbase, &grab);
         else apply_tagged<WB, POINT, false>(A, D, R, tag_bits, scnt2, wbase, &grab);
     } else if (UNIQ) {
@@ -2956,9 +2613,9 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
     }
 }
 
-template <bool UNIQ, int WB, bool PSUM = false, bool POINT = false, bool BIG = false, bool TAGGED = false, int WIDE = 1>
+template <bool UNIQ, int WB, bool PSUM = false, bool POINT = false, bool BIG = false, bool TAGGED = false>
 __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
-    accum_body<UNIQ, WB, PSUM, POINT, BIG, TAGGED, false, WIDE>(A);
+    accum_body<UNIQ, WB, PSUM, POINT, BIG, TAGGED, false>(A);
 }
 template <int WB, bool POINT>
 __global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_accum_pair(const AccArgs A) {
@@ -3143,6 +2800,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_dense(const ScanArgs A) {
     }
     flag_if_any(A, bad, kStBounds);
     flag_if_any(A, ovf, kStOverflow);
+    if (A.tagged && tid == 0) A.taken[blockIdx.x] = (n_items + gridDim.x - 1u) / gridDim.x;  // (item_of: no workgroup takes more)
     for (uint32_t i = tid; i < A.n_win; i += kThreads) A.counts[(size_t)i * A.n_slots + blockIdx.x] = bcur[i];
 }
 
@@ -3362,22 +3020,11 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // (the largest such size: for 1000 paths of 100 k steps, no cutting at all).
     // (z: bit 0 = the item walks the ids downwards, set by k_item_dirs; from bit 1 up, 1 + the
     // ordinal of the split path the item is a piece of, or 0 for a whole path)
-    // (FLATGFA_TAIL_PATHS=n, FLATGFA_TAIL_PIECES=k: the n shortest whole paths -- the ones k_scan's workgroups
-    // take last -- are cut into k pieces each, so that the deal ends on small items)
-    std::vector<uint32_t> tail_k(whole.size(), 1u);
-    if (const char *tp = getenv("FLATGFA_TAIL_PATHS")) {
-        const uint32_t n_tail = std::min<uint32_t>((uint32_t)strtoul(tp, nullptr, 10), (uint32_t)whole.size());
-        const uint32_t k_tail = getenv("FLATGFA_TAIL_PIECES") ? std::max(1u, (uint32_t)strtoul(getenv("FLATGFA_TAIL_PIECES"), nullptr, 10)) : 4u;
-        std::vector<uint32_t> order(whole.size());
-        std::iota(order.begin(), order.end(), 0u);
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return whole[a].y - whole[a].x > whole[b].y - whole[b].x; });
-        for (uint32_t i = 0; i < n_tail; ++i) tail_k[order[whole.size() - 1 - i]] = k_tail;
-    }
     const auto cut = [&](uint64_t piece, std::vector<uint4> *out) -> uint32_t {
         uint32_t n_split = 0;
         for (const uint4 &w : whole) {
             const uint64_t b = w.x, n = (uint64_t)w.y - w.x;
-            const uint32_t k = std::max((uint32_t)((n + piece - 1) / piece), n >= 4096 ? tail_k[(size_t)(&w - whole.data())] : 1u);
+            const uint32_t k = (uint32_t)((n + piece - 1) / piece);
             const uint32_t z = k > 1 ? (++n_split) << 1 : 0u;
             for (uint32_t j = 0; j < k; ++j)
                 out->push_back(make_uint4((uint32_t)(b + n * j / k), (uint32_t)(b + n * (j + 1) / k), z, w.w));
@@ -3627,6 +3274,8 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     }
     FAST_TRY(hipMalloc(&fp->counts, slots * 4));
     FAST_TRY(hipMemset(fp->counts, 0, slots * 4));
+    FAST_TRY(hipMalloc(&fp->taken, (size_t)fp->n_slots * 4));
+    FAST_TRY(hipMemset(fp->taken, 0xFF, (size_t)fp->n_slots * 4));  // (nothing known until a tagged k_scan has run)
     FAST_TRY(hipMalloc(&fp->counts0, slots * 4));
     FAST_TRY(hipMemset(fp->counts0, 0, slots * 4));
     FAST_TRY(hipMalloc(&fp->dir, (size_t)fp->dstride * n_win * sizeof(uint2)));
@@ -3660,13 +3309,6 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             fp->dense = !fp->dbg && strtol(f, nullptr, 10) != 0 && dense_lds_bytes(fp->nwp) + 64 <= kLdsLimit;
             fp->dense_maybe = false;
         }
-    }
-    if (!items.empty() && fp->tagged && short_items.empty() && medium_items.empty() && getenv("FLATGFA_ALTERNATE")) {
-        std::vector<uint4> back(items.size());
-        FAST_TRY(hipMemcpy(back.data(), fp->items, items.size() * sizeof(uint4), hipMemcpyDeviceToHost));  // (with the directions k_item_dirs found)
-        std::reverse(back.begin(), back.end());
-        FAST_TRY(hipMalloc(&fp->items_rev, (items.size() + 1) * sizeof(uint4)));
-        FAST_TRY(hipMemcpy(fp->items_rev, back.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
     }
     if (!short_items.empty()) {
         FAST_TRY(hipMalloc(&fp->short_items, short_items.size() * sizeof(uint4)));
@@ -3706,8 +3348,6 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 11, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(11, kMaxShared)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
-    FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, false, false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
-    FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, false, false, true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 13, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(13, 0)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 13, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(13, 0)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum_pair<12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, 0)));
@@ -3720,9 +3360,6 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     const bool pair_ok = fp->tagged && fp->n_shared == 0 && wb == 12 && fp->acc_parts == 1 && n_win <= 2 * fp->n_cus;
     fp->acc_pair = pair_ok && fp->est_records / n_win >= 65536;
     if (const char *f = getenv("FLATGFA_ACC_PAIR")) fp->acc_pair = pair_ok && strtol(f, nullptr, 10) != 0;
-    // The tagged walk K steps wide (apply_tagged_wide; 4096-segment windows): FLATGFA_ACC_WIDE=1|2|3.
-    fp->acc_wide = 1;
-    if (const char *f = getenv("FLATGFA_ACC_WIDE")) fp->acc_wide = std::max(1u, std::min(3u, (uint32_t)strtoul(f, nullptr, 10)));
     if (fp->acc_pair) {
         FAST_TRY(hipMalloc(&fp->pair_part, (size_t)n_win * 2 * 2 * (1u << wb) * 4));
         FAST_TRY(hipMalloc(&fp->pair_flag, (size_t)n_win * 4));
@@ -3939,9 +3576,9 @@ void fast_plan_destroy(FastPlan *fp) {
     for (uint32_t r = 0; r < fp->n_more; ++r) fast_plan_destroy(&fp->more[r]);
     delete[] fp->more;
     for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot, (void *)fp->perm,
-                    (void *)fp->elist, (void *)fp->wave_off, (void *)fp->fat_off, (void *)fp->fat_woff, (void *)fp->items, (void *)fp->items_rev, (void *)fp->short_items,
+                    (void *)fp->elist, (void *)fp->wave_off, (void *)fp->fat_off, (void *)fp->fat_woff, (void *)fp->items, (void *)fp->short_items,
                     (void *)fp->medium_items, (void *)fp->rev_steps, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part,
-                    (void *)fp->pair_part, (void *)fp->pair_flag})
+                    (void *)fp->pair_part, (void *)fp->pair_flag, (void *)fp->taken})
         if (p) (void)hipFree(p);
     *fp = FastPlan();
 }
@@ -4002,14 +3639,14 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     const bool tagged = fp.tagged && !ps;
     sa.tagged = tagged ? 1u : 0u;
     sa.tag_limit = std::max(2u, fp.tag_limit);
-    if (tagged && fp.items_rev && !fp.n_short && !fp.n_medium && !sa.ranged && ((fp.n_calls++) & 1u)) sa.items = reinterpret_cast<uint4 *>(fp.items_rev);
+    sa.taken = fp.taken;
     sa.tprof = nullptr;
     if (getenv("FLATGFA_SCAN_TIME") && hipMalloc(&sa.tprof, kTprofRow * 8 * (size_t)fp.n_slots) == hipSuccess) (void)hipMemset(sa.tprof, 0, kTprofRow * 8 * (size_t)fp.n_slots);
     AccArgs aa{fp.n_range, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.counts0, scan_skip ? 2u : has_pre ? 1u : 0u, fp.buckets,
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
                fp.work_counter, scan_skip ? 0u : fp.max_back, depth_out, uniq_out, status, fp.dbg,
                reinterpret_cast<const uint4 *>(fp.items), g.seg_len, ps ? reinterpret_cast<ulonglong2 *>(fp.psum_part) : nullptr,
-               fp.fat_off, fp.fat_woff, fp.acc_parts, tagged ? fp.n_shared : 0u, nullptr, fp.pair_part, fp.pair_flag, fp.accumulate ? 1u : 0u};
+               fp.fat_off, fp.fat_woff, fp.acc_parts, tagged ? fp.n_shared : 0u, nullptr, fp.pair_part, fp.pair_flag, fp.accumulate ? 1u : 0u, getenv("FLATGFA_NO_PLAIN") ? nullptr : fp.taken};  // (FLATGFA_NO_PLAIN: measurements)
     if (const char *sk = getenv("FLATGFA_ACC_SKIP")) aa.dbg = (uint32_t)strtoul(sk, nullptr, 10);  // (diagnostic: pass 2 without its revisit counts 128 / depth 256 / claims 64 / words behind the first 1024)
     const size_t tprof_words = (size_t)fp.n_win * fp.acc_parts * kAccWaves * 16;
     if (getenv("FLATGFA_ACC_TIME") && uniq_out && hipMalloc(&aa.tprof, tprof_words * 4) != hipSuccess) aa.tprof = nullptr;
@@ -4090,8 +3727,6 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
             if (fp.dense && fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12, false, true, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
             else if (fp.dense && fp.wb == 13) hipLaunchKernelGGL((k_accum<true, 13, false, true, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
             else if (fp.wb == 11) hipLaunchKernelGGL((k_accum<true, 11, false, false, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
-            else if (fp.wb == 12 && fp.acc_wide == 2) hipLaunchKernelGGL((k_accum<true, 12, false, false, false, true, 2>), agrid, dim3(kAccThreads), tl, stream, aa);
-            else if (fp.wb == 12 && fp.acc_wide == 3) hipLaunchKernelGGL((k_accum<true, 12, false, false, false, true, 3>), agrid, dim3(kAccThreads), tl, stream, aa);
             else if (fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12, false, false, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
             else hipLaunchKernelGGL((k_accum<true, 13, false, false, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
         } else if (uniq_out) {

@@ -27,7 +27,6 @@ struct FastPlan {
     uint32_t acc_parts = 1;  // workgroups per window in pass 2 (small graphs: fewer windows than CUs)
     uint64_t est_records = 0;  // records k_scan will make of its items (counted when the plan is made)
     bool acc_pair = false;     // tagged calls with unique depth run two workgroups per window, both resident on a CU (k_accum_pair)
-    uint32_t acc_wide = 1;     // the tagged walk takes this many times 64 records per step (apply_tagged_wide)
     uint32_t *pair_part = nullptr, *pair_flag = nullptr;  // their halves of the result vectors, and how many are there
     uint32_t n_slots = 0;      // sub-buckets per window = persistent workgroups of pass 1
     uint32_t n_win = 0;        // accumulation windows
@@ -51,8 +50,6 @@ struct FastPlan {
     void *items = nullptr;         // uint4[n_items + max_back] whole paths and pieces of long paths, longest first,
                                    // with room for the short paths k_scan_short hands back
     uint32_t n_items = 0;
-    void *items_rev = nullptr;     // the same list back to front (see run_range: every other tagged call walks the items in this order)
-    mutable uint32_t n_calls = 0;  // tagged calls so far
     uint32_t max_back = 0;
     bool accumulate = false;       // a group of paths behind the first (see fast_plan_create): pass 2 adds to the outputs
     bool too_many_items = false;   // create_range's verdict: only the number of items (or of split paths) per k_scan workgroup stands between this range and a tagged plan
@@ -69,6 +66,7 @@ struct FastPlan {
     void *medium_items = nullptr;  // uint4[n_medium] longer paths with few enough runs for a 2048-entry hash set
     uint32_t n_medium = 0, n_medium_rev = 0;  // (laid out like short_items)
     uint32_t lds_bytes_medium = 0;
+    uint32_t *taken = nullptr;         // u32[n_slots] items each workgroup of the last tagged k_scan took
     uint32_t *work_counter = nullptr;  // how many short paths were handed back in this call
     void *psum_part = nullptr;         // ulonglong2[n_win * dstride] per-window path sums of k_scan's items (on first use)
     uint32_t *other_ids = nullptr;     // u32[n_other] the paths k_scan_short walks (their sums need k_path_sums)

@@ -67,13 +67,10 @@ def main():
             continue
         if "k_accum" in func:  # pass 2: pinned record registers -- v120..v122 (rec_request / rec_take), and in the
             # build with two workgroups per CU (k_accum_pair, 64 registers) v61..v63 (rec_request_lo / rec_take_lo)
-            mt = re.search(r"k_accumILb\dELi\d+ELb\dELb\dELb\dELb1ELi(\d)EE", func)  # (the last two template arguments: tagged, steps per step)
-            tagged = mt is not None
-            wide = int(mt.group(1)) if mt else 1
-            # (the wide walk keeps three steps of `wide` registers each in flight: v(123 - 3 wide) .. v122)
-            pins = {61, 62, 63} if "k_accum_pair" in func else set(range(123 - 3 * wide, 123)) if tagged and wide > 1 else tagged_pins if tagged else {120, 121, 122}  # (the build with 64 registers lands its records in v61..v63)
+            tagged = re.search(r"k_accumILb\dELi\d+ELb\dELb\dELb\dELb1EE", func) is not None  # (the last template argument)
+            pins = {61, 62, 63} if "k_accum_pair" in func else tagged_pins if tagged else {120, 121, 122}  # (the build with 64 registers lands its records in v61..v63)
             if regs_of(s) & pins:
-                m = re.match(r"^global_load_dword v(\d+), (v\[\d+:\d+\], off|v\d+, s\[\d+:\d+\])( offset:(256|512))?$", s)
+                m = re.match(r"^global_load_dword v(\d+), (v\[\d+:\d+\], off|v\d+, s\[\d+:\d+\])$", s)
                 t = re.match(r"^v_mov_b32(_e32)? v(\d+), v(\d+)$", s)
                 if m and int(m.group(1)) in pins:
                     n_acc_load += 1
