@@ -434,6 +434,34 @@ def main():
             c6 = time.perf_counter()
             extras["cpu_end_to_end"] = {"what": "oracle seg_depth_with_uniq + oracle SegDepth::emit, one core, arrays in memory",
                                         "total_ms": round((c6 - c5) * 1e3, 3), "same_bytes": bool(cpu_text == text)}
+            # The reference's own measurement (bench/config.toml:29-32, bench/bench.py:68-85): the whole
+            # PROCESS `fgfa -i G.flatgfa depth` under hyperfine --warmup=1 --min-runs=3, output discarded --
+            # exec to exit, so HIP start-up, code-object load and the first upload are all inside.  Beside it
+            # the same command with -d, and the oracle's process for both (one core; mmap -> compute -> emit).
+            def processes(cmd, runs=5):
+                ts = []
+                for k in range(runs + 1):  # the first run is the warm-up
+                    c0 = time.perf_counter()
+                    rc = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+                    c1 = time.perf_counter()
+                    if rc != 0:
+                        return {"error": f"exit code {rc}", "command": " ".join(cmd)}
+                    if k:
+                        ts.append((c1 - c0) * 1e3)
+                return {"mean_ms": round(float(np.mean(ts)), 2), "stddev_ms": round(float(np.std(ts)), 2), "min_ms": round(min(ts), 2),
+                        "max_ms": round(max(ts), 2), "runs": len(ts), "warmup_runs": 1}
+            fgfa = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
+            cpu_exe = fo.cpu_cli()
+            extras["cli_process"] = {
+                "what": "whole-process wall time, exec to exit, stdout discarded, 1 warm-up + 5 runs each (the reference times "
+                        "`fgfa -i G.flatgfa depth` this way: bench/config.toml:29-32); graph file in " + tmpdir,
+                "graph_file_bytes": os.path.getsize(fpath),
+                "fgfa_depth": processes([fgfa, "-i", fpath, "depth"]),
+                "fgfa_depth_d": processes([fgfa, "-i", fpath, "depth", "-d"]),
+                "cpu_oracle_depth": processes([cpu_exe, fpath]),
+                "cpu_oracle_depth_d": processes([cpu_exe, fpath, "-d"]),
+                "cpu": "oracle/fgfa_depth_cpu.c: one core, mmap -> depth.rs loops -> emit into one buffer -> one write",
+            }
             # BASELINE.json configs[4]: which paths share an oriented handle with which (all pairs)
             g2.path_overlaps([0])  # builds the per-path handle bitsets (once per resident graph)
             c5 = time.perf_counter()

@@ -117,6 +117,12 @@ int64_t flatgfa_find_path(flatgfa_t gfa, const uint8_t *name, size_t len);
 
 /* Number of visible HIP devices (0 if none). */
 int flatgfa_device_count(void);
+/* Start the HIP runtime on `device` ahead of need: the runtime's own start-up (a tenth of a second
+ * and more on a cold process), the pinned staging buffers of flatgfa_to_device, the first copy and
+ * the first kernel launch of the process.  Meant to be called from a helper thread while the caller
+ * maps or parses its graph (`fgfa` does); everything it does would otherwise happen inside the
+ * first flatgfa_to_device.  Returns 0, or FLATGFA_ERR_NO_DEVICE / FLATGFA_ERR_HIP. */
+int flatgfa_warm_device(int device);
 /* Copy the graph's structure-of-arrays image (steps, path spans, segment lengths) into the
  * HBM of `device` and keep it resident until flatgfa_free.  Depth calls do this lazily on
  * device 0 if it has not been done. */

@@ -446,13 +446,25 @@ def build(force: bool = False) -> str:
     so = os.path.join(out_dir, "libdepth_oracle.so")
     srcs = [os.path.join(HERE, "depth_oracle.c"), os.path.join(HERE, "overlap_oracle.c")]
     srcs = [s for s in srcs if os.path.exists(s)]
-    if not force and os.path.exists(so) and all(
-            os.path.getmtime(so) >= os.path.getmtime(s) for s in srcs):
+    deps = srcs + [os.path.join(HERE, "fgfa_depth_cpu.c")]
+    if not force and os.path.exists(so) and os.path.exists(os.path.join(out_dir, "fgfa_depth_cpu")) and all(
+            os.path.getmtime(so) >= os.path.getmtime(s) for s in deps if os.path.exists(s)):
         return so
     os.makedirs(out_dir, exist_ok=True)
     subprocess.check_call(["gcc", "-O3", "-march=x86-64-v2", "-std=c11", "-fPIC", "-shared", "-pthread",
                            "-Wall", "-Wextra", "-o", so] + srcs)
+    # the CPU process bench.py times next to the product's CLI (fgfa_depth_cpu FILE.flatgfa [-d])
+    main_c = os.path.join(HERE, "fgfa_depth_cpu.c")
+    if os.path.exists(main_c):
+        subprocess.check_call(["gcc", "-O3", "-march=x86-64-v2", "-std=c11", "-pthread", "-Wall", "-Wextra", "-o",
+                               os.path.join(out_dir, "fgfa_depth_cpu"), main_c, os.path.join(HERE, "depth_oracle.c")])
     return so
+
+
+def cpu_cli() -> str:
+    """Path of the oracle's stand-alone depth process (built with the library)."""
+    build()
+    return os.path.join(HERE, "_build", "fgfa_depth_cpu")
 
 
 def lib() -> ctypes.CDLL:

@@ -50,6 +50,7 @@ SIGNATURES = {
     "flatgfa_pool": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_uint64), POINTER(c_uint64)]),
     "flatgfa_find_path": (c_int64, [c_void_p, c_char_p, c_size_t]),
     "flatgfa_device_count": (c_int, []),
+    "flatgfa_warm_device": (c_int, [c_int]),
     "flatgfa_to_device": (c_int, [c_void_p, c_int]),
     "flatgfa_residency_ms": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),
     "flatgfa_seg_depth": (c_int, [c_void_p, c_void_p, c_void_p]),

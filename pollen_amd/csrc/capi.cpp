@@ -370,6 +370,40 @@ static hipError_t upload(void *dst, const void *src, size_t bytes, hipStream_t s
     return (hipError_t)failed.load();
 }
 
+int flatgfa_warm_device(int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_error("no HIP device is visible; the depth queries have no CPU fallback");
+        return FLATGFA_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { set_error("device index out of range"); return FLATGFA_ERR_ARG; }
+    CAPI_HIP(hipSetDevice(device));
+    {   // the staging buffers an upload will want (kept by the process)
+        static const int kThreads = [] {
+            const char *e = getenv("FLATGFA_UPLOAD_THREADS");
+            const int n = e ? atoi(e) : 4;
+            return n < 1 ? 1 : n > kMaxUploadThreads ? kMaxUploadThreads : n;
+        }();
+        StagePool &pool = *stage_pool();
+        std::lock_guard<std::mutex> lk(pool.mu);
+        CAPI_HIP(pool.ensure(device, 2 * kThreads));
+        // the process's first asynchronous copy and first launch (queues, the library's code object)
+        uint32_t *d = nullptr;
+        hipStream_t s = nullptr;
+        CAPI_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        hipError_t e = hipMalloc(&d, 4096);
+        if (e == hipSuccess) e = hipMemcpyAsync(d, pool.stage[0], 4096, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            fgfa_dev::warm_launch(s);  // (loads the library's code object)
+            e = hipStreamSynchronize(s);
+        }
+        if (d) (void)hipFree(d);
+        (void)hipStreamDestroy(s);
+        CAPI_HIP(e);
+    }
+    return FLATGFA_OK;
+}
+
 static int ensure_device(CStore *cs, int device) {
     std::lock_guard<std::mutex> lk(cs->dev_mu);
     if (cs->on_device) {

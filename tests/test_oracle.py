@@ -126,3 +126,16 @@ def test_out_of_range_is_an_error():
     pools.paths["steps_end"][0] = 9
     with pytest.raises(fo.ParseError):
         fo.seg_depth(pools)
+
+
+@pytest.mark.parametrize("gfa", golden_gfas()[:6], ids=fixture_id)
+def test_cpu_process_matches_golden(gfa, tmp_path):
+    """oracle/fgfa_depth_cpu.c (the CPU process bench.py times beside the product's CLI): .flatgfa in,
+    the two depth tables out, byte for byte what slow_odgi / the oracle's emitters give."""
+    import subprocess
+    pools = fo.parse_gfa(read(gfa))
+    f = tmp_path / "g.flatgfa"
+    f.write_bytes(fo.dump_flatgfa(pools))
+    exe = fo.cpu_cli()
+    assert subprocess.run([exe, str(f), "-d"], capture_output=True, check=True).stdout == read(gfa[:-4] + ".depth.tsv")
+    assert subprocess.run([exe, str(f)], capture_output=True, check=True).stdout == fo.fgfa_depth(pools, False)
