@@ -197,6 +197,10 @@ void flatgfa_sharded_free(flatgfa_sharded_t *sh);
  * the whole handle cuts, and whether the exchange is RCCL's. */
 int flatgfa_sharded_layout(flatgfa_sharded_t *sh, int shard, int *device, uint64_t *step_begin, uint64_t *step_end,
                            uint32_t *first_path, uint32_t *n_pieces, uint32_t *n_split_paths, int *uses_rccl);
+/* Bytes every shard contributes to the one collective of a call: 4 per segment for node depth alone;
+ * with unique depth 8, plus 4 per segment for every 32 / bits(n_shards) paths that were cut (their
+ * touch counters share words: with eight shards, 12 bytes per segment whatever was cut). */
+uint64_t flatgfa_sharded_collective_bytes(flatgfa_sharded_t *sh, int with_uniq);
 /* seg_depth_with_uniq (depth.rs:15-39) / seg_depth (:45-56) over all shards: results as
  * flatgfa_seg_depth's. */
 int flatgfa_sharded_seg_depth(flatgfa_sharded_t *sh, uint64_t *depth_out, uint64_t *uniq_out);

@@ -69,6 +69,7 @@ SIGNATURES = {
     "flatgfa_sharded_free": (None, [c_void_p]),
     "flatgfa_sharded_layout": (c_int, [c_void_p, c_int, POINTER(c_int), POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint32),
                                        POINTER(c_uint32), POINTER(c_uint32), POINTER(c_int)]),
+    "flatgfa_sharded_collective_bytes": (c_uint64, [c_void_p, c_int]),
     "flatgfa_sharded_seg_depth": (c_int, [c_void_p, c_void_p, c_void_p]),
     "flatgfa_sharded_path_depth": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_void_p]),
     "flatgfa_sharded_enqueue": (c_int, [c_void_p, c_int]),

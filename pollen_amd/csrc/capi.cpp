@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <memory>
 #include <sys/mman.h>
+#include <fcntl.h>
 #include <unistd.h>
 #include <algorithm>
 #include <atomic>
@@ -212,12 +213,33 @@ int flatgfa_write_flatgfa_prealloc(flatgfa_t gfa, const char *filename, const ui
     }
     size_t n = 0;
     if (!fgfa::prealloc_file_size(gfa->view, cap, &n, &err)) { set_error(err); return FLATGFA_ERR_BOUNDS; }
-    std::vector<uint8_t> buf(n, 0);  // (a fresh mapped file reads as zeros behind what is written)
-    fgfa::dump_flatgfa_prealloc(gfa->view, cap, buf.data());
-    FILE *f = fopen(filename, "wb");
-    if (!f) { set_error(std::string("cannot create ") + filename); return FLATGFA_ERR_IO; }
-    const size_t w = fwrite(buf.data(), 1, n, f);
-    if (fclose(f) != 0 || w != n) { set_error(std::string("short write to ") + filename); return FLATGFA_ERR_IO; }
+    // The file is the sum of the CAPACITIES (up to 2^46 bytes; `-p 1000` is already gigabytes), most of it
+    // never written: made sparse with ftruncate, then the table of contents and each pool's `len`
+    // entries written at their offsets -- what the reference's map_new_file + file::init amount to
+    // (memfile.rs:12-33, file.rs:255-272).  A fresh file reads as zeros behind what is written.
+    const int fd = open(filename, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) { set_error(std::string("cannot create ") + filename); return FLATGFA_ERR_IO; }
+    bool ok = ftruncate(fd, (off_t)n) == 0;
+    const auto put = [&](const void *p, size_t bytes, uint64_t at) {
+        const char *c = (const char *)p;
+        while (ok && bytes) {
+            const ssize_t w = pwrite(fd, c, bytes, (off_t)at);
+            if (w <= 0) { ok = false; break; }
+            c += w;
+            at += (uint64_t)w;
+            bytes -= (size_t)w;
+        }
+    };
+    fgfa::Toc toc;
+    toc.magic = fgfa::kMagic;
+    for (int i = 0; i < 11; ++i) toc.pool[i] = fgfa::TocSize{gfa->view.pool_len(i), cap[i]};
+    put(&toc, sizeof toc, 0);
+    uint64_t off = sizeof toc;
+    for (int i = 0; i < 11; ++i) {
+        put(gfa->view.pool_data(i), gfa->view.pool_len(i) * fgfa::kPoolElemSize[i], off);
+        off += cap[i] * fgfa::kPoolElemSize[i];
+    }
+    if (close(fd) != 0 || !ok) { set_error(std::string("short write to ") + filename); return FLATGFA_ERR_IO; }
     return FLATGFA_OK;
 }
 

@@ -1465,6 +1465,7 @@ struct AccArgs {
     uint32_t *pair_flag;  // k_accum_pair: [n_win] how many halves are there (zero between calls)
     uint32_t accumulate;  // the outputs hold the counts of the paths walked before (another group of the same call): add to them
     const uint32_t *taken;  // tagged: [n_slots] items each k_scan workgroup took (ScanArgs::taken)
+    uint32_t *fullest;      // this range's fullest sub-bucket beyond half the capacity (read and cleared by fast_plan_grow)
 };
 
 // FLATGFA_ACC_TIME: charge the time since the last mark to phase `ph` of this wave; the wave's
@@ -2477,7 +2478,10 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
         *c = 0u;
         // (a sub-bucket more than half full: flatgfa_dev_status makes room before a later call -- whose
         // items k_scan may deal to other workgroups -- runs out of it)
-        if (v > (A.cap >> 1)) atomicMax(A.status + 2, v);
+        if (v > (A.cap >> 1)) {
+            atomicMax(A.status + 2, v);
+            if (A.fullest) atomicMax(A.fullest, v);  // (which range of the plan it was: only that one is given more room)
+        }
         if (TAGGED && UNIQ) {
             const uint32_t c1 = min(v, A.cap);
             v = min(A.has_pre == 1 ? A.counts0[(size_t)win * A.n_slots + sl] : A.has_pre ? v : 0u, c1);  // (2: k_scan did not run, all are earlier records)
@@ -3274,8 +3278,9 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     }
     FAST_TRY(hipMalloc(&fp->counts, slots * 4));
     FAST_TRY(hipMemset(fp->counts, 0, slots * 4));
-    FAST_TRY(hipMalloc(&fp->taken, (size_t)fp->n_slots * 4));
+    FAST_TRY(hipMalloc(&fp->taken, ((size_t)fp->n_slots + 1) * 4));
     FAST_TRY(hipMemset(fp->taken, 0xFF, (size_t)fp->n_slots * 4));  // (nothing known until a tagged k_scan has run)
+    FAST_TRY(hipMemset(fp->taken + fp->n_slots, 0, 4));              // (the word behind them: this range's fullest sub-bucket beyond half the capacity)
     FAST_TRY(hipMalloc(&fp->counts0, slots * 4));
     FAST_TRY(hipMemset(fp->counts0, 0, slots * 4));
     FAST_TRY(hipMalloc(&fp->dir, (size_t)fp->dstride * n_win * sizeof(uint2)));
@@ -3566,8 +3571,18 @@ static bool grow_range(FastPlan *fp, uint32_t factor) {
 bool fast_plan_grow(FastPlan *fp, bool ahead_of_need) {
     if (!fp->eligible || fp->cap_forced) return false;
     const uint32_t factor = ahead_of_need ? 2u : 4u;  // (ahead of need: what was more than half full is then at most half full)
-    bool ok = grow_range(fp, factor);
-    for (uint32_t r = 0; r < fp->n_more && (ok || ahead_of_need); ++r) ok = grow_range(&fp->more[r], factor) && ok;  // (the status word does not say which range ran out)
+    // Ahead of need only the ranges (or path groups) whose own word says so are given more room: their
+    // bucket arrays may be gigabytes each, and one hot window is no reason to double them all.
+    const auto wants = [&](FastPlan *q) {
+        if (!ahead_of_need || !q->taken) return true;
+        uint32_t v = 0;
+        if (hipMemcpy(&v, q->taken + q->n_slots, 4, hipMemcpyDeviceToHost) != hipSuccess) return true;
+        if (v) (void)hipMemset(q->taken + q->n_slots, 0, 4);
+        return v > (q->cap >> 1);
+    };
+    bool ok = wants(fp) ? grow_range(fp, factor) : true;
+    for (uint32_t r = 0; r < fp->n_more && (ok || ahead_of_need); ++r)
+        if (wants(&fp->more[r])) ok = grow_range(&fp->more[r], factor) && ok;  // (after an overflow: the status word does not say which range ran out)
     if (!ok && !ahead_of_need) fp->eligible = false;  // the atomic kernels take over
     return ok;
 }
@@ -3646,7 +3661,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
                fp.work_counter, scan_skip ? 0u : fp.max_back, depth_out, uniq_out, status, fp.dbg,
                reinterpret_cast<const uint4 *>(fp.items), g.seg_len, ps ? reinterpret_cast<ulonglong2 *>(fp.psum_part) : nullptr,
-               fp.fat_off, fp.fat_woff, fp.acc_parts, tagged ? fp.n_shared : 0u, nullptr, fp.pair_part, fp.pair_flag, fp.accumulate ? 1u : 0u, getenv("FLATGFA_NO_PLAIN") ? nullptr : fp.taken};  // (FLATGFA_NO_PLAIN: measurements)
+               fp.fat_off, fp.fat_woff, fp.acc_parts, tagged ? fp.n_shared : 0u, nullptr, fp.pair_part, fp.pair_flag, fp.accumulate ? 1u : 0u, getenv("FLATGFA_NO_PLAIN") ? nullptr : fp.taken, fp.taken ? fp.taken + fp.n_slots : nullptr};  // (FLATGFA_NO_PLAIN: measurements)
     if (const char *sk = getenv("FLATGFA_ACC_SKIP")) aa.dbg = (uint32_t)strtoul(sk, nullptr, 10);  // (diagnostic: pass 2 without its revisit counts 128 / depth 256 / claims 64 / words behind the first 1024)
     const size_t tprof_words = (size_t)fp.n_win * fp.acc_parts * kAccWaves * 16;
     if (getenv("FLATGFA_ACC_TIME") && uniq_out && hipMalloc(&aa.tprof, tprof_words * 4) != hipSuccess) aa.tprof = nullptr;

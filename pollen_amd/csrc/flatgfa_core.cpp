@@ -82,7 +82,7 @@ View Store::view() const {
     v.steps = pool_of(steps);
     v.seq_data = pool_of(seq_data);
     v.overlaps = pool_of(overlaps);
-    v.alignment = pool_of(alignment);
+    v.alignment = {reinterpret_cast<const AlignOp *>(alignment.data()), alignment.size()};
     v.name_data = pool_of(name_data);
     v.optional_data = pool_of(optional_data);
     v.line_order = pool_of(line_order);
@@ -492,7 +492,7 @@ bool view_flatgfa(const uint8_t *data, size_t n, View *out, std::string *err) {
     out->steps = {(const Handle *)ptr[pSteps], (size_t)toc.pool[pSteps].len};
     out->seq_data = {(const uint8_t *)ptr[pSeqData], (size_t)toc.pool[pSeqData].len};
     out->overlaps = {(const Span *)ptr[pOverlaps], (size_t)toc.pool[pOverlaps].len};
-    out->alignment = {(const uint32_t *)ptr[pAlignment], (size_t)toc.pool[pAlignment].len};
+    out->alignment = {(const AlignOp *)ptr[pAlignment], (size_t)toc.pool[pAlignment].len};
     out->name_data = {(const uint8_t *)ptr[pNameData], (size_t)toc.pool[pNameData].len};
     out->optional_data = {(const uint8_t *)ptr[pOptionalData], (size_t)toc.pool[pOptionalData].len};
     out->line_order = {(const uint8_t *)ptr[pLineOrder], (size_t)toc.pool[pLineOrder].len};
@@ -529,7 +529,10 @@ bool validate_spans(const View &v, std::string *err) {
 
 bool validate_step_ids(const View &v) {
     uint32_t mx = 0;
-    for (size_t i = 0; i < v.steps.len; ++i) mx = std::max(mx, v.steps[i].bits);
+    for (size_t i = 0; i < v.steps.len; ++i) {
+        const uint32_t b = v.steps[i].bits;  // (a copy: std::max takes references, and the pool is align-1)
+        mx = std::max(mx, b);
+    }
     return v.steps.len == 0 || (size_t)(mx >> 1) < v.segs.len;
 }
 
@@ -627,7 +630,7 @@ void put_alignment(const View &v, Span a, std::string *o) {
     static const char letters[4] = {'M', 'N', 'D', 'I'};  // print.rs:14-23
     if (a.start == a.end) o->append("0M");
     for (uint32_t i = a.start; i < a.end; ++i) {
-        uint32_t op = v.alignment[i];
+        uint32_t op = v.alignment[i].bits;
         put_u64(o, op >> 8);
         o->push_back(letters[op & 3]);
     }

@@ -45,6 +45,11 @@ struct Handle {
     uint32_t segment() const { return bits >> 1; }
     bool is_forward() const { return (bits & 1u) == 0; }
 };
+// flatgfa.rs:213-249 -- one op of a CIGAR-like alignment: opcode in the low byte, length above it.  A packed
+// wrapper, so that a reference into a file image (whose pools start at any byte) is an align-1 reference.
+struct AlignOp {
+    uint32_t bits;
+};
 // file.rs:29-38, 12-27
 struct TocSize {
     uint64_t len, capacity;
@@ -55,7 +60,7 @@ struct Toc {
 };
 #pragma pack(pop)
 static_assert(sizeof(Span) == 8 && sizeof(Segment) == 24 && sizeof(Path) == 24, "layout");
-static_assert(sizeof(Link) == 16 && sizeof(Handle) == 4 && sizeof(Toc) == 184, "layout");
+static_assert(sizeof(Link) == 16 && sizeof(Handle) == 4 && sizeof(Toc) == 184 && sizeof(AlignOp) == 4 && alignof(AlignOp) == 1, "layout");
 
 constexpr uint64_t kMagic = 0xB1011054ull;  // file.rs:9
 // flatgfa.rs:262-269
@@ -86,7 +91,7 @@ struct View {
     Pool<Handle> steps;
     Pool<uint8_t> seq_data;
     Pool<Span> overlaps;
-    Pool<uint32_t> alignment;
+    Pool<AlignOp> alignment;
     Pool<uint8_t> name_data;
     Pool<uint8_t> optional_data;
     Pool<uint8_t> line_order;

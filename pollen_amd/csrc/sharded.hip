@@ -7,10 +7,14 @@
 // than a shard's share).  Every shard lives on its own device -- a slice of the steps, rebased
 // spans, the segment lengths, a depth plan, a stream, a host thread that enqueues for it -- and
 // one call is: the local kernels on every shard, ONE all-reduce (RCCL, ncclUint32 / ncclSum) of the
-// fused [depth | uniq | touch_0 .. touch_K-1] vector, and a fix-up of uniq for the K paths that were
-// cut: a piece counts as a path of its own on its shard, so a segment touched by m pieces of one
-// path was counted m times; touch_k (the 0/1 vector "piece of split path k touches s", which is
-// unique depth over that piece alone) sums to m, and uniq[s] -= max(m - 1, 0).  Exact: integer sums.
+// fused [depth | uniq | touch] vector, and a fix-up of uniq for the K paths that were cut: a piece
+// counts as a path of its own on its shard, so a segment touched by m pieces of one path was counted
+// m times; touch_k (the 0/1 vector "piece of split path k touches s", which is unique depth over
+// that piece alone) sums to m, and uniq[s] -= max(m - 1, 0).  Exact: integer sums.  The K touch
+// vectors travel PACKED: a path has at most n_shards pieces, so its count needs b = bits(n_shards)
+// bits, and 32 / b counters share a word -- with eight shards all K <= 7 of them fit ONE u32 per
+// segment (the collective carries 12 bytes per segment, not 8 + 4 K); fields cannot carry into each
+// other because no sum exceeds n_shards.
 // Path depth needs no reduction beyond the node depth: every shard measures its pieces against
 // the reduced vector and the host adds the pieces of a cut path up (both sums of
 // measure_path, depth.rs:116-131, are sums over steps).
@@ -83,15 +87,29 @@ const Rccl *rccl(std::string *why) {
     return &r;
 }
 
-// uniq[s] -= sum over the split paths of (pieces that touch s) - 1
-__global__ __launch_bounds__(256) void k_fix_uniq(uint32_t *__restrict__ uniq, const uint32_t *__restrict__ touch, uint32_t n_segs, uint32_t n_split) {
+// uniq[s] -= sum over the split paths of (pieces that touch s) - 1.  Split path k's count is field k % per_word
+// (`bits` wide) of word k / per_word of the packed touch vector.
+__global__ __launch_bounds__(256) void k_fix_uniq(uint32_t *__restrict__ uniq, const uint32_t *__restrict__ touch, uint32_t n_segs, uint32_t n_split,
+                                                  uint32_t bits, uint32_t per_word) {
+    const uint32_t mask = (1u << bits) - 1u;
     for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < n_segs; s += gridDim.x * 256u) {
         uint32_t over = 0;
-        for (uint32_t k = 0; k < n_split; ++k) {
-            const uint32_t m = touch[(size_t)k * n_segs + s];
-            over += m > 1u ? m - 1u : 0u;
+        for (uint32_t k0 = 0; k0 < n_split; k0 += per_word) {
+            uint32_t w = touch[(size_t)(k0 / per_word) * n_segs + s];
+            for (uint32_t k = k0; k < n_split && k < k0 + per_word && w; ++k, w >>= bits) {
+                const uint32_t m = w & mask;
+                over += m > 1u ? m - 1u : 0u;
+            }
         }
         if (over) uniq[s] -= over;
+    }
+}
+
+// a piece's 0/1 touch vector into its field of the packed word (the packed vector is zeroed at the start of every call)
+__global__ __launch_bounds__(256) void k_pack_touch(uint32_t *__restrict__ packed, const uint32_t *__restrict__ touch, uint32_t n_segs, uint32_t shift) {
+    for (uint32_t s = blockIdx.x * 256u + threadIdx.x; s < n_segs; s += gridDim.x * 256u) {
+        const uint32_t t = touch[s];
+        if (t) packed[s] |= (t & 1u) << shift;  // (a shard's pieces belong to different split paths: no two of its kernels write one field)
     }
 }
 
@@ -126,7 +144,7 @@ struct Shard {
         flatgfa_dev_plan_t *plan = nullptr;
     };
     std::vector<Touch> touch;
-    uint32_t *d_send = nullptr, *d_recv = nullptr, *d_tmp = nullptr;  // [(2 + K) * S] each; S scratch
+    uint32_t *d_send = nullptr, *d_recv = nullptr, *d_tmp = nullptr;  // [(2 + W) * S] each (W words of packed touch counters per segment); 2 S scratch
     uint64_t *d_sums = nullptr;                                       // [2 * pieces]
     ncclComm_t comm = nullptr;
     // the shard's host thread
@@ -146,6 +164,7 @@ enum { kCmdQuit = 1, kCmdLocal, kCmdExchange, kCmdSync, kCmdPathSums };
 struct flatgfa_sharded {
     flatgfa_t gfa = nullptr;
     uint32_t S = 0, P = 0, K = 0;
+    uint32_t bits = 1, per_word = 32, W = 0;  // a touch counter's width, counters per word, words per segment (see k_fix_uniq)
     int n = 0;
     bool use_rccl = false;
     bool with_uniq = true;  // of the call in flight
@@ -165,18 +184,24 @@ namespace {
         }                                                                               \
     } while (0)
 
-size_t vec_count(const flatgfa_sharded &h, bool with_uniq) { return (size_t)h.S * (with_uniq ? 2 + h.K : 1); }
+size_t vec_count(const flatgfa_sharded &h, bool with_uniq) { return (size_t)h.S * (with_uniq ? 2 + h.W : 1); }
 
 // the local kernels of one call on shard s (its thread; its device is current)
 int shard_local(flatgfa_sharded &h, Shard &s) {
     if (h.S == 0) return FLATGFA_OK;
     int rc = flatgfa_dev_seg_depth(s.plan, s.d_send, h.with_uniq ? s.d_send + h.S : nullptr, s.stream);
     if (rc) { s.err = flatgfa_last_error(); return rc; }
-    if (h.with_uniq)
+    if (h.with_uniq && h.W) {
+        SH_HIP(hipMemsetAsync(s.d_send + 2 * (size_t)h.S, 0, (size_t)h.W * h.S * 4, s.stream));
         for (Shard::Touch &t : s.touch) {
-            rc = flatgfa_dev_seg_depth(t.plan, s.d_tmp, s.d_send + (size_t)(2 + t.split) * h.S, s.stream);
+            rc = flatgfa_dev_seg_depth(t.plan, s.d_tmp, s.d_tmp + h.S, s.stream);  // (unique depth over one piece: 0 or 1)
             if (rc) { s.err = flatgfa_last_error(); return rc; }
+            const uint32_t k = (uint32_t)t.split;
+            hipLaunchKernelGGL(k_pack_touch, dim3(std::min<uint32_t>((h.S + 255u) / 256u, 2048u)), dim3(256), 0, s.stream,
+                               s.d_send + (size_t)(2 + k / h.per_word) * h.S, s.d_tmp + h.S, h.S, (k % h.per_word) * h.bits);
+            SH_HIP(hipGetLastError());
         }
+    }
     return FLATGFA_OK;
 }
 
@@ -190,7 +215,7 @@ int shard_exchange(flatgfa_sharded &h, Shard &s) {
     }
     if (h.with_uniq && h.K && (h.use_rccl || h.n == 1)) {
         hipLaunchKernelGGL(k_fix_uniq, dim3(std::min<uint32_t>((h.S + 255u) / 256u, 2048u)), dim3(256), 0, s.stream, s.d_recv + h.S,
-                           s.d_recv + 2 * (size_t)h.S, h.S, h.K);
+                           s.d_recv + 2 * (size_t)h.S, h.S, h.K, h.bits, h.per_word);
         SH_HIP(hipGetLastError());
     }
     return FLATGFA_OK;
@@ -289,7 +314,7 @@ int exchange_by_adds(flatgfa_sharded &h) {
     }
     if (h.with_uniq && h.K)
         hipLaunchKernelGGL(k_fix_uniq, dim3(std::min<uint32_t>((h.S + 255u) / 256u, 2048u)), dim3(256), 0, root.stream, root.d_recv + h.S,
-                           root.d_recv + 2 * (size_t)h.S, h.S, h.K);
+                           root.d_recv + 2 * (size_t)h.S, h.S, h.K, h.bits, h.per_word);
     SH_HIP(hipGetLastError());
     for (int i = 1; i < h.n; ++i)
         SH_HIP(hipMemcpyPeerAsync(h.sh[i]->d_recv, h.sh[i]->device, root.d_recv, root.device, cnt * 4, root.stream));
@@ -429,6 +454,15 @@ flatgfa_sharded_t *flatgfa_sharded_create(flatgfa_t gfa, const int *devices, int
             for (Piece &pc : s->pieces) pc.split = split_of[pc.path];
     }
     h->K = (uint32_t)h->split_paths.size();
+    // a split path has at most n_shards pieces: its touch count fits bits(n_shards) bits
+    h->bits = 1;
+    while ((1u << h->bits) <= (uint32_t)n_shards) h->bits += 1;
+    h->per_word = 32u / h->bits;
+    h->W = (h->K + h->per_word - 1) / h->per_word;
+    if (S == 0 && T != 0) {  // (as the single-device route: a step names a segment, and there is none)
+        set_error("a step refers to a segment id that is out of range");
+        return nullptr;
+    }
     // ---- RCCL, or adds ----
     const bool force = getenv("FLATGFA_SHARD_FORCE_RCCL") != nullptr;
     h->use_rccl = distinct && (n_shards > 1 || force) && !(flags & FLATGFA_SHARD_NO_RCCL);
@@ -444,7 +478,7 @@ flatgfa_sharded_t *flatgfa_sharded_create(flatgfa_t gfa, const int *devices, int
         for (int i = 0; i < n_shards; ++i) h->sh[i]->comm = comms[i];
     }
     // ---- the shards' images ----
-    const size_t cnt = (size_t)S * (2 + h->K);
+    const size_t cnt = (size_t)S * (2 + h->W);
     for (auto &sp : h->sh) {
         Shard &s = *sp;
 #define CR_HIP(expr)                                                                          \
@@ -485,11 +519,12 @@ flatgfa_sharded_t *flatgfa_sharded_create(flatgfa_t gfa, const int *devices, int
             t.split = s.pieces[i].split;
             const uint32_t span[2] = {s.pieces[i].lb, s.pieces[i].le};
             CR_HIP(hipMalloc(&t.d_span, 8));
-            CR_HIP(hipMemcpy(t.d_span, span, 8, hipMemcpyHostToDevice));
-            flatgfa_dev_graph_t gt{s.d_steps, (uint64_t)n_loc, t.d_span, t.d_span + 1, 1u, (uint32_t)S, s.d_seg_len};
-            t.plan = flatgfa_dev_plan_create(&gt, span, span + 1);
-            if (!t.plan) { (void)hipFree(t.d_span); return nullptr; }
-            s.touch.push_back(t);
+            s.touch.push_back(t);  // (owned by the shard from here on: freed with it whatever fails below)
+            Shard::Touch &tt = s.touch.back();
+            CR_HIP(hipMemcpy(tt.d_span, span, 8, hipMemcpyHostToDevice));
+            flatgfa_dev_graph_t gt{s.d_steps, (uint64_t)n_loc, tt.d_span, tt.d_span + 1, 1u, (uint32_t)S, s.d_seg_len};
+            tt.plan = flatgfa_dev_plan_create(&gt, span, span + 1);
+            if (!tt.plan) return nullptr;
         }
         if (S) {
             CR_HIP(hipMalloc(&s.d_send, cnt * 4));
@@ -500,7 +535,7 @@ flatgfa_sharded_t *flatgfa_sharded_create(flatgfa_t gfa, const int *devices, int
             } else {
                 CR_HIP(hipMalloc(&s.d_recv, cnt * 4));
             }
-            if (!s.touch.empty()) CR_HIP(hipMalloc(&s.d_tmp, S * 4));
+            if (!s.touch.empty()) CR_HIP(hipMalloc(&s.d_tmp, 2 * S * 4));
         }
         if (np) CR_HIP(hipMalloc(&s.d_sums, np * 16));
 #undef CR_HIP
@@ -535,9 +570,16 @@ int flatgfa_sharded_sync(flatgfa_sharded_t *h) {
     return run_all(*h, kCmdSync);
 }
 
+static int fetch_locked(flatgfa_sharded_t *h, int shard, uint64_t *depth_out, uint64_t *uniq_out);
+
 int flatgfa_sharded_fetch(flatgfa_sharded_t *h, int shard, uint64_t *depth_out, uint64_t *uniq_out) {
     if (!h || shard < 0 || shard >= h->n || (!depth_out && h->S)) { set_error("flatgfa_sharded_fetch: bad argument"); return FLATGFA_ERR_ARG; }
     std::lock_guard<std::mutex> lk(h->op_mu);
+    return fetch_locked(h, shard, depth_out, uniq_out);
+}
+
+// (the caller holds op_mu)
+static int fetch_locked(flatgfa_sharded_t *h, int shard, uint64_t *depth_out, uint64_t *uniq_out) {
     if (uniq_out && !h->with_uniq) { set_error("flatgfa_sharded_fetch: the last call computed node depth only"); return FLATGFA_ERR_ARG; }
     Shard &s = *h->sh[shard];
     if (h->S == 0) return FLATGFA_OK;
@@ -555,14 +597,18 @@ int flatgfa_sharded_fetch(flatgfa_sharded_t *h, int shard, uint64_t *depth_out, 
 
 int flatgfa_sharded_seg_depth(flatgfa_sharded_t *h, uint64_t *depth_out, uint64_t *uniq_out) {
     if (!h || (!depth_out && h->S)) { set_error("flatgfa_sharded_seg_depth: NULL argument"); return FLATGFA_ERR_ARG; }
-    int rc;
-    {
-        std::lock_guard<std::mutex> lk(h->op_mu);
-        rc = enqueue_locked(*h, uniq_out != nullptr);
-        if (!rc) rc = run_all(*h, kCmdSync);
-    }
+    // one critical section from the enqueue to the copy out: another thread's call on the same handle
+    // in between would overwrite the reduced vectors (or leave them without unique depth)
+    std::lock_guard<std::mutex> lk(h->op_mu);
+    int rc = enqueue_locked(*h, uniq_out != nullptr);
+    if (!rc) rc = run_all(*h, kCmdSync);
     if (rc) return rc;
-    return flatgfa_sharded_fetch(h, 0, depth_out, uniq_out);
+    return fetch_locked(h, 0, depth_out, uniq_out);
+}
+
+uint64_t flatgfa_sharded_collective_bytes(flatgfa_sharded_t *h, int with_uniq) {
+    if (!h) return 0;
+    return (uint64_t)vec_count(*h, with_uniq != 0) * 4u;
 }
 
 int flatgfa_sharded_path_depth(flatgfa_sharded_t *h, const uint32_t *path_ids, uint32_t n_ids, uint64_t *length_out, double *mean_out) {

@@ -364,6 +364,10 @@ class ShardedFlatGFA:
                         "pieces": npc.value, "split_paths": nsp.value, "rccl": bool(uses.value)})
         return out
 
+    def collective_bytes(self, with_uniq: bool = True) -> int:
+        """Bytes every shard contributes to the one collective of a call (the cut paths' touch counters travel packed)."""
+        return int(_lib.lib().flatgfa_sharded_collective_bytes(self._h, 1 if with_uniq else 0))
+
     def seg_depth_with_uniq(self) -> Tuple[np.ndarray, np.ndarray]:
         S = self.graph.segment_count
         d, u = np.zeros(S, dtype=np.uint64), np.zeros(S, dtype=np.uint64)

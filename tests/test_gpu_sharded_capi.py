@@ -143,3 +143,24 @@ def test_cfgL_sharded_eight_ways_on_one_device():
         assert [x["pieces"] for x in lay] == [125] * 8 and lay[0]["split_paths"] == 0
         d, u = sh.seg_depth_with_uniq()
         assert (d == want_d).all() and (u == want_u).all()
+
+
+@pytest.mark.parametrize("n_shards,bits", [(2, 2), (4, 3), (8, 4), (13, 4), (20, 5)])
+def test_touch_counters_travel_packed(n_shards, bits):
+    """The cut paths' touch vectors share words in the collective: a path has at most n_shards pieces, so
+    its count takes bits(n_shards) bits and 32 / bits of them fit a u32 -- eight shards: every cut path in
+    ONE word per segment (12 bytes per segment on the wire, not 8 + 4 per cut path).  Three long paths over
+    few segments: every shard holds pieces, pieces of one path revisit each other's segments, and one
+    path is cut into more pieces than a narrower counter could count."""
+    S = 3_000
+    g = pa.synth(17, S, 3, 40_000, "pangenome", True)
+    lay, _ = check_sharded(g, n_shards)
+    K = lay[0]["split_paths"]
+    assert K >= 1
+    with pa.ShardedFlatGFA(g, n_shards, devices=[0] * n_shards) as sh:
+        per_word = 32 // bits
+        words = -(-K // per_word)
+        assert sh.collective_bytes(True) == 4 * S * (2 + words)
+        assert sh.collective_bytes(False) == 4 * S
+        if n_shards == 8:
+            assert words == 1
