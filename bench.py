@@ -536,6 +536,12 @@ def main():
             extras["cpu_all_cores"] = {"value": round(N / float(np.median(mts)), 1), "unit": "path-steps/s",
                                        "cores": nthr, "kind": "port, path-parallel (pthreads)"}
 
+    steps_all = [N_local]
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.int64, device=coll_device)
+        t[rank] = N_local
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        steps_all = [int(x) for x in t.cpu().tolist()]
     if rank == 0:
         value = N_job * args.steps / elapsed
         metric = f"path-steps/sec on `depth` ({S / 1e6:g}M seg / {N_job / 1e6:g}M step GFA)"
@@ -558,7 +564,8 @@ def main():
             "config": {"workload": f"{args.workload}: seg_depth_with_uniq on synth(seed={'1' if strong or world == 1 else '1+rank'}, "
                                    f"S={S}, P={P}, L={L}, model={model})" + (" per GPU" if world > 1 and not strong else ""),
                        "segments": S, "paths_per_gpu": P_local if strong else P,
-                       "steps_per_gpu": N_local, "steps_per_job_step": N_job, "sharding": sharding},
+                       "steps_per_gpu": N_local, "steps_per_gpu_all_ranks": steps_all, "steps_per_job_step": N_job, "sharding": sharding,
+                       "collective_bytes": 8 * S if world > 1 else 0},
             "bit_exact_vs_oracle": verified,
             "roofline": roofline, "cpu_baseline": cpu, "commit": git_head(),
         }
@@ -647,7 +654,9 @@ def main_host_c(args, torch, dist, pa, dev):
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: seg_depth_with_uniq on synth(seed=1, S={S}, P={P}, L={L}, model={model})",
-                       "segments": S, "steps_per_job_step": N, "host": "c",
+                       "segments": S, "steps_per_job_step": N, "host": "c", "steps_per_gpu": N_local,
+                       "steps_per_gpu_all_ranks": [x["step_end"] - x["step_begin"] for x in lay],
+                       "collective_bytes": sh.collective_bytes(True) if args.gpus > 1 or lay[0]["rccl"] else 0,
                        "sharding": f"flatgfa_sharded_* (C ABI, one process): {args.gpus} shards on devices {devices}, "
                                    f"{lay[0]['split_paths']} paths cut, exchange by " + ("RCCL ncclAllReduce inside libflatgfa.so" if lay[0]["rccl"] else "device-side adds (shards share a device)"),
                        "shards": [{k: x[k] for k in ("device", "step_begin", "step_end", "pieces")} for x in lay]},

@@ -37,7 +37,7 @@ def shard_paths(path_begin: np.ndarray, path_end: np.ndarray, world: int) -> Lis
     total = int(ends[-1])
     cuts = [0]
     for r in range(1, world):
-        target = total * r / world
+        target = total * r // world  # (the even cut, in whole steps: flatgfa_sharded_create computes the same -- the two routes agree wherever that one cuts between paths)
         k = int(np.searchsorted(ends, target, side="left"))  # first k with ends[k] >= target
         k = min(k, P)
         if k > 0 and abs(int(ends[k - 1]) - target) <= abs(int(ends[k]) - target):

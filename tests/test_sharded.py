@@ -134,6 +134,8 @@ def test_bench_multirank_control_flow_on_one_gpu(scaling):
     assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["bit_exact_vs_oracle"] is True
     assert line["config"]["steps_per_job_step"] == (1_000_000 if scaling == "strong" else 2_000_000)
     assert line["allreduce_ms"] > 0 and line["roofline"]["kernel"]
+    assert line["config"]["collective_bytes"] == 8 * 10_000
+    assert line["config"]["steps_per_gpu_all_ranks"] == ([500_000, 500_000] if scaling == "strong" else [1_000_000, 1_000_000])
 
 
 @pytest.mark.gpu
@@ -159,3 +161,43 @@ def test_bench_host_c_two_shards_on_one_gpu():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["bit_exact_vs_oracle"] is True
     assert line["config"]["host"] == "c" and len(line["config"]["shards"]) == 2
     assert sum(x["step_end"] - x["step_begin"] for x in line["config"]["shards"]) == 1_000_000
+    # the same cut as the torch route's (shard_paths): both put the even cut at a path boundary here
+    assert line["config"]["steps_per_gpu_all_ranks"] == [500_000, 500_000]
+    assert line["config"]["collective_bytes"] == 8 * 10_000  # (no path cut: [depth | uniq] alone)
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_under_the_launcher_is_the_plain_run():
+    """`--gpus 1` launched through torch.distributed.run (how the driver's scaling run starts its N = 1 point)
+    prints the same metric, config and workload as the plain `python bench.py`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = [os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--workload", "cfgS", "--no-extras", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    a = subprocess.run([sys.executable] + args, capture_output=True, text=True, env=env, timeout=600)
+    b = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port())] + args, capture_output=True, text=True, env=env, timeout=600)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-1000:], b.stderr[-1000:])
+    la, lb = (json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]) for r in (a, b))
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "config", "bit_exact_vs_oracle"):
+        assert la[k] == lb[k], k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1000, 100, 8), (37, 5000, 4), (12, 20_000, 3), (9, 999, 2)])
+def test_the_two_routes_cut_the_same_way_between_paths(shape):
+    """shard_paths (one process per GPU) and flatgfa_sharded_create with whole paths (one process, the C ABI)
+    put every cut at the same path boundary: the one nearest the even cut."""
+    import pollen_amd as pa
+    from pollen_amd.sharded import shard_paths
+    P, L, n = shape
+    g = pa.synth(3, 5000, P, L, "pangenome", False)
+    _, pb, pe, _ = g.soa()
+    want = shard_paths(pb, pe, n)
+    with pa.ShardedFlatGFA(g, n, devices=[0] * n, flags=pa.SHARD_WHOLE_PATHS) as sh:
+        lay = sh.layout()
+    for r, (lo, hi) in enumerate(want):
+        steps = int(pe[hi - 1]) - int(pb[lo]) if hi > lo else 0
+        assert lay[r]["step_end"] - lay[r]["step_begin"] == steps and lay[r]["pieces"] == hi - lo, (r, lay[r], lo, hi)
