@@ -688,15 +688,15 @@ extern "C" int flatgfa_dev_plan_describe(flatgfa_dev_plan_t *pl, char *out, int 
     if (!f.eligible) {
         s = "path=atomic (k_depth_scan / k_depth_uniq_path)";
     } else {
-        const bool alone = (f.n_short || f.n_medium) && f.n_items == 0 && f.exact_short;  // (k_scan's launch is left out)
-        s = "path=bucketed pass1=" + std::string(alone ? "" : f.dense ? "k_scan_dense+" : "k_scan+") + (f.n_short ? "k_scan_short+" : "") + (f.n_medium ? "k_scan_medium+" : "");
+        const bool alone = (f.n_short || f.n_medium || f.n_tiny) && f.n_items == 0 && f.exact_short;  // (k_scan's launch is left out)
+        s = "path=bucketed pass1=" + std::string(alone ? "" : f.dense ? "k_scan_dense+" : "k_scan+") + (f.n_short ? "k_scan_short+" : "") + (f.n_medium ? "k_scan_medium+" : "") + (f.n_tiny ? "k_scan_tiny+" : "");
         s.pop_back();
         s += std::string("") +
             " pass2=" + (f.tagged ? (f.n_shared ? "tagged(shared bitsets)" : f.acc_pair ? "tagged(two workgroups per window)" : "tagged") : (f.big_groups ? "directory(one-item shortcut)" : "directory")) +
             " windows=" + std::to_string(f.n_win) + "x" + std::to_string(1u << f.wb) + " ranges=" + std::to_string((f.n_more + 1) / f.n_groups) +
             (f.n_groups > 1 ? " path_groups=" + std::to_string(f.n_groups) : std::string()) +
             " workgroups_per_window=" + std::to_string(f.acc_parts) + " items=" + std::to_string(f.n_items) + " split_paths=" + std::to_string(f.n_shared) +
-            " short_paths=" + std::to_string(f.n_short) + " medium_paths=" + std::to_string(f.n_medium) + " bucket_cap=" + std::to_string(f.cap);
+            " short_paths=" + std::to_string(f.n_short) + " medium_paths=" + std::to_string(f.n_medium) + " tiny_paths=" + std::to_string(f.n_tiny) + " bucket_cap=" + std::to_string(f.cap);
     }
     const int n = (int)std::min<size_t>(s.size(), (size_t)cap - 1);
     memcpy(out, s.data(), (size_t)n);

@@ -808,6 +808,194 @@ constexpr auto k_walk_short = k_scan_short<UNIQ, kWaves, kShortHash, true>;
 template <bool UNIQ>
 constexpr auto k_walk_medium = k_scan_short<UNIQ, kMediumWaves, kMediumHash, false>;
 
+// ------------------------------------------------------------ pass 1, tiny paths ---
+//
+// k_scan_tiny: paths of at most 128 steps (a million contigs of a hundred steps took k_scan_short a
+// millisecond: a block of 1024 lanes-times-steps for a hundred steps, a 4 KB hash set wiped and a
+// queue drained with two lanes in sixty-four busy, per path).  Here a wave holds a whole path in two
+// registers per lane (steps l and 64 + l), three paths' loads in flight, and keeps no queue:
+//   * first visits: each step's segment id goes into a per-wave hash set of 256 ids (one
+//     compare-and-swap per probe; whichever step of a (path, segment) pair gets there first is the
+//     first visit -- unique depth counts segments, not positions);
+//   * a record starts where the id is not the previous id plus one, where the first-visit flag
+//     changes, and at window boundaries, so a record lies in one window and counts for depth only
+//     or for depth and unique depth as a whole (bits 24 / 25, as k_scan_short's: pass 2 applies
+//     them without claims);
+//   * its length is the distance to the next start, read off the two ballot masks;
+//   * records are queued per wave and leave 64 at a time.
+#ifndef FGFA_TINY_ABLATE
+#define FGFA_TINY_ABLATE 0  /* measurements only (results are then wrong): 1 = no first-visit test, 2 = no records */
+#endif
+constexpr uint32_t kTinyMax = 128;   // steps
+constexpr uint32_t kTinyTab = 256;   // entries of a wave's id set (at most half full)
+constexpr uint32_t kTinyQueue = 64 + kTinyMax;  // a wave's record queue: what is left over + one path of all starts
+
+// (landing registers: path slot d's steps l and 64 + l in v(118 + 2 d), v(119 + 2 d))
+template <int D>
+__device__ __forceinline__ void tiny_request(const uint32_t *p, uint32_t off0, uint32_t off1) {
+#define FGFA_TREQ(R0, R1) asm volatile("global_load_dword " R0 ", %0, %2\n\tglobal_load_dword " R1 ", %1, %2" ::"v"(off0), "v"(off1), "s"(p) : "memory", R0, R1)
+    if (D == 0) FGFA_TREQ("v118", "v119");
+    else if (D == 1) FGFA_TREQ("v120", "v121");
+    else FGFA_TREQ("v122", "v123");
+#undef FGFA_TREQ
+}
+template <int D>
+__device__ __forceinline__ void tiny_take(uint32_t n_since, uint32_t &a0, uint32_t &a1) {
+    // (loads and stores return in issue order: slot D's pair is there once at most the n_since operations issued behind it are outstanding)
+    if (n_since >= 8u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n_since >= 6u) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (n_since >= 4u) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define FGFA_TTAKE(R0, R1) asm volatile("v_mov_b32 %0, " R0 "\n\tv_mov_b32 %1, " R1 : "=v"(a0), "=v"(a1)::"memory")
+    if (D == 0) FGFA_TTAKE("v118", "v119");
+    else if (D == 1) FGFA_TTAKE("v120", "v121");
+    else FGFA_TTAKE("v122", "v123");
+#undef FGFA_TTAKE
+}
+
+template <bool UNIQ>
+__global__ __launch_bounds__(kThreads) void k_scan_tiny(const ScanArgs A) {
+    extern __shared__ uint32_t lds[];
+    // layout: [bcur: kShortMaxWin][id sets: kWaves * kTinyTab][record queues: kWaves * kTinyQueue entries of 8 bytes]
+    uint32_t *bcur = lds;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint32_t *tab = lds + kShortMaxWin + wave * kTinyTab;
+    uint2 *q = reinterpret_cast<uint2 *>(lds + kShortMaxWin + kWaves * kTinyTab) + wave * kTinyQueue;  // {record, window}
+    uint32_t fill = 0;  // (uniform) entries in the queue: fewer than 64 between paths
+    uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;
+    Wave w;
+    w.q = w.pq = nullptr;
+    w.fill = w.pfill = 0;
+    w.vm[0] = w.vm[1] = w.vm[2] = 0;
+    w.lane = lane;
+    for (uint32_t i = threadIdx.x; i < kShortMaxWin; i += kThreads) bcur[i] = i < A.n_win ? A.counts[(size_t)i * A.n_slots + blockIdx.x] : 0u;
+    if (UNIQ) reinterpret_cast<uint4 *>(tab)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    // This wave's paths: gi, gi + stride, ...  Their descriptors come 64 at a time (one load, a path
+    // per lane) and are handed out by v_readlane; a path's steps are requested three paths ahead.
+    const uint32_t stride = gridDim.x * kWaves;
+    uint32_t gi = blockIdx.x * kWaves + (uint32_t)wave;  // the path whose steps are requested next
+    uint32_t bx = 0, by = 0, bk = 64u;                   // (per lane) the batch; how many of it are handed out
+    uint32_t pb[3] = {0u, 0u, 0u}, pn[3] = {0u, 0u, 0u};  // the paths in flight: first step, number of steps (0: none)
+    uint32_t since[3] = {0u, 0u, 0u};                     // memory operations issued behind each slot's loads
+    const auto next_path = [&](uint32_t &b, uint32_t &n) {
+        n = 0u;
+        b = 0u;
+        if (gi >= A.n_short) return;
+        if (bk >= 64u) {
+            const uint64_t idx = (uint64_t)gi + (uint64_t)lane * stride;
+            uint2 d = make_uint2(0u, 0u);
+            if (idx < A.n_short) d = *reinterpret_cast<const uint2 *>(A.short_items + idx);
+            bx = d.x;
+            by = d.y;
+            bk = 0u;
+        }
+        b = (uint32_t)__builtin_amdgcn_readlane((int)bx, (int)bk);
+        n = (uint32_t)__builtin_amdgcn_readlane((int)by, (int)bk) - b;
+        bk += 1u;
+        gi = gi + stride >= gi ? gi + stride : 0xFFFFFFFFu;
+    };
+#define FGFA_TINY_REQ(D)                                                                            \
+    do {                                                                                            \
+        next_path(pb[D], pn[D]);                                                                    \
+        if (pn[D]) {                                                                                \
+            /* lanes beyond the path re-read its first step */                                      \
+            const uint32_t o0 = (uint32_t)lane < pn[D] ? 4u * (uint32_t)lane : 0u;                  \
+            const uint32_t o1 = 64u + (uint32_t)lane < pn[D] ? 256u + 4u * (uint32_t)lane : 0u;    \
+            tiny_request<D>(A.steps + pb[D], o0, o1);                                               \
+            since[0] += 2u, since[1] += 2u, since[2] += 2u;                                         \
+            since[D] = 0u;                                                                          \
+        }                                                                                           \
+    } while (0)
+    FGFA_TINY_REQ(0);
+    FGFA_TINY_REQ(1);
+    FGFA_TINY_REQ(2);
+    bool bad = false, ovf = false;
+#define FGFA_TINY_PATH(D)                                                                                              \
+    if (pn[D]) {                                                                                                       \
+        uint32_t a0, a1;                                                                                               \
+        tiny_take<D>(since[D], a0, a1);                                                                                \
+        const uint32_t n = pn[D];                                                                                      \
+        FGFA_TINY_REQ(D);                                                                                              \
+        const bool v0 = (uint32_t)lane < n, v1 = 64u + (uint32_t)lane < n;                                             \
+        uint32_t x0 = a0 >> 1, x1 = a1 >> 1;                                                                           \
+        bad |= (v0 && x0 >= A.n_segs) || (v1 && x1 >= A.n_segs);                                                       \
+        x0 = x0 < A.n_segs ? x0 : 0u;                                                                                  \
+        x1 = x1 < A.n_segs ? x1 : 0u;                                                                                  \
+        bool f0 = true, f1 = true;  /* first visits */                                                                 \
+        if (UNIQ && !(FGFA_TINY_ABLATE & 1)) {                                                                         \
+            uint32_t h0 = (x0 * 0x9E3779B1u) >> 24, h1 = (x1 * 0x9E3779B1u) >> 24;                                     \
+            bool t0 = v0, t1 = v1;                                                                                     \
+            uint32_t probes = 0;                                                                                       \
+            while (__builtin_amdgcn_ballot_w64(t0 || t1)) {                                                            \
+                if (++probes > 2u * kTinyTab) {  /* cannot happen: the set holds at most 128 ids */                    \
+                    atomicOr(A.status, kStInternal);                                                                   \
+                    break;                                                                                             \
+                }                                                                                                      \
+                if (t0) {                                                                                              \
+                    const uint32_t k = atomicCAS(&tab[h0], 0u, x0 + 1u);                                               \
+                    if (k == 0u || k == x0 + 1u) f0 = k == 0u, t0 = false;                                             \
+                    else h0 = (h0 + 1u) & (kTinyTab - 1u);                                                             \
+                }                                                                                                      \
+                if (t1) {                                                                                              \
+                    const uint32_t k = atomicCAS(&tab[h1], 0u, x1 + 1u);                                               \
+                    if (k == 0u || k == x1 + 1u) f1 = k == 0u, t1 = false;                                             \
+                    else h1 = (h1 + 1u) & (kTinyTab - 1u);                                                             \
+                }                                                                                                      \
+            }                                                                                                          \
+            reinterpret_cast<uint4 *>(tab)[lane] = make_uint4(0u, 0u, 0u, 0u);  /* clean for the next path */          \
+        }                                                                                                              \
+        /* where records start */                                                                                      \
+        const uint32_t k0 = x0 | (f0 ? 0x80000000u : 0u), k1 = x1 | (f1 ? 0x80000000u : 0u);  /* id and flag in one word */ \
+        const uint32_t q0 = __builtin_amdgcn_update_dpp(0u, k0, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);              \
+        uint32_t q1 = __builtin_amdgcn_update_dpp(0u, k1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);                    \
+        const uint32_t k0_last = __builtin_amdgcn_readlane(k0, 63);                                                    \
+        q1 = lane == 0 ? k0_last : q1;                                                                                 \
+        const bool s0 = v0 && (lane == 0 || k0 != q0 + 1u || (x0 & 4095u) == 0u);                                      \
+        const bool s1 = v1 && (k1 != q1 + 1u || (x1 & 4095u) == 0u);                                                   \
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(s0), m1 = __builtin_amdgcn_ballot_w64(s1);           \
+        /* a record's length: to the next start, or to the end of the path */                                          \
+        const unsigned long long r0 = (m0 >> 1) >> lane, r1 = (m1 >> 1) >> lane;                                       \
+        const uint32_t len0 = r0 ? (uint32_t)__builtin_ctzll(r0) + 1u                                                  \
+                                 : m1 ? 64u - (uint32_t)lane + (uint32_t)__builtin_ctzll(m1) : n - (uint32_t)lane;     \
+        const uint32_t len1 = r1 ? (uint32_t)__builtin_ctzll(r1) + 1u : n - 64u - (uint32_t)lane;                      \
+        /* The records are queued (a path has a dozen: a store instruction per path would run with ten lanes in */     \
+        /* sixty-four busy) and leave 64 at a time; which ones go together does not matter to pass 2.             */    \
+        if (!(FGFA_TINY_ABLATE & 2)) {                                                                                 \
+            if (s0) q[fill + lane_rank(m0)] = make_uint2((x0 & 4095u) | ((len0 - 1u) << kShortWinBits) | ((UNIQ && f0 ? 3u : 1u) << 24), x0 >> kShortWinBits); \
+            fill += (uint32_t)__builtin_popcountll(m0);                                                                \
+            if (s1) q[fill + lane_rank(m1)] = make_uint2((x1 & 4095u) | ((len1 - 1u) << kShortWinBits) | ((UNIQ && f1 ? 3u : 1u) << 24), x1 >> kShortWinBits); \
+            fill += (uint32_t)__builtin_popcountll(m1);                                                                \
+            while (fill >= 64u) {                                                                                      \
+                fill -= 64u;                                                                                           \
+                const uint2 e = q[fill + (uint32_t)lane];                                                              \
+                const uint32_t pos = take_slots(bcur, lane, true, e.y);                                                \
+                ovf |= put<false>(A, w, mine, true, pos, e.y, e.x);                                                    \
+                since[0] += 1u, since[1] += 1u, since[2] += 1u;                                                        \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+#pragma unroll 1
+    while (pn[0] || pn[1] || pn[2]) {
+        FGFA_TINY_PATH(0)
+        FGFA_TINY_PATH(1)
+        FGFA_TINY_PATH(2)
+    }
+#undef FGFA_TINY_PATH
+#undef FGFA_TINY_REQ
+    if (fill) {  // what is left in the queue
+        const bool v = (uint32_t)lane < fill;
+        const uint2 e = v ? q[lane] : make_uint2(0u, 0u);
+        const uint32_t pos = take_slots(bcur, lane, v, e.y);
+        ovf |= put<false>(A, w, mine, v, pos, e.y, e.x);
+    }
+    flag_if_any(A, bad, kStBounds);
+    flag_if_any(A, ovf, kStOverflow);
+    __syncthreads();
+    for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads) A.counts[(size_t)wdw * A.n_slots + blockIdx.x] = bcur[wdw];
+}
+
 // ============================================================ pass 1, long items ===
 //
 // k_scan keeps no per-path state.  A wave's run queue holds (start id, position) pairs; the
@@ -2868,7 +3056,7 @@ uint32_t scan_lds_bytes(uint32_t nwp, bool tagged_only = false) { return ((tagge
 int alloc_buckets(FastPlan *fp, uint64_t want_cap) {
     const uint64_t slots = (uint64_t)fp->n_win * fp->n_slots;
     uint64_t max_cap = ((1ull << 30) - 1) / ((uint64_t)(fp->n_win + 1) * fp->n_slots);
-    if (want_cap > max_cap && !fp->dbg && fp->tagged && !fp->n_short && !fp->n_medium) {  // (k_scan's tagged builds only)
+    if (want_cap > max_cap && !fp->dbg && fp->tagged && !fp->n_short && !fp->n_medium && !fp->n_tiny) {  // (k_scan's tagged builds only)
         size_t free_b = 0, total_b = 0;
         uint64_t budget = 64ull << 30;
         if (const char *e = getenv("FLATGFA_BUCKET_GB")) budget = strtoull(e, nullptr, 10) << 30;
@@ -2952,7 +3140,8 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // contig on the reverse strand) has far fewer runs when it is read backwards, and the order of a
     // path's steps does not matter to the counts: such a path is walked from a reversed copy of its
     // steps, made here once (rev_steps; every copy starts at a multiple of 16).
-    std::vector<uint4> items, short_items, medium_items, short_rev, medium_rev, whole, rev_list;
+    std::vector<uint4> items, short_items, medium_items, short_rev, medium_rev, whole, rev_list, tiny_items;
+    const bool no_tiny = getenv("FLATGFA_NO_TINY") != nullptr;  // (measurements, tests: tiny paths go to k_scan_short as before)
     uint64_t rev_len = 0;
     for (uint32_t p = 0; p < g.n_paths; ++p) {
         const uint64_t b = hb[p], e = he[p], n = e - b;
@@ -2960,9 +3149,12 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         const bool in_reach = ((e + 15) & ~15ull) <= g.n_steps;  // the last block must not read past the step array
         const bool down = short_max && !no_rev && runs_down[p] < runs[p] && rev_len + n + 2048 < 0xFFFFFFFFull;
         const uint32_t rn = short_max ? (down ? runs_down[p] : runs[p]) : 0u;
-        const bool is_short = n <= short_max && (down || in_reach) && (rn + 16 <= kQCap || short_any);
-        const bool is_medium = !is_short && short_max && (down || in_reach) && rn <= kMediumRuns;
-        if ((is_short || is_medium) && down) {
+        const bool is_tiny = n <= std::min<uint64_t>(short_max, kTinyMax) && !no_tiny;  // (k_scan_tiny: a wave holds the whole path)
+        const bool is_short = !is_tiny && n <= short_max && (down || in_reach) && (rn + 16 <= kQCap || short_any);
+        const bool is_medium = !is_tiny && !is_short && short_max && (down || in_reach) && rn <= kMediumRuns;
+        if (is_tiny) {
+            tiny_items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
+        } else if ((is_short || is_medium) && down) {
             const uint32_t at = (uint32_t)rev_len;
             rev_list.push_back(make_uint4((uint32_t)b, (uint32_t)e, at, p));
             (is_short ? short_rev : medium_rev).push_back(make_uint4(at, at + (uint32_t)n, kNoSlot, p));
@@ -3101,7 +3293,8 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     fp->n_items = (uint32_t)items.size();
     fp->n_short = (uint32_t)short_items.size();
     fp->n_medium = (uint32_t)medium_items.size();
-    if (items.empty() && short_items.empty() && medium_items.empty()) return true;
+    fp->n_tiny = (uint32_t)tiny_items.size();
+    if (items.empty() && short_items.empty() && medium_items.empty() && tiny_items.empty()) return true;
     fp->max_back = std::min<uint32_t>(fp->n_short, kMaxHandBack);
     fp->exact_short = !short_any;  // the run counts the lists were made from are exact: nothing is handed back
     fp->dstride = fp->n_items + fp->max_back + 1;
@@ -3121,7 +3314,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // bitset per split path (none to spare with 8192-segment windows; a window shared by several
     // workgroups cannot share bitsets).  FLATGFA_TAGGED=0 keeps the directory (tests, measurements).
     {
-        const uint32_t grid = (fp->n_short || fp->n_medium) ? fp->n_slots : std::min<uint32_t>(fp->n_items, fp->n_slots);
+        const uint32_t grid = (fp->n_short || fp->n_medium || fp->n_tiny) ? fp->n_slots : std::min<uint32_t>(fp->n_items, fp->n_slots);
         const uint64_t per_wg = grid ? ((uint64_t)fp->n_items + fp->max_back + grid - 1) / grid : 0;
         const char *t = getenv("FLATGFA_TAGGED");
         const uint32_t shared_cap = wb <= 12 ? kMaxShared : 0u;
@@ -3159,7 +3352,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         fp->tagged = taggable && per_wg <= limit && most <= limit;
         // what fast_plan_create may do about a plan that is not: walk the paths in groups (fewer items, fewer
         // split paths per group), or take 4096-segment windows (pass 2 then has LDS for split paths' bitsets)
-        fp->too_many_items = base_ok && !fp->tagged && fp->acc_parts == 1 && !fp->n_short && !fp->n_medium && (taggable || (wb <= 12 && fp->n_shared > shared_cap));
+        fp->too_many_items = base_ok && !fp->tagged && fp->acc_parts == 1 && !fp->n_short && !fp->n_medium && !fp->n_tiny && (taggable || (wb <= 12 && fp->n_shared > shared_cap));
         fp->want_wb12 = base_ok && !fp->tagged && wb == 13 && fp->n_shared > 0 && fp->acc_parts == 1;
         if (!fp->tagged && n_win > kMaxWin) {  // so many windows only without cursor snapshots: the caller cuts smaller ranges
             const bool many = fp->too_many_items, w12 = fp->want_wb12;
@@ -3323,10 +3516,15 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         FAST_TRY(hipMalloc(&fp->medium_items, medium_items.size() * sizeof(uint4)));
         FAST_TRY(hipMemcpy(fp->medium_items, medium_items.data(), medium_items.size() * sizeof(uint4), hipMemcpyHostToDevice));
     }
+    if (!tiny_items.empty()) {
+        FAST_TRY(hipMalloc(&fp->tiny_items, tiny_items.size() * sizeof(uint4)));
+        FAST_TRY(hipMemcpy(fp->tiny_items, tiny_items.data(), tiny_items.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    }
     {
         std::vector<uint32_t> other;
         for (const uint4 &it : short_items) other.push_back(it.w);
         for (const uint4 &it : medium_items) other.push_back(it.w);
+        for (const uint4 &it : tiny_items) other.push_back(it.w);
         fp->n_other = (uint32_t)other.size();
         if (!other.empty()) {
             FAST_TRY(hipMalloc(&fp->other_ids, other.size() * 4));
@@ -3340,6 +3538,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipFuncSetAttribute((const void *)k_walk_short<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     FAST_TRY(hipFuncSetAttribute((const void *)k_walk_medium<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     FAST_TRY(hipFuncSetAttribute((const void *)k_walk_medium<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    fp->lds_bytes_tiny = (kShortMaxWin + kWaves * kTinyTab + kWaves * kTinyQueue * 2u) * 4u;
     FAST_TRY(hipMalloc(&fp->work_counter, 256));
     FAST_TRY(hipMemset(fp->work_counter, 0, 256));
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModePlain, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
@@ -3592,7 +3791,7 @@ void fast_plan_destroy(FastPlan *fp) {
     delete[] fp->more;
     for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot, (void *)fp->perm,
                     (void *)fp->elist, (void *)fp->wave_off, (void *)fp->fat_off, (void *)fp->fat_woff, (void *)fp->items, (void *)fp->short_items,
-                    (void *)fp->medium_items, (void *)fp->rev_steps, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part,
+                    (void *)fp->medium_items, (void *)fp->tiny_items, (void *)fp->rev_steps, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part,
                     (void *)fp->pair_part, (void *)fp->pair_flag, (void *)fp->taken})
         if (p) (void)hipFree(p);
     *fp = FastPlan();
@@ -3606,7 +3805,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
         return FLATGFA_ERR_ARG;
     }
     const uint32_t stride = fp.n_slots * fp.cap;
-    const bool has_pre = fp.n_short || fp.n_medium;
+    const bool has_pre = fp.n_short || fp.n_medium || fp.n_tiny;
     // one persistent workgroup per CU; k_scan may be handed short paths back, so it gets a full grid when there are any
     // (and whenever the wave-per-path kernels ran: it saves their cursors for pass 2)
     // -- unless it has no items of its own and nothing can come back (the run counts of the lists are
@@ -3668,6 +3867,15 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     // The wave-per-path kernels: the paths read from the graph's steps, then those read from their
     // reversed copies (a handed-back one is walked by k_scan from the graph's own steps).
     if (fp.n_short && hipMemsetAsync(fp.work_counter, 0, 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
+    if (fp.n_tiny) {  // paths a wave holds whole (at most 128 steps)
+        ScanArgs sk = sa;
+        sk.short_items = reinterpret_cast<const uint4 *>(fp.tiny_items);
+        sk.n_short = fp.n_tiny;
+        const uint32_t kgrid = std::min<uint32_t>((fp.n_tiny + kWaves - 1) / kWaves, fp.n_slots);
+        ProfScope pscope(uniq_out ? "k_scan_tiny<uniq>" : "k_scan_tiny<depth>", stream);
+        if (uniq_out) hipLaunchKernelGGL(k_scan_tiny<true>, dim3(kgrid), dim3(kThreads), fp.lds_bytes_tiny, stream, sk);
+        else hipLaunchKernelGGL(k_scan_tiny<false>, dim3(kgrid), dim3(kThreads), fp.lds_bytes_tiny, stream, sk);
+    }
     for (int medium = 0; medium < 2; ++medium) {
         const uint32_t n_all = medium ? fp.n_medium : fp.n_short, n_rev = medium ? fp.n_medium_rev : fp.n_short_rev;
         const uint4 *list = reinterpret_cast<const uint4 *>(medium ? fp.medium_items : fp.short_items);

@@ -66,6 +66,9 @@ struct FastPlan {
     void *medium_items = nullptr;  // uint4[n_medium] longer paths with few enough runs for a 2048-entry hash set
     uint32_t n_medium = 0, n_medium_rev = 0;  // (laid out like short_items)
     uint32_t lds_bytes_medium = 0;
+    void *tiny_items = nullptr;    // uint4[n_tiny] paths of at most 128 steps: a wave holds one whole (k_scan_tiny)
+    uint32_t n_tiny = 0;
+    uint32_t lds_bytes_tiny = 0;
     uint32_t *taken = nullptr;         // u32[n_slots] items each workgroup of the last tagged k_scan took
     uint32_t *work_counter = nullptr;  // how many short paths were handed back in this call
     void *psum_part = nullptr;         // ulonglong2[n_win * dstride] per-window path sums of k_scan's items (on first use)

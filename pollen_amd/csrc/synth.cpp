@@ -1,6 +1,6 @@
 // Synthetic pangenome-shaped FlatGFA generator (readable spec in
-// oracle/synth.py, which tests/test_synth.py requires this file to match
-// bit-for-bit).  Paths are independent, so they are generated on host threads.
+// oracle/synth.py, which tests/test_host.py::test_synth_cxx_matches_numpy_spec requires this file to
+// match bit-for-bit).  Paths are independent, so they are generated on host threads.
 #include <algorithm>
 #include <cstdio>
 #include <thread>

@@ -653,3 +653,51 @@ def test_a_workgroup_never_takes_more_items_than_it_has_tags(mode, monkeypatch):
         assert (d.cpu().numpy().view(np.uint32) == want_d).all(), text
         assert (u.cpu().numpy().view(np.uint32) == want_u).all(), text
     plan.close()
+
+
+@pytest.mark.parametrize("n_paths,max_len", [(5000, 128), (20000, 40), (700, 64), (300, 129)])
+def test_tiny_paths_are_held_whole_by_a_wave(n_paths, max_len, monkeypatch):
+    """k_scan_tiny: paths of at most 128 steps, a wave holding one whole (two steps per lane), first visits
+    through a per-wave set of ids, records cut where the first-visit flag changes and at window
+    boundaries.  Paths of every length from 1 up, walks that revisit their own segments, run down the ids,
+    sit on a window boundary (4095 | 4096) and on the last segment; mixed with a few longer paths.
+    FLATGFA_NO_TINY sends the same graph through k_scan_short: both must give the oracle's counts."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    for v in ("FLATGFA_TAGGED", "FLATGFA_SHORT_MAX", "FLATGFA_PIECE_STEPS", "FLATGFA_NO_TINY"):
+        monkeypatch.delenv(v, raising=False)
+    rng = np.random.default_rng(n_paths + max_len)
+    S = 3 * 4096 + 77
+    walks = []
+    for p in range(n_paths):
+        n = int(rng.integers(1, max_len + 1))
+        start = int(rng.choice([rng.integers(0, S), 4090, 8190, S - 3, 0]))
+        jumps = rng.choice([1, 1, 1, 1, 1, 2, -1, -1, -3, 0, 5, 4096, -4000], size=n)
+        walks.append(((start + np.cumsum(jumps)) % S).astype(np.uint32))
+    for n in (3000, 9000):  # ... and two that are not tiny
+        walks.append(((int(rng.integers(0, S)) + np.cumsum(rng.choice([1, 1, 1, 2, -1], size=n))) % S).astype(np.uint32))
+    lens = np.array([len(x) for x in walks], dtype=np.uint32)
+    stp = (np.concatenate(walks) << 1) | rng.integers(0, 2, size=int(lens.sum())).astype(np.uint32)
+    pe = np.cumsum(lens).astype(np.uint32)
+    pb = (pe - lens).astype(np.uint32)
+    paths = np.zeros(len(lens), dtype=fo.PATH_DT)
+    paths["steps_start"], paths["steps_end"] = pb, pe
+    pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
+    pools.paths, pools.steps, pools.segs = paths, stp, np.zeros(S, dtype=fo.SEG_DT)
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    for no_tiny in (False, True):
+        if no_tiny:
+            monkeypatch.setenv("FLATGFA_NO_TINY", "1")
+        plan = DepthPlan(DeviceGraph(stp, pb, pe, S))
+        text = plan.describe()
+        assert ("k_scan_tiny" in text) == (not no_tiny), text
+        d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        for k in range(3):
+            plan.seg_depth(d, u if k != 1 else None)
+            plan.status()
+            assert (d.cpu().numpy().view(np.uint32) == want_d).all(), text
+            if k != 1:
+                assert (u.cpu().numpy().view(np.uint32) == want_u).all(), text
+        plan.close()

@@ -53,6 +53,7 @@ def main():
     tagged_pins = set(range(123 - depth, 123))
     bad, n_load, n_take, func = [], 0, 0, "?"
     n_acc_load = n_acc_take = 0
+    n_tiny_load = n_tiny_take = 0
     budgets = {}
     for ln in lines:
         s = ln.split(";")[0].strip()
@@ -79,6 +80,18 @@ def main():
                 else:
                     bad.append(f"{func}: {s}")
             continue
+        if "k_scan_tiny" in func:  # three paths' steps in flight: v118..v123 (tiny_request / tiny_take)
+            pins = set(range(118, 124))
+            if regs_of(s) & pins:
+                m = re.match(r"^global_load_dword v(\d+), v\d+, s\[\d+:\d+\]$", s)
+                t = re.match(r"^v_mov_b32(_e32)? v(\d+), v(\d+)$", s)
+                if m and int(m.group(1)) in pins:
+                    n_tiny_load += 1
+                elif t and int(t.group(3)) in pins and int(t.group(2)) not in pins:
+                    n_tiny_take += 1
+                else:
+                    bad.append(f"{func}: {s}")
+            continue
         if "k_scan" not in func or "k_scan_dense" in func:  # only the kernels that use the landing sets (everything is inlined into them)
             continue
         touched = regs_of(s) & PINNED
@@ -99,13 +112,15 @@ def main():
             bad.append(f"{name}: {v} VGPRs > 128")
     if n_acc_load == 0 or n_acc_take == 0:
         bad.append("no pinned record loads/takes found in k_accum -- did the kernel change?")
+    if n_tiny_load == 0 or n_tiny_take == 0:
+        bad.append("no pinned loads/takes found in k_scan_tiny -- did the kernel change?")
     if n_load == 0 or n_take == 0:
         bad.append("no pinned loads/takes found -- did the kernel change?")
     if bad:
         print("pinned-VGPR check FAILED:\n  " + "\n  ".join(bad[:20]))
         return 1
     print(f"pinned-VGPR check ok: k_accum {n_acc_load} record loads, {n_acc_take} takes, nothing else touches v120..v122 (tagged walk: v{123 - depth}..v122, k_accum_pair: v61..v63); "
-          f"k_scan {n_load} loads, {n_take} takes, nothing else touches v80..v127; "
+          f"k_scan_tiny {n_tiny_load} loads, {n_tiny_take} takes (v118..v123); k_scan {n_load} loads, {n_take} takes, nothing else touches v80..v127; "
           f"k_scan budgets {sorted(set(v for k, v in budgets.items() if 'k_scan' in k))}")
     return 0
 

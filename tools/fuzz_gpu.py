@@ -22,7 +22,11 @@ ENVS = [{}, {"FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0"}, {"FL
         {"FLATGFA_PIECE_STEPS": "4096", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
         {"FLATGFA_SCAN_ALWAYS": "1", "FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_WB": "12", "FLATGFA_DEPTH_PATH": "bucketed"},
         {"FLATGFA_WB": "11", "FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_PATH_GROUPS": "2", "FLATGFA_DEPTH_PATH": "bucketed"},
-        {"FLATGFA_PATH_GROUPS": "5", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"}]
+        {"FLATGFA_PATH_GROUPS": "5", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_TAG_LIMIT": "3", "FLATGFA_TAG_MEAN_ONLY": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},  # k_scan's workgroups run out of tags
+        {"FLATGFA_TAG_LIMIT": "6", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_NO_PLAIN": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_NO_TINY": "1", "FLATGFA_DEPTH_PATH": "bucketed"}]
 
 
 def random_graph(rng):
