@@ -697,6 +697,15 @@ extern "C" int flatgfa_dev_plan_describe(flatgfa_dev_plan_t *pl, char *out, int 
             (f.n_groups > 1 ? " path_groups=" + std::to_string(f.n_groups) : std::string()) +
             " workgroups_per_window=" + std::to_string(f.acc_parts) + " items=" + std::to_string(f.n_items) + " split_paths=" + std::to_string(f.n_shared) +
             " short_paths=" + std::to_string(f.n_short) + " medium_paths=" + std::to_string(f.n_medium) + " tiny_paths=" + std::to_string(f.n_tiny) + " bucket_cap=" + std::to_string(f.cap);
+        // the record buckets of all ranges and path groups: how they are laid out, what they take
+        const auto records_of = [](const FastPlan &q) { return q.packed ? q.bucket_records : ((uint64_t)q.n_win + 1) * q.n_slots * q.cap; };
+        uint64_t recs = records_of(f);
+        bool packed = f.packed;
+        for (uint32_t r = 0; r < f.n_more; ++r) {
+            recs += records_of(f.more[r]);
+            packed = packed || f.more[r].packed;
+        }
+        s += std::string(" buckets=") + (packed ? "packed" : "even") + " scratch_mb=" + std::to_string((recs * 4 + (1u << 20) - 1) >> 20);
     }
     const int n = (int)std::min<size_t>(s.size(), (size_t)cap - 1);
     memcpy(out, s.data(), (size_t)n);

@@ -149,6 +149,10 @@ struct ScanArgs {
     uint32_t *status;
     uint32_t dbg;
     uint32_t tagged;     // records carry their item's tag (see kTagShift); k_scan_dense reads this, k_scan is a build of its own
+    // Packed buckets (k_scan<kModePacked...>): every (window, workgroup) sub-bucket has exactly the room its records
+    // need -- counted once, with the items dealt in a fixed order -- and a workgroup's sub-buckets lie back to back:
+    const uint32_t *pk_off;   // [n_slots][n_win + 1] where each of the workgroup's sub-buckets starts in its region (the last entry: the region's end, a sink)
+    const uint64_t *pk_base;  // [n_slots] where the workgroup's region starts in `buckets`
     uint32_t *taken;     // tagged: [n_slots] how many items each workgroup took (its private tags are 0 .. taken - 1): pass 2 clears all of a wave's
                          // bitsets at once where a sub-bucket has no more tags than the wave has bitsets, and none changes hands inside it
     uint32_t tag_limit;  // tagged: how many items a workgroup may take (its private tags are 0 .. tag_limit - 1; the split paths' lie above)
@@ -177,8 +181,20 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(
 // Store a record at slot `pos` of this workgroup's sub-bucket of window `win`.  Branch free:
 // lanes with nothing to store (or no room) write to the sink window.  Returns whether the record
 // did not fit (the call is then completed on a larger plan, see flatgfa_dev_status).
-template <bool DBG, bool BIG = false, typename W>
+template <bool DBG, bool BIG = false, bool PACKED = false, typename W>
 __device__ __forceinline__ bool put(const ScanArgs &A, W &w, uint32_t *mine, bool e, uint32_t pos, uint32_t win, uint32_t rec) {
+    if constexpr (PACKED) {
+        // the sub-bucket's start and end in the workgroup's region (two neighbouring LDS words); what does not fit
+        // (a call that makes other records than the one the layout was counted on) goes to the region's sink
+        const uint32_t wq = e ? win : 0u;
+        const uint32_t lo = w.poff[wq], hi = w.poff[wq + 1u];
+        const bool fits = e && pos < hi - lo;
+        mine[fits ? lo + pos : w.poff[A.n_win]] = rec;
+        w.vm[0] += 1;
+        w.vm[1] += 1;
+        w.vm[2] += 1;
+        return e && !fits;
+    }
     const bool ok = e && pos < A.cap;
     if (BIG) {
         // A bucket array of 2^30 records or more (many windows times sub-buckets deep enough for the few
@@ -1005,6 +1021,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_tiny(const ScanArgs A) {
 // number of steps).  Entries leave the queue oldest first, 64 at a time, each as one record.
 
 struct RWave {
+    const uint32_t *poff;  // packed buckets: the workgroup's row of ScanArgs::pk_off, in LDS
     uint32_t dir;  // +1 / -1 (as unsigned): which way the current item's runs go (uniform; the queue never holds two items)
     uint32_t tagc; // what every record of the current item carries besides its range: 1 << 24, or the item's tag << kTagShift
     uint2 *q;
@@ -1068,9 +1085,10 @@ __device__ __forceinline__ void tmark(const ScanArgs &A, RWave &w, int ph) {
 // next item nobody has taken yet (two cells, by item parity), how many waves have left the item
 // (two cells), and how many items are complete.
 // k_scan's builds: plain, diagnostic (FLATGFA_DEBUG_SKIP), ranged (one of several walks of a graph beyond 16 M segments)
-constexpr int kModePlain = 0, kModeDbg = 1, kModeRanged = 2, kModeBig = 3, kModeRangedBig = 4;  // (Big: builds of their own for bucket arrays of 2^30 records or more, see put())
-constexpr bool mode_ranged(int m) { return m == kModeRanged || m == kModeRangedBig; }
+constexpr int kModePlain = 0, kModeDbg = 1, kModeRanged = 2, kModeBig = 3, kModeRangedBig = 4, kModePacked = 5, kModePackedRanged = 6;  // (Big: builds of their own for bucket arrays of 2^30 records or more, see put(); Packed: sub-buckets of exactly the size their records need, items dealt in a fixed order)
+constexpr bool mode_ranged(int m) { return m == kModeRanged || m == kModeRangedBig || m == kModePackedRanged; }
 constexpr bool mode_big(int m) { return m == kModeBig || m == kModeRangedBig; }
+constexpr bool mode_packed(int m) { return m == kModePacked || m == kModePackedRanged; }
 #ifndef FGFA_WIDE
 #define FGFA_WIDE 4
 #endif
@@ -1142,13 +1160,13 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const uint32_t l1 = cross[k] ? wmask - rel[k] : lenm1[k];
-        ovf |= put<DBG, mode_big(MODE)>(A, w, mine, valid[k], pos[k], win[k], rel[k] | (l1 << wb) | w.tagc);
+        ovf |= put<DBG, mode_big(MODE), mode_packed(MODE)>(A, w, mine, valid[k], pos[k], win[k], rel[k] | (l1 << wb) | w.tagc);
     }
     if (__builtin_amdgcn_ballot_w64(any_cross)) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t pos2 = cross[k] ? atomicAdd(&bcur[win[k] + 1u], 1u) : 0u;
-            ovf |= put<DBG, mode_big(MODE)>(A, w, mine, cross[k], pos2, win[k] + 1u, ((lenm1[k] - (wmask - rel[k]) - 1u) << wb) | w.tagc);
+            ovf |= put<DBG, mode_big(MODE), mode_packed(MODE)>(A, w, mine, cross[k], pos2, win[k] + 1u, ((lenm1[k] - (wmask - rel[k]) - 1u) << wb) | w.tagc);
         }
     }
     flag_if_any(A, ovf, kStOverflow);
@@ -1355,19 +1373,22 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     constexpr uint32_t kRing = TAGGED ? kCtlRing - 1u : 1u;  // which cell of the control rings an item uses: its ordinal & kRing
     extern __shared__ uint32_t lds[];
     // layout: [bcur: nwp][snap: nwp, untagged only][control words][run queues: kWaves * kQ2 entries of 8 bytes]
-    constexpr uint32_t kTables = TAGGED ? 1u : 2u;
+    constexpr bool PACKED = mode_packed(MODE);
+    static_assert(!PACKED || TAGGED, "packed buckets are for tagged calls");
+    constexpr uint32_t kTables = TAGGED && !PACKED ? 1u : 2u;
     uint32_t *bcur = lds;
-    uint32_t *snap = lds + A.nwp;  // the cursors when the current item started (not kept in a tagged call)
+    uint32_t *snap = lds + A.nwp;  // the cursors when the current item started (not kept in a tagged call; a packed one keeps its sub-buckets' offsets there: n_win + 1 <= nwp words)
     uint32_t *ctl = lds + kTables * A.nwp;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the span math on the scalar unit
-    uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;  // this workgroup's sub-bucket of window 0
+    uint32_t *mine = PACKED ? A.buckets + A.pk_base[blockIdx.x] : A.buckets + (size_t)blockIdx.x * A.cap;  // this workgroup's sub-bucket of window 0 (packed: its region)
     if (TAGGED && MODE == kModePlain && A.tprof && threadIdx.x == 0) {
         A.tprof[kTprofRow * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
         // where it runs: HW_ID (wave, SIMD, CU, shader array and engine) and XCC_ID
         A.tprof[kTprofRow * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     }
     RWave w;
+    w.poff = snap;
     w.q = reinterpret_cast<uint2 *>(lds + kTables * A.nwp + kCtlWords) + (uint32_t)wave * kQ2;
     w.fill = 0;
     w.vm[0] = w.vm[1] = w.vm[2] = 0;
@@ -1389,6 +1410,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         const uint32_t c = i < A.n_win ? A.counts[(size_t)i * A.n_slots + blockIdx.x] : 0u;
         bcur[i] = c;
         if (!TAGGED) snap[i] = c;
+        if (PACKED) snap[i] = i <= A.n_win ? A.pk_off[(size_t)blockIdx.x * (A.n_win + 1u) + i] : 0u;
         if (A.has_pre && i < A.n_win) A.counts0[(size_t)i * A.n_slots + blockIdx.x] = c;
     }
     if (threadIdx.x < kCtlWords)
@@ -1470,7 +1492,9 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
 
     while (job < n_items) {
         uint32_t next_job;
-        if (TAGGED) {
+        if (PACKED) {
+            next_job = (rr + 1u) * gridDim.x + blockIdx.x;  // a fixed deal: the layout of the buckets was counted on it
+        } else if (TAGGED) {
             uint32_t *ahead = &ctl[kCtlJobs + ((rr + 2u) & kRing)];
             uint32_t st = 0;
             if (lane == 0) st = atomicCAS(ahead, kJobEmpty, kJobPending);  // who fetches the item after the next?
@@ -1497,7 +1521,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         const uint32_t next_job_s = __builtin_amdgcn_readfirstlane(next_job);
         uint4 next_item = make_uint4(0u, 0u, 0u, 0u);
         uint32_t next_place = next_job_s | 0x80000000u;
-        if (TAGGED && FGFA_ITEM_RING && many_items) {
+        if (TAGGED && !PACKED && FGFA_ITEM_RING && many_items) {
             if (next_job_s < n_items) {
                 const uint32_t *dc = ctl + kCtlDesc + 4u * ((rr + 1u) & kRing);
                 next_item = make_uint4(dc[0], dc[1], dc[2], dc[3]);
@@ -1605,7 +1629,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         if (out == gridDim.x - 1u) {
             // items nobody took (every workgroup out of tags): the call is completed through the atomic kernels
             const uint32_t taken = __hip_atomic_load(A.work_counter + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint64_t)taken + 2ull * gridDim.x < n_items) atomicOr(A.status, kStBackOverflow);
+            if (!PACKED && (uint64_t)taken + 2ull * gridDim.x < n_items) atomicOr(A.status, kStBackOverflow);
             A.work_counter[1] = 0u;
             A.work_counter[2] = 0u;
         }
@@ -1654,6 +1678,7 @@ struct AccArgs {
     uint32_t accumulate;  // the outputs hold the counts of the paths walked before (another group of the same call): add to them
     const uint32_t *taken;  // tagged: [n_slots] items each k_scan workgroup took (ScanArgs::taken)
     uint32_t *fullest;      // this range's fullest sub-bucket beyond half the capacity (read and cleared by fast_plan_grow)
+    const uint2 *pk;        // packed buckets: [n_win][n_slots] {where the sub-bucket starts in `buckets`, its room}; else null
 };
 
 // FLATGFA_ACC_TIME: charge the time since the last mark to phase `ph` of this wave; the wave's
@@ -1898,7 +1923,7 @@ __device__ __forceinline__ void add_n(uint32_t *out, uint32_t i0, uint32_t nvali
 // they count for).  Each wave takes sixteen sub-buckets per round and requests the first 64 x 16
 // bytes of every one before it applies any, so a round pays the memory latency once.
 template <bool UNIQ, int WB, int kPerRound = 16>
-__device__ __forceinline__ void apply_flat(const AccArgs &A, int *D, int *R, const uint32_t *scnt, const uint32_t *wbase) {
+__device__ __forceinline__ void apply_flat(const AccArgs &A, int *D, int *R, const uint32_t *scnt, const uint32_t *sstart, const uint32_t *wbase) {
     const int lane = threadIdx.x & 63;
     // wave-uniform: sub-bucket addressing stays scalar.  The waves of all of the window's workgroups share the sub-buckets out.
     const uint32_t uw = __builtin_amdgcn_readfirstlane(blockIdx.y * kAccWaves + (threadIdx.x >> 6)), nw = A.parts * kAccWaves;
@@ -1911,7 +1936,7 @@ __device__ __forceinline__ void apply_flat(const AccArgs &A, int *D, int *R, con
             const uint32_t sc = s < A.n_slots ? s : 0u;
             cnt[k] = s < A.n_slots ? scnt[sc] : 0u;
             // unconditional (slot 0 always exists): a predicated load would be waited for on the spot
-            r[k] = reinterpret_cast<const uint4 *>(wbase + (size_t)sc * A.cap)[(uint32_t)lane < (cnt[k] >> 2) ? lane : 0];
+            r[k] = reinterpret_cast<const uint4 *>(wbase + sstart[sc])[(uint32_t)lane < (cnt[k] >> 2) ? lane : 0];
         }
 #pragma unroll
         for (int k = 0; k < kPerRound; ++k) {
@@ -1928,7 +1953,7 @@ __device__ __forceinline__ void apply_flat(const AccArgs &A, int *D, int *R, con
             const uint32_t s = s0 + k * nw;
             if (s >= A.n_slots) break;
             const uint32_t c = scnt[s];
-            const uint32_t *bk = wbase + (size_t)s * A.cap;
+            const uint32_t *bk = wbase + sstart[s];
             for (uint32_t i = 64 + lane; i < (c >> 2); i += 64) {
                 const uint4 v = reinterpret_cast<const uint4 *>(bk)[i];
                 apply_record<UNIQ, WB>(D, R, v.x);
@@ -2625,6 +2650,7 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
     __shared__ __attribute__((aligned(16))) int cells[(UNIQ ? 2 : 1) * (kW + 64)];
     __shared__ unsigned long long wave_tot[kAccWaves];
     __shared__ uint32_t scnt[kMaxSlots];
+    __shared__ uint32_t sstart[kMaxSlots];  // where each sub-bucket starts, counted from wbase (s * cap, or a packed plan's own table)
     __shared__ __attribute__((aligned(8))) uint2 scnt2[TAGGED && UNIQ ? kMaxSlots : 1];  // tagged: where k_scan's records start and end in each sub-bucket
     __shared__ __attribute__((aligned(16))) uint32_t bits[UNIQ && !TAGGED ? kAccWaves * kSlots * (kW / 32) : 4];
     __shared__ uint32_t marks[UNIQ && !TAGGED ? kAccWaves * 64 : 4];
@@ -2660,25 +2686,35 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
         }
     }
     for (uint32_t sl = tid; sl < A.n_slots; sl += kAccThreads) {
-        if ((sl % nw) / kAccWaves != blockIdx.y) continue;  // (whoever walks a sub-bucket reads and clears its count)
+        if ((sl % nw) / kAccWaves != blockIdx.y) {  // (whoever walks a sub-bucket reads and clears its count)
+            sstart[sl] = A.pk ? A.pk[(size_t)win * A.n_slots + sl].x : sl * A.cap;  // (apply_flat's unconditional loads may look at sub-bucket 0)
+            continue;
+        }
         uint32_t *c = A.counts + (size_t)win * A.n_slots + sl;
         uint32_t v = *c;
         *c = 0u;
-        // (a sub-bucket more than half full: flatgfa_dev_status makes room before a later call -- whose
-        // items k_scan may deal to other workgroups -- runs out of it)
-        if (v > (A.cap >> 1)) {
+        // where the sub-bucket starts (counted from wbase) and how much room it has
+        uint32_t start = sl * A.cap, room = A.cap;
+        if (A.pk) {
+            const uint2 e = A.pk[(size_t)win * A.n_slots + sl];
+            start = e.x;
+            room = e.y;
+        } else if (v > (A.cap >> 1)) {
+            // (a sub-bucket more than half full: flatgfa_dev_status makes room before a later call -- whose
+            // items k_scan may deal to other workgroups -- runs out of it)
             atomicMax(A.status + 2, v);
             if (A.fullest) atomicMax(A.fullest, v);  // (which range of the plan it was: only that one is given more room)
         }
+        sstart[sl] = start;
         if (TAGGED && UNIQ) {
-            const uint32_t c1 = min(v, A.cap);
+            const uint32_t c1 = min(v, room);
             v = min(A.has_pre == 1 ? A.counts0[(size_t)win * A.n_slots + sl] : A.has_pre ? v : 0u, c1);  // (2: k_scan did not run, all are earlier records)
             // (bit 31 of the count: the sub-bucket's private tags are 0 .. kTagSlots - 1 at most, so no bitset changes hands inside it)
-            scnt2[sl] = make_uint2(sl * A.cap + v, (c1 - v) | (A.taken && A.taken[sl] <= kTagSlots ? 0x80000000u : 0u));  // k_scan's records: where they start in the window's buckets, how many
+            scnt2[sl] = make_uint2(start + v, (c1 - v) | (A.taken && A.taken[sl] <= kTagSlots ? 0x80000000u : 0u));  // k_scan's records: where they start in the window's buckets, how many
         } else if (UNIQ && A.has_pre == 1) {
             v = A.counts0[(size_t)win * A.n_slots + sl];
         }
-        scnt[sl] = min(v, A.cap);
+        scnt[sl] = min(v, room);
     }
     if (tid == 0) grab = kAccWaves;
     if (TAGGED && UNIQ)  // the split paths' bitsets (the private ones are cleared when they change hands)
@@ -2686,9 +2722,9 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
     const uint32_t nvalid = min(kW, A.n_segs - w0);
     for (uint32_t i = tid; i < (UNIQ ? 2u : 1u) * (kW + 64); i += kAccThreads) cells[i] = 0;
     __syncthreads();
-    const uint32_t *wbase = A.buckets + (size_t)win * A.n_slots * A.cap;
+    const uint32_t *wbase = A.pk ? A.buckets : A.buckets + (size_t)win * A.n_slots * A.cap;  // (a packed plan's starts count from the array's)
     tm.mark(0);
-    if (flat) apply_flat<UNIQ, WB, (PAIR ? 4 : 16)>(A, D, R, scnt, wbase);
+    if (flat) apply_flat<UNIQ, WB, (PAIR ? 4 : 16)>(A, D, R, scnt, sstart, wbase);
     tm.mark(1);
     if (UNIQ && TAGGED) {
         if (PAIR) apply_tagged<WB, POINT, false, true>(A, D, R, tag_bits, scnt2, wbase, &grab);
@@ -3084,6 +3120,9 @@ int alloc_buckets(FastPlan *fp, uint64_t want_cap) {
 
 }  // namespace
 
+static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
+                     uint32_t *status, hipStream_t stream, const PathSums *ps, bool count_only);
+
 // The plan of one range of segments, [seg_base, seg_base + n_range): the whole graph, or one of
 // the ranges of a graph beyond 16 M segments.
 static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp, uint32_t seg_base,
@@ -3108,7 +3147,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     if (fp->n_slots > kMaxSlots) return true;
     fp->n_win = n_win;
     fp->wb = wb;
-    fp->nwp = (n_win + 63u) & ~63u;
+    fp->nwp = (n_win + 1u + 63u) & ~63u;  // (one entry more than windows: a packed plan's offset table ends with the region's end)
     fp->lds_bytes_scan = scan_lds_bytes(fp->nwp, n_win > kMaxWin);
     if (fp->lds_bytes_scan + 64 > kLdsLimit) return true;
     if (const char *d = getenv("FLATGFA_DEBUG_SKIP")) fp->dbg = (uint32_t)strtoul(d, nullptr, 10);
@@ -3464,10 +3503,19 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         cap = strtoull(forced, nullptr, 10);
         fp->cap_forced = true;
     }
-    {
+    // Packed buckets (below, once the items are on the device): where an even share for every sub-bucket would take
+    // gigabytes -- whole-genome graphs, whose paths leave most sub-buckets of a window empty and a few deep --
+    // the plan counts what every sub-bucket gets and lays them out back to back.  For tagged plans whose
+    // records all come from k_scan; FLATGFA_PACKED=0|1 never / whenever possible (tests, measurements).
+    bool want_packed = fp->tagged && !fp->n_short && !fp->n_medium && !fp->n_tiny && !fp->dbg && !fp->cap_forced && n_win <= kMaxWin && fp->acc_parts == 1 &&
+                       (slots + fp->n_slots) * std::max<uint64_t>(cap, 4) * 4 > (2ull << 30);
+    if (const char *f = getenv("FLATGFA_PACKED"))
+        want_packed = strtol(f, nullptr, 10) != 0 && fp->tagged && !fp->n_short && !fp->n_medium && !fp->n_tiny && !fp->dbg && !fp->cap_forced && n_win <= kMaxWin && fp->acc_parts == 1;
+    if (!want_packed) {
         const int rc = alloc_buckets(fp, std::max<uint64_t>(cap, 4));
         if (rc < 0) return false;
         if (rc == 0) return true;  // not eligible; the caller's destroy releases what was allocated
+        fp->bucket_records = (slots + fp->n_slots) * (uint64_t)fp->cap;
     }
     FAST_TRY(hipMalloc(&fp->counts, slots * 4));
     FAST_TRY(hipMemset(fp->counts, 0, slots * 4));
@@ -3548,6 +3596,8 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeRanged, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeBig, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModeRangedBig, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModePacked, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModePackedRanged, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     // pass 2 of a tagged call keeps its bitsets in dynamic shared memory (next to about 60 KB of static arrays, 93 KB with 8192-segment windows)
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 11, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(11, kMaxShared)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
@@ -3570,6 +3620,85 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         FAST_TRY(hipMemset(fp->pair_flag, 0, (size_t)n_win * 4));
     }
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    if (want_packed && (fp->dense || fp->dense_maybe)) {  // (pass 1 by partition keeps the even layout)
+        want_packed = false;
+        const int rc = alloc_buckets(fp, std::max<uint64_t>(cap, 4));
+        if (rc < 0) return false;
+        if (rc == 0) return true;
+        fp->bucket_records = (slots + fp->n_slots) * (uint64_t)fp->cap;
+    }
+    if (want_packed) {
+        // The counting call: k_scan alone, every sub-bucket without room (all records go to a sink), the
+        // items dealt in the fixed order every later call uses.  Its cursors are the layout.
+        const size_t row = (size_t)n_win + 1;
+        uint32_t *d_status = nullptr;
+        FAST_TRY(hipMalloc(&fp->pk_off, row * fp->n_slots * 4));
+        FAST_TRY(hipMemset(fp->pk_off, 0, row * fp->n_slots * 4));
+        FAST_TRY(hipMalloc(&fp->pk_base, (size_t)fp->n_slots * 8));
+        FAST_TRY(hipMemset(fp->pk_base, 0, (size_t)fp->n_slots * 8));
+        FAST_TRY(hipMalloc(&fp->buckets, 4096));
+        FAST_TRY(hipMalloc(&d_status, 256));
+        FAST_TRY(hipMemset(d_status, 0, 256));
+        fp->packed = true;
+        fp->cap = 0;
+        fp->eligible = true;
+        const int rc = run_range(*fp, g, nullptr, nullptr, d_status, nullptr, nullptr, true);
+        std::vector<uint32_t> cnt(slots);
+        hipError_t e = rc == FLATGFA_OK ? hipDeviceSynchronize() : hipErrorUnknown;
+        if (e == hipSuccess) e = hipMemcpy(cnt.data(), fp->counts, slots * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemset(fp->counts, 0, slots * 4);
+        uint32_t st = 0;
+        if (e == hipSuccess) e = hipMemcpy(&st, d_status, 4, hipMemcpyDeviceToHost);
+        (void)hipFree(d_status);
+        fp->eligible = false;
+        FAST_TRY(e);
+        if (st & kStBounds) {  // (an id out of range: the atomic kernels report it; no layout to be had)
+            fp->packed = false;
+            return true;
+        }
+        std::vector<uint32_t> off(row * fp->n_slots);
+        std::vector<uint64_t> base(fp->n_slots);
+        std::vector<uint2> pk(slots);
+        uint64_t total = 0, deepest = 0;
+        bool fits = true;
+        for (uint32_t gq = 0; gq < fp->n_slots; ++gq) {
+            uint64_t o = 0;
+            base[gq] = total;
+            for (uint32_t wq = 0; wq < n_win; ++wq) {
+                const uint64_t room = ((uint64_t)cnt[(size_t)wq * fp->n_slots + gq] + 3) & ~3ull;  // (sub-buckets start on 16 bytes: pass 2 reads four records at a time)
+                off[gq * row + wq] = (uint32_t)o;
+                pk[(size_t)wq * fp->n_slots + gq] = make_uint2((uint32_t)(total + o), (uint32_t)room);
+                deepest = std::max(deepest, room);
+                o += room;
+            }
+            off[gq * row + n_win] = (uint32_t)o;  // the region's sink
+            o += 64;
+            fits = fits && o < (1ull << 30);      // (a region's byte offsets take 32 bits)
+            total += o;
+        }
+        fits = fits && total < (1ull << 32);
+        (void)hipFree(fp->buckets);
+        fp->buckets = nullptr;
+        if (!fits) {  // (not the case this layout is for: the even one, if it can be had)
+            fp->packed = false;
+            (void)hipFree(fp->pk_off);
+            (void)hipFree(fp->pk_base);
+            fp->pk_off = nullptr;
+            fp->pk_base = nullptr;
+            const int rc2 = alloc_buckets(fp, std::max<uint64_t>(cap, 4));
+            if (rc2 < 0) return false;
+            if (rc2 == 0) return true;
+            fp->bucket_records = (slots + fp->n_slots) * (uint64_t)fp->cap;
+        } else {
+            FAST_TRY(hipMalloc(&fp->buckets, std::max<uint64_t>(total, 64) * 4));
+            FAST_TRY(hipMemcpy(fp->pk_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+            FAST_TRY(hipMemcpy(fp->pk_base, base.data(), base.size() * 8, hipMemcpyHostToDevice));
+            FAST_TRY(hipMalloc(&fp->pk, slots * sizeof(uint2)));
+            FAST_TRY(hipMemcpy(fp->pk, pk.data(), slots * sizeof(uint2), hipMemcpyHostToDevice));
+            fp->cap = (uint32_t)std::max<uint64_t>(deepest, 4);  // (what describe() reports: the deepest sub-bucket)
+            fp->bucket_records = total;
+        }
+    }
     fp->eligible = true;
     return true;
 }
@@ -3747,6 +3876,7 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
 // Scratch for path sums riding on seg_depth: one {sum len, sum depth * len} per (window, item).
 // False when that would be out of proportion (then the caller walks the steps a second time).
 bool fast_plan_want_path_sums(FastPlan *fp) {
+    if (fp->packed) return false;  // (its calls are tagged; the fused sums ride on the directory)
     if (!fp->eligible || fp->wb != 12 || fp->acc_parts > 1 || fp->n_more || fp->n_win > kMaxWin) return false;  // (the fused form needs a window's final depth in one workgroup, and the directory: k_scan's untagged build)
     if (((uint64_t)fp->n_win + 1) * fp->n_slots * fp->cap >= (1ull << 30)) return false;  // (... which knows 32-bit bucket offsets only)
     if (fp->psum_part) return true;
@@ -3769,6 +3899,12 @@ static bool grow_range(FastPlan *fp, uint32_t factor) {
 
 bool fast_plan_grow(FastPlan *fp, bool ahead_of_need) {
     if (!fp->eligible || fp->cap_forced) return false;
+    if (fp->packed || std::any_of(fp->more, fp->more + fp->n_more, [](const FastPlan &q) { return q.packed; })) {
+        // packed buckets have the room the counted call needed and no more: a call that makes other
+        // records (the steps changed behind the plan) is completed through the atomic kernels
+        if (!ahead_of_need) fp->eligible = false;
+        return false;
+    }
     const uint32_t factor = ahead_of_need ? 2u : 4u;  // (ahead of need: what was more than half full is then at most half full)
     // Ahead of need only the ranges (or path groups) whose own word says so are given more room: their
     // bucket arrays may be gigabytes each, and one hot window is no reason to double them all.
@@ -3792,14 +3928,14 @@ void fast_plan_destroy(FastPlan *fp) {
     for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot, (void *)fp->perm,
                     (void *)fp->elist, (void *)fp->wave_off, (void *)fp->fat_off, (void *)fp->fat_woff, (void *)fp->items, (void *)fp->short_items,
                     (void *)fp->medium_items, (void *)fp->tiny_items, (void *)fp->rev_steps, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part,
-                    (void *)fp->pair_part, (void *)fp->pair_flag, (void *)fp->taken})
+                    (void *)fp->pair_part, (void *)fp->pair_flag, (void *)fp->taken, (void *)fp->pk_off, (void *)fp->pk_base, (void *)fp->pk})
         if (p) (void)hipFree(p);
     *fp = FastPlan();
 }
 
 // One range of the graph: the outputs are the range's own stretch of the result vectors.
 static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
-                     uint32_t *status, hipStream_t stream, const PathSums *ps) {
+                     uint32_t *status, hipStream_t stream, const PathSums *ps, bool count_only) {
     if (ps && (uniq_out || fp.wb != 12 || !g.seg_len || !fp.psum_part || fp.n_range != g.n_segs)) {
         set_error("fast_seg_depth: path sums ride on seg_depth with 4096-segment windows only");
         return FLATGFA_ERR_ARG;
@@ -3854,13 +3990,17 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     sa.tagged = tagged ? 1u : 0u;
     sa.tag_limit = std::max(2u, fp.tag_limit);
     sa.taken = fp.taken;
+    sa.pk_off = fp.pk_off;
+    sa.pk_base = fp.pk_base;
+    if (fp.packed && !tagged) { set_error("fast_seg_depth: a plan with packed buckets runs tagged calls only"); return FLATGFA_ERR_ARG; }
     sa.tprof = nullptr;
     if (getenv("FLATGFA_SCAN_TIME") && hipMalloc(&sa.tprof, kTprofRow * 8 * (size_t)fp.n_slots) == hipSuccess) (void)hipMemset(sa.tprof, 0, kTprofRow * 8 * (size_t)fp.n_slots);
     AccArgs aa{fp.n_range, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.counts0, scan_skip ? 2u : has_pre ? 1u : 0u, fp.buckets,
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
                fp.work_counter, scan_skip ? 0u : fp.max_back, depth_out, uniq_out, status, fp.dbg,
                reinterpret_cast<const uint4 *>(fp.items), g.seg_len, ps ? reinterpret_cast<ulonglong2 *>(fp.psum_part) : nullptr,
-               fp.fat_off, fp.fat_woff, fp.acc_parts, tagged ? fp.n_shared : 0u, nullptr, fp.pair_part, fp.pair_flag, fp.accumulate ? 1u : 0u, getenv("FLATGFA_NO_PLAIN") ? nullptr : fp.taken, fp.taken ? fp.taken + fp.n_slots : nullptr};  // (FLATGFA_NO_PLAIN: measurements)
+               fp.fat_off, fp.fat_woff, fp.acc_parts, tagged ? fp.n_shared : 0u, nullptr, fp.pair_part, fp.pair_flag, fp.accumulate ? 1u : 0u, getenv("FLATGFA_NO_PLAIN") ? nullptr : fp.taken, fp.taken ? fp.taken + fp.n_slots : nullptr,
+               fp.packed ? reinterpret_cast<const uint2 *>(fp.pk) : nullptr};  // (FLATGFA_NO_PLAIN: measurements)
     if (const char *sk = getenv("FLATGFA_ACC_SKIP")) aa.dbg = (uint32_t)strtoul(sk, nullptr, 10);  // (diagnostic: pass 2 without its revisit counts 128 / depth 256 / claims 64 / words behind the first 1024)
     const size_t tprof_words = (size_t)fp.n_win * fp.acc_parts * kAccWaves * 16;
     if (getenv("FLATGFA_ACC_TIME") && uniq_out && hipMalloc(&aa.tprof, tprof_words * 4) != hipSuccess) aa.tprof = nullptr;
@@ -3915,13 +4055,15 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
         }
     }
     if (grid) {
-        if (fp.acc_parts > 1 && !fp.accumulate) {  // (a later group of paths adds to what is there)
+        if (fp.acc_parts > 1 && !fp.accumulate && !count_only) {  // (a later group of paths adds to what is there)
             sa.zero_a = depth_out;
             sa.zero_b = uniq_out;
         }
         ProfScope pscope(fp.dense ? "k_scan_dense" : "k_scan", stream);
         if (fp.dense) hipLaunchKernelGGL(k_scan_dense, dim3(grid), dim3(kThreads), dense_lds_bytes(fp.nwp), stream, sa);
         else if (fp.dbg) hipLaunchKernelGGL((k_scan<kModeDbg, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
+        else if (fp.packed && sa.ranged) hipLaunchKernelGGL((k_scan<kModePackedRanged, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
+        else if (fp.packed) hipLaunchKernelGGL((k_scan<kModePacked, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
         else if (sa.big && !tagged) { set_error("fast_seg_depth: a bucket array this large needs a tagged call"); return FLATGFA_ERR_ARG; }
         else if (sa.big && sa.ranged) hipLaunchKernelGGL((k_scan<kModeRangedBig, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
         else if (sa.big) hipLaunchKernelGGL((k_scan<kModeBig, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
@@ -3930,6 +4072,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
         else if (tagged) hipLaunchKernelGGL((k_scan<kModePlain, true>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
         else hipLaunchKernelGGL((k_scan<kModePlain, false>), dim3(grid), dim3(kThreads), fp.lds_bytes_scan, stream, sa);
     }
+    if (count_only) return hipGetLastError() == hipSuccess ? FLATGFA_OK : FLATGFA_ERR_HIP;  // (the counting call of a packed plan: pass 1 alone)
     if (fp.acc_parts > 1 && !grid && !fp.accumulate) {  // the window's workgroups add to the outputs: cleared by k_scan, or here when it does not run
         ProfScope pscope("memset_outputs", stream);
         if (hipMemsetAsync(depth_out, 0, (size_t)fp.n_range * 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
@@ -4047,10 +4190,10 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
 
 int fast_seg_depth(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
                    uint32_t *status, hipStream_t stream, const PathSums *ps) {
-    int rc = run_range(fp, g, depth_out, uniq_out, status, stream, ps);
+    int rc = run_range(fp, g, depth_out, uniq_out, status, stream, ps, false);
     for (uint32_t r = 0; r < fp.n_more && rc == FLATGFA_OK; ++r) {
         const FastPlan &q = fp.more[r];
-        rc = run_range(q, g, depth_out + q.seg_base, uniq_out ? uniq_out + q.seg_base : nullptr, status, stream, nullptr);
+        rc = run_range(q, g, depth_out + q.seg_base, uniq_out ? uniq_out + q.seg_base : nullptr, status, stream, nullptr, false);
     }
     return rc;
 }

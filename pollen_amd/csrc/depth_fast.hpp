@@ -28,6 +28,13 @@ struct FastPlan {
     uint64_t est_records = 0;  // records k_scan will make of its items (counted when the plan is made)
     bool acc_pair = false;     // tagged calls with unique depth run two workgroups per window, both resident on a CU (k_accum_pair)
     uint32_t *pair_part = nullptr, *pair_flag = nullptr;  // their halves of the result vectors, and how many are there
+    // Packed buckets: every (window, workgroup) sub-bucket has exactly the room its records need (counted once when the
+    // plan is made, k_scan dealing its items in a fixed order from then on), a workgroup's sub-buckets back to back.
+    bool packed = false;
+    uint32_t *pk_off = nullptr;    // u32[n_slots][n_win + 1] sub-bucket starts within the workgroup's region; the last entry is its sink
+    uint64_t *pk_base = nullptr;   // u64[n_slots] where each workgroup's region starts
+    void *pk = nullptr;            // uint2[n_win][n_slots] {start in the array, room} for pass 2
+    uint64_t bucket_records = 0;   // records the bucket array has room for (what flatgfa_dev_plan_describe reports as scratch)
     uint32_t n_slots = 0;      // sub-buckets per window = persistent workgroups of pass 1
     uint32_t n_win = 0;        // accumulation windows
     uint32_t wb = 12;          // log2 of the window size (4096 segments, 8192 beyond 4 M segments)

@@ -19,7 +19,7 @@ FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
 @pytest.fixture(params=["auto", "bucketed", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3", "ranges", "dense",
-                        "untagged", "untagged_pieces", "untagged_noshort", "pair", "groups3"])
+                        "untagged", "untagged_pieces", "untagged_noshort", "pair", "groups3", "packed"])
 def device_path(request, monkeypatch):
     """Runs a test once per device path: the default (up to 8 M steps the plan times the bucketed
     path against the atomic kernels on the graph at hand and keeps the faster), the bucketed path
@@ -49,6 +49,11 @@ def device_path(request, monkeypatch):
     monkeypatch.delenv("FLATGFA_TAGGED", raising=False)
     monkeypatch.delenv("FLATGFA_ACC_PAIR", raising=False)
     monkeypatch.delenv("FLATGFA_PATH_GROUPS", raising=False)
+    monkeypatch.delenv("FLATGFA_PACKED", raising=False)
+    if request.param == "packed":  # record buckets laid out to the count (by default only where the even layout would take gigabytes), every path an item of k_scan
+        monkeypatch.setenv("FLATGFA_PACKED", "1")
+        monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
+        monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
     if request.param == "groups3":  # the paths walked in three groups, the second and third adding to the first's counts (by default only plans with more items per workgroup than a tag can name)
         monkeypatch.setenv("FLATGFA_PATH_GROUPS", "3")
         monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")

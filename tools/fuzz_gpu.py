@@ -26,7 +26,10 @@ ENVS = [{}, {"FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0"}, {"FL
         {"FLATGFA_TAG_LIMIT": "3", "FLATGFA_TAG_MEAN_ONLY": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},  # k_scan's workgroups run out of tags
         {"FLATGFA_TAG_LIMIT": "6", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
         {"FLATGFA_NO_PLAIN": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
-        {"FLATGFA_NO_TINY": "1", "FLATGFA_DEPTH_PATH": "bucketed"}]
+        {"FLATGFA_NO_TINY": "1", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_PACKED": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_PACKED": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed", "FLATGFA_PIECE_STEPS": "3000"},
+        {"FLATGFA_PACKED": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed", "FLATGFA_RANGE_SEGS": "65536"}]
 
 
 def random_graph(rng):
