@@ -706,3 +706,51 @@ def test_tiny_paths_are_held_whole_by_a_wave(n_paths, max_len, monkeypatch):
             if k != 1:
                 assert (u.cpu().numpy().view(np.uint32) == want_u).all(), text
         plan.close()
+
+
+def test_packed_buckets_and_steps_that_change_behind_the_plan(monkeypatch):
+    """Packed record buckets have exactly the room the counted call needed.  The same steps: every call
+    fits (and the plan says what it took).  Other steps behind the plan's back -- runs broken up, so
+    that more records are made than were counted: the records that do not fit go to the sink, the
+    call is flagged, and flatgfa_dev_status completes it through the atomic kernels: the counts are
+    those of the steps as they are now."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.setenv("FLATGFA_PACKED", "1")
+    monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
+    for v in ("FLATGFA_TAGGED", "FLATGFA_PIECE_STEPS", "FLATGFA_BUCKET_CAP"):
+        monkeypatch.delenv(v, raising=False)
+    S = 1_300_000
+    g = pa.synth(41, S, 300, 20_000, "chromosome", False)
+    steps, pb, pe, _ = g.soa()
+    pools = pools_of(g)
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    graph = DeviceGraph(steps, pb, pe, S)
+    plan = DepthPlan(graph)
+    text = plan.describe()
+    assert "buckets=packed" in text and "pass2=tagged" in text, text
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    for k in range(3):
+        plan.seg_depth(d, u if k != 1 else None)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == want_d).all()
+        if k != 1:
+            assert (u.cpu().numpy().view(np.uint32) == want_u).all()
+    # every other step of the first hundred paths now jumps somewhere else: many more runs than were counted
+    rng = np.random.default_rng(5)
+    changed = steps.copy()
+    idx = np.arange(0, 100 * 20_000, 2)
+    changed[idx] = (rng.integers(0, S, size=len(idx)).astype(np.uint32) << 1)
+    graph.steps.copy_(torch.from_numpy(changed.view(np.int32)))
+    torch.cuda.synchronize()
+    pools.steps = changed
+    want_d2, want_u2 = fo.seg_depth_with_uniq(pools)
+    plan.seg_depth(d, u)
+    plan.status()   # completes the call
+    assert (d.cpu().numpy().view(np.uint32) == want_d2).all() and (u.cpu().numpy().view(np.uint32) == want_u2).all()
+    plan.seg_depth(d, u)  # and later calls take the atomic kernels right away
+    plan.status()
+    assert (d.cpu().numpy().view(np.uint32) == want_d2).all() and (u.cpu().numpy().view(np.uint32) == want_u2).all()
+    plan.close()
