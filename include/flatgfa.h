@@ -288,7 +288,9 @@ int flatgfa_dev_path_overlaps(flatgfa_dev_plan_t *plan, const uint32_t *query_id
  * before it returns, into the same output buffers -- which therefore must not have been
  * modified in between.  Only the last call can be completed that way: if several node-depth calls
  * were enqueued since the last status and one of them ran out of room, this returns
- * FLATGFA_ERR_HIP (call status after every call where step values may change behind a plan). */
+ * FLATGFA_ERR_HIP (call status after every call where step values may change behind a plan).
+ * A plan belongs to ONE stream: every call of the plan, and this one, must be enqueued on the same
+ * stream (this call may release and reallocate the plan's scratch once that stream is idle). */
 int flatgfa_dev_status(flatgfa_dev_plan_t *plan, void *stream);
 
 /* Which kernels this plan's calls run -- the choices made when it was created, some of them by
