@@ -398,6 +398,13 @@ def main():
         del a, b
         if roofline:
             roofline["frac_of_measured_copy"] = round(roofline["achieved"] / extras["d2d_copy_gbs"], 5)
+            if roofline.get("traffic"):
+                # the bytes the kernel really moves (PMC: step reads + record writes, partial lines included) over its
+                # duration, against what a device-to-device copy achieves on THIS box: how much of the memory system's
+                # practical rate the kernel uses -- what is left is a matter of bytes, not of the kernel's schedule
+                moved = roofline["traffic"] / (roofline["kernel_avg_ms"] * 1e-3) / 1e9
+                roofline["traffic_gbs"] = round(moved, 1)
+                roofline["traffic_frac_of_measured_copy"] = round(moved / extras["d2d_copy_gbs"], 5)
         # end to end through the host API on a fresh handle: .flatgfa mmap -> H2D -> kernels -> D2H -> TSV text
         import tempfile
         tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
