@@ -1089,6 +1089,13 @@ constexpr int kModePlain = 0, kModeDbg = 1, kModeRanged = 2, kModeBig = 3, kMode
 constexpr bool mode_ranged(int m) { return m == kModeRanged || m == kModeRangedBig || m == kModePackedRanged; }
 constexpr bool mode_big(int m) { return m == kModeBig || m == kModeRangedBig; }
 constexpr bool mode_packed(int m) { return m == kModePacked || m == kModePackedRanged; }
+// A wave's run queue.  A packed call keeps two LDS tables for up to 4096 windows (cursors and the sub-buckets'
+// offsets), which leaves its queues 88 entries less: a block of (nearly) all starts is then queued behind a
+// drain down to one entry, and one of more than 1005 starts -- ids without any run at all, which such a plan is
+// not made for -- is flagged and the call completed through the atomic kernels.
+constexpr uint32_t kQPacked = 64 + 944;
+template <int MODE>
+constexpr uint32_t kQueueOf = mode_packed(MODE) ? kQPacked : kQ2;
 #ifndef FGFA_WIDE
 #define FGFA_WIDE 4
 #endif
@@ -1175,7 +1182,7 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
 // Emit the oldest entries, 64 at a time, while at least 65 are queued, then move what is left to
 // the front of the queue.  With `all`, a terminator is appended and everything is emitted.
 template <int MODE, int WIDE = 1>
-__device__ __forceinline__ void drain_raw(const ScanArgs &A, RWave &w, uint32_t *bcur, uint32_t *mine, bool all) {
+__device__ __forceinline__ void drain_raw(const ScanArgs &A, RWave &w, uint32_t *bcur, uint32_t *mine, bool all, bool to_one = false) {  // (to_one: down to the one entry that closes the last run)
     if (all) {
         if (w.lane == 0) w.q[w.fill] = make_uint2(kInvalid, 0u);
         w.fill += 1u;
@@ -1187,7 +1194,7 @@ __device__ __forceinline__ void drain_raw(const ScanArgs &A, RWave &w, uint32_t 
             base += 64u * WIDE;
         }
     }
-    while (w.fill - base >= 65u || (all && w.fill - base >= 2u)) {
+    while (w.fill - base >= 65u || ((all || to_one) && w.fill - base >= 2u)) {
         const uint32_t n = min(64u, w.fill - 1u - base);
         emit_raw<MODE, 1>(A, w, bcur, mine, base, n);
         base += n;
@@ -1300,6 +1307,7 @@ template <int MODE>
 __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *bcur, uint32_t *mine, uint32_t *ctl, uint32_t need,
                                          uint32_t (&a)[16], const uint32_t (&pj)[16], uint32_t nsteps) {
     constexpr bool DBG = MODE == kModeDbg;
+    constexpr uint32_t kQ = kQueueOf<MODE>;
     unsigned long long m[16], act[4];
     uint32_t cnt[4];
     const bool partial = nsteps < 1024u;  // (wave-uniform) a partial block ends with a terminator
@@ -1328,17 +1336,24 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
     tmark<DBG>(A, w, 2);
     if (FGFA_SKIP(kDbgNoEmit)) {
         w.fill = 0;
-    } else if (w.fill >= 65u || w.fill + total + 2u > kQ2) {
+    } else if (w.fill >= 65u || w.fill + total + 2u > kQ) {
         if (!w.epoch_ok) {
             if (epoch_now(ctl) >= need) {
                 w.epoch_ok = true;
-            } else if (w.fill + total + 2u > kQ2) {
+            } else if (w.fill + total + 2u > kQ) {
                 while (epoch_now(ctl) < need) __builtin_amdgcn_s_sleep(2);
                 w.epoch_ok = true;
             }
             tmark<DBG>(A, w, 1);
         }
         if (w.epoch_ok) drain_raw<MODE>(A, w, bcur, mine, false);
+        if (mode_packed(MODE) && w.fill + total + 2u > kQ) {  // (the shorter queue of a packed call; epoch_ok holds here)
+            drain_raw<MODE>(A, w, bcur, mine, false, true);
+            if (w.fill + total + 2u > kQ) {
+                if (w.lane == 0) atomicOr(A.status, kStBackOverflow);
+                return;
+            }
+        }
         tmark<DBG>(A, w, 3);
     }
     const uint32_t off[4] = {(s01 & 0xFFFFu) - cnt[0], t0 + (s01 >> 16) - cnt[1], t0 + t1 + (s23 & 0xFFFFu) - cnt[2],
@@ -1389,7 +1404,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     }
     RWave w;
     w.poff = snap;
-    w.q = reinterpret_cast<uint2 *>(lds + kTables * A.nwp + kCtlWords) + (uint32_t)wave * kQ2;
+    w.q = reinterpret_cast<uint2 *>(lds + kTables * A.nwp + kCtlWords) + (uint32_t)wave * kQueueOf<MODE>;
     w.fill = 0;
     w.vm[0] = w.vm[1] = w.vm[2] = 0;
     w.lane = lane;
@@ -1541,7 +1556,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         if ((uint32_t)wave == head_wave && it.t0 > it.b) tile_narrow_raw(A, w, it.b, (uint32_t)(it.t0 - it.b));
         if ((uint32_t)wave == tail_wave) {
             for (uint64_t t = it.tail; t < it.e; t += 64) {  // fewer than 16 steps, but for a block left out by make_item
-                if (w.fill + 66u > kQ2) {
+                if (w.fill + 66u > kQueueOf<MODE>) {
                     while (epoch_now(ctl) < need) __builtin_amdgcn_s_sleep(2);
                     w.epoch_ok = true;
                     drain_raw<MODE>(A, w, bcur, mine, false);
@@ -3072,7 +3087,7 @@ __global__ __launch_bounds__(256) void k_item_dirs(const uint32_t *__restrict__ 
 }
 
 // (a plan of at most kMaxWin windows may run either build of k_scan: sized for the untagged one)
-uint32_t scan_lds_bytes(uint32_t nwp, bool tagged_only = false) { return ((tagged_only ? 1u : 2u) * nwp + kCtlWords + kWaves * kQ2 * 2u) * 4u; }
+uint32_t scan_lds_bytes(uint32_t nwp, bool tagged_only = false, bool packed = false) { return ((tagged_only && !packed ? 1u : 2u) * nwp + kCtlWords + kWaves * (packed ? kQPacked : kQ2) * 2u) * 4u; }
 
 #define FAST_TRY(expr)                                                                      \
     do {                                                                                    \
@@ -3507,10 +3522,10 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // gigabytes -- whole-genome graphs, whose paths leave most sub-buckets of a window empty and a few deep --
     // the plan counts what every sub-bucket gets and lays them out back to back.  For tagged plans whose
     // records all come from k_scan; FLATGFA_PACKED=0|1 never / whenever possible (tests, measurements).
-    bool want_packed = fp->tagged && !fp->n_short && !fp->n_medium && !fp->n_tiny && !fp->dbg && !fp->cap_forced && n_win <= kMaxWin && fp->acc_parts == 1 &&
-                       (slots + fp->n_slots) * std::max<uint64_t>(cap, 4) * 4 > (2ull << 30);
-    if (const char *f = getenv("FLATGFA_PACKED"))
-        want_packed = strtol(f, nullptr, 10) != 0 && fp->tagged && !fp->n_short && !fp->n_medium && !fp->n_tiny && !fp->dbg && !fp->cap_forced && n_win <= kMaxWin && fp->acc_parts == 1;
+    const bool can_pack = fp->tagged && !fp->n_short && !fp->n_medium && !fp->n_tiny && !fp->dbg && !fp->cap_forced && n_win <= kMaxWinTagged && fp->acc_parts == 1 &&
+                          scan_lds_bytes(fp->nwp, true, true) + 64 <= kLdsLimit;
+    bool want_packed = can_pack && (slots + fp->n_slots) * std::max<uint64_t>(cap, 4) * 4 > (2ull << 30);
+    if (const char *f = getenv("FLATGFA_PACKED")) want_packed = can_pack && strtol(f, nullptr, 10) != 0;
     if (!want_packed) {
         const int rc = alloc_buckets(fp, std::max<uint64_t>(cap, 4));
         if (rc < 0) return false;
@@ -3642,6 +3657,8 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         fp->packed = true;
         fp->cap = 0;
         fp->eligible = true;
+        const uint32_t lds_even = fp->lds_bytes_scan;
+        fp->lds_bytes_scan = scan_lds_bytes(fp->nwp, true, true);
         const int rc = run_range(*fp, g, nullptr, nullptr, d_status, nullptr, nullptr, true);
         std::vector<uint32_t> cnt(slots);
         hipError_t e = rc == FLATGFA_OK ? hipDeviceSynchronize() : hipErrorUnknown;
@@ -3654,8 +3671,10 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         FAST_TRY(e);
         if (st & kStBounds) {  // (an id out of range: the atomic kernels report it; no layout to be had)
             fp->packed = false;
+            fp->lds_bytes_scan = lds_even;
             return true;
         }
+        const bool countable = !(st & kStBackOverflow);  // (blocks without any runs do not fit a packed call's queues: the even layout)
         std::vector<uint32_t> off(row * fp->n_slots);
         std::vector<uint64_t> base(fp->n_slots);
         std::vector<uint2> pk(slots);
@@ -3676,11 +3695,12 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             fits = fits && o < (1ull << 30);      // (a region's byte offsets take 32 bits)
             total += o;
         }
-        fits = fits && total < (1ull << 32);
+        fits = fits && countable && total < (1ull << 32);
         (void)hipFree(fp->buckets);
         fp->buckets = nullptr;
         if (!fits) {  // (not the case this layout is for: the even one, if it can be had)
             fp->packed = false;
+            fp->lds_bytes_scan = lds_even;
             (void)hipFree(fp->pk_off);
             (void)hipFree(fp->pk_base);
             fp->pk_off = nullptr;

@@ -754,3 +754,47 @@ def test_packed_buckets_and_steps_that_change_behind_the_plan(monkeypatch):
     plan.status()
     assert (d.cpu().numpy().view(np.uint32) == want_d2).all() and (u.cpu().numpy().view(np.uint32) == want_u2).all()
     plan.close()
+
+
+@pytest.mark.parametrize("cont,want", [(0.0, "even"), (0.05, "packed"), (0.5, "packed")])
+def test_packed_buckets_and_blocks_of_nearly_all_starts(cont, want, monkeypatch):
+    """A packed call's run queues are 88 entries shorter than a block can have starts (two LDS tables for up to
+    4096 windows).  A block whose starts do not fit behind what is queued is appended after a drain down
+    to one entry (ids that continue a run five times in a hundred: 970 starts per block); blocks without any
+    run at all (more than 1005 starts) are flagged by the counting call, and the plan keeps the even layout."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.setenv("FLATGFA_PACKED", "1")
+    monkeypatch.setenv("FLATGFA_DENSE", "0")      # (pass 1 by runs whatever the run count: the plan would otherwise partition)
+    monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
+    for v in ("FLATGFA_TAGGED", "FLATGFA_PIECE_STEPS", "FLATGFA_BUCKET_CAP"):
+        monkeypatch.delenv(v, raising=False)
+    rng = np.random.default_rng(int(cont * 100) + 3)
+    S, P, L = 1_200_000, 40, 50_000
+    ids = rng.integers(0, S, size=P * L).astype(np.int64)
+    keep = rng.random(P * L) < cont
+    keep[::L] = False
+    run = np.arange(P * L)
+    last_start = np.maximum.accumulate(np.where(~keep, run, 0))
+    ids = (ids[last_start] + (run - last_start)) % S   # a step that continues follows the one before by +1
+    stp = (ids.astype(np.uint32) << 1) | rng.integers(0, 2, size=P * L).astype(np.uint32)
+    pe = (np.arange(1, P + 1) * L).astype(np.uint32)
+    pb = (pe - L).astype(np.uint32)
+    paths = np.zeros(P, dtype=fo.PATH_DT)
+    paths["steps_start"], paths["steps_end"] = pb, pe
+    pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
+    pools.paths, pools.steps, pools.segs = paths, stp, np.zeros(S, dtype=fo.SEG_DT)
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    plan = DepthPlan(DeviceGraph(stp, pb, pe, S))
+    text = plan.describe()
+    assert f"buckets={want}" in text, text
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    for k in range(3):
+        plan.seg_depth(d, u if k != 1 else None)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == want_d).all(), text
+        if k != 1:
+            assert (u.cpu().numpy().view(np.uint32) == want_u).all(), text
+    plan.close()
