@@ -2350,17 +2350,18 @@ __device__ __forceinline__ void claim_step(uint32_t rec, uint32_t sb, unsigned l
 #ifndef FGFA_TAG_ABLATE
 #define FGFA_TAG_ABLATE 0  /* measurements only (results are then wrong): 1 = no claims, 2 = no bitset hand-overs, 4 = claims stop behind the depth updates, 8 = behind the first word's OR, 16 = no further words */
 #endif
-template <int WB, bool POINT, bool SHARED, bool LOW = false>
+template <int WB, bool POINT, bool SHARED, bool LOW = false, int SLOTS = (int)kTagSlots>
 __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, uint32_t *bits, const uint2 *scnt2, const uint32_t *wbase,
                                              uint32_t *grab) {
     constexpr uint32_t kW = 1u << WB, kNW = kW / 32u;
-    constexpr uint32_t kPriv = kAccWaves * kTagSlots;  // slot ids: the waves' private bitsets first, the shared ones behind
+    constexpr uint32_t kSlots = (uint32_t)SLOTS;  // private bitsets per wave: kTagSlots, or twice as many where the LDS allows (k_scan's order of the tags holds for any multiple)
+    constexpr uint32_t kPriv = kAccWaves * kSlots;  // slot ids: the waves' private bitsets first, the shared ones behind
     const int lane = threadIdx.x & 63;
     const uint32_t lane4 = 4u * (uint32_t)lane;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t y16 = blockIdx.y * kAccWaves, nw = A.parts * kAccWaves;
     const uint32_t shlo = kTagCount - A.n_shared;  // tags from here up name split paths
-    const uint32_t bits0 = lds_addr(bits), priv_b = bits0 + ((wv * kTagSlots) << (WB - 3));  // (LDS byte addresses)
+    const uint32_t bits0 = lds_addr(bits), priv_b = bits0 + ((wv * kSlots) << (WB - 3));  // (LDS byte addresses)
     const uint32_t dbase = lds_addr(D), rbase = lds_addr(R);
     uint32_t one = 1u, mone = ~0u;  // (the LDS adds take their operand from a register)
     asm volatile("" : "+v"(one), "+v"(mone));
@@ -2419,13 +2420,13 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
     int hmax = -1;  // (uniform) the highest private tag met in the open sub-bucket (the wave's first one is walked the general way: nothing says it is new)
     const auto clear_slots = [&](int from, int to) {  // the bitsets of the tags from .. to change hands
         for (int t = from; t <= to; ++t) {
-            uint32_t *bs = bits + (wv * kTagSlots + ((uint32_t)t & (kTagSlots - 1u))) * kNW;
+            uint32_t *bs = bits + (wv * kSlots + ((uint32_t)t & (kSlots - 1u))) * kNW;
             for (uint32_t i = lane; i < kNW / 2u; i += 64) reinterpret_cast<uint2 *>(bs)[i] = make_uint2(0u, 0u);
         }
     };
     const auto claim = [&](uint32_t rec, uint32_t tag, unsigned long long act, bool any_shared) {
-        // each lane's bitset: its wave's slot tag mod kTagSlots, or its split path's
-        uint32_t sb = priv_b + ((tag & (kTagSlots - 1u)) << (WB - 3));
+        // each lane's bitset: its wave's slot tag mod kSlots, or its split path's
+        uint32_t sb = priv_b + ((tag & (kSlots - 1u)) << (WB - 3));
         if (SHARED && any_shared) sb = tag >= shlo ? bits0 + ((kPriv + kTagCount - 1u - tag) << (WB - 3)) : sb;
         if (POINT) {  // every record is one segment (k_scan_dense)
             const uint32_t rel = rec & (kW - 1u), bit = 1u << (rel & 31u);
@@ -2460,21 +2461,21 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
         const unsigned long long vm = NV >= 64u ? ~0ull : (1ull << NV) - 1ull;  /* the lanes that hold a record */     \
         const uint32_t last = NV - 1u;                                                                                 \
         if (FR & 2u) {  /* a sub-bucket whose private tags each have a slot: all of them cleared here, none changes hands */ \
-            for (uint32_t i = lane; i < kTagSlots * kNW / 4u; i += 64) reinterpret_cast<uint4 *>(bits + wv * kTagSlots * kNW)[i] = make_uint4(0u, 0u, 0u, 0u); \
-            hmax = (int)kTagSlots - 1;                                                                                 \
+            for (uint32_t i = lane; i < kSlots * kNW / 4u; i += 64) reinterpret_cast<uint4 *>(bits + wv * kSlots * kNW)[i] = make_uint4(0u, 0u, 0u, 0u); \
+            hmax = (int)kSlots - 1;                                                                                 \
         } else if (FR) hmax = -1;  /* the private slots start over with this sub-bucket */                             \
         FGFA_TAG_GEN(K, NV, FR);                                                                                       \
         const uint32_t tag = rec >> kTagShift;                                                                         \
         const unsigned long long shm = SHARED ? __builtin_amdgcn_ballot_w64(tag >= shlo) & vm : 0ull;                  \
         const unsigned long long pvm = vm & ~shm;  /* the lanes whose tag names an item of their own */                \
         bool general = false;                                                                                          \
-        if (!(FGFA_TAG_ABLATE & 2) && (__builtin_amdgcn_ballot_w64((uint32_t)hmax - tag >= kTagSlots) & pvm)) {        \
-            /* tags beyond those met so far (or, which cannot be, kTagSlots behind): their bitsets change hands. */     \
+        if (!(FGFA_TAG_ABLATE & 2) && (__builtin_amdgcn_ballot_w64((uint32_t)hmax - tag >= kSlots) & pvm)) {        \
+            /* tags beyond those met so far (or, which cannot be, kSlots behind): their bitsets change hands. */     \
             /* The last record's tag is the highest unless waves that ran ahead have interleaved the items */          \
             const int c = (int)__builtin_amdgcn_readlane(tag, (int)last);                                              \
-            general = !((pvm >> last) & 1ull) || (__builtin_amdgcn_ballot_w64((int)tag > c || (int)(tag + kTagSlots) <= c) & pvm); \
+            general = !((pvm >> last) & 1ull) || (__builtin_amdgcn_ballot_w64((int)tag > c || (int)(tag + kSlots) <= c) & pvm); \
             if (!general) {                                                                                            \
-                clear_slots(max(hmax + 1, c - (int)(kTagSlots - 1u)), c);                                              \
+                clear_slots(max(hmax + 1, c - (int)(kSlots - 1u)), c);                                              \
                 hmax = c;                                                                                              \
             }                                                                                                          \
         }                                                                                                              \
@@ -2486,17 +2487,17 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
                 unsigned long long act = todo;                                                                         \
                 const bool pv = ((todo & pvm) >> lane) & 1ull;                                                         \
                 if (todo & pvm) {                                                                                      \
-                    /* the lanes before the first one whose tag is kTagSlots beyond the lowest go first: */            \
+                    /* the lanes before the first one whose tag is kSlots beyond the lowest go first: */            \
                     /* records of such tags lie in order */                                                            \
                     const uint32_t tmin = wave_min_u32(pv ? tag : ~0u);                                                \
-                    const unsigned long long beyond = __builtin_amdgcn_ballot_w64(pv && tag >= tmin + kTagSlots);      \
+                    const unsigned long long beyond = __builtin_amdgcn_ballot_w64(pv && tag >= tmin + kSlots);      \
                     if (beyond) act = todo & ((1ull << __builtin_ctzll(beyond)) - 1ull);                               \
-                    if ((int)(tmin + kTagSlots) <= hmax || !act) {  /* cannot happen: k_scan's gate */                 \
+                    if ((int)(tmin + kSlots) <= hmax || !act) {  /* cannot happen: k_scan's gate */                 \
                         atomicOr(A.status, kStInternal);                                                               \
                         act = todo;                                                                                    \
                     }                                                                                                  \
                     const int hnew = max(hmax, (int)wave_max_u32(((act & pvm) >> lane) & 1ull ? tag : 0u));            \
-                    clear_slots(max(hmax + 1, hnew - (int)(kTagSlots - 1u)), hnew);                                    \
+                    clear_slots(max(hmax + 1, hnew - (int)(kSlots - 1u)), hnew);                                    \
                     hmax = hnew;                                                                                       \
                 }                                                                                                      \
                 claim(rec, tag, act, shm != 0ull);                                                                     \
@@ -2649,14 +2650,14 @@ __global__ __launch_bounds__(256) void k_path_reduce(const uint4 *__restrict__ i
 
 // the "seen" bitsets of a tagged call: dynamic shared memory, (kAccWaves * kTagSlots + n_shared) * window / 8 bytes
 extern __shared__ __attribute__((aligned(16))) uint32_t tag_bits[];
-uint32_t tagged_lds_bytes(uint32_t wb, uint32_t n_shared) { return (kAccWaves * kTagSlots + n_shared) * ((1u << wb) / 8u); }
+uint32_t tagged_lds_bytes(uint32_t wb, uint32_t n_shared, uint32_t slots = kTagSlots) { return (kAccWaves * slots + n_shared) * ((1u << wb) / 8u); }
 
 // PAIR (tagged, unique depth, no split paths): TWO workgroups per window, each with half of its
 // sub-buckets, and both resident on a CU (64 registers, under 80 KB of LDS): the walk issues about
 // one instruction per cycle and CU where two are possible, and eight waves per SIMD hide more of its
 // LDS round trips than four.  Both leave their partial vectors in scratch; the second one to
 // finish adds the other's to its own and writes the results.
-template <bool UNIQ, int WB, bool PSUM, bool POINT, bool BIG, bool TAGGED, bool PAIR>
+template <bool UNIQ, int WB, bool PSUM, bool POINT, bool BIG, bool TAGGED, bool PAIR, int SLOTS = (int)kTagSlots>
 __device__ __forceinline__ void accum_body(const AccArgs &A) {
     constexpr uint32_t kW = 1u << WB;
     constexpr int kPer = kW / kAccThreads;  // cells per thread: 4 or 8
@@ -2725,7 +2726,7 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
             const uint32_t c1 = min(v, room);
             v = min(A.has_pre == 1 ? A.counts0[(size_t)win * A.n_slots + sl] : A.has_pre ? v : 0u, c1);  // (2: k_scan did not run, all are earlier records)
             // (bit 31 of the count: the sub-bucket's private tags are 0 .. kTagSlots - 1 at most, so no bitset changes hands inside it)
-            scnt2[sl] = make_uint2(start + v, (c1 - v) | (A.taken && A.taken[sl] <= kTagSlots ? 0x80000000u : 0u));  // k_scan's records: where they start in the window's buckets, how many
+            scnt2[sl] = make_uint2(start + v, (c1 - v) | (A.taken && A.taken[sl] <= (uint32_t)SLOTS ? 0x80000000u : 0u));  // k_scan's records: where they start in the window's buckets, how many
         } else if (UNIQ && A.has_pre == 1) {
             v = A.counts0[(size_t)win * A.n_slots + sl];
         }
@@ -2733,7 +2734,7 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
     }
     if (tid == 0) grab = kAccWaves;
     if (TAGGED && UNIQ)  // the split paths' bitsets (the private ones are cleared when they change hands)
-        for (uint32_t i = tid; i < A.n_shared * (kW / 32); i += kAccThreads) tag_bits[kAccWaves * kTagSlots * (kW / 32) + i] = 0u;
+        for (uint32_t i = tid; i < A.n_shared * (kW / 32); i += kAccThreads) tag_bits[kAccWaves * (uint32_t)SLOTS * (kW / 32) + i] = 0u;
     const uint32_t nvalid = min(kW, A.n_segs - w0);
     for (uint32_t i = tid; i < (UNIQ ? 2u : 1u) * (kW + 64); i += kAccThreads) cells[i] = 0;
     __syncthreads();
@@ -2743,8 +2744,8 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
     tm.mark(1);
     if (UNIQ && TAGGED) {
         if (PAIR) apply_tagged<WB, POINT, false, true>(A, D, R, tag_bits, scnt2, wbase, &grab);
-        else if (A.n_shared) apply_tagged<WB, POINT, true>(A, D, R, tag_bits, scnt2, wbase, &grab);
-        else apply_tagged<WB, POINT, false>(A, D, R, tag_bits, scnt2, wbase, &grab);
+        else if (A.n_shared) apply_tagged<WB, POINT, true, false, SLOTS>(A, D, R, tag_bits, scnt2, wbase, &grab);
+        else apply_tagged<WB, POINT, false, false, SLOTS>(A, D, R, tag_bits, scnt2, wbase, &grab);
     } else if (UNIQ) {
         apply_groups<WB, false, POINT, BIG>(A, D, R, bits + wave * (kSlots * (kW / 32)), marks + wave * 64, pend + wave * (3 * kPend), wbase, win,
                                 ge0, ge1, true, be_first, slf_first);
@@ -2856,9 +2857,9 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
     }
 }
 
-template <bool UNIQ, int WB, bool PSUM = false, bool POINT = false, bool BIG = false, bool TAGGED = false>
+template <bool UNIQ, int WB, bool PSUM = false, bool POINT = false, bool BIG = false, bool TAGGED = false, int SLOTS = (int)kTagSlots>
 __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
-    accum_body<UNIQ, WB, PSUM, POINT, BIG, TAGGED, false>(A);
+    accum_body<UNIQ, WB, PSUM, POINT, BIG, TAGGED, false, SLOTS>(A);
 }
 template <int WB, bool POINT>
 __global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_accum_pair(const AccArgs A) {
@@ -3617,6 +3618,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 11, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(11, kMaxShared)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, kMaxShared)));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, false, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, 64, 8)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 13, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(13, 0)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 13, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(13, 0)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum_pair<12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, 0)));
@@ -3629,6 +3631,18 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     const bool pair_ok = fp->tagged && fp->n_shared == 0 && wb == 12 && fp->acc_parts == 1 && n_win <= 2 * fp->n_cus;
     fp->acc_pair = pair_ok && fp->est_records / n_win >= 65536;
     if (const char *f = getenv("FLATGFA_ACC_PAIR")) fp->acc_pair = pair_ok && strtol(f, nullptr, 10) != 0;
+    // Private bitsets per wave of the tagged walk: four, or eight where a sub-bucket holds the records of more
+    // items than that (a 64-record step then spans more tags than four bitsets serve in one round: 3125 paths
+    // of 32 k steps 77 -> 58 us, 16 000 paths of 100 k 0.81 -> 0.56 ms) and the LDS allows it: 4096-segment
+    // windows, at most 64 split paths; one workgroup per window then (k_accum_pair has no room for them).
+    // With four items or fewer per workgroup four are as good and cheaper to clear (cfg-L: +3 % with eight).
+    {
+        const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(fp->n_items, 1u), fp->n_slots);
+        const bool can8 = fp->tagged && wb == 12 && fp->n_shared <= 64 && fp->acc_parts == 1;
+        fp->acc_slots = can8 && (uint64_t)fp->n_items + fp->max_back > 4ull * grid ? 8u : kTagSlots;
+        if (const char *f = getenv("FLATGFA_ACC_SLOTS")) fp->acc_slots = can8 && strtol(f, nullptr, 10) == 8 ? 8u : kTagSlots;
+        if (fp->acc_slots == 8) fp->acc_pair = false;
+    }
     if (fp->acc_pair) {
         FAST_TRY(hipMalloc(&fp->pair_part, (size_t)n_win * 2 * 2 * (1u << wb) * 4));
         FAST_TRY(hipMalloc(&fp->pair_flag, (size_t)n_win * 4));
@@ -4113,6 +4127,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
             if (fp.dense && fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12, false, true, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
             else if (fp.dense && fp.wb == 13) hipLaunchKernelGGL((k_accum<true, 13, false, true, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
             else if (fp.wb == 11) hipLaunchKernelGGL((k_accum<true, 11, false, false, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
+            else if (fp.wb == 12 && fp.acc_slots == 8 && fp.n_shared <= 64) hipLaunchKernelGGL((k_accum<true, 12, false, false, false, true, 8>), agrid, dim3(kAccThreads), tagged_lds_bytes(12, fp.n_shared, 8), stream, aa);
             else if (fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12, false, false, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
             else hipLaunchKernelGGL((k_accum<true, 13, false, false, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
         } else if (uniq_out) {

@@ -19,7 +19,7 @@ FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
 @pytest.fixture(params=["auto", "bucketed", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3", "ranges", "dense",
-                        "untagged", "untagged_pieces", "untagged_noshort", "pair", "groups3", "packed"])
+                        "untagged", "untagged_pieces", "untagged_noshort", "pair", "groups3", "packed", "slots8"])
 def device_path(request, monkeypatch):
     """Runs a test once per device path: the default (up to 8 M steps the plan times the bucketed
     path against the atomic kernels on the graph at hand and keeps the faster), the bucketed path
@@ -50,6 +50,11 @@ def device_path(request, monkeypatch):
     monkeypatch.delenv("FLATGFA_ACC_PAIR", raising=False)
     monkeypatch.delenv("FLATGFA_PATH_GROUPS", raising=False)
     monkeypatch.delenv("FLATGFA_PACKED", raising=False)
+    monkeypatch.delenv("FLATGFA_ACC_SLOTS", raising=False)
+    if request.param == "slots8":  # eight private bitsets per pass-2 wave wherever the plan allows them (by default only where a workgroup of pass 1 takes more than four items)
+        monkeypatch.setenv("FLATGFA_ACC_SLOTS", "8")
+        monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
+        monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
     if request.param == "packed":  # record buckets laid out to the count (by default only where the even layout would take gigabytes), every path an item of k_scan
         monkeypatch.setenv("FLATGFA_PACKED", "1")
         monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
