@@ -3624,12 +3624,15 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum_pair<12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, 0)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum_pair<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, 0)));
     // Two pass-2 workgroups per window (k_accum_pair): tagged plans without split paths whose windows
-    // do not fill the chip twice over anyway.  FLATGFA_ACC_PAIR=0|1 (measurements, tests).
-    // Worth it where a window has work enough to pay for a second workgroup's setup, scan and exchange:
-    // cfg-L (43 k records per window) is 7 % slower that way, the chromosome model (122 k) 4 % faster,
-    // ten thousand contigs 13 %.
+    // do not fill the chip twice over anyway.  FLATGFA_ACC_PAIR=1 (measurements, tests).
+    // In round 3 it paid where a window had 64 k records or more (the chromosome model 4 % faster, ten
+    // thousand contigs 13 %); since the one-workgroup walk clears a plain sub-bucket's bitsets at once
+    // and takes eight bitsets per wave where tags are many, it no longer does (same box: chromosome model
+    // 95 against 79 us, ids without runs 175 against 149, ten thousand contigs 165 against 118) -- and the
+    // table of sub-bucket starts (packed buckets) took the 4 KB of LDS that let two of its workgroups share
+    // a CU: off by default.
     const bool pair_ok = fp->tagged && fp->n_shared == 0 && wb == 12 && fp->acc_parts == 1 && n_win <= 2 * fp->n_cus;
-    fp->acc_pair = pair_ok && fp->est_records / n_win >= 65536;
+    fp->acc_pair = false;
     if (const char *f = getenv("FLATGFA_ACC_PAIR")) fp->acc_pair = pair_ok && strtol(f, nullptr, 10) != 0;
     // Private bitsets per wave of the tagged walk: four, or eight where a sub-bucket holds the records of more
     // items than that (a 64-record step then spans more tags than four bitsets serve in one round: 3125 paths
