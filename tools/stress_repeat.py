@@ -13,7 +13,9 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 bad = 0
 for name, (S, P, L, model) in {"cfgL": (1_000_000, 1000, 100_000, "pangenome"), "short": (1_000_000, 50_000, 1000, "pangenome"),
                                "mixed-4M": (4_000_000, 3000, 20_000, "pangenome"), "uniform": (300_000, 200, 50_000, "uniform"),
-                               "chromosome": (2_000_000, 300, 150_000, "chromosome")}.items():
+                               "chromosome": (2_000_000, 300, 150_000, "chromosome"), "tiny": (500_000, 300_000, 90, "pangenome"),
+                               "32k (eight bitsets per wave)": (1_000_000, 2000, 32_000, "pangenome"),
+                               "16M haplotypes (packed buckets)": (16_000_000, 4000, 100_000, "haplotype")}.items():
     g = pa.synth(9, S, P, L, model, False)
     steps, pb, pe, seg_len = g.soa()
     plan = dev.DepthPlan(dev.DeviceGraph(steps, pb, pe, S, seg_len, device="cuda:0"))
