@@ -78,6 +78,9 @@ int main(int argc, char **argv) {
     // milliseconds.  All of that starts now, on a thread of its own, while this one maps or parses
     // the graph (and, for a mapped file, has the kernel map the step pool's pages in).
     const bool wants_device = cmd == "depth" || cmd == "window-depth" || cmd == "overlap";
+    // (`fgfa` only ever uses device 0: on a node with several GPUs the runtime need not bring the others up.  Set
+    // before the first HIP call; a caller's own choice of visible devices is left alone.)
+    if (wants_device && !getenv("ROCR_VISIBLE_DEVICES") && !getenv("HIP_VISIBLE_DEVICES")) (void)setenv("ROCR_VISIBLE_DEVICES", "0", 0);
     std::thread warm;
     if (wants_device && !getenv("FLATGFA_NO_WARM")) warm = std::thread([] { (void)flatgfa_warm_device(0); });
 
