@@ -365,6 +365,43 @@ def main():
                     (cd.cpu().numpy().view(np.uint32) == want[0]).all() and (cu.cpu().numpy().view(np.uint32) == want[1]).all())}
             cplan.close()
             del gc, cs, cplan, cd, cu
+        # What the Infinity Cache contributes: a plan keeps the first so-many megabytes of the steps resident
+        # there (read without the nt hint; flatgfa_dev_plan_describe: cache_resident_mb).  The same graph
+        # through a plan made with that switched off, same loop, kernels by HIP events:
+        if args.workload == "cfgL":
+            os.environ["FLATGFA_MALL_MB"] = "0"
+            try:
+                plan0 = dev.DepthPlan(graph)
+            finally:
+                del os.environ["FLATGFA_MALL_MB"]
+            d0 = torch.zeros(S, dtype=torch.int32, device=device)
+            u0 = torch.zeros(S, dtype=torch.int32, device=device)
+            for _ in range(3):
+                plan0.seg_depth(d0, u0)
+            plan0.status()
+            dev.profile_enable(True)
+            dev.profile_read()
+            c0 = time.perf_counter()
+            for _ in range(16):
+                plan0.seg_depth(d0, u0)
+            plan0.status()
+            c1 = time.perf_counter()
+            dev.profile_enable(False)
+            per0 = {}
+            for name, ms in dev.profile_read():
+                per0.setdefault(name, []).append(ms)
+            same = bool((d0.cpu().numpy() == op.buf[:S].cpu().numpy()).all()) if hasattr(op, "buf") else None
+            extras["cache_residency"] = {
+                "what": "k_scan reads the first cache_resident_mb of the steps without the nt hint, so that they are still in the 256 MiB "
+                        "Infinity Cache at the next call; `without` = a plan of the same graph made with FLATGFA_MALL_MB=0 (every step read "
+                        "from HBM, as when more graphs are queried in turn than the cache holds: extras.rotate)",
+                "plan": plan.describe().split(" ")[-1],
+                "k_scan_ms": round(kern_avg_ms.get("k_scan", 0.0), 5),
+                "k_scan_ms_without": round(float(np.mean(per0.get("k_scan", [0.0]))), 5),
+                "frac_without": round(kernel_bytes("k_scan", N_local, P_local, S, 2) / (float(np.mean(per0.get("k_scan", [1.0]))) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "same_depth_vector": same}
+            plan0.close()
+            del plan0, d0, u0
         # The timed loop walks the same 400 MB image every step; MI355X has 256 MiB of Infinity
         # Cache and FETCH_SIZE counts its hits as fetches.  Cycle K resident images (> 1 GB): if
         # the cache helped, this is slower.

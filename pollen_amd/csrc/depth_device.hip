@@ -270,7 +270,13 @@ struct flatgfa_dev_plan {
     bool last_fast = false;
     uint32_t calls_since_status = 0;   // node-depth calls enqueued since the last flatgfa_dev_status: only the last can be completed there
     uint32_t *all_ids = nullptr;       // 0..n_paths-1 (path_depth_all without the bucketed path)
+    int64_t cache_claim = 0;           // bytes of the device's Infinity Cache this plan's resident steps lay claim to (g_cache_claimed)
 };
+
+// The Infinity Cache (256 MiB on MI355X) is one per device: what the plans of a process keep resident in it is
+// budgeted per device, first come first served, and given back when a plan is destroyed.
+static std::mutex g_cache_mu;
+static int64_t g_cache_claimed[64] = {};
 
 extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int n_cus, uint32_t **coarse_cache,
                                               uint32_t **qbits_cache, size_t *qbits_bytes, bool *qbits_all, const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out,
@@ -331,6 +337,37 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
     const char *force = getenv("FLATGFA_DEPTH_PATH");
     if (!(force && std::string(force) == "atomic")) {
         if (!fast_plan_create(pl->g, hb, he, &pl->fast)) { flatgfa_dev_plan_destroy(pl); return nullptr; }
+    }
+    // Steps kept in the Infinity Cache.  k_scan streams the steps past the caches (nt: whole lines read once),
+    // which is right for what does not fit them -- but a resident graph is queried again and again, and the
+    // first so-many megabytes of its steps, read WITHOUT the hint, are still in the 256 MiB cache when the next
+    // call comes (the nt reads of the rest hit there but do not allocate, so they do not push it out): cfg-L's
+    // k_scan 102 -> 88 us with 160 MB.  Only as much as the call's other traffic leaves room for -- its
+    // records are written and read back through the same cache (8 bytes each), its results written (8
+    // bytes per segment): a graph of 64 M segments has none to spare and would pay 12 % for the lines the
+    // plain reads push out of the L2 -- and only what the device's other plans have not claimed.
+    // FLATGFA_MALL_MB=n pins the amount (0: none).
+    if (pl->fast.eligible && g->n_steps && pl->fast.n_items) {  // (k_scan's reads: the wave-per-path kernels and the partition read plainly anyway)
+        uint64_t records = pl->fast.est_records;
+        for (uint32_t r = 0; r < pl->fast.n_more; ++r) records += pl->fast.more[r].est_records;
+        int64_t budget = (230ll << 20) - 8ll * (int64_t)g->n_segs - 8ll * (int64_t)records;
+        budget = std::min<int64_t>(budget, 160ll << 20);
+        if (const char *f = getenv("FLATGFA_MALL_MB")) budget = (int64_t)strtoull(f, nullptr, 10) << 20;
+        budget = std::min<int64_t>(budget, (int64_t)g->n_steps * 4);
+        {
+            std::lock_guard<std::mutex> lk(g_cache_mu);
+            if (pl->device >= 0 && pl->device < 64) {
+                if (!getenv("FLATGFA_MALL_MB")) budget = std::min<int64_t>(budget, (160ll << 20) - g_cache_claimed[pl->device]);
+                if (budget < (32ll << 20) || (int64_t)g->n_steps * 4 < (64ll << 20)) budget = 0;  // (not worth the L2 lines; graphs of a few million steps are launch-bound anyway)
+                budget = std::max<int64_t>(budget, 0);
+                g_cache_claimed[pl->device] += budget;
+                pl->cache_claim = budget;
+            } else {
+                budget = 0;
+            }
+        }
+        pl->fast.mall_steps = (uint64_t)budget / 4;
+        for (uint32_t r = 0; r < pl->fast.n_more; ++r) pl->fast.more[r].mall_steps = pl->fast.mall_steps;
     }
     // Size the sub-buckets for this graph now, with one query into scratch outputs, so that no
     // later call runs out of room (the record counts per sub-bucket depend on the steps only):
@@ -467,6 +504,10 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
 
 extern "C" void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *pl) {
     if (!pl) return;
+    if (pl->cache_claim) {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if (pl->device >= 0 && pl->device < 64) g_cache_claimed[pl->device] -= pl->cache_claim;
+    }
     fast_plan_destroy(&pl->fast);
     if (pl->overlap_bits) (void)hipFree(pl->overlap_bits);
     if (pl->overlap_qbits) (void)hipFree(pl->overlap_qbits);
@@ -705,7 +746,8 @@ extern "C" int flatgfa_dev_plan_describe(flatgfa_dev_plan_t *pl, char *out, int 
             recs += records_of(f.more[r]);
             packed = packed || f.more[r].packed;
         }
-        s += std::string(" buckets=") + (packed ? "packed" : "even") + " scratch_mb=" + std::to_string((recs * 4 + (1u << 20) - 1) >> 20);
+        s += std::string(" buckets=") + (packed ? "packed" : "even") + " scratch_mb=" + std::to_string((recs * 4 + (1u << 20) - 1) >> 20) +
+             " cache_resident_mb=" + std::to_string((f.mall_steps * 4) >> 20);
     }
     const int n = (int)std::min<size_t>(s.size(), (size_t)cap - 1);
     memcpy(out, s.data(), (size_t)n);

@@ -153,6 +153,7 @@ struct ScanArgs {
     // need -- counted once, with the items dealt in a fixed order -- and a workgroup's sub-buckets lie back to back:
     const uint32_t *pk_off;   // [n_slots][n_win + 1] where each of the workgroup's sub-buckets starts in its region (the last entry: the region's end, a sink)
     const uint64_t *pk_base;  // [n_slots] where the workgroup's region starts in `buckets`
+    uint64_t mall_steps; // blocks that start below this step index are read without the nt hint, so that they stay in the Infinity Cache from one call to the next (FastPlan::mall_steps)
     uint32_t *taken;     // tagged: [n_slots] how many items each workgroup took (its private tags are 0 .. taken - 1): pass 2 clears all of a wave's
                          // bitsets at once where a sub-bucket has no more tags than the wave has bitsets, and none changes hands inside it
     uint32_t tag_limit;  // tagged: how many items a workgroup may take (its private tags are 0 .. tag_limit - 1; the split paths' lie above)
@@ -282,6 +283,27 @@ __device__ __forceinline__ void load_block_async(W &w, const uint4 *p) {
 // k_scan's pattern: instruction k of a block reads the block's k-th KiB, 16 bytes per lane -- each
 // instruction is one fully coalesced 1 KiB read -- so that lane l ends up with four groups of four
 // consecutive steps: steps 256k + 4l .. 256k + 4l + 3 of the block in registers 4k .. 4k + 3.
+// (the same reads without the nt hint: they allocate in the L2 and the Infinity Cache -- ScanArgs::mall_steps)
+template <int SET, typename W>
+__device__ __forceinline__ void load_block_coal_plain(W &w, const uint4 *p) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w.vm[k] = k == SET ? 0u : w.vm[k] + 4u;
+    if (SET == 0)
+        asm volatile("global_load_dwordx4 v[96:99], %0, off\n\t"
+                     "global_load_dwordx4 v[100:103], %0, off offset:1024\n\t"
+                     "global_load_dwordx4 v[104:107], %0, off offset:2048\n\t"
+                     "global_load_dwordx4 v[108:111], %0, off offset:3072" ::"v"(p) : "memory", FGFA_CLOB_A);
+    else if (SET == 1)
+        asm volatile("global_load_dwordx4 v[112:115], %0, off\n\t"
+                     "global_load_dwordx4 v[116:119], %0, off offset:1024\n\t"
+                     "global_load_dwordx4 v[120:123], %0, off offset:2048\n\t"
+                     "global_load_dwordx4 v[124:127], %0, off offset:3072" ::"v"(p) : "memory", FGFA_CLOB_B);
+    else
+        asm volatile("global_load_dwordx4 v[80:83], %0, off\n\t"
+                     "global_load_dwordx4 v[84:87], %0, off offset:1024\n\t"
+                     "global_load_dwordx4 v[88:91], %0, off offset:2048\n\t"
+                     "global_load_dwordx4 v[92:95], %0, off offset:3072" ::"v"(p) : "memory", FGFA_CLOB_C);
+}
 template <int SET, typename W>
 __device__ __forceinline__ void load_block_coal(W &w, const uint4 *p) {
 #pragma unroll
@@ -1469,6 +1491,11 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     uint32_t resv;    // the block this wave takes after those
     // (a partial block is read whole: make_item has made sure that stays inside the step array)
 #define FGFA_BLOCK_PTR(j) (it.src + (size_t)(j) * 256)
+#define FGFA_LOAD_BLOCK(SET, j)                                                                   \
+    do {                                                                                          \
+        if (MODE != kModeDbg && it.t0 + (uint64_t)(j) * 1024u < A.mall_steps) load_block_coal_plain<SET>(w, FGFA_BLOCK_PTR(j)); \
+        else load_block_coal<SET>(w, FGFA_BLOCK_PTR(j));                                          \
+    } while (0)
     // (An item's first 64 blocks are its waves' own: wave w takes blocks j, j + 16, j + 32 and j + 48,
     // j = w less the blocks of the items before, mod 16 -- items of ten blocks would otherwise leave
     // the same six waves without work every time.)
@@ -1479,9 +1506,9 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         blk[1] = blk[0] + kWaves;                                           \
         blk[2] = blk[0] + 2u * kWaves;                                      \
         resv = blk[0] + 3u * kWaves;                                        \
-        if (blk[0] < it.nblk) load_block_coal<0>(w, FGFA_BLOCK_PTR(blk[0])); \
-        if (blk[1] < it.nblk) load_block_coal<1>(w, FGFA_BLOCK_PTR(blk[1])); \
-        if (blk[2] < it.nblk) load_block_coal<2>(w, FGFA_BLOCK_PTR(blk[2])); \
+        if (blk[0] < it.nblk) FGFA_LOAD_BLOCK(0, blk[0]);                   \
+        if (blk[1] < it.nblk) FGFA_LOAD_BLOCK(1, blk[1]);                   \
+        if (blk[2] < it.nblk) FGFA_LOAD_BLOCK(2, blk[2]);                   \
     } while (0)
     // one block: wait for its data, take the next free block for its register set, process it
 #define FGFA_BLOCK(SET)                                                                       \
@@ -1493,7 +1520,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         take_block<SET>(a);                                                                   \
         const uint32_t mine_now = blk[SET];                                                   \
         blk[SET] = resv;  /* taken one block ago, so that the LDS round trip is off this path */ \
-        if (blk[SET] < it.nblk) load_block_coal<SET>(w, FGFA_BLOCK_PTR(blk[SET]));            \
+        if (blk[SET] < it.nblk) FGFA_LOAD_BLOCK(SET, blk[SET]);                               \
         uint32_t got = 0;                                                                     \
         if (lane == 0) got = atomicAdd(&ctl[kCtlNext + (rr & kRing)], 1u);                    \
         if (!FGFA_SKIP(kDbgNoTiles)) {                                                        \
@@ -1632,6 +1659,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
 #undef FGFA_PRELOAD
 #undef FGFA_BLOCK
 #undef FGFA_BLOCK_PTR
+#undef FGFA_LOAD_BLOCK
 #undef FGFA_ITEM_TAG
     // publish how many records this workgroup left in each window's sub-bucket
     if (TAGGED && MODE == kModePlain && A.tprof && lane == 0) A.tprof[kTprofRow * blockIdx.x + 4 + wave] = __builtin_amdgcn_s_memrealtime();
@@ -4027,6 +4055,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     sa.tagged = tagged ? 1u : 0u;
     sa.tag_limit = std::max(2u, fp.tag_limit);
     sa.taken = fp.taken;
+    sa.mall_steps = fp.mall_steps;
     sa.pk_off = fp.pk_off;
     sa.pk_base = fp.pk_base;
     if (fp.packed && !tagged) { set_error("fast_seg_depth: a plan with packed buckets runs tagged calls only"); return FLATGFA_ERR_ARG; }

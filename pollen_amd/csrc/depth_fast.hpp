@@ -31,6 +31,7 @@ struct FastPlan {
     uint32_t *pair_part = nullptr, *pair_flag = nullptr;  // their halves of the result vectors, and how many are there
     // Packed buckets: every (window, workgroup) sub-bucket has exactly the room its records need (counted once when the
     // plan is made, k_scan dealing its items in a fixed order from then on), a workgroup's sub-buckets back to back.
+    uint64_t mall_steps = 0;       // the steps below this index are read without the nt hint: they stay in the Infinity Cache from call to call (plan_create decides)
     bool packed = false;
     uint32_t *pk_off = nullptr;    // u32[n_slots][n_win + 1] sub-bucket starts within the workgroup's region; the last entry is its sink
     uint64_t *pk_base = nullptr;   // u64[n_slots] where each workgroup's region starts
