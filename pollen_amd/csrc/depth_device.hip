@@ -350,7 +350,7 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
     if (pl->fast.eligible && g->n_steps && pl->fast.n_items) {  // (k_scan's reads: the wave-per-path kernels and the partition read plainly anyway)
         uint64_t records = pl->fast.est_records;
         for (uint32_t r = 0; r < pl->fast.n_more; ++r) records += pl->fast.more[r].est_records;
-        int64_t budget = (230ll << 20) - 8ll * (int64_t)g->n_segs - 8ll * (int64_t)records;
+        int64_t budget = (244ll << 20) - 8ll * (int64_t)g->n_segs - 8ll * (int64_t)records;
         budget = std::min<int64_t>(budget, 160ll << 20);
         if (const char *f = getenv("FLATGFA_MALL_MB")) budget = (int64_t)strtoull(f, nullptr, 10) << 20;
         budget = std::min<int64_t>(budget, (int64_t)g->n_steps * 4);

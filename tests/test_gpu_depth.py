@@ -803,3 +803,57 @@ def test_packed_buckets_and_blocks_of_nearly_all_starts(cont, want, monkeypatch)
         if k != 1:
             assert (u.cpu().numpy().view(np.uint32) == want_u).all(), text
     plan.close()
+
+
+def test_steps_kept_in_the_infinity_cache_are_budgeted_per_device(monkeypatch):
+    """k_scan reads the first cache_resident_mb of a plan's steps without the nt hint (they stay in the 256 MiB
+    Infinity Cache between calls).  The amount is what the call's other traffic leaves of the cache and what the
+    device's other plans have not claimed; a destroyed plan gives its share back; FLATGFA_MALL_MB pins it.
+    Whatever the amount, the counts are the same (it is a cache policy of the step loads, nothing else)."""
+    import re
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    for v in ("FLATGFA_MALL_MB", "FLATGFA_TAGGED", "FLATGFA_SHORT_MAX", "FLATGFA_PIECE_STEPS"):
+        monkeypatch.delenv(v, raising=False)
+    S = 1_000_000
+    g = pa.synth(51, S, 250, 100_000, "pangenome", False)  # 25 M steps = 100 MB
+    steps, pb, pe, _ = g.soa()
+    want_d, want_u = fo.seg_depth_with_uniq(pools_of(g))
+    graph = DeviceGraph(steps, pb, pe, S)
+
+    def resident(plan):
+        return int(re.search(r"cache_resident_mb=(\d+)", plan.describe()).group(1))
+
+    def check(plan):
+        d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        for _ in range(2):
+            plan.seg_depth(d, u)
+            plan.status()
+            assert (d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all()
+
+    a = DepthPlan(graph)
+    ra = resident(a)
+    assert 90 <= ra <= 100, a.describe()       # all of its steps: they fit what a call's traffic leaves
+    b = DepthPlan(graph)
+    rb = resident(b)
+    assert rb <= 160 - ra and rb in (0, *range(32, 161)), b.describe()  # what the first left of the device's budget (nothing below 32 MB)
+    check(a)
+    check(b)
+    a.close()
+    c = DepthPlan(graph)
+    assert resident(c) >= 32, c.describe()     # the first plan's share is free again
+    check(c)
+    c.close()
+    b.close()
+    monkeypatch.setenv("FLATGFA_MALL_MB", "0")
+    z = DepthPlan(graph)
+    assert resident(z) == 0
+    check(z)
+    z.close()
+    monkeypatch.setenv("FLATGFA_MALL_MB", "37")
+    p = DepthPlan(graph)
+    assert resident(p) == 37
+    check(p)
+    p.close()
