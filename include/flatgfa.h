@@ -76,7 +76,8 @@ enum {
     FLATGFA_ERR_NO_DEVICE = -3, /* no usable HIP device; there is no CPU fallback */
     FLATGFA_ERR_HIP = -4,       /* a HIP runtime call failed; see flatgfa_last_error() */
     FLATGFA_ERR_IO = -5,
-    FLATGFA_ERR_TOO_LARGE = -6  /* more than 2^32-1 steps */
+    FLATGFA_ERR_TOO_LARGE = -6, /* more than 2^32-1 steps */
+    FLATGFA_ERR_PARSE = -7      /* GFA text the reference's parser panics on (flatgfa_translate_prealloc; the parse calls that return a handle return NULL) */
 };
 
 /* Thread-local description of the last failure in this thread ("" if none). */
@@ -98,6 +99,17 @@ int flatgfa_write_flatgfa(flatgfa_t gfa, const char *filename);
  * guess from `factor`.  FLATGFA_ERR_BOUNDS where a pool does not fit its capacity (the reference's
  * fixed-capacity store panics there).  flatgfa_load reads such files as it reads any other. */
 int flatgfa_write_flatgfa_prealloc(flatgfa_t gfa, const char *filename, const uint8_t *gfa_text, size_t text_len, uint32_t factor);
+/* prealloc_translate itself (cli/main.rs:216-248): GFA text -> preallocated container with no graph
+ * in between.  The output file is created at the size its capacities add up to and mapped
+ * (memfile::map_new_file, memfile.rs:24-33), file::init (file.rs:255-272) writes the empty table of
+ * contents, the parser pushes straight into the file's regions (Parser::for_slice, parse.rs:170-174)
+ * and the table's lengths are set at the end (Toc::for_fixed_store).  from_stream == 0: the text of
+ * `-I GFA` (capacities estimated from it, Parser::parse_mem); != 0: the text came from stdin
+ * (capacities guessed from `factor`, Parser::parse_stream).  Byte for byte the file that
+ * flatgfa_parse_bytes + flatgfa_write_flatgfa_prealloc leave.  FLATGFA_ERR_BOUNDS where a pool
+ * does not fit (the reference panics with the file as it then is: capacities in the table, every
+ * length 0 -- so it is left here), FLATGFA_ERR_PARSE where the text does not parse. */
+int flatgfa_translate_prealloc(const uint8_t *gfa_text, size_t text_len, int from_stream, const char *filename, uint32_t factor);
 /* GFA text (flatgfa/src/print.rs:99-153).  *text is malloc'd; release with flatgfa_free_text. */
 int flatgfa_print_gfa(flatgfa_t gfa, char **text, size_t *len);
 void flatgfa_free_text(char *text);

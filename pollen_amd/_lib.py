@@ -44,6 +44,7 @@ SIGNATURES = {
     "flatgfa_load": (c_void_p, [c_char_p]),
     "flatgfa_write_flatgfa": (c_int, [c_void_p, c_char_p]),
     "flatgfa_write_flatgfa_prealloc": (c_int, [c_void_p, c_char_p, c_char_p, c_size_t, c_uint32]),
+    "flatgfa_translate_prealloc": (c_int, [c_char_p, c_size_t, c_int, c_char_p, c_uint32]),
     "flatgfa_print_gfa": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]),
     "flatgfa_free_text": (None, [c_void_p]),
     "flatgfa_synth": (c_void_p, [c_uint64, c_uint32, c_uint32, c_uint32, c_int, c_bool]),

@@ -253,6 +253,41 @@ static int give_text(const std::string &s, char **text, size_t *len) {
     return FLATGFA_OK;
 }
 
+int flatgfa_translate_prealloc(const uint8_t *gfa_text, size_t text_len, int from_stream, const char *filename, uint32_t factor) {
+    if (!filename || (text_len && !gfa_text)) { set_error("flatgfa_translate_prealloc: NULL argument"); return FLATGFA_ERR_ARG; }
+    const uint8_t *text = gfa_text ? gfa_text : (const uint8_t *)"";
+    uint64_t cap[11];
+    std::string err;
+    if (from_stream) {
+        fgfa::guess_toc(factor, cap);
+    } else if (!fgfa::estimate_toc(text, text_len, cap, &err)) {
+        set_error(err);
+        return FLATGFA_ERR_BOUNDS;
+    }
+    size_t n = 0;
+    if (!fgfa::toc_file_size(cap, &n, &err)) { set_error(err); return FLATGFA_ERR_BOUNDS; }
+    // memfile::map_new_file (memfile.rs:24-33): created, sized (sparse: it reads as zeros), mapped shared
+    const int fd = open(filename, O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) { set_error(std::string("cannot create ") + filename); return FLATGFA_ERR_IO; }
+    if (ftruncate(fd, (off_t)n) != 0) {
+        close(fd);
+        set_error(std::string("cannot size ") + filename);
+        return FLATGFA_ERR_IO;
+    }
+    void *m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) { set_error(std::string("cannot map ") + filename); return FLATGFA_ERR_IO; }
+    const bool ok = fgfa::parse_gfa_prealloc(text, text_len, from_stream != 0, cap, (uint8_t *)m, &err);
+    const bool flushed = msync(m, n, MS_SYNC) == 0;  // (mmap.flush())
+    munmap(m, n);
+    if (!ok) {
+        set_error(err);
+        return err.rfind("preallocated flatgfa:", 0) == 0 ? FLATGFA_ERR_BOUNDS : FLATGFA_ERR_PARSE;
+    }
+    if (!flushed) { set_error(std::string("cannot flush ") + filename); return FLATGFA_ERR_IO; }
+    return FLATGFA_OK;
+}
+
 int flatgfa_print_gfa(flatgfa_t gfa, char **text, size_t *len) {
     if (!gfa || !text) { set_error("flatgfa_print_gfa: NULL argument"); return FLATGFA_ERR_ARG; }
     if (!steps_name_segments(gfa)) return FLATGFA_ERR_BOUNDS;

@@ -376,6 +376,9 @@ struct Wave {
 #ifndef FGFA_QCAP
 #define FGFA_QCAP 416
 #endif
+#ifndef FGFA_SHORT_ABLATE
+#define FGFA_SHORT_ABLATE 0  /* measurements only (results are wrong): 1 loads only, 2 runs queued but not emitted, 4 no claims, 8 no record stores, 16 hash set not wiped */
+#endif
 constexpr uint32_t kQCap = FGFA_QCAP;  // at least 63 left over + up to 256 from four steps of every lane; a short path has at most kQCap - 16 runs, hence bitset words: its 512-entry hash set must not fill up
 constexpr uint32_t kPCap = 96;   // parked claims (two words each): 31 left over + up to 64 from one chunk
 
@@ -474,7 +477,7 @@ __device__ __forceinline__ void emit_chunk(const ScanArgs &A, Wave &w, uint32_t 
     uint32_t kind = 0, pos;
     if (UNIQ) {
         const uint32_t mask = valid ? (0xFFFFFFFFu >> (31u - lenm1)) << (id & 31u) : 0u;
-        const uint32_t old = claim_hashed<HASH>(A, seen, valid, id >> 5, mask);
+        const uint32_t old = (FGFA_SHORT_ABLATE & 4) ? 0u : claim_hashed<HASH>(A, seen, valid, id >> 5, mask);
         pos = take_slots(bcur, w.lane, valid, win);
         const uint32_t nb = mask & ~old;
         kind = (nb == mask) ? 2u : 0u;
@@ -483,7 +486,8 @@ __device__ __forceinline__ void emit_chunk(const ScanArgs &A, Wave &w, uint32_t 
         pos = take_slots(bcur, w.lane, valid, win);
     }
     const uint32_t word = (id & ((1u << kShortWinBits) - 1u)) | (lenm1 << kShortWinBits) | ((kind + 1u) << 24);  // bit 24: counts for depth, bit 25: for uniq
-    flag_if_any(A, put<false>(A, w, mine, valid, pos, win, word), kStOverflow);
+    if (!(FGFA_SHORT_ABLATE & 8)) flag_if_any(A, put<false>(A, w, mine, valid, pos, win, word), kStOverflow);
+    else if (word == 0xDEADBEEFu && pos == 77u) atomicOr(A.status, kStBounds);
 }
 
 // Turn parked claims into uniq records, one per stretch of new bits: the newest 64 while at
@@ -804,7 +808,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
         const ShortBlk cur = slot[SET];                                                                 \
         slot[SET] = stream_next(A, g, lane);                                                            \
         if (slot[SET].valid) load_block_async<SET>(w, FGFA_SPTR(slot[SET]));                            \
-        if (!handed_back) {                                                                             \
+        if (FGFA_SHORT_ABLATE & 1) {                                                                    \
+            uint32_t x_ = a[0];                                                                         \
+            for (int k_ = 1; k_ < 16; ++k_) x_ ^= a[k_];                                                \
+            if (x_ == 0xDEADBEEFu) atomicOr(A.status, kStBounds);                                       \
+        } else if (!handed_back) {                                                                      \
             const uint32_t lo = cur.b > cur.pos ? cur.b - cur.pos : 0u;                                 \
             const uint32_t hi = cur.e - cur.pos < 1024u ? cur.e - cur.pos : 1024u;                      \
             if (!block16<UNIQ, HASH, QONLY>(A, w, tab, bcur, mine, a, cur.nl, lo, hi, cur.pos)) {       \
@@ -822,8 +830,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
                 }                                                                                       \
                 handed_back = false;                                                                    \
             } else {                                                                                    \
+                if (FGFA_SHORT_ABLATE & 2) w.fill = 0;                                                  \
                 drain<UNIQ, HASH>(A, w, tab, bcur, mine, true);                                         \
-                if (UNIQ)                                                                               \
+                if (UNIQ && !(FGFA_SHORT_ABLATE & 16))                                                  \
                     for (uint32_t i = lane; i < kTab / 2; i += 64)                                      \
                         reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0u, 0u, 0u, 0u);                 \
             }                                                                                           \

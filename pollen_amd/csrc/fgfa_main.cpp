@@ -8,7 +8,9 @@
 // With no -i/-I the GFA text is read from stdin; with no COMMAND the graph is written out
 // (-o binary, -O text, otherwise text on stdout).  `depth` output is byte-identical to the
 // reference's and is computed on the GPU.  Everything else in the reference CLI is out of scope.
+#include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <cstdio>
@@ -73,6 +75,31 @@ int main(int argc, char **argv) {
     }
     std::string cmd = i < argc ? argv[i++] : "";
 
+    // The special case the reference's main starts with (cli/main.rs:61-66): `-m -o OUT` with no command and
+    // no -i is prealloc_translate -- GFA text (the mapped -I file, or stdin) parsed straight into the mapped,
+    // preallocated output; no graph is built.
+    if (mutate && cmd.empty() && !in_flat && out_flat) {
+        const uint32_t factor = prealloc ? (uint32_t)strtoul(prealloc, nullptr, 10) : 32u;
+        int rc;
+        if (in_gfa) {
+            const int fd = open(in_gfa, O_RDONLY);
+            struct stat sb;
+            if (fd < 0 || fstat(fd, &sb) != 0) { fprintf(stderr, "fgfa: cannot open %s\n", in_gfa); return 1; }
+            void *m = sb.st_size ? mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+            close(fd);
+            if (m == MAP_FAILED) { fprintf(stderr, "fgfa: cannot map %s\n", in_gfa); return 1; }
+            rc = flatgfa_translate_prealloc((const uint8_t *)m, (size_t)sb.st_size, 0, out_flat, factor);
+            if (m) munmap(m, (size_t)sb.st_size);
+        } else {
+            std::string buf;
+            char tmp[1 << 16];
+            ssize_t r;
+            while ((r = read(STDIN_FILENO, tmp, sizeof tmp)) > 0) buf.append(tmp, (size_t)r);
+            rc = flatgfa_translate_prealloc((const uint8_t *)buf.data(), buf.size(), 1, out_flat, factor);
+        }
+        return rc ? die("write") : 0;
+    }
+
     // A one-shot query is mostly start-up: the HIP runtime takes a tenth of a second and more to come
     // up in a cold process, the staging buffers, the first copy and the first launch another thirty
     // milliseconds.  All of that starts now, on a thread of its own, while this one maps or parses
@@ -85,17 +112,8 @@ int main(int argc, char **argv) {
     if (wants_device && !getenv("FLATGFA_NO_WARM")) warm = std::thread([] { (void)flatgfa_warm_device(0); });
 
     flatgfa_t g;
-    std::string gfa_text;  // (kept for -m -o: the capacities of the preallocated file are measured on it)
     if (in_flat) {
         g = flatgfa_load(in_flat);
-    } else if (in_gfa && mutate && out_flat) {
-        FILE *f = fopen(in_gfa, "rb");
-        if (!f) { fprintf(stderr, "fgfa: cannot open %s\n", in_gfa); return 1; }
-        char tmp[1 << 16];
-        size_t r;
-        while ((r = fread(tmp, 1, sizeof tmp, f)) > 0) gfa_text.append(tmp, r);
-        fclose(f);
-        g = flatgfa_parse_bytes((const uint8_t *)gfa_text.data(), gfa_text.size());
     } else if (in_gfa) {
         g = flatgfa_parse(in_gfa);
     } else {
@@ -123,10 +141,7 @@ int main(int argc, char **argv) {
 
     int rc = 0;
     if (cmd.empty()) {
-        if (out_flat && mutate) {  // prealloc_translate (cli/main.rs:216-248): estimates from the text, or a guess for stdin
-            const uint32_t factor = prealloc ? (uint32_t)strtoul(prealloc, nullptr, 10) : 32u;
-            if (flatgfa_write_flatgfa_prealloc(g, out_flat, in_gfa ? (const uint8_t *)gfa_text.data() : nullptr, gfa_text.size(), factor)) rc = die("write");
-        } else if (out_flat) {
+        if (out_flat) {
             if (flatgfa_write_flatgfa(g, out_flat)) rc = die("write");
         } else {
             char *text = nullptr;

@@ -158,7 +158,7 @@ bool parse_orient(Cursor *c, uint32_t *orient) {
 }
 
 // gfaline.rs:174-198; ops are appended to `out`.
-bool parse_align(Cursor *c, std::vector<uint32_t> *out, const char **why) {
+bool parse_align(Cursor *c, std::vector<uint32_t> *out, const char **why) {  // (a scratch list: the ops reach the store once their line has parsed)
     while (!c->empty() && *c->p >= '0' && *c->p <= '9') {
         uint64_t len;
         parse_num(c, &len);
@@ -217,7 +217,8 @@ bool parse_step_chunk(const StepChunk &c, const NameMap &names, Handle *steps) {
     return n == c.want;
 }
 
-void parse_steps_parallel(const std::vector<Cursor> &deferred, const NameMap &names, Store *st, StepsPre *pre) {
+template <class S>
+void parse_steps_parallel(const std::vector<Cursor> &deferred, const NameMap &names, S *st, StepsPre *pre) {
     size_t kChunk = 1 << 20, min_bytes = 4u << 20;
     if (const char *f = getenv("FLATGFA_PARSE_CHUNK")) kChunk = std::max<size_t>(1, strtoull(f, nullptr, 10));      // tests
     if (const char *f = getenv("FLATGFA_PARSE_MIN_BYTES")) min_bytes = strtoull(f, nullptr, 10);                    // tests
@@ -292,10 +293,9 @@ void parse_steps_parallel(const std::vector<Cursor> &deferred, const NameMap &na
     pre->ok = true;
 }
 
-}  // namespace
-
-bool parse_gfa(const uint8_t *buf, size_t n, Store *st, std::string *err, bool stream_mode) {
-    *st = Store();
+// Parser<P: StoreFamily> (parse.rs:12-22): the same parser for the heap store and for the store inside a file.
+template <class S>
+bool parse_gfa_into(const uint8_t *buf, size_t n, S *st, std::string *err, bool stream_mode) {
     const auto t_begin = std::chrono::steady_clock::now();
     NameMap names;
     std::vector<Cursor> deferred;
@@ -461,6 +461,73 @@ bool parse_gfa(const uint8_t *buf, size_t n, Store *st, std::string *err, bool s
         fprintf(stderr, "parse_gfa: lines %.1f ms, steps %.1f ms (%s), links/paths %.1f ms\n", ms(t_begin, t_lines), ms(t_lines, t_steps),
                 pre.ok ? "threads" : "in order", ms(t_steps, std::chrono::steady_clock::now()));
     }
+    return true;
+}
+
+}  // namespace
+
+bool parse_gfa(const uint8_t *buf, size_t n, Store *st, std::string *err, bool stream_mode) {
+    *st = Store();
+    return parse_gfa_into(buf, n, st, err, stream_mode);
+}
+
+uint64_t FixedStore::pool_len(int ix) const {
+    switch (ix) {
+        case pHeader: return header.size();
+        case pSegs: return segs.size();
+        case pPaths: return paths.size();
+        case pLinks: return links.size();
+        case pSteps: return steps.size();
+        case pSeqData: return seq_data.size();
+        case pOverlaps: return overlaps.size();
+        case pAlignment: return alignment.size();
+        case pNameData: return name_data.size();
+        case pOptionalData: return optional_data.size();
+        case pLineOrder: return line_order.size();
+    }
+    return 0;
+}
+
+bool toc_file_size(const uint64_t cap[11], size_t *total, std::string *err) {
+    unsigned __int128 t = sizeof(Toc);
+    for (int i = 0; i < 11; ++i) t += (unsigned __int128)cap[i] * kPoolElemSize[i];
+    if (t > (unsigned __int128)1 << 46) { *err = "preallocated flatgfa: file too large"; return false; }
+    *total = (size_t)t;
+    return true;
+}
+
+bool parse_gfa_prealloc(const uint8_t *buf, size_t n, bool stream_mode, const uint64_t cap[11], uint8_t *file, std::string *err) {
+    // file::init (file.rs:255-272): the table of contents with every length 0, then the store over what follows it
+    Toc toc;
+    toc.magic = kMagic;
+    for (int i = 0; i < 11; ++i) toc.pool[i] = TocSize{0, cap[i]};
+    memcpy(file, &toc, sizeof toc);
+    uint8_t *at[11];
+    size_t off = sizeof toc;
+    for (int i = 0; i < 11; ++i) {
+        at[i] = file + off;
+        off += cap[i] * kPoolElemSize[i];
+    }
+    FixedStore st;
+    st.header = FixedVec<uint8_t>(at[pHeader], cap[pHeader], pHeader);
+    st.segs = FixedVec<Segment>(reinterpret_cast<Segment *>(at[pSegs]), cap[pSegs], pSegs);
+    st.paths = FixedVec<Path>(reinterpret_cast<Path *>(at[pPaths]), cap[pPaths], pPaths);
+    st.links = FixedVec<Link>(reinterpret_cast<Link *>(at[pLinks]), cap[pLinks], pLinks);
+    st.steps = FixedVec<Handle>(reinterpret_cast<Handle *>(at[pSteps]), cap[pSteps], pSteps);
+    st.seq_data = FixedVec<uint8_t>(at[pSeqData], cap[pSeqData], pSeqData);
+    st.overlaps = FixedVec<Span>(reinterpret_cast<Span *>(at[pOverlaps]), cap[pOverlaps], pOverlaps);
+    st.alignment = FixedVec<AlignOp>(reinterpret_cast<AlignOp *>(at[pAlignment]), cap[pAlignment], pAlignment);
+    st.name_data = FixedVec<uint8_t>(at[pNameData], cap[pNameData], pNameData);
+    st.optional_data = FixedVec<uint8_t>(at[pOptionalData], cap[pOptionalData], pOptionalData);
+    st.line_order = FixedVec<uint8_t>(at[pLineOrder], cap[pLineOrder], pLineOrder);
+    try {
+        if (!parse_gfa_into(buf, n, &st, err, stream_mode)) return false;
+    } catch (const CapacityError &e) {  // (the push that does not fit: the reference's fixed-capacity store panics)
+        *err = std::string("preallocated flatgfa: the ") + kPoolName[e.pool] + " pool needs more than the " + std::to_string(e.capacity) + " entries its capacity allows";
+        return false;
+    }
+    for (int i = 0; i < 11; ++i) toc.pool[i].len = st.pool_len(i);  // Toc::for_fixed_store
+    memcpy(file, &toc, sizeof toc);
     return true;
 }
 

@@ -118,6 +118,70 @@ struct Store {
     View view() const;
 };
 
+// A fixed-capacity vector over a region of a mapped file: the reference's SliceVec (file.rs:215-225,
+// pool.rs FixedStore).  Only what the parser uses of std::vector.  Pushing beyond the capacity throws
+// CapacityError where the reference panics.  Elements are align-1 PODs (a pool starts at any byte).
+struct CapacityError {
+    int pool;
+    uint64_t capacity;
+};
+template <class T>
+class FixedVec {
+  public:
+    FixedVec() = default;
+    FixedVec(T *p, size_t cap, int pool) : p_(p), cap_(cap), pool_(pool) { static_assert(alignof(T) == 1, "pools start at any byte"); }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    T *data() { return p_; }
+    const T *data() const { return p_; }
+    T *end() { return p_ + n_; }
+    void push_back(const T &v) {
+        need(1);
+        p_[n_++] = v;
+    }
+    template <class It>
+    void insert(T *at, It b, It e) {  // (appends only)
+        (void)at;
+        need((size_t)(e - b));
+        for (; b != e; ++b) p_[n_++] = T{*b};
+    }
+    template <class It>
+    void assign(It b, It e) {
+        resize(0);
+        insert(end(), b, e);
+    }
+    void resize(size_t m) {  // (what is given up reads as zeros again, as the fresh file does)
+        if (m > n_) need(m - n_);
+        if (m > n_) memset((void *)(p_ + n_), 0, (m - n_) * sizeof(T));
+        else memset((void *)(p_ + m), 0, (n_ - m) * sizeof(T));
+        n_ = m;
+    }
+
+  private:
+    void need(size_t k) const {
+        if (k > cap_ - n_) throw CapacityError{pool_, (uint64_t)cap_};
+    }
+    T *p_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+    int pool_ = 0;
+};
+
+// The reference's FixedGFAStore over a file image laid out by a table of contents (file.rs:227-253).
+struct FixedStore {
+    FixedVec<uint8_t> header;
+    FixedVec<Segment> segs;
+    FixedVec<Path> paths;
+    FixedVec<Link> links;
+    FixedVec<Handle> steps;
+    FixedVec<uint8_t> seq_data;
+    FixedVec<Span> overlaps;
+    FixedVec<AlignOp> alignment;
+    FixedVec<uint8_t> name_data;
+    FixedVec<uint8_t> optional_data;
+    FixedVec<uint8_t> line_order;
+    uint64_t pool_len(int ix) const;
+};
+
 // namemap.rs:7-33
 class NameMap {
   public:
@@ -146,6 +210,12 @@ void dump_flatgfa(const View &v, uint8_t *buf);
 bool estimate_toc(const uint8_t *buf, size_t n, uint64_t cap[11], std::string *err);
 void guess_toc(uint64_t factor, uint64_t cap[11]);
 bool prealloc_file_size(const View &v, const uint64_t cap[11], size_t *total, std::string *err);
+// prealloc_translate proper (cli/main.rs:216-248, file.rs:255-272): `file` is the mapped, zero-filled output of
+// toc_file_size(cap) bytes.  file::init writes the empty table of contents, the parser pushes straight into the
+// file's regions (Parser::for_slice), and the table's lengths are set when it is done.  False, with the table
+// still empty, where a pool does not fit its capacity (the reference's panic) or the text does not parse.
+bool toc_file_size(const uint64_t cap[11], size_t *total, std::string *err);
+bool parse_gfa_prealloc(const uint8_t *buf, size_t n, bool stream_mode, const uint64_t cap[11], uint8_t *file, std::string *err);
 void dump_flatgfa_prealloc(const View &v, const uint64_t cap[11], uint8_t *buf);
 
 // print.rs:99-153 (preserved order when line_order is non-empty, else normalized)

@@ -414,6 +414,14 @@ def parse_stream_bytes(gfa: bytes) -> FlatGFA:
     return FlatGFA(_lib.lib().flatgfa_parse_stream_bytes(gfa, len(gfa)))
 
 
+def translate_prealloc(gfa: bytes, filename: Union[str, os.PathLike], factor: int = 32, from_stream: bool = False) -> None:
+    """`fgfa -m -p FACTOR -o OUT [-I GFA]` (cli/main.rs:216-248): the text is parsed straight into the
+    mapped, preallocated output file (file.rs:255-272); no graph is built in between.  `from_stream`:
+    the text came from stdin (capacities guessed from `factor`, parse_stream's rules)."""
+    _check(_lib.lib().flatgfa_translate_prealloc(gfa, len(gfa), 1 if from_stream else 0, os.fsencode(filename), int(factor)),
+           "translate_prealloc")
+
+
 def load(filename: Union[str, os.PathLike]) -> FlatGFA:
     """Map a binary `.flatgfa` file (file::view, flatgfa/src/file.rs:185)."""
     return FlatGFA(_lib.lib().flatgfa_load(os.fsencode(filename)))

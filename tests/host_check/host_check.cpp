@@ -126,7 +126,7 @@ int main(int argc, char **argv) {
     //    accept them, never read or write out of bounds
     h = 0xcbf29ce484222325ull;
     uint64_t seed = 42;
-    size_t accepted = 0, rejected = 0;
+    size_t accepted = 0, rejected = 0, pre_fit = 0, pre_full = 0;
     for (int round = 0; round < 600 && !texts.empty(); ++round) {
         std::string t = texts[rng(seed) % texts.size()];
         if (t.size() > 20000) t.resize(20000 + rng(seed) % 64);
@@ -147,15 +147,47 @@ int main(int argc, char **argv) {
         }
         Store st;
         std::string err;
-        if (parse_gfa((const uint8_t *)t.data(), t.size(), &st, &err, (round & 1) != 0)) {
+        const bool heap_ok = parse_gfa((const uint8_t *)t.data(), t.size(), &st, &err, (round & 1) != 0);
+        if (heap_ok) {
             ++accepted;
             h = exercise(st, h);
         } else {
             ++rejected;
             h = fnv(h, err.data(), err.size());
         }
+        // the same text parsed straight into a preallocated image (file.rs:255-272), one byte off any alignment: the
+        // image a heap parse + dump_flatgfa_prealloc leaves, or the push that does not fit, or the same parse error
+        uint64_t cap[11];
+        std::string perr;
+        size_t total = 0;
+        if (round % 3 == 0) guess_toc(1 + rng(seed) % 3, cap);
+        else if (!estimate_toc((const uint8_t *)t.data(), t.size(), cap, &perr)) continue;
+        if (!toc_file_size(cap, &total, &perr) || total > (64u << 20)) continue;
+        std::vector<uint8_t> img(total + 1);
+        const bool pre_ok = parse_gfa_prealloc((const uint8_t *)t.data(), t.size(), (round & 1) != 0, cap, img.data() + 1, &perr);
+        if (pre_ok) {
+            ++pre_fit;
+            size_t t2 = 0;
+            std::vector<uint8_t> want(total + 1);
+            if (!heap_ok || !prealloc_file_size(st.view(), cap, &t2, &perr) || t2 != total) {
+                fprintf(stderr, "host_check: round %d: the preallocated parse accepted what the heap parse did not\n", round);
+                return 3;
+            }
+            dump_flatgfa_prealloc(st.view(), cap, want.data() + 1);
+            if (memcmp(want.data() + 1, img.data() + 1, total) != 0) {
+                fprintf(stderr, "host_check: round %d: the preallocated parse left a different image\n", round);
+                return 3;
+            }
+        } else {
+            const bool capacity = perr.rfind("preallocated flatgfa:", 0) == 0;
+            pre_full += capacity ? 1 : 0;
+            if (!capacity && (heap_ok || perr != err)) {
+                fprintf(stderr, "host_check: round %d: heap parse %s, preallocated parse says '%s'\n", round, heap_ok ? "ok" : err.c_str(), perr.c_str());
+                return 3;
+            }
+        }
     }
-    printf("mutated_texts %016llx accepted=%zu rejected=%zu\n", (unsigned long long)h, accepted, rejected);
+    printf("mutated_texts %016llx accepted=%zu rejected=%zu preallocated: %zu fit, %zu over capacity\n", (unsigned long long)h, accepted, rejected, pre_fit, pre_full);
     all = fnv(all, &h, 8);
     // 3. damaged .flatgfa images: the table of contents and the spans are attacker-shaped (file.rs:185-213)
     h = 0xcbf29ce484222325ull;

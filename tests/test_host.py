@@ -355,3 +355,72 @@ def test_cli_inplace_round_trip(tmp_path):
         assert r.returncode == 0, r.stderr
         assert os.path.getsize(out) > 100_000
         assert subprocess.run([fgfa, "-i", out], capture_output=True).stdout == open(gfa, "rb").read()
+
+
+# ---- prealloc_translate proper: the text parsed straight into the mapped output (cli/main.rs:216-248, file.rs:255-272) ----
+
+@pytest.mark.parametrize("gfa", golden_gfas(), ids=fixture_id)
+def test_translate_prealloc_writes_the_same_file_with_no_graph_in_between(gfa, tmp_path):
+    """Parser::for_slice over the file's own regions: byte for byte what the restated prealloc_translate leaves
+    (and so what parse + write_flatgfa_prealloc leaves), for the text of a file (estimated capacities,
+    parse_mem) and for stdin's (guessed capacities, parse_stream)."""
+    text = open(gfa, "rb").read()
+    out = str(tmp_path / "direct.flatgfa")
+    out2 = str(tmp_path / "by_way_of_a_graph.flatgfa")
+    for stream in (False, True):
+        try:
+            if stream:  # (the oracle restates parse_mem; parse_stream's order of links and paths is the heap route's, checked above)
+                pa.parse_stream_bytes(text).write_flatgfa_prealloc(out2, None, factor=16)
+                want = open(out2, "rb").read()
+            else:
+                want = fo.dump_flatgfa_prealloc(fo.parse_gfa(text), fo.estimate_toc(text))
+        except (fo.ParseError, pa.FlatGFAError):
+            with pytest.raises(pa.FlatGFAError) as ei:
+                pa.translate_prealloc(text, out, factor=16, from_stream=stream)
+            assert ei.value.code in (-2, -7)
+            continue
+        pa.translate_prealloc(text, out, factor=16, from_stream=stream)
+        assert open(out, "rb").read() == want
+        back = pa.load(out)
+        assert str(back) == str(pa.parse_stream_bytes(text) if stream else pa.parse_bytes(text))
+
+
+def test_translate_prealloc_overflow_parse_errors_and_threads(tmp_path, monkeypatch):
+    text = open(os.path.join(GOLDEN, "ref_tiny.gfa"), "rb").read()
+    out = str(tmp_path / "t.flatgfa")
+    # a pool that does not fit its capacity: the reference's fixed store panics on that push, with the file as
+    # file::init left it (capacities, every length 0) plus whatever was pushed before
+    with pytest.raises(pa.FlatGFAError) as ei:
+        pa.translate_prealloc(text, out, factor=1, from_stream=True)  # Toc::guess(1): one path of capacity, two paths
+    assert ei.value.code == -2 and "paths" in str(ei.value)
+    head = np.frombuffer(open(out, "rb").read()[:184], dtype="<u8")
+    assert head[0] == 0xB1011054 and (head[1::2] == 0).all() and list(head[2::2]) == fo.guess_toc(1)
+    assert os.path.getsize(out) == 184 + sum(c * s for c, s in zip(fo.guess_toc(1), (1, 24, 24, 16, 4, 1, 8, 4, 1, 1, 1)))
+    # text the parser rejects
+    for bad in (b"S\t1\tA\nX\tfoo\n", b"S\t1\tA\nP\tp\t2+\t*\n", b"S\t1\tA\nL\t1\t+\t1\t+\t4Q\n"):
+        with pytest.raises(pa.FlatGFAError) as ei:
+            pa.translate_prealloc(bad, out)
+        assert ei.value.code in (-2, -7), bad
+    # the step lists parsed by threads into the file (each chunk into its own stretch of the steps region)
+    rng = np.random.default_rng(5)
+    S, P, L = 3000, 40, 4000
+    lines = [b"H\tVN:Z:1.0"] + [b"S\t%d\t%s" % (i + 1, b"ACGT"[: 1 + i % 4]) for i in range(S)]
+    for p in range(P):
+        ids = rng.integers(1, S + 1, L)
+        lines.append(b"P\tpath%d\t" % p + b",".join(b"%d%s" % (i, b"+-"[i & 1: (i & 1) + 1]) for i in ids) + b"\t*")
+    lines += [b"L\t%d\t+\t%d\t-\t%dM" % (i + 1, (i * 7) % S + 1, i % 200) for i in range(500)]
+    big = b"\n".join(lines) + b"\n"
+    want = fo.dump_flatgfa_prealloc(fo.parse_gfa(big), fo.estimate_toc(big))
+    for env in ({"FLATGFA_PARSE_THREADS": "0"}, {"FLATGFA_PARSE_MIN_BYTES": "0", "FLATGFA_PARSE_CHUNK": "777", "FLATGFA_PARSE_THREADS": "5"}):
+        for k in ("FLATGFA_PARSE_THREADS", "FLATGFA_PARSE_MIN_BYTES", "FLATGFA_PARSE_CHUNK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pa.translate_prealloc(big, out)
+        assert open(out, "rb").read() == want, env
+    # ... and a step list the threads give up on (a trailing comma, which the reference accepts): what they had
+    # written is taken back (zeros again) and the sequential parser does it all
+    odd = big.replace(b"\t*\n", b",\t*\n", 1)
+    want = fo.dump_flatgfa_prealloc(fo.parse_gfa(odd), fo.estimate_toc(odd))
+    pa.translate_prealloc(odd, out)
+    assert open(out, "rb").read() == want
