@@ -2966,11 +2966,20 @@ constexpr int kDensePer = kDenseTile / kThreads;  // steps per thread and tile
 // the next tile's steps are meant to stay in flight across the barriers of this tile.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-uint32_t dense_lds_bytes(uint32_t nwp) { return (5u * nwp + 64u + kDenseTile) * 4u; }
+uint32_t dense_lds_bytes(uint32_t nwp) { return (6u * nwp + 64u + kDenseTile + 64u) * 4u; }  // (behind the stage: a sink, the totals of two tiles)
 
+// A tile goes through four phases -- P1 count (a returning LDS atomic per step), P2 the bins' prefix
+// sum (one wave), P3 scatter into the stage, P4 write-out -- each needing the one before it finished
+// by all waves.  Run one tile at a time that is five barriers a tile and the phases' times add up
+// (per tile and wave, cycles: steps 600-1500, P1 1700, P2 1100 with fifteen waves idle, P3 1500, P4
+// 1400-2700; FGFA_DENSE_PROF).  So two tiles are in flight, two phases between barriers: P1 of tile
+// t + 1 beside P3 of tile t, then P2 of t + 1 (wave 0) beside P4 of t -- two barriers a tile, and
+// LDS round trips of one phase behind the other's instructions.  `delta` and the tile's total are
+// double-buffered (P2 of t + 1 writes them while P4 of t reads its own).
 __global__ __launch_bounds__(kThreads) void k_scan_dense(const ScanArgs A) {
     extern __shared__ uint32_t lds[];
-    uint32_t *bcur = lds, *snap = lds + A.nwp, *base = lds + 2u * A.nwp, *delta = lds + 3u * A.nwp, *hist = lds + 4u * A.nwp, *stage = lds + 5u * A.nwp + 64u;
+    uint32_t *bcur = lds, *snap = lds + A.nwp, *base = lds + 2u * A.nwp, *delta0 = lds + 3u * A.nwp, *hist = lds + 4u * A.nwp, *stage = lds + 5u * A.nwp + 64u;
+    uint32_t *delta1 = stage + kDenseTile + 64u;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     if (A.zero_a) {
         for (uint32_t i = blockIdx.x * kThreads + tid; i < A.n_segs; i += gridDim.x * kThreads) {
@@ -2993,34 +3002,63 @@ __global__ __launch_bounds__(kThreads) void k_scan_dense(const ScanArgs A) {
     const uint32_t n_items = A.n_items + back;
     const uint32_t wb = A.wb, wmask = (1u << wb) - 1u;
     uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;
+    const bool small = ((uint64_t)A.n_win + 1u) * A.stride < (1ull << 32);  // a record's place in the bucket array fits 32 bits
     bool bad = false, ovf = false;
+#ifdef FGFA_DENSE_PROF
+    unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl = __builtin_readcyclecounter();
+#define DP(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = __builtin_readcyclecounter(); tp[i] += n_ - tl; tl = n_; } while (0)
+#else
+#define DP(i)
+#endif
     for (uint32_t rr = 0;; ++rr) {
         const uint32_t job = item_of(rr, blockIdx.x, gridDim.x);
         if (job >= n_items) break;
         const uint4 d = A.items[job];
         const uint32_t place = job < A.n_items ? A.perm[job] : job | 0x80000000u;
         const uint32_t tagc = A.tagged ? ((d.z >> 1) ? kTagCount - (d.z >> 1) : rr) << kTagShift : 1u << 24;  // (see kTagShift)
-        // the next tile's steps are requested before this one is partitioned
-        uint32_t nxt[kDensePer];
-        const auto request = [&](uint64_t t0) {
-#pragma unroll
-            for (int k = 0; k < kDensePer; ++k) {
-                const uint64_t i = t0 + (uint32_t)k * kThreads + tid;
-                nxt[k] = i < d.y ? A.steps[i] : 0u;
-            }
+        // The steps of a full tile land in v112..v119, two dwordx4 per thread (steps 4 tid .. 4 tid + 3 of either half),
+        // requested a tile ahead: in C++ hipcc waits for a load as soon as its registers are copied into the next
+        // iteration's, and its vmcnt(0) waits for the record stores of the tile before as well.  As in k_scan: the
+        // registers are pinned (tools/check_pinned_vgprs.py), the wait is counted by hand -- eight stores at most have
+        // been issued since -- and the ids are taken out by the shifts that drop the orientation bit.
+        static_assert(kDensePer == 8 && kDenseTile == 8 * kThreads, "the landing registers hold eight steps per thread");
+        const auto issue = [&](uint64_t t0) {
+            const uint32_t *p0 = A.steps + t0 + 4u * tid, *p1 = p0 + kDenseTile / 2;
+            asm volatile("global_load_dwordx4 v[112:115], %0, off nt\n\tglobal_load_dwordx4 v[116:119], %1, off nt" ::"v"(p0), "v"(p1)
+                         : "memory", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
         };
-        request(d.x);
-        for (uint64_t t0 = d.x; t0 < d.y; t0 += kDenseTile) {
-            const uint32_t cnt = (uint32_t)min((uint64_t)kDenseTile, (uint64_t)d.y - t0);
-            uint32_t lr[kDensePer], cur[kDensePer];  // a step's rank in its window's bin; its (range-relative) id, or ~0 if it does not count
+        bool stores8 = false;  // the only vector-memory operations issued since the landing loads are eight record stores
+        // P1: a step's (range-relative) id, or ~0 if it does not count, and its rank in its window's bin.
+        // A full tile of a plan without ranges takes the plain form of every phase: no step of it is left out, so
+        // nothing is predicated -- the general form costs 46 vector and 56 scalar instructions a step (a branch
+        // around every atomic and every store), and a CU issues one scalar instruction per cycle for all its waves.
+        uint32_t cur[kDensePer], lr[kDensePer], ncur[kDensePer], nlr[kDensePer];
+        const auto is_plain = [&](uint64_t t0) { return !A.ranged && t0 + kDenseTile <= (uint64_t)d.y; };
+        const auto count = [&](uint64_t t0) {
+            if (is_plain(t0)) {
+                if (stores8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("v_lshrrev_b32 %0, 1, v112\n\tv_lshrrev_b32 %1, 1, v113\n\tv_lshrrev_b32 %2, 1, v114\n\tv_lshrrev_b32 %3, 1, v115\n\t"
+                             "v_lshrrev_b32 %4, 1, v116\n\tv_lshrrev_b32 %5, 1, v117\n\tv_lshrrev_b32 %6, 1, v118\n\tv_lshrrev_b32 %7, 1, v119"
+                             : "=v"(ncur[0]), "=v"(ncur[1]), "=v"(ncur[2]), "=v"(ncur[3]), "=v"(ncur[4]), "=v"(ncur[5]), "=v"(ncur[6]), "=v"(ncur[7])
+                             :
+                             : "memory");
+                if (is_plain(t0 + kDenseTile)) issue(t0 + kDenseTile);
+                stores8 = false;
 #pragma unroll
-            for (int k = 0; k < kDensePer; ++k) cur[k] = nxt[k];
-            if (t0 + kDenseTile < d.y) request(t0 + kDenseTile);
+                for (int k = 0; k < kDensePer; ++k) {
+                    bad |= ncur[k] >= A.n_segs;
+                    ncur[k] = min(ncur[k], A.n_segs - 1u);  // (a bad id: the call fails, and until it does everything stays in bounds)
+                    nlr[k] = atomicAdd(&hist[ncur[k] >> wb], 1u);
+                }
+                return;
+            }
+            const uint32_t cnt = (uint32_t)min((uint64_t)kDenseTile, (uint64_t)d.y - t0);
 #pragma unroll
             for (int k = 0; k < kDensePer; ++k) {
                 const uint32_t i = (uint32_t)k * kThreads + tid;
                 bool valid = i < cnt;
-                uint32_t id = cur[k] >> 1;
+                uint32_t id = (valid ? A.steps[t0 + i] : 0u) >> 1;
                 if (A.ranged) {
                     bad |= valid && id >= A.n_total;
                     valid = valid && id - A.seg_base < A.n_segs;
@@ -3029,46 +3067,108 @@ __global__ __launch_bounds__(kThreads) void k_scan_dense(const ScanArgs A) {
                     bad |= valid && id >= A.n_segs;
                     valid = valid && id < A.n_segs;
                 }
-                cur[k] = valid ? id : ~0u;
-                lr[k] = valid ? atomicAdd(&hist[id >> wb], 1u) : 0u;
+                ncur[k] = valid ? id : ~0u;
+                nlr[k] = valid ? atomicAdd(&hist[id >> wb], 1u) : 0u;
             }
-            lds_barrier();
-            if (tid < 64u) {  // exclusive prefix sum of the bins, by one wave: nwp / 64 consecutive bins per lane
+            if (is_plain(t0 + kDenseTile)) issue(t0 + kDenseTile);  // (cannot be: a tile that is not full is its item's last)
+            stores8 = false;
+        };
+        // P2, by one wave: exclusive prefix sum of the bins, nwp / 64 consecutive bins per lane; the cursors move
+        // on and the bins are empty again.  delta[bin] = what turns a place in the stage into the record's place in
+        // the bucket array, counted from this workgroup's first sub-bucket (less than 2^30: fast_plan_create).
+        const auto prefix = [&](uint32_t par) {
+            if (tid < 64u) {
+                uint32_t *delta = par ? delta1 : delta0;
                 const uint32_t per = A.nwp >> 6;
                 uint32_t sum = 0;
                 for (uint32_t k = 0; k < per; ++k) sum += hist[lane * per + k];
-                uint32_t run = wave_scan_incl(sum) - sum;
+                const uint32_t incl = wave_scan_incl(sum);
+                uint32_t run = incl - sum;
+                bool over = false;
                 for (uint32_t k = 0; k < per; ++k) {
-                    base[lane * per + k] = run;
-                    delta[lane * per + k] = bcur[lane * per + k] - run;  // place in the stage -> slot in the sub-bucket
-                    run += hist[lane * per + k];
+                    const uint32_t bin = lane * per + k;
+                    const uint32_t hk = hist[bin], bk = bcur[bin];
+                    base[bin] = run;
+                    delta[bin] = bin * A.stride + bk - run;  // (modulo 2^32 in a plan with more records than that: P4 then takes the window's part off again)
+                    bcur[bin] = bk + hk;
+                    over |= bk + hk > A.cap;
+                    hist[bin] = 0u;
+                    run += hk;
+                }
+                const bool any_over = __builtin_amdgcn_ballot_w64(over) != 0ull;
+                if (lane == 63u) {
+                    stage[kDenseTile + 1u + par] = incl;  // the tile's records
+                    stage[kDenseTile + 3u + par] = any_over ? 1u : 0u;  // ... and whether any of them is beyond its sub-bucket's end
                 }
             }
-            lds_barrier();
+        };
+        if (is_plain(d.x)) issue(d.x);
+        count(d.x);
+        lds_barrier();
+        prefix(0u);
+        lds_barrier();
+        uint32_t par = 0;
+        for (uint64_t t0 = d.x; t0 < d.y; t0 += kDenseTile, par ^= 1u) {
+            const bool more = t0 + kDenseTile < d.y;
+            const bool plain = !A.ranged && t0 + kDenseTile <= d.y;
 #pragma unroll
-            for (int k = 0; k < kDensePer; ++k) {
-                if (cur[k] != ~0u) {
-                    stage[base[cur[k] >> wb] + lr[k]] = cur[k];  // (the id: its window and its place in the window)
+            for (int k = 0; k < kDensePer; ++k) cur[k] = ncur[k], lr[k] = nlr[k];
+            DP(0);
+            if (more) count(t0 + kDenseTile);
+            DP(1);
+            // P3 (branch free, so that a thread's lookups are in flight together: a step that does not count goes to a sink)
+            if (plain) {
+#pragma unroll
+                for (int k = 0; k < kDensePer; ++k) stage[base[cur[k] >> wb] + lr[k]] = cur[k];  // (the id: its window and its place in the window)
+            } else {
+#pragma unroll
+                for (int k = 0; k < kDensePer; ++k) {
+                    const bool valid = cur[k] != ~0u;
+                    const uint32_t at = base[valid ? cur[k] >> wb : 0u] + lr[k];
+                    stage[valid ? at : kDenseTile] = cur[k];
                 }
             }
+            DP(2);
             lds_barrier();
-            // The stage holds the tile sorted by window: consecutive places are consecutive slots of
+            DP(3);
+            if (more) prefix(par ^ 1u);
+            DP(4);
+            // P4.  The stage holds the tile sorted by window: consecutive places are consecutive slots of
             // a sub-bucket until the window changes.  (A wave per bin instead -- uniform addresses, no
             // bin lookup per record -- was measured 20 % slower: sixteen bins in a row, each waiting
             // for its own LDS reads.)
-            const uint32_t total = base[A.nwp - 1u] + hist[A.nwp - 1u];
-            for (uint32_t j = tid; j < total; j += kThreads) {
-                const uint32_t id = stage[j], wn = id >> wb;
-                const uint32_t pos = delta[wn] + j;
-                if (pos < A.cap) mine[(size_t)wn * A.stride + pos] = (id & wmask) | tagc;
-                else ovf = true;
+            const uint32_t *delta = par ? delta1 : delta0;
+            const uint32_t total = stage[kDenseTile + 1u + par];
+            const bool over = stage[kDenseTile + 3u + par] != 0u;
+            uint32_t sid[kDensePer], dl[kDensePer];
+#pragma unroll
+            for (int k = 0; k < kDensePer; ++k) sid[k] = stage[(uint32_t)k * kThreads + tid];
+            if (plain && !over && small) {
+#pragma unroll
+                for (int k = 0; k < kDensePer; ++k) dl[k] = delta[sid[k] >> wb];
+#pragma unroll
+                for (int k = 0; k < kDensePer; ++k) mine[dl[k] + ((uint32_t)k * kThreads + tid)] = (sid[k] & wmask) | tagc;
+                stores8 = true;
+            } else {
+#pragma unroll
+                for (int k = 0; k < kDensePer; ++k) {
+                    const uint32_t j = (uint32_t)k * kThreads + tid;
+                    sid[k] = j < total ? sid[k] : 0u;
+                    dl[k] = delta[sid[k] >> wb];
+                }
+#pragma unroll
+                for (int k = 0; k < kDensePer; ++k) {
+                    const uint32_t j = (uint32_t)k * kThreads + tid;
+                    const uint32_t wn = sid[k] >> wb, pos = dl[k] + j - wn * A.stride;
+                    if (j < total) {
+                        if (pos < A.cap) mine[(size_t)wn * A.stride + pos] = (sid[k] & wmask) | tagc;
+                        else ovf = true;
+                    }
+                }
             }
+            DP(5);
             lds_barrier();
-            for (uint32_t i = tid; i < A.nwp; i += kThreads) {
-                bcur[i] += hist[i];
-                hist[i] = 0u;
-            }
-            lds_barrier();
+            DP(6);
         }
         const uint32_t at = place & 0x7FFFFFFFu;
         for (uint32_t i = tid; i < A.n_win; i += kThreads) {
@@ -3079,6 +3179,9 @@ __global__ __launch_bounds__(kThreads) void k_scan_dense(const ScanArgs A) {
         if (tid == 0) A.islot[at] = blockIdx.x | (place & 0x80000000u);
         __syncthreads();
     }
+#ifdef FGFA_DENSE_PROF
+    if ((blockIdx.x == 0 || blockIdx.x == 100) && (tid == 0 || tid == 1000)) printf("dense wg %u tid %u: between %llu count %llu scatter %llu barrierA %llu prefix %llu writeout %llu barrierB %llu\n", blockIdx.x, tid, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6]);
+#endif
     flag_if_any(A, bad, kStBounds);
     flag_if_any(A, ovf, kStOverflow);
     if (A.tagged && tid == 0) A.taken[blockIdx.x] = (n_items + gridDim.x - 1u) / gridDim.x;  // (item_of: no workgroup takes more)

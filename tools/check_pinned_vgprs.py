@@ -54,6 +54,7 @@ def main():
     bad, n_load, n_take, func = [], 0, 0, "?"
     n_acc_load = n_acc_take = 0
     n_tiny_load = n_tiny_take = 0
+    n_dense_load = n_dense_take = 0
     budgets = {}
     for ln in lines:
         s = ln.split(";")[0].strip()
@@ -92,7 +93,19 @@ def main():
                 else:
                     bad.append(f"{func}: {s}")
             continue
-        if "k_scan" not in func or "k_scan_dense" in func:  # only the kernels that use the landing sets (everything is inlined into them)
+        if "k_scan_dense" in func:  # a full tile's steps land in v112..v119 (two dwordx4 a thread), taken out by the shifts that drop the orientation bit
+            pins = set(range(112, 120))
+            if regs_of(s) & pins:
+                m = re.match(r"^global_load_dwordx4 v\[(112:115|116:119)\], v\[(\d+):(\d+)\], off nt$", s)
+                t = OK_TAKE.match(s)
+                if m and int(m.group(2)) not in pins and int(m.group(3)) not in pins:
+                    n_dense_load += 1
+                elif t and int(t.group(3)) in pins and int(t.group(2)) not in pins:
+                    n_dense_take += 1
+                else:
+                    bad.append(f"{func}: {s}")
+            continue
+        if "k_scan" not in func:  # only the kernels that use the landing sets (everything is inlined into them)
             continue
         touched = regs_of(s) & PINNED
         if not touched:
@@ -114,13 +127,15 @@ def main():
         bad.append("no pinned record loads/takes found in k_accum -- did the kernel change?")
     if n_tiny_load == 0 or n_tiny_take == 0:
         bad.append("no pinned loads/takes found in k_scan_tiny -- did the kernel change?")
+    if n_dense_load == 0 or n_dense_take == 0:
+        bad.append("no pinned loads/takes found in k_scan_dense -- did the kernel change?")
     if n_load == 0 or n_take == 0:
         bad.append("no pinned loads/takes found -- did the kernel change?")
     if bad:
         print("pinned-VGPR check FAILED:\n  " + "\n  ".join(bad[:20]))
         return 1
     print(f"pinned-VGPR check ok: k_accum {n_acc_load} record loads, {n_acc_take} takes, nothing else touches v120..v122 (tagged walk: v{123 - depth}..v122, k_accum_pair: v61..v63); "
-          f"k_scan_tiny {n_tiny_load} loads, {n_tiny_take} takes (v118..v123); k_scan {n_load} loads, {n_take} takes, nothing else touches v80..v127; "
+          f"k_scan_tiny {n_tiny_load} loads, {n_tiny_take} takes (v118..v123); k_scan_dense {n_dense_load} loads, {n_dense_take} takes (v112..v119); k_scan {n_load} loads, {n_take} takes, nothing else touches v80..v127; "
           f"k_scan budgets {sorted(set(v for k, v in budgets.items() if 'k_scan' in k))}")
     return 0
 
