@@ -85,6 +85,10 @@ constexpr int kShortHash = 9;              // per-wave hash set of 512 (bitset w
 // The medium-path variant: eight waves per workgroup, each with a hash set of 2048 entries, for paths
 // whose run count (known to the plan) fits it.
 constexpr int kMediumHash = 11, kMediumWaves = 8;
+#ifndef FGFA_SHORT_WAVES
+#define FGFA_SHORT_WAVES 16
+#endif
+constexpr int kShortWaves = FGFA_SHORT_WAVES;  // waves of a k_scan_short workgroup (measurements: fewer = lower occupancy)
 constexpr uint32_t kMediumRuns = 1500;
 constexpr uint32_t kMaxHandBack = 4096;    // short paths k_scan_short may hand back to k_scan per call
 
@@ -851,7 +855,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
 }
 
 template <bool UNIQ>
-constexpr auto k_walk_short = k_scan_short<UNIQ, kWaves, kShortHash, true>;
+constexpr auto k_walk_short = k_scan_short<UNIQ, kShortWaves, kShortHash, true>;
 template <bool UNIQ>
 constexpr auto k_walk_medium = k_scan_short<UNIQ, kMediumWaves, kMediumHash, false>;
 
@@ -3735,7 +3739,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             FAST_TRY(hipMemcpy(fp->other_ids, other.data(), other.size() * 4, hipMemcpyHostToDevice));
         }
     }
-    fp->lds_bytes_short = (kShortMaxWin + kWaves * (kQCap + 2 * kPCap + (2u << kShortHash))) * 4u;
+    fp->lds_bytes_short = (kShortMaxWin + kShortWaves * (kQCap + 2 * kPCap + (2u << kShortHash))) * 4u;
     fp->lds_bytes_medium = (kShortMaxWin + kMediumWaves * (kQCap + 2 * kPCap + (2u << kMediumHash))) * 4u;
     // (the attribute belongs to the kernel, not to the plan: plans of different sizes live side by side)
     FAST_TRY(hipFuncSetAttribute((const void *)k_walk_short<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
@@ -4209,15 +4213,15 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
                 sk.path_begin = g.path_begin;
                 sk.path_end = g.path_end;
             }
-            const uint32_t per_wg = medium ? kMediumWaves : kWaves;
+            const uint32_t per_wg = medium ? kMediumWaves : kShortWaves;
             const uint32_t kgrid = std::min<uint32_t>((n + per_wg - 1) / per_wg, fp.n_slots);
             ProfScope pscope(medium ? (uniq_out ? "k_scan_medium<uniq>" : "k_scan_medium<depth>") : (uniq_out ? "k_scan_short<uniq>" : "k_scan_short<depth>"), stream);
             if (medium) {
                 if (uniq_out) hipLaunchKernelGGL(k_walk_medium<true>, dim3(kgrid), dim3(kMediumWaves * 64), fp.lds_bytes_medium, stream, sk);
                 else hipLaunchKernelGGL(k_walk_medium<false>, dim3(kgrid), dim3(kMediumWaves * 64), fp.lds_bytes_medium, stream, sk);
             } else {
-                if (uniq_out) hipLaunchKernelGGL(k_walk_short<true>, dim3(kgrid), dim3(kThreads), fp.lds_bytes_short, stream, sk);
-                else hipLaunchKernelGGL(k_walk_short<false>, dim3(kgrid), dim3(kThreads), fp.lds_bytes_short, stream, sk);
+                if (uniq_out) hipLaunchKernelGGL(k_walk_short<true>, dim3(kgrid), dim3(kShortWaves * 64), fp.lds_bytes_short, stream, sk);
+                else hipLaunchKernelGGL(k_walk_short<false>, dim3(kgrid), dim3(kShortWaves * 64), fp.lds_bytes_short, stream, sk);
             }
         }
     }
