@@ -2698,7 +2698,7 @@ uint32_t tagged_lds_bytes(uint32_t wb, uint32_t n_shared, uint32_t slots = kTagS
 // one instruction per cycle and CU where two are possible, and eight waves per SIMD hide more of its
 // LDS round trips than four.  Both leave their partial vectors in scratch; the second one to
 // finish adds the other's to its own and writes the results.
-template <bool UNIQ, int WB, bool PSUM, bool POINT, bool BIG, bool TAGGED, bool PAIR, int SLOTS = (int)kTagSlots>
+template <bool UNIQ, int WB, bool PSUM, bool POINT, bool BIG, bool TAGGED, bool PAIR, int SLOTS = (int)kTagSlots, bool LOWREG = PAIR>
 __device__ __forceinline__ void accum_body(const AccArgs &A) {
     constexpr uint32_t kW = 1u << WB;
     constexpr int kPer = kW / kAccThreads;  // cells per thread: 4 or 8
@@ -2781,10 +2781,12 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
     __syncthreads();
     const uint32_t *wbase = A.pk ? A.buckets : A.buckets + (size_t)win * A.n_slots * A.cap;  // (a packed plan's starts count from the array's)
     tm.mark(0);
-    if (flat) apply_flat<UNIQ, WB, (PAIR ? 4 : 16)>(A, D, R, scnt, sstart, wbase);
+    if (flat) apply_flat<UNIQ, WB, (LOWREG ? 4 : 16)>(A, D, R, scnt, sstart, wbase);
     tm.mark(1);
     if (UNIQ && TAGGED) {
         if (PAIR) apply_tagged<WB, POINT, false, true>(A, D, R, tag_bits, scnt2, wbase, &grab);
+        else if (LOWREG && A.n_shared) apply_tagged<WB, POINT, true, true, SLOTS>(A, D, R, tag_bits, scnt2, wbase, &grab);
+        else if (LOWREG) apply_tagged<WB, POINT, false, true, SLOTS>(A, D, R, tag_bits, scnt2, wbase, &grab);
         else if (A.n_shared) apply_tagged<WB, POINT, true, false, SLOTS>(A, D, R, tag_bits, scnt2, wbase, &grab);
         else apply_tagged<WB, POINT, false, false, SLOTS>(A, D, R, tag_bits, scnt2, wbase, &grab);
     } else if (UNIQ) {
@@ -2905,6 +2907,12 @@ __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
 template <int WB, bool POINT>
 __global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_accum_pair(const AccArgs A) {
     accum_body<true, WB, false, POINT, false, true, true>(A);
+}
+// Half-size windows, TWO of them resident on a CU (64 registers): eight waves per SIMD without a second
+// workgroup's setup, scan and exchange per window.
+template <int WB>
+__global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_accum_small(const AccArgs A) {
+    accum_body<true, WB, false, false, false, true, false, (int)kTagSlots, true>(A);
 }
 
 // Plan time: how many runs (as k_scan_short cuts them: +1 continuations, cut at multiples of 32)
@@ -3765,6 +3773,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 12, false, false, false, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, 64, 8)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 13, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(13, 0)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum<true, 13, false, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(13, 0)));
+    FAST_TRY(hipFuncSetAttribute((const void *)k_accum_small<11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(11, kMaxShared)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum_pair<12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, 0)));
     FAST_TRY(hipFuncSetAttribute((const void *)k_accum_pair<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tagged_lds_bytes(12, 0)));
     // Two pass-2 workgroups per window (k_accum_pair): tagged plans without split paths whose windows
@@ -4274,6 +4283,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
             const uint32_t tl = tagged_lds_bytes(fp.wb, fp.n_shared);
             if (fp.dense && fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12, false, true, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
             else if (fp.dense && fp.wb == 13) hipLaunchKernelGGL((k_accum<true, 13, false, true, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
+            else if (fp.wb == 11 && getenv("FLATGFA_ACC_SMALL")) hipLaunchKernelGGL((k_accum_small<11>), agrid, dim3(kAccThreads), tl, stream, aa);
             else if (fp.wb == 11) hipLaunchKernelGGL((k_accum<true, 11, false, false, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);
             else if (fp.wb == 12 && fp.acc_slots == 8 && fp.n_shared <= 64) hipLaunchKernelGGL((k_accum<true, 12, false, false, false, true, 8>), agrid, dim3(kAccThreads), tagged_lds_bytes(12, fp.n_shared, 8), stream, aa);
             else if (fp.wb == 12) hipLaunchKernelGGL((k_accum<true, 12, false, false, false, true>), agrid, dim3(kAccThreads), tl, stream, aa);

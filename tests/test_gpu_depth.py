@@ -19,7 +19,7 @@ FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
 @pytest.fixture(params=["auto", "bucketed", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3", "ranges", "dense",
-                        "untagged", "untagged_pieces", "untagged_noshort", "pair", "groups3", "packed", "slots8"])
+                        "untagged", "untagged_pieces", "untagged_noshort", "pair", "groups3", "packed", "slots8", "small11"])
 def device_path(request, monkeypatch):
     """Runs a test once per device path: the default (up to 8 M steps the plan times the bucketed
     path against the atomic kernels on the graph at hand and keeps the faster), the bucketed path
@@ -51,6 +51,13 @@ def device_path(request, monkeypatch):
     monkeypatch.delenv("FLATGFA_PATH_GROUPS", raising=False)
     monkeypatch.delenv("FLATGFA_PACKED", raising=False)
     monkeypatch.delenv("FLATGFA_ACC_SLOTS", raising=False)
+    monkeypatch.delenv("FLATGFA_WB", raising=False)
+    monkeypatch.delenv("FLATGFA_ACC_SMALL", raising=False)
+    if request.param == "small11":  # windows of 2048 segments, two pass-2 workgroups of 64 registers resident per CU (k_accum_small: a measurement's build, profiles/NOTES.md R4.9)
+        monkeypatch.setenv("FLATGFA_WB", "11")
+        monkeypatch.setenv("FLATGFA_ACC_SMALL", "1")
+        monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
+        monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
     if request.param == "slots8":  # eight private bitsets per pass-2 wave wherever the plan allows them (by default only where a workgroup of pass 1 takes more than four items)
         monkeypatch.setenv("FLATGFA_ACC_SLOTS", "8")
         monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")

@@ -70,7 +70,7 @@ def main():
         if "k_accum" in func:  # pass 2: pinned record registers -- v120..v122 (rec_request / rec_take), and in the
             # build with two workgroups per CU (k_accum_pair, 64 registers) v61..v63 (rec_request_lo / rec_take_lo)
             tagged = re.search(r"k_accumILb\dELi\d+ELb\dELb\dELb\dELb1ELi\d+EE", func) is not None  # (the template argument before the last: tagged)
-            pins = {61, 62, 63} if "k_accum_pair" in func else tagged_pins if tagged else {120, 121, 122}  # (the build with 64 registers lands its records in v61..v63)
+            pins = {61, 62, 63} if ("k_accum_pair" in func or "k_accum_small" in func) else tagged_pins if tagged else {120, 121, 122}  # (the build with 64 registers lands its records in v61..v63)
             if regs_of(s) & pins:
                 m = re.match(r"^global_load_dword v(\d+), (v\[\d+:\d+\], off|v\d+, s\[\d+:\d+\])$", s)
                 t = re.match(r"^v_mov_b32(_e32)? v(\d+), v(\d+)$", s)

@@ -31,7 +31,8 @@ ENVS = [{}, {"FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0"}, {"FL
         {"FLATGFA_PACKED": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed", "FLATGFA_PIECE_STEPS": "3000"},
         {"FLATGFA_PACKED": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed", "FLATGFA_RANGE_SEGS": "65536"},
         {"FLATGFA_ACC_SLOTS": "8", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
-        {"FLATGFA_ACC_SLOTS": "4", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed", "FLATGFA_ACC_PAIR": "0"}]
+        {"FLATGFA_ACC_SLOTS": "4", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed", "FLATGFA_ACC_PAIR": "0"},
+        {"FLATGFA_WB": "11", "FLATGFA_ACC_SMALL": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"}]
 
 
 def random_graph(rng):
@@ -111,7 +112,7 @@ def main():
         pools.paths, pools.steps, pools.segs = paths, steps, segs
         want_d, want_u = fo.seg_depth_with_uniq(pools)
         env = ENVS[case % len(ENVS)]
-        for k in ("FLATGFA_SHORT_MAX", "FLATGFA_BUCKET_CAP", "FLATGFA_PIECE_STEPS", "FLATGFA_DEPTH_PATH", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS", "FLATGFA_DENSE", "FLATGFA_BIG_GROUPS", "FLATGFA_TAGGED", "FLATGFA_ACC_PAIR", "FLATGFA_SCAN_ALWAYS", "FLATGFA_WB", "FLATGFA_PATH_GROUPS"):
+        for k in ("FLATGFA_SHORT_MAX", "FLATGFA_BUCKET_CAP", "FLATGFA_PIECE_STEPS", "FLATGFA_DEPTH_PATH", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS", "FLATGFA_DENSE", "FLATGFA_BIG_GROUPS", "FLATGFA_TAGGED", "FLATGFA_ACC_PAIR", "FLATGFA_SCAN_ALWAYS", "FLATGFA_WB", "FLATGFA_PATH_GROUPS", "FLATGFA_ACC_SMALL"):
             os.environ.pop(k, None)
         os.environ.update(env)
         graph = dev.DeviceGraph(steps, pb, pe, S, seg_len, device="cuda:0")
