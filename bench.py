@@ -31,6 +31,7 @@ is single-threaded) timed on this host.
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -275,6 +276,20 @@ def main():
     roofline = None
     if dom:
         B_dom = kernel_bytes(dom, N_local, P_local, S, 2)
+        # A kernel that is launched several times per call on different paths (k_scan_short: once for the paths read
+        # forwards, once for the reversed copies) reads its share of the steps per launch; a plan with segment ranges
+        # walks ALL steps once per range.  `achieved` is per launch: the launch's bytes over the launch's time.
+        launches = len(per[dom]) / max(n_timed_steps, 1)
+        m_ranges = re.search(r"ranges=(\d+)", plan.describe())
+        shares = max(1.0, launches / max(1, int(m_ranges.group(1)) if m_ranges else 1))
+        # ... and where several scan kernels share the paths out, each reads its own paths' steps (the plan says how many)
+        m_steps = re.search(r" steps=(\d+)/(\d+)/(\d+)/(\d+)", plan.describe())
+        cls = {"k_scan_short": 1, "k_scan_medium": 2, "k_scan_tiny": 3, "k_scan_dense": 0, "k_scan": 0}.get(dom.split("<")[0])
+        if m_steps and cls is not None and not dom.startswith("k_accum"):
+            B_dom = 4 * int(m_steps.group(1 + cls)) + 8 * P_local
+        if dom.startswith("k_accum"):
+            shares = max(1.0, launches)  # (pass 2: a launch per range of segments, each writing its range's counts)
+        B_dom = int(B_dom / shares)
         achieved = B_dom / (kern_avg_ms[dom] * 1e-3) / 1e9
         # HBM bytes per launch of the dominant kernel from the PMC counters: they need separate
         # rocprofv3 --pmc passes (tools/profile_round.sh), so the committed summary of the same
@@ -296,6 +311,7 @@ def main():
                                    "achieved": round(whole, 2) if whole else None,
                                    "frac": round(whole / HBM_PEAK_GBS, 5) if whole else None},
                     "kernels_avg_ms": {k: round(v, 5) for k, v in kern_avg_ms.items()},
+                    "kernel_launches_per_step": {k: round(len(v) / max(n_timed_steps, 1), 2) for k, v in per.items()},
                     "plan_choice": plan.describe(),
                     "kernel_timing": f"HIP events around each launch: steps {EVENT_AT}, {EVENT_AT + EVENT_EVERY}, ... of the timed region "
                                      f"({n_region_samples} of {args.steps} steps; never step 0) plus {SAMPLE_STEPS} consecutive steps right "

@@ -737,7 +737,9 @@ extern "C" int flatgfa_dev_plan_describe(flatgfa_dev_plan_t *pl, char *out, int 
             " windows=" + std::to_string(f.n_win) + "x" + std::to_string(1u << f.wb) + " ranges=" + std::to_string((f.n_more + 1) / f.n_groups) +
             (f.n_groups > 1 ? " path_groups=" + std::to_string(f.n_groups) : std::string()) +
             " workgroups_per_window=" + std::to_string(f.acc_parts) + " items=" + std::to_string(f.n_items) + " split_paths=" + std::to_string(f.n_shared) +
-            " short_paths=" + std::to_string(f.n_short) + " medium_paths=" + std::to_string(f.n_medium) + " tiny_paths=" + std::to_string(f.n_tiny) + " bucket_cap=" + std::to_string(f.cap);
+            " short_paths=" + std::to_string(f.n_short) + " medium_paths=" + std::to_string(f.n_medium) + " tiny_paths=" + std::to_string(f.n_tiny) +
+            " steps=" + std::to_string(f.class_steps[0]) + "/" + std::to_string(f.class_steps[1]) + "/" + std::to_string(f.class_steps[2]) + "/" + std::to_string(f.class_steps[3]) +  // (by k_scan / short / medium / tiny)
+            " bucket_cap=" + std::to_string(f.cap);
         // the record buckets of all ranges and path groups: how they are laid out, what they take
         const auto records_of = [](const FastPlan &q) { return q.packed ? q.bucket_records : ((uint64_t)q.n_win + 1) * q.n_slots * q.cap; };
         uint64_t recs = records_of(f);

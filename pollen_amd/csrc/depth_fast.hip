@@ -372,6 +372,7 @@ __device__ __forceinline__ void take_block(uint32_t (&a)[16]) {
 // `vm` are wave-uniform.
 struct Wave {
     uint32_t *q, *pq;
+    uint32_t *dummy;  // 64 (key, bits) pairs no path's words hash to: where lanes without a run probe (claim_hashed)
     uint32_t fill, pfill;
     uint32_t vm[3];  // memory instructions issued since the loads into landing set 0 / 1 / 2 (see wait_block)
     int lane;
@@ -409,23 +410,31 @@ __device__ __forceinline__ void push_partial(Wave &w, bool e, uint32_t word, uin
 // The path's "seen" words live in a small per-wave hash set instead of a bitset over all
 // segments.  The plan only sends a path here when its runs fit the set.
 template <int BITS>
-__device__ __forceinline__ uint32_t claim_hashed(const ScanArgs &A, uint32_t *tab, bool valid, uint32_t word, uint32_t mask) {
+__device__ __forceinline__ uint32_t claim_hashed(const ScanArgs &A, uint32_t *tab, uint32_t *dummy, int lane, bool valid, uint32_t word, uint32_t mask) {
+    // The first probe -- nearly always the last -- is taken by all lanes with nothing predicated: a lane without a
+    // run probes an entry of its own in `dummy` (64 pairs behind the hash sets), a lane whose probe finds another
+    // word's entry ORs nothing.  (As a loop with the probes under `if (todo)` hipcc spent eighty scalar
+    // instructions per chunk on exec masks.)
     uint32_t h = (word * 0x9E3779B1u) >> (32 - BITS);
-    bool todo = valid;
-    uint32_t old = 0, probes = 0;
+    const uint32_t key = word + 1u;
+    uint32_t *e = valid ? tab + 2u * h : dummy + 2u * (uint32_t)lane;
+    uint32_t k = atomicCAS(e, 0u, key);
+    bool ok = k == 0u || k == key;
+    uint32_t old = atomicOr(e + 1, ok ? mask : 0u);
+    bool todo = valid && !ok;
+    uint32_t probes = 1;
     while (__builtin_amdgcn_ballot_w64(todo)) {
         if (++probes > (1u << BITS)) {  // cannot happen while the plan matches the steps: the set would be full
             atomicOr(A.status, kStBounds);
             break;
         }
+        h = (h + 1u) & ((1u << BITS) - 1u);
         if (todo) {
-            uint32_t *e = tab + 2u * h;
-            const uint32_t k = atomicCAS(e, 0u, word + 1u);
-            if (k == 0u || k == word + 1u) {
+            e = tab + 2u * h;
+            k = atomicCAS(e, 0u, key);
+            if (k == 0u || k == key) {
                 old = atomicOr(e + 1, mask);
                 todo = false;
-            } else {
-                h = (h + 1u) & ((1u << BITS) - 1u);
             }
         }
     }
@@ -481,7 +490,7 @@ __device__ __forceinline__ void emit_chunk(const ScanArgs &A, Wave &w, uint32_t 
     uint32_t kind = 0, pos;
     if (UNIQ) {
         const uint32_t mask = valid ? (0xFFFFFFFFu >> (31u - lenm1)) << (id & 31u) : 0u;
-        const uint32_t old = (FGFA_SHORT_ABLATE & 4) ? 0u : claim_hashed<HASH>(A, seen, valid, id >> 5, mask);
+        const uint32_t old = (FGFA_SHORT_ABLATE & 4) ? 0u : claim_hashed<HASH>(A, seen, w.dummy, w.lane, valid, id >> 5, mask);
         pos = take_slots(bcur, w.lane, valid, win);
         const uint32_t nb = mask & ~old;
         kind = (nb == mask) ? 2u : 0u;
@@ -765,7 +774,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
     constexpr uint32_t kTab = 1u << HASH;
     constexpr int kThr = WAVES * 64;
     extern __shared__ uint32_t lds[];
-    // layout: [bcur: kShortMaxWin][run queues: WAVES * kQCap][parked-claim queues: WAVES * 2 * kPCap][hash sets: WAVES * 2 * kTab]
+    // layout: [bcur: kShortMaxWin][run queues: WAVES * kQCap][parked-claim queues: WAVES * 2 * kPCap][hash sets: WAVES * 2 * kTab][dummy: 128]
     uint32_t *bcur = lds;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -774,6 +783,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
     Wave w;
     w.q = lds + kShortMaxWin + wave * kQCap;
     w.pq = lds + kShortMaxWin + WAVES * kQCap + wave * (2 * kPCap);
+    w.dummy = lds + kShortMaxWin + WAVES * (kQCap + 2 * kPCap + 2 * kTab);  // (shared by the waves: what lands there is never read)
     w.fill = w.pfill = 0;
     w.vm[0] = w.vm[1] = w.vm[2] = 0;
     w.lane = lane;
@@ -3501,6 +3511,17 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     fp->n_short = (uint32_t)short_items.size();
     fp->n_medium = (uint32_t)medium_items.size();
     fp->n_tiny = (uint32_t)tiny_items.size();
+    {
+        const auto steps_of = [](const std::vector<uint4> &v) {
+            uint64_t n = 0;
+            for (const uint4 &d : v) n += d.y - d.x;
+            return n;
+        };
+        fp->class_steps[0] = steps_of(items);
+        fp->class_steps[1] = steps_of(short_items);
+        fp->class_steps[2] = steps_of(medium_items);
+        fp->class_steps[3] = steps_of(tiny_items);
+    }
     if (items.empty() && short_items.empty() && medium_items.empty() && tiny_items.empty()) return true;
     fp->max_back = std::min<uint32_t>(fp->n_short, kMaxHandBack);
     fp->exact_short = !short_any;  // the run counts the lists were made from are exact: nothing is handed back
@@ -3747,8 +3768,8 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             FAST_TRY(hipMemcpy(fp->other_ids, other.data(), other.size() * 4, hipMemcpyHostToDevice));
         }
     }
-    fp->lds_bytes_short = (kShortMaxWin + kShortWaves * (kQCap + 2 * kPCap + (2u << kShortHash))) * 4u;
-    fp->lds_bytes_medium = (kShortMaxWin + kMediumWaves * (kQCap + 2 * kPCap + (2u << kMediumHash))) * 4u;
+    fp->lds_bytes_short = (kShortMaxWin + kShortWaves * (kQCap + 2 * kPCap + (2u << kShortHash)) + 128u) * 4u;
+    fp->lds_bytes_medium = (kShortMaxWin + kMediumWaves * (kQCap + 2 * kPCap + (2u << kMediumHash)) + 128u) * 4u;
     // (the attribute belongs to the kernel, not to the plan: plans of different sizes live side by side)
     FAST_TRY(hipFuncSetAttribute((const void *)k_walk_short<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     FAST_TRY(hipFuncSetAttribute((const void *)k_walk_short<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));

@@ -77,6 +77,7 @@ struct FastPlan {
     uint32_t lds_bytes_medium = 0;
     void *tiny_items = nullptr;    // uint4[n_tiny] paths of at most 128 steps: a wave holds one whole (k_scan_tiny)
     uint32_t n_tiny = 0;
+    uint64_t class_steps[4] = {0, 0, 0, 0};  // steps walked by k_scan / k_scan_short / k_scan_medium / k_scan_tiny (flatgfa_dev_plan_describe)
     uint32_t lds_bytes_tiny = 0;
     uint32_t *taken = nullptr;         // u32[n_slots] items each workgroup of the last tagged k_scan took
     uint32_t *work_counter = nullptr;  // how many short paths were handed back in this call

@@ -864,3 +864,41 @@ def test_steps_kept_in_the_infinity_cache_are_budgeted_per_device(monkeypatch):
     assert resident(p) == 37
     check(p)
     p.close()
+
+
+def test_plan_says_how_many_steps_each_scan_kernel_walks(monkeypatch):
+    """`steps=a/b/c/d` of a plan's description: the steps walked by k_scan / k_scan_short / k_scan_medium / k_scan_tiny
+    (bench.py prices a kernel's launches against the bytes of its own paths).  Every step is in exactly one class."""
+    import re
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    for v in ("FLATGFA_SHORT_MAX", "FLATGFA_NO_TINY", "FLATGFA_TAGGED", "FLATGFA_WB", "FLATGFA_PACKED"):
+        monkeypatch.delenv(v, raising=False)
+    S = 300_000
+    rng = np.random.default_rng(11)
+    lens = np.concatenate([rng.integers(1, 100, 500), rng.integers(200, 2000, 300), rng.integers(3000, 9000, 60), rng.integers(40_000, 90_000, 12)])
+    rng.shuffle(lens)
+    starts = rng.integers(0, S - 100_000, len(lens))
+    ids = np.concatenate([np.arange(s, s + n) for s, n in zip(starts, lens)]).astype(np.uint32)
+    steps = (ids << 1).astype(np.uint32)
+    pe = np.cumsum(lens).astype(np.uint32)
+    pb = (pe - lens).astype(np.uint32)
+    plan = DepthPlan(DeviceGraph(steps, pb, pe, S))
+    text = plan.describe()
+    m = re.search(r" steps=(\d+)/(\d+)/(\d+)/(\d+)", text)
+    assert m, text
+    by = [int(x) for x in m.groups()]
+    assert sum(by) == len(steps), text
+    assert by[3] == int(lens[lens <= 128].sum()) and by[0] >= int(lens[lens >= 40_000].sum()), text
+    assert all(by), text  # (runs of consecutive ids: the paths of 200 .. 9000 steps have few runs, so single waves walk them)
+    import torch
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    plan.seg_depth(d, u)
+    plan.status()
+    want = np.bincount(ids, minlength=S)
+    assert (d.cpu().numpy() == want).all()
+    seen = np.zeros(S, dtype=np.int64)
+    for s, n in zip(starts, lens):
+        seen[s:s + n] += 1
+    assert (u.cpu().numpy() == seen).all()
