@@ -122,7 +122,9 @@ constexpr uint32_t kDbgNoStore = 1, kDbgNoTiles = 8, kDbgHotLoads = 16, kDbgTime
 #define FGFA_SKIP(bit) (DBG && (A.dbg & (bit)))
 
 struct ScanArgs {
-    const uint32_t *path_begin, *path_end;  // set when `steps` is the reversed copy: a handed-back path is walked from the graph's own steps
+    const uint32_t *path_begin, *path_end;  // the graph's spans: a handed-back path that was read from its reversed copy is walked by k_scan from the graph's own steps
+    const uint32_t *rev_steps;  // the wave-per-path kernels: the reversed copies, which the paths from n_fwd on in the list are read from (one launch for both)
+    uint32_t n_fwd;
     uint32_t seg_base, n_total, ranged;  // ranged: this walk keeps what falls into [seg_base, seg_base + n_segs) of the graph's n_total segments
     uint32_t *zero_a, *zero_b;  // k_scan clears these vectors of n_segs counts first (pass 2 adds to them when windows are shared); or null
     unsigned long long *zero_c, *zero_d;  // ... and these two of n_zero64 sums (the paths' sums k_path_reduce adds to); or null
@@ -807,9 +809,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
     }
     ShortBlk slot[2];
     bool handed_back = false;  // the current path did not fit the run queue
-    const uint4 *steps4 = reinterpret_cast<const uint4 *>(A.steps);
+    const uint4 *steps4 = reinterpret_cast<const uint4 *>(A.steps), *rev4 = reinterpret_cast<const uint4 *>(A.rev_steps);
     // lanes beyond the last one holding steps re-read lane 0's chunk
-#define FGFA_SPTR(K) (steps4 + (size_t)(K).pos / 4 + ((uint32_t)lane < (K).nl ? lane * 4 : 0))
+#define FGFA_SPTR(K) (((K).item >= A.n_fwd ? rev4 : steps4) + (size_t)(K).pos / 4 + ((uint32_t)lane < (K).nl ? lane * 4 : 0))
     slot[0] = stream_next(A, g, lane);
     if (slot[0].valid) load_block_async<0>(w, FGFA_SPTR(slot[0]));
     slot[1] = stream_next(A, g, lane);
@@ -839,7 +841,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
                 if (lane == 0) {                                                                        \
                     const uint32_t k = atomicAdd(A.work_counter, 1u);                                   \
                     const uint32_t hp = A.short_items[cur.item].w;                                      \
-                    if (k < A.max_back) A.items[A.n_items + k] = A.path_begin ? make_uint4(A.path_begin[hp], A.path_end[hp], 0u, hp) : make_uint4(cur.b, cur.e, 0u, hp); \
+                    if (k < A.max_back) A.items[A.n_items + k] = cur.item >= A.n_fwd ? make_uint4(A.path_begin[hp], A.path_end[hp], 0u, hp) : make_uint4(cur.b, cur.e, 0u, hp); \
                     else atomicOr(A.status, kStBackOverflow);                                           \
                 }                                                                                       \
                 handed_back = false;                                                                    \
@@ -4165,6 +4167,8 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     sa.zero_c = sa.zero_d = nullptr;
     sa.n_zero64 = 0;
     sa.path_begin = sa.path_end = nullptr;
+    sa.rev_steps = nullptr;
+    sa.n_fwd = ~0u;
     sa.steps = g.steps;
     sa.n_steps = g.n_steps;
     sa.items = reinterpret_cast<uint4 *>(fp.items);
@@ -4231,18 +4235,16 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     for (int medium = 0; medium < 2; ++medium) {
         const uint32_t n_all = medium ? fp.n_medium : fp.n_short, n_rev = medium ? fp.n_medium_rev : fp.n_short_rev;
         const uint4 *list = reinterpret_cast<const uint4 *>(medium ? fp.medium_items : fp.short_items);
-        for (int rev = 0; rev < 2; ++rev) {
-            const uint32_t n = rev ? n_rev : n_all - n_rev;
+        {
+            const uint32_t n = n_all;
             if (!n) continue;
             ScanArgs sk = sa;
-            sk.short_items = list + (rev ? n_all - n_rev : 0u);
+            sk.short_items = list;
             sk.n_short = n;
-            if (rev) {
-                sk.steps = fp.rev_steps;
-                sk.n_steps = fp.n_rev_steps;
-                sk.path_begin = g.path_begin;
-                sk.path_end = g.path_end;
-            }
+            sk.n_fwd = n_all - n_rev;  // (the reversed ones lie behind the others in the list)
+            sk.rev_steps = fp.rev_steps;
+            sk.path_begin = g.path_begin;
+            sk.path_end = g.path_end;
             const uint32_t per_wg = medium ? kMediumWaves : kShortWaves;
             const uint32_t kgrid = std::min<uint32_t>((n + per_wg - 1) / per_wg, fp.n_slots);
             ProfScope pscope(medium ? (uniq_out ? "k_scan_medium<uniq>" : "k_scan_medium<depth>") : (uniq_out ? "k_scan_short<uniq>" : "k_scan_short<depth>"), stream);
