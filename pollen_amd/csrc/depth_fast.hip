@@ -84,7 +84,12 @@ constexpr uint32_t kDummyBase = 1u << 20;  // ids from here up stand in for step
 constexpr int kShortHash = 9;              // per-wave hash set of 512 (bitset word index + 1, bits) pairs
 // The medium-path variant: eight waves per workgroup, each with a hash set of 2048 entries, for paths
 // whose run count (known to the plan) fits it.
-constexpr int kMediumHash = 11, kMediumWaves = 8;
+#ifndef FGFA_MEDIUM_PAIRED
+#define FGFA_MEDIUM_PAIRED 1
+#endif
+constexpr bool kMediumPaired = FGFA_MEDIUM_PAIRED != 0;  // two waves per path and hash set (k_scan_short<..., PAIRED>)
+constexpr int kMediumHash = 11, kMediumWaves = kMediumPaired ? 14 : 8;
+constexpr uint32_t kQPaired = 320;  // a paired wave's run queue: 63 left over + up to 256 from four steps of every lane
 #ifndef FGFA_SHORT_WAVES
 #define FGFA_SHORT_WAVES 16
 #endif
@@ -375,6 +380,7 @@ __device__ __forceinline__ void take_block(uint32_t (&a)[16]) {
 struct Wave {
     uint32_t *q, *pq;
     uint32_t *dummy;  // 64 (key, bits) pairs no path's words hash to: where lanes without a run probe (claim_hashed)
+    uint32_t qcap;    // entries the run queue holds (uniform)
     uint32_t fill, pfill;
     uint32_t vm[3];  // memory instructions issued since the loads into landing set 0 / 1 / 2 (see wait_block)
     int lane;
@@ -649,7 +655,7 @@ __device__ __forceinline__ bool block16(const ScanArgs &A, Wave &w, uint32_t *se
     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
     const unsigned long long below = __builtin_amdgcn_ballot_w64(cnt != 0u) & ((1ull << w.lane) - 1ull);
     const int src = below ? 63 - __builtin_clzll(below) : w.lane;
-    if (w.fill + total <= kQCap) {
+    if (w.fill + total <= w.qcap) {
         // pass B, lane-local: `cur` is the start of the run in progress, 0 standing in for the
         // one that entered the lane (then the entry holds just the run's last id until patched)
         uint32_t *const p0 = w.q + w.fill + (incl - slots);
@@ -717,6 +723,7 @@ struct ShortBlk {
     uint32_t nl;       // lanes holding steps
     uint32_t item;     // the path's position in the list of short paths
     bool last, valid;  // last block of its path; there is a block at all
+    bool skip;         // (paired waves) no block: the path's end as seen by the wave whose partner walks its last block
 };
 
 // The blocks of this wave's paths, in order.  The descriptors of the wave's next 64 paths are read
@@ -747,6 +754,7 @@ __device__ __forceinline__ void stream_fetch(const ScanArgs &A, ShortStream &g, 
 }
 __device__ __forceinline__ ShortBlk stream_next(const ScanArgs &A, ShortStream &g, int lane) {
     ShortBlk k;
+    k.skip = false;
     k.valid = g.gi < A.n_short;
     k.b = g.b;
     k.e = g.e;
@@ -771,32 +779,60 @@ __device__ __forceinline__ ShortBlk stream_next(const ScanArgs &A, ShortStream &
 // queued first and emitted when it is complete (short paths; those that do not fit are handed
 // back to k_scan); otherwise they are emitted as they come (medium paths, whose run count the
 // plan knows).
-template <bool UNIQ, int WAVES, int HASH, bool QONLY>
+// PAIRED (medium paths): TWO waves per path and hash set -- the even wave of a pair walks the path's even
+// blocks, the odd one its odd blocks (a block is walked on its own, the claims are LDS atomics, the records
+// go through the workgroup's cursors: nothing else is shared) -- so that a 16 KB set costs a CU's LDS eight
+// bytes per lane instead of sixteen and fourteen waves fit where eight did.  When a path ends both waves
+// meet (a counter in LDS each adds to and then polls; both are resident, neither waits for anything else),
+// wipe half of the set each and meet again.
+template <bool PAIRED>
+__device__ __forceinline__ void pair_meet(uint32_t *ctr, int lane, uint32_t &target) {
+    if (!PAIRED) return;
+    target += 2u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this wave's claims and wipes are in the LDS before its count is)
+    if (lane == 0) atomicAdd(ctr, 1u);
+    while ((int)(*reinterpret_cast<volatile uint32_t *>(ctr) - target) < 0) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+template <bool UNIQ, int WAVES, int HASH, bool QONLY, bool PAIRED = false>
 __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
+    static_assert(!PAIRED || (!QONLY && WAVES % 2 == 0), "pairs walk medium paths");
     constexpr uint32_t kTab = 1u << HASH;
     constexpr int kThr = WAVES * 64;
+    constexpr int kSets = PAIRED ? WAVES / 2 : WAVES;
+    constexpr uint32_t kQ = PAIRED ? kQPaired : kQCap;
     extern __shared__ uint32_t lds[];
-    // layout: [bcur: kShortMaxWin][run queues: WAVES * kQCap][parked-claim queues: WAVES * 2 * kPCap][hash sets: WAVES * 2 * kTab][dummy: 128]
+    // layout: [bcur: kShortMaxWin][run queues: WAVES * kQ][parked-claim queues: WAVES * 2 * kPCap][hash sets: kSets * 2 * kTab][dummy: 128][pair counters: kSets]
     uint32_t *bcur = lds;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint32_t *tab = lds + kShortMaxWin + WAVES * (kQCap + 2 * kPCap) + wave * (2 * kTab);
+    const int set = PAIRED ? wave >> 1 : wave;
+    const uint32_t me = PAIRED ? (uint32_t)wave & 1u : 0u;
+    uint32_t *tab = lds + kShortMaxWin + WAVES * (kQ + 2 * kPCap) + set * (2 * kTab);
     uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;
     Wave w;
-    w.q = lds + kShortMaxWin + wave * kQCap;
-    w.pq = lds + kShortMaxWin + WAVES * kQCap + wave * (2 * kPCap);
-    w.dummy = lds + kShortMaxWin + WAVES * (kQCap + 2 * kPCap + 2 * kTab);  // (shared by the waves: what lands there is never read)
+    w.q = lds + kShortMaxWin + wave * kQ;
+    w.pq = lds + kShortMaxWin + WAVES * kQ + wave * (2 * kPCap);
+    w.dummy = lds + kShortMaxWin + WAVES * (kQ + 2 * kPCap) + kSets * (2 * kTab);  // (shared by the waves: what lands there is never read)
+    uint32_t *meet = w.dummy + 128 + set;
+    uint32_t met = 0;  // what the pair's counter reads when both have arrived
+    w.qcap = kQ;
     w.fill = w.pfill = 0;
     w.vm[0] = w.vm[1] = w.vm[2] = 0;
     w.lane = lane;
     for (uint32_t i = threadIdx.x; i < kShortMaxWin; i += kThr) bcur[i] = i < A.n_win ? A.counts[(size_t)i * A.n_slots + blockIdx.x] : 0u;
-    if (UNIQ)
-        for (uint32_t i = lane; i < kTab / 2; i += 64) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0u, 0u, 0u, 0u);
+    // (a wave wipes its own set, or its half of the pair's)
+    const auto wipe = [&]() {
+        for (uint32_t i = (uint32_t)lane + 64u * me; i < kTab / 2; i += PAIRED ? 128u : 64u) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0u, 0u, 0u, 0u);
+    };
+    if (UNIQ) wipe();
+    if (PAIRED && threadIdx.x < (uint32_t)kSets) w.dummy[128 + threadIdx.x] = 0u;
     __syncthreads();
 
     ShortStream g;
-    g.stride = gridDim.x * WAVES;
-    g.gi = blockIdx.x * WAVES + wave;
+    g.stride = gridDim.x * kSets;
+    g.gi = blockIdx.x * kSets + set;
     {
         const uint4 d = g.gi < A.n_short ? A.short_items[g.gi] : make_uint4(0u, 0u, 0u, 0u);
         g.b = d.x;
@@ -807,24 +843,41 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
         g.bk = 64u;
         stream_fetch(A, g, lane);
     }
+    // this wave's next block: of a pair, the blocks of its parity, and -- where the path's last block is the
+    // partner's -- the path's end without a block
+    const auto next_own = [&]() {
+        ShortBlk k = stream_next(A, g, lane);
+        if (PAIRED && k.valid && ((((k.pos - (k.b & ~15u)) >> 10) & 1u) != me)) {
+            if (k.last) {
+                k.skip = true;
+                k.nl = 0u;
+            } else {
+                k = stream_next(A, g, lane);  // (the same path's next block: this wave's)
+            }
+        }
+        return k;
+    };
     ShortBlk slot[2];
     bool handed_back = false;  // the current path did not fit the run queue
     const uint4 *steps4 = reinterpret_cast<const uint4 *>(A.steps), *rev4 = reinterpret_cast<const uint4 *>(A.rev_steps);
     // lanes beyond the last one holding steps re-read lane 0's chunk
 #define FGFA_SPTR(K) (((K).item >= A.n_fwd ? rev4 : steps4) + (size_t)(K).pos / 4 + ((uint32_t)lane < (K).nl ? lane * 4 : 0))
-    slot[0] = stream_next(A, g, lane);
-    if (slot[0].valid) load_block_async<0>(w, FGFA_SPTR(slot[0]));
-    slot[1] = stream_next(A, g, lane);
-    if (slot[1].valid) load_block_async<1>(w, FGFA_SPTR(slot[1]));
+    slot[0] = next_own();
+    if (slot[0].valid && !slot[0].skip) load_block_async<0>(w, FGFA_SPTR(slot[0]));
+    slot[1] = next_own();
+    if (slot[1].valid && !slot[1].skip) load_block_async<1>(w, FGFA_SPTR(slot[1]));
 #define FGFA_SBLOCK(SET)                                                                                \
     if (slot[SET].valid) {                                                                              \
-        wait_block<SET>(w);                                                                             \
-        uint32_t a[16];                                                                                 \
-        take_block<SET>(a);                                                                             \
         const ShortBlk cur = slot[SET];                                                                 \
-        slot[SET] = stream_next(A, g, lane);                                                            \
-        if (slot[SET].valid) load_block_async<SET>(w, FGFA_SPTR(slot[SET]));                            \
-        if (FGFA_SHORT_ABLATE & 1) {                                                                    \
+        uint32_t a[16];                                                                                 \
+        if (!cur.skip) {                                                                                \
+            wait_block<SET>(w);                                                                         \
+            take_block<SET>(a);                                                                         \
+        }                                                                                               \
+        slot[SET] = next_own();                                                                         \
+        if (slot[SET].valid && !slot[SET].skip) load_block_async<SET>(w, FGFA_SPTR(slot[SET]));         \
+        if (cur.skip) {                                                                                 \
+        } else if (FGFA_SHORT_ABLATE & 1) {                                                             \
             uint32_t x_ = a[0];                                                                         \
             for (int k_ = 1; k_ < 16; ++k_) x_ ^= a[k_];                                                \
             if (x_ == 0xDEADBEEFu) atomicOr(A.status, kStBounds);                                       \
@@ -848,9 +901,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
             } else {                                                                                    \
                 if (FGFA_SHORT_ABLATE & 2) w.fill = 0;                                                  \
                 drain<UNIQ, HASH>(A, w, tab, bcur, mine, true);                                         \
-                if (UNIQ && !(FGFA_SHORT_ABLATE & 16))                                                  \
-                    for (uint32_t i = lane; i < kTab / 2; i += 64)                                      \
-                        reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0u, 0u, 0u, 0u);                 \
+                if (UNIQ && !(FGFA_SHORT_ABLATE & 16)) {                                                \
+                    pair_meet<PAIRED>(meet, lane, met);  /* both are through with the path's claims */  \
+                    wipe();                                                                             \
+                    pair_meet<PAIRED>(meet, lane, met);  /* ... and the set is empty for the next */    \
+                }                                                                                       \
             }                                                                                           \
         }                                                                                               \
     }
@@ -869,7 +924,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
 template <bool UNIQ>
 constexpr auto k_walk_short = k_scan_short<UNIQ, kShortWaves, kShortHash, true>;
 template <bool UNIQ>
-constexpr auto k_walk_medium = k_scan_short<UNIQ, kMediumWaves, kMediumHash, false>;
+constexpr auto k_walk_medium = k_scan_short<UNIQ, kMediumWaves, kMediumHash, false, kMediumPaired>;
 
 // ------------------------------------------------------------ pass 1, tiny paths ---
 //
@@ -3770,8 +3825,9 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             FAST_TRY(hipMemcpy(fp->other_ids, other.data(), other.size() * 4, hipMemcpyHostToDevice));
         }
     }
-    fp->lds_bytes_short = (kShortMaxWin + kShortWaves * (kQCap + 2 * kPCap + (2u << kShortHash)) + 128u) * 4u;
-    fp->lds_bytes_medium = (kShortMaxWin + kMediumWaves * (kQCap + 2 * kPCap + (2u << kMediumHash)) + 128u) * 4u;
+    fp->lds_bytes_short = (kShortMaxWin + kShortWaves * (kQCap + 2 * kPCap + (2u << kShortHash)) + 128u + 16u) * 4u;
+    fp->lds_bytes_medium = kMediumPaired ? (kShortMaxWin + kMediumWaves * (kQPaired + 2 * kPCap) + (kMediumWaves / 2) * (2u << kMediumHash) + 128u + 16u) * 4u
+                                         : (kShortMaxWin + kMediumWaves * (kQCap + 2 * kPCap + (2u << kMediumHash)) + 128u + 16u) * 4u;
     // (the attribute belongs to the kernel, not to the plan: plans of different sizes live side by side)
     FAST_TRY(hipFuncSetAttribute((const void *)k_walk_short<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     FAST_TRY(hipFuncSetAttribute((const void *)k_walk_short<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
@@ -4245,7 +4301,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
             sk.rev_steps = fp.rev_steps;
             sk.path_begin = g.path_begin;
             sk.path_end = g.path_end;
-            const uint32_t per_wg = medium ? kMediumWaves : kShortWaves;
+            const uint32_t per_wg = medium ? (kMediumPaired ? kMediumWaves / 2 : kMediumWaves) : kShortWaves;  // paths a workgroup walks at a time
             const uint32_t kgrid = std::min<uint32_t>((n + per_wg - 1) / per_wg, fp.n_slots);
             ProfScope pscope(medium ? (uniq_out ? "k_scan_medium<uniq>" : "k_scan_medium<depth>") : (uniq_out ? "k_scan_short<uniq>" : "k_scan_short<depth>"), stream);
             if (medium) {

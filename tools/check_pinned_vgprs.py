@@ -107,16 +107,17 @@ def main():
             continue
         if "k_scan" not in func:  # only the kernels that use the landing sets (everything is inlined into them)
             continue
-        touched = regs_of(s) & PINNED
+        pinned = set(range(96, 128)) if "k_scan_short" in func else PINNED  # (the wave-per-path kernels land their blocks in v96..v127 only)
+        touched = regs_of(s) & pinned
         if not touched:
             continue
         m = OK_LOAD.match(s)
-        if m and int(m.group(1)) in PINNED and int(m.group(1)) % 4 == 0 and int(m.group(2)) == int(m.group(1)) + 3 \
-                and int(m.group(3)) not in PINNED and int(m.group(4)) not in PINNED:
+        if m and int(m.group(1)) in pinned and int(m.group(1)) % 4 == 0 and int(m.group(2)) == int(m.group(1)) + 3 \
+                and int(m.group(3)) not in pinned and int(m.group(4)) not in pinned:
             n_load += 1
             continue
         m = OK_TAKE.match(s)
-        if m and int(m.group(3)) in PINNED and int(m.group(2)) not in PINNED:
+        if m and int(m.group(3)) in pinned and int(m.group(2)) not in pinned:
             n_take += 1
             continue
         bad.append(f"{func}: {s}")
