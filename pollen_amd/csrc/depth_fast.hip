@@ -3361,7 +3361,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
 // The plan of one range of segments, [seg_base, seg_base + n_range): the whole graph, or one of
 // the ranges of a graph beyond 16 M segments.
 static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp, uint32_t seg_base,
-                         uint32_t n_range, uint32_t max_win, uint32_t force_wb) {
+                         uint32_t n_range, uint32_t max_win, uint32_t force_wb, uint32_t siblings = 1) {
     *fp = FastPlan();
     fp->seg_base = seg_base;
     fp->n_range = n_range;
@@ -3755,7 +3755,8 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // records all come from k_scan; FLATGFA_PACKED=0|1 never / whenever possible (tests, measurements).
     const bool can_pack = fp->tagged && !fp->n_short && !fp->n_medium && !fp->n_tiny && !fp->dbg && !fp->cap_forced && n_win <= kMaxWinTagged && fp->acc_parts == 1 &&
                           scan_lds_bytes(fp->nwp, true, true) + 64 <= kLdsLimit;
-    bool want_packed = can_pack && (slots + fp->n_slots) * std::max<uint64_t>(cap, 4) * 4 > (2ull << 30);
+    // (the even layout may take 2 GB for a graph's buckets: this plan's share when segment ranges and path groups make several of it)
+    bool want_packed = can_pack && (slots + fp->n_slots) * std::max<uint64_t>(cap, 4) * 4 > std::max<uint64_t>(128ull << 20, (2ull << 30) / std::max(1u, siblings));
     if (const char *f = getenv("FLATGFA_PACKED")) want_packed = can_pack && strtol(f, nullptr, 10) != 0;
     if (!want_packed) {
         const int rc = alloc_buckets(fp, std::max<uint64_t>(cap, 4));
@@ -3975,7 +3976,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
 // The plans of all segment ranges for one set of path spans, appended to `plans`.  *all: every one
 // of them is eligible; *many: one of them is kept from tagged calls by its number of items alone.
 static bool append_ranges(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, uint32_t max_win, uint32_t force_wb,
-                          std::vector<FastPlan> *plans, bool *all, bool *many, bool *want12 = nullptr) {
+                          std::vector<FastPlan> *plans, bool *all, bool *many, bool *want12 = nullptr, uint32_t n_groups = 1) {
     uint64_t max_range = (uint64_t)max_win << (force_wb ? force_wb : 13u);
     if (const char *f = getenv("FLATGFA_RANGE_SEGS")) max_range = std::max<uint64_t>(8192, strtoull(f, nullptr, 10) & ~8191ull);  // tests
     const uint32_t n_ranges = (uint32_t)((g.n_segs + max_range - 1) / max_range);
@@ -3987,7 +3988,7 @@ static bool append_ranges(const flatgfa_dev_graph_t &g, const uint32_t *hb, cons
     for (uint32_t r = 0; r < n_ranges; ++r) {
         const uint32_t base = r * per;
         FastPlan q;
-        if (!create_range(g, hb, he, &q, base, std::min<uint32_t>(per, g.n_segs - base), max_win, force_wb)) {
+        if (!create_range(g, hb, he, &q, base, std::min<uint32_t>(per, g.n_segs - base), max_win, force_wb, n_ranges * n_groups)) {
             fast_plan_destroy(&q);
             return false;
         }
@@ -4101,7 +4102,7 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const ui
                     for (uint32_t p = 0; p < g.n_paths; ++p) hbk[p] = hek[p] = hb[p];  // (a path outside the group: no steps)
                     for (size_t i = lo; i < hi; ++i) hek[busy[i]] = he[busy[i]];
                     const size_t first = plans.size();
-                    hip_ok = append_ranges(g, hbk.data(), hek.data(), max_win, force_wb, &plans, &g_all, &g_many);
+                    hip_ok = append_ranges(g, hbk.data(), hek.data(), max_win, force_wb, &plans, &g_all, &g_many, nullptr, n_groups);
                     for (size_t i = first; i < plans.size(); ++i) {
                         plans[i].accumulate = k > 0;
                         g_all = g_all && plans[i].tagged;  // (a group is only worth it tagged)
