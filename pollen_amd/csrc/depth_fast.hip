@@ -82,8 +82,9 @@ constexpr uint32_t kShortMaxSegs = 1u << 20;
 constexpr uint32_t kShortMax = 2048;       // steps; longer paths go through k_scan (or the medium variant)
 constexpr uint32_t kDummyBase = 1u << 20;  // ids from here up stand in for steps outside the path (never emitted)
 constexpr int kShortHash = 9;              // per-wave hash set of 512 (bitset word index + 1, bits) pairs
-// The medium-path variant: eight waves per workgroup, each with a hash set of 2048 entries, for paths
-// whose run count (known to the plan) fits it.
+// The medium-path variant: hash sets of 2048 entries, for paths whose run count (known to the plan) fits
+// one -- seven sets and fourteen waves per workgroup, two waves per path (eight and eight, one wave per
+// path, when built with -DFGFA_MEDIUM_PAIRED=0).
 #ifndef FGFA_MEDIUM_PAIRED
 #define FGFA_MEDIUM_PAIRED 1
 #endif
@@ -3393,7 +3394,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     uint64_t short_max = (fp->dbg || ranged || wb != kShortWinBits || n_win > kShortMaxWin || g.n_segs > kShortMaxSegs) ? 0 : kShortMax;  // (the wave-per-path kernels know nothing of ranges)
     if (const char *forced = getenv("FLATGFA_SHORT_MAX")) short_max = std::min<uint64_t>(short_max, strtoull(forced, nullptr, 10));
     // Which kernel walks a path depends on how many runs it has: short paths must fit the run queue,
-    // paths with at most kMediumRuns runs are walked by single waves too, eight per CU, each with a
+    // paths with at most kMediumRuns runs are walked wave by wave too, by pairs of waves that share a
     // bigger hash set (k_scan_short's medium variant).  The counts come from a one-off kernel.
     std::vector<uint32_t> runs, runs_down;
     if (short_max) {
