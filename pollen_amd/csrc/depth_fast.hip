@@ -624,21 +624,26 @@ __device__ __forceinline__ bool block16(const ScanArgs &A, Wave &w, uint32_t *se
                                         uint32_t (&a)[16], uint32_t nl, uint32_t rel_lo, uint32_t rel_hi, uint32_t blk_pos) {
     const bool active = (uint32_t)w.lane < nl;
     const bool last_lane = (uint32_t)w.lane + 1u == nl;
-    if (rel_lo > 0u || rel_hi < 16u * nl) {
+    const bool partial = rel_lo > 0u || rel_hi < 16u * nl;
+    // An id beyond the graph is looked for in everything the block holds, the steps of the neighbouring paths
+    // (or a reversed copy's padding) included: only if there is one are the path's own steps checked one by one.
+    uint32_t mx = a[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) mx = max(mx, a[k]);
+    if (mx >= A.n_segs) {
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const uint32_t rel = 16u * (uint32_t)w.lane + (uint32_t)k;
-            const bool inside = rel >= rel_lo && rel < rel_hi;
-            a[k] = !inside ? kDummyBase + ((blk_pos + rel) & 0xFFFFu) : clamp_id(A, a[k]);
+            if (rel >= rel_lo && rel < rel_hi) a[k] = clamp_id(A, a[k]);
         }
-    } else {
-        uint32_t mx = a[0];
+    }
+    if (partial) {  // (every block of a path of a thousand steps: four instructions a step and no branch -- as `inside ? clamp_id(..) : dummy` it was nine and six scalar ones)
+        const int lo_l = (int)rel_lo - 16 * w.lane, hi_l = (int)rel_hi - 16 * w.lane;
+        const uint32_t lo_c = (uint32_t)min(max(lo_l, 0), 16), hi_c = (uint32_t)min(max(hi_l, 0), 16);
+        const uint32_t m16 = hi_c > lo_c ? ((1u << hi_c) - 1u) & ~((1u << lo_c) - 1u) : 0u;  // this lane's steps inside the path
+        const uint32_t d0 = kDummyBase + ((blk_pos + 16u * (uint32_t)w.lane) & 0xFFFFu);       // (a multiple of 16: the placeholder of step k is d0 | k)
 #pragma unroll
-        for (int k = 1; k < 16; ++k) mx = max(mx, a[k]);
-        if (mx >= A.n_segs) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) a[k] = clamp_id(A, a[k]);
-        }
+        for (int k = 0; k < 16; ++k) a[k] = (m16 >> k) & 1u ? a[k] : d0 | (uint32_t)k;
     }
     // a block is walked on its own: its first step opens a run, its last step closes one
     const uint32_t first = __builtin_amdgcn_readfirstlane(a[0]);
