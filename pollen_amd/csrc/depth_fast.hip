@@ -951,7 +951,10 @@ constexpr auto k_walk_medium = k_scan_short<UNIQ, kMediumWaves, kMediumHash, fal
 #define FGFA_TINY_ABLATE 0  /* measurements only (results are then wrong): 1 = no first-visit test, 2 = no records */
 #endif
 constexpr uint32_t kTinyMax = 128;   // steps
-constexpr uint32_t kTinyTab = 256;   // entries of a wave's id set (at most half full)
+#ifndef FGFA_TINY_BITS
+#define FGFA_TINY_BITS 8
+#endif
+constexpr uint32_t kTinyBits = FGFA_TINY_BITS, kTinyTab = 1u << kTinyBits;   // entries of a wave's id set (at most half full)
 constexpr uint32_t kTinyQueue = 64 + kTinyMax;  // a wave's record queue: what is left over + one path of all starts
 
 // (landing registers: path slot d's steps l and 64 + l in v(118 + 2 d), v(119 + 2 d))
@@ -980,12 +983,13 @@ __device__ __forceinline__ void tiny_take(uint32_t n_since, uint32_t &a0, uint32
 template <bool UNIQ>
 __global__ __launch_bounds__(kThreads) void k_scan_tiny(const ScanArgs A) {
     extern __shared__ uint32_t lds[];
-    // layout: [bcur: kShortMaxWin][id sets: kWaves * kTinyTab][record queues: kWaves * kTinyQueue entries of 8 bytes]
+    // layout: [bcur: kShortMaxWin][id sets: kWaves * kTinyTab][record queues: kWaves * kTinyQueue entries of 8 bytes][dummy: 128]
     uint32_t *bcur = lds;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     uint32_t *tab = lds + kShortMaxWin + wave * kTinyTab;
     uint2 *q = reinterpret_cast<uint2 *>(lds + kShortMaxWin + kWaves * kTinyTab) + wave * kTinyQueue;  // {record, window}
+    uint32_t *dummy = lds + kShortMaxWin + kWaves * kTinyTab + kWaves * kTinyQueue * 2u;  // 128 words nobody reads (shared by the waves)
     uint32_t fill = 0;  // (uniform) entries in the queue: fewer than 64 between paths
     uint32_t *mine = A.buckets + (size_t)blockIdx.x * A.cap;
     Wave w;
@@ -994,7 +998,8 @@ __global__ __launch_bounds__(kThreads) void k_scan_tiny(const ScanArgs A) {
     w.vm[0] = w.vm[1] = w.vm[2] = 0;
     w.lane = lane;
     for (uint32_t i = threadIdx.x; i < kShortMaxWin; i += kThreads) bcur[i] = i < A.n_win ? A.counts[(size_t)i * A.n_slots + blockIdx.x] : 0u;
-    if (UNIQ) reinterpret_cast<uint4 *>(tab)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    if (UNIQ)
+        for (uint32_t i = (uint32_t)lane; i < kTinyTab / 4u; i += 64u) reinterpret_cast<uint4 *>(tab)[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     // This wave's paths: gi, gi + stride, ...  Their descriptors come 64 at a time (one load, a path
     // per lane) and are handed out by v_readlane; a path's steps are requested three paths ahead.
@@ -1049,10 +1054,18 @@ __global__ __launch_bounds__(kThreads) void k_scan_tiny(const ScanArgs A) {
         x1 = x1 < A.n_segs ? x1 : 0u;                                                                                  \
         bool f0 = true, f1 = true;  /* first visits */                                                                 \
         if (UNIQ && !(FGFA_TINY_ABLATE & 1)) {                                                                         \
-            uint32_t h0 = (x0 * 0x9E3779B1u) >> 24, h1 = (x1 * 0x9E3779B1u) >> 24;                                     \
-            bool t0 = v0, t1 = v1;                                                                                     \
+            uint32_t h0 = (x0 * 0x9E3779B1u) >> (32 - kTinyBits), h1 = (x1 * 0x9E3779B1u) >> (32 - kTinyBits);                                     \
+            /* the first probe -- nearly always the last -- by all lanes, nothing predicated (a lane without a step */   \
+            /* probes a word of its own in `dummy`): as `if (t0) CAS` the loop was mostly scalar exec-mask traffic  */   \
+            uint32_t *e0 = v0 ? &tab[h0] : &dummy[lane], *e1 = v1 ? &tab[h1] : &dummy[64 + lane];                      \
+            const uint32_t c0 = atomicCAS(e0, 0u, x0 + 1u), c1 = atomicCAS(e1, 0u, x1 + 1u);                           \
+            f0 = c0 == 0u;                                                                                             \
+            f1 = c1 == 0u;                                                                                             \
+            bool t0 = v0 && c0 != 0u && c0 != x0 + 1u, t1 = v1 && c1 != 0u && c1 != x1 + 1u;                           \
+            h0 = (h0 + 1u) & (kTinyTab - 1u);                                                                          \
+            h1 = (h1 + 1u) & (kTinyTab - 1u);                                                                          \
             uint32_t probes = 0;                                                                                       \
-            while (__builtin_amdgcn_ballot_w64(t0 || t1)) {                                                            \
+            while (__builtin_amdgcn_ballot_w64(t0 || t1)) {  /* (the few that met another id's entry; unpredicated like the first probe this loop measured 3 % slower) */ \
                 if (++probes > 2u * kTinyTab) {  /* cannot happen: the set holds at most 128 ids */                    \
                     atomicOr(A.status, kStInternal);                                                                   \
                     break;                                                                                             \
@@ -1068,7 +1081,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_tiny(const ScanArgs A) {
                     else h1 = (h1 + 1u) & (kTinyTab - 1u);                                                             \
                 }                                                                                                      \
             }                                                                                                          \
-            reinterpret_cast<uint4 *>(tab)[lane] = make_uint4(0u, 0u, 0u, 0u);  /* clean for the next path */          \
+            for (uint32_t i_ = (uint32_t)lane; i_ < kTinyTab / 4u; i_ += 64u) reinterpret_cast<uint4 *>(tab)[i_] = make_uint4(0u, 0u, 0u, 0u);  /* clean for the next path */ \
         }                                                                                                              \
         /* where records start */                                                                                      \
         const uint32_t k0 = x0 | (f0 ? 0x80000000u : 0u), k1 = x1 | (f1 ? 0x80000000u : 0u);  /* id and flag in one word */ \
@@ -3840,7 +3853,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipFuncSetAttribute((const void *)k_walk_short<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     FAST_TRY(hipFuncSetAttribute((const void *)k_walk_medium<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     FAST_TRY(hipFuncSetAttribute((const void *)k_walk_medium<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-    fp->lds_bytes_tiny = (kShortMaxWin + kWaves * kTinyTab + kWaves * kTinyQueue * 2u) * 4u;
+    fp->lds_bytes_tiny = (kShortMaxWin + kWaves * kTinyTab + kWaves * kTinyQueue * 2u + 128u) * 4u;
     FAST_TRY(hipMalloc(&fp->work_counter, 256));
     FAST_TRY(hipMemset(fp->work_counter, 0, 256));
     FAST_TRY(hipFuncSetAttribute((const void *)k_scan<kModePlain, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
