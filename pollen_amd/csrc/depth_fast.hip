@@ -391,7 +391,7 @@ struct Wave {
 #define FGFA_QCAP 416
 #endif
 #ifndef FGFA_SHORT_ABLATE
-#define FGFA_SHORT_ABLATE 0  /* measurements only (results are wrong): 1 loads only, 2 runs queued but not emitted, 4 no claims, 8 no record stores, 16 hash set not wiped */
+#define FGFA_SHORT_ABLATE 0  /* measurements only (results are wrong): 1 loads only, 2 runs queued but not emitted, 4 no claims, 8 no record stores, 16 hash set not wiped, 32 partly new claims dropped */
 #endif
 constexpr uint32_t kQCap = FGFA_QCAP;  // at least 63 left over + up to 256 from four steps of every lane; a short path has at most kQCap - 16 runs, hence bitset words: its 512-entry hash set must not fill up
 constexpr uint32_t kPCap = 96;   // parked claims (two words each): 31 left over + up to 64 from one chunk
@@ -503,7 +503,7 @@ __device__ __forceinline__ void emit_chunk(const ScanArgs &A, Wave &w, uint32_t 
         pos = take_slots(bcur, w.lane, valid, win);
         const uint32_t nb = mask & ~old;
         kind = (nb == mask) ? 2u : 0u;
-        push_partial(w, (nb != mask) & (nb != 0u), id >> 5, nb);
+        push_partial(w, (nb != mask) & (nb != 0u) & !(FGFA_SHORT_ABLATE & 32), id >> 5, nb);
     } else {
         pos = take_slots(bcur, w.lane, valid, win);
     }
