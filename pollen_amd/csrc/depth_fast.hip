@@ -69,8 +69,10 @@ constexpr uint32_t kLdsLimit = 160 * 1024;
 constexpr uint32_t kStBounds = 1u, kStDebug = 2u, kStOverflow = 4u, kStInternal = 8u, kStBackOverflow = 16u;  // (16: more short paths handed back than the list holds: larger buckets would not help, the atomic kernels complete the call)  // (8: an invariant between the two passes did not hold -- a bug, reported as an error rather than as counts)
 
 // ---- the wave-per-path kernels (k_scan_short): windows of 4096 segments, at most 256 of them ----
-constexpr uint32_t kRunBits = 11;  // a queued run is (start id << 11) | (len - 1)
+constexpr uint32_t kRunBits = 11;  // a run of a depth-only call is cut at multiples of 2^11 ids (it then never crosses a window's end)
 constexpr uint32_t kRunSpan = 1u << kRunBits;
+constexpr uint32_t kPosBits = 10;                        // a queued entry is (id << 10) | the step's position in its block: a run STARTS there
+constexpr uint32_t kTermEntry = 0xFFFFFFFFu << kPosBits;  // ... or, with this id, ends there: what closes a block's last run (never emitted)
 // Where their runs are cut: depth-only runs at ids that are multiples of 2048 (a record never
 // crosses a window); with unique depth at multiples of 32, so that a run lies inside ONE word of
 // the "seen" bitset and is claimed with a single returning LDS OR.
@@ -90,7 +92,7 @@ constexpr int kShortHash = 9;              // per-wave hash set of 512 (bitset w
 #endif
 constexpr bool kMediumPaired = FGFA_MEDIUM_PAIRED != 0;  // two waves per path and hash set (k_scan_short<..., PAIRED>)
 constexpr int kMediumHash = 11, kMediumWaves = kMediumPaired ? 14 : 8;
-constexpr uint32_t kQPaired = 320;  // a paired wave's run queue: 63 left over + up to 256 from four steps of every lane
+constexpr uint32_t kQPaired = 328;  // a paired wave's run queue: 64 left over + up to 256 from sixteen lanes + the entry that closes a block
 #ifndef FGFA_SHORT_WAVES
 #define FGFA_SHORT_WAVES 16
 #endif
@@ -393,7 +395,7 @@ struct Wave {
 #ifndef FGFA_SHORT_ABLATE
 #define FGFA_SHORT_ABLATE 0  /* measurements only (results are wrong): 1 loads only, 2 runs queued but not emitted, 4 no claims, 8 no record stores, 16 hash set not wiped, 32 partly new claims dropped */
 #endif
-constexpr uint32_t kQCap = FGFA_QCAP;  // at least 63 left over + up to 256 from four steps of every lane; a short path has at most kQCap - 16 runs, hence bitset words: its 512-entry hash set must not fill up
+constexpr uint32_t kQCap = FGFA_QCAP;  // at least 64 left over + up to 257 from sixteen lanes of a block; a short path has at most kQCap - 16 runs, hence bitset words: its 512-entry hash set must not fill up
 constexpr uint32_t kPCap = 96;   // parked claims (two words each): 31 left over + up to 64 from one chunk
 
 __device__ __forceinline__ uint32_t clamp_id(const ScanArgs &A, uint32_t id) {
@@ -402,12 +404,6 @@ __device__ __forceinline__ uint32_t clamp_id(const ScanArgs &A, uint32_t id) {
         return 0u;
     }
     return id;
-}
-
-__device__ __forceinline__ void enqueue(Wave &w, bool e, uint32_t rec) {
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(e);
-    if (e) w.q[w.fill + lane_rank(m)] = rec;
-    w.fill += (uint32_t)__builtin_popcountll(m);
 }
 
 __device__ __forceinline__ void push_partial(Wave &w, bool e, uint32_t word, uint32_t bits) {
@@ -493,9 +489,10 @@ __device__ __forceinline__ uint32_t take_slots(uint32_t *bcur, int lane, bool va
 // into uniq records 32..64 entries at a time, so its bit-stretch loop runs with most lanes busy.
 template <bool UNIQ, int HASH>
 __device__ __forceinline__ void emit_chunk(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
-                                           bool valid, uint32_t rec) {
-    const uint32_t id = rec >> kRunBits, lenm1 = rec & (kRunSpan - 1), win = id >> kShortWinBits;
-    valid = valid && id < kDummyBase;  // runs of placeholder ids are dropped here
+                                           bool valid, uint32_t ent, uint32_t next) {
+    // a run lasts until the next entry's position (positions start over with every block: modulo 1024)
+    const uint32_t id = ent >> kPosBits, lenm1 = (next - ent - 1u) & ((1u << kPosBits) - 1u), win = id >> kShortWinBits;
+    valid = valid && id < kDummyBase;  // runs of placeholder ids and the entries that only close a run are dropped here
     uint32_t kind = 0, pos;
     if (UNIQ) {
         const uint32_t mask = valid ? (0xFFFFFFFFu >> (31u - lenm1)) << (id & 31u) : 0u;
@@ -535,18 +532,31 @@ __device__ __forceinline__ void drain_partial(const ScanArgs &A, Wave &w, uint32
     }
 }
 
-// Emit the newest 64 queued runs while at least 64 are queued (all of them when `all`).
+// Emit the oldest entries, 64 at a time, while at least 65 are queued (an entry needs the one behind it: that is
+// where its run ends), then move what is left to the front of the queue.  With `all` the newest entry closes a
+// block, and everything is emitted.
 template <bool UNIQ, int HASH>
 __device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine, bool all) {
-    while (w.fill >= 64u || (all && w.fill)) {
-        const uint32_t n = min(w.fill, 64u);
-        w.fill -= n;
+    uint32_t base = 0;
+    while (w.fill - base >= 65u || (all && w.fill - base >= 2u)) {
+        const uint32_t n = min(64u, w.fill - 1u - base);
         const bool valid = (uint32_t)w.lane < n;
-        const uint32_t rec = valid ? w.q[w.fill + w.lane] : 0u;
-        emit_chunk<UNIQ, HASH>(A, w, seen, bcur, mine, valid, rec);
+        const uint32_t at = base + (valid ? (uint32_t)w.lane : 0u);
+        const uint32_t ent = w.q[at], next = w.q[at + 1u];
+        emit_chunk<UNIQ, HASH>(A, w, seen, bcur, mine, valid, ent, next);
+        base += n;
         if (UNIQ) drain_partial(A, w, bcur, mine, false);
     }
-    if (UNIQ && all) drain_partial(A, w, bcur, mine, true);
+    if (all) {
+        w.fill = 0;
+        if (UNIQ) drain_partial(A, w, bcur, mine, true);
+    } else if (base) {
+        const uint32_t rem = w.fill - base;  // 1 .. 64
+        const bool mv = (uint32_t)w.lane < rem;
+        const uint32_t v = mv ? w.q[base + w.lane] : 0u;
+        if (mv) w.q[w.lane] = v;
+        w.fill = rem;
+    }
 }
 
 // Pass A of block16 for eight consecutive steps of every lane, hand-scheduled: Mj (a lane mask in
@@ -576,28 +586,26 @@ __device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen
     } while (0)
 
 // Pass B of block16 for eight consecutive steps of every lane, hand-scheduled: for step j, the
-// lanes where a run starts (mask Mj) append (cur << 11) | (id before step j - cur) at their queue
-// cursor `p` and make step j's id their `cur`.  Written as asm so that each step is one scalar
-// instruction (exec = lanes that start a run) and five vector ones, with no branches; exec is
-// restored before the statement ends.  PM is the id before step 0.
-#define FGFA_PASSB_STEP(T, PMJ, XJ, MJ)                \
-    "s_and_b64 exec, %[sv], %[" MJ "]\n\t"             \
-    "v_sub_u32 %[" T "], %[" PMJ "], %[cur]\n\t"       \
-    "v_lshl_or_b32 %[" T "], %[cur], 11, %[" T "]\n\t" \
-    "ds_write_b32 %[p], %[" T "]\n\t"                  \
-    "v_add_u32 %[p], 4, %[p]\n\t"                      \
-    "v_mov_b32 %[cur], %[" XJ "]\n\t"
-#define FGFA_PASSB8(CUR, P, PM, X0, X1, X2, X3, X4, X5, X6, X7, M0, M1, M2, M3, M4, M5, M6, M7)                      \
+// lanes where a run starts (mask Mj) append (step j's id << 10) | step j's position at their queue
+// cursor `p`.  One scalar (exec = lanes that start a run), one LDS and three vector instructions per
+// step (two for a lane's first), no branches; exec is restored before the statement ends.  B16 is 16 x lane.
+#define FGFA_PASSB_STEP(T, XJ, J, MJ)                       \
+    "s_and_b64 exec, %[sv], %[" MJ "]\n\t"                  \
+    "v_lshl_or_b32 %[" T "], %[" XJ "], 10, %[b16]\n\t"     \
+    "v_or_b32 %[" T "], " J ", %[" T "]\n\t"                \
+    "ds_write_b32 %[p], %[" T "]\n\t"                       \
+    "v_add_u32 %[p], 4, %[p]\n\t"
+#define FGFA_PASSB8(P, B16, J0, J1, J2, J3, J4, J5, J6, J7, X0, X1, X2, X3, X4, X5, X6, X7, M0, M1, M2, M3, M4, M5, M6, M7)   \
     do {                                                                                                             \
         unsigned long long sv_;                                                                                      \
         uint32_t t0_, t1_;                                                                                           \
-        asm volatile("s_mov_b64 %[sv], exec\n\t" FGFA_PASSB_STEP("t0", "pm", "x0", "m0")                             \
-                         FGFA_PASSB_STEP("t1", "x0", "x1", "m1") FGFA_PASSB_STEP("t0", "x1", "x2", "m2")             \
-                             FGFA_PASSB_STEP("t1", "x2", "x3", "m3") FGFA_PASSB_STEP("t0", "x3", "x4", "m4")         \
-                                 FGFA_PASSB_STEP("t1", "x4", "x5", "m5") FGFA_PASSB_STEP("t0", "x5", "x6", "m6")     \
-                                     FGFA_PASSB_STEP("t1", "x6", "x7", "m7") "s_mov_b64 exec, %[sv]"                 \
-                     : [cur] "+v"(CUR), [p] "+v"(P), [sv] "=&s"(sv_), [t0] "=&v"(t0_), [t1] "=&v"(t1_)               \
-                     : [pm] "v"(PM), [x0] "v"(X0), [x1] "v"(X1), [x2] "v"(X2), [x3] "v"(X3), [x4] "v"(X4),           \
+        asm volatile("s_mov_b64 %[sv], exec\n\t" FGFA_PASSB_STEP("t0", "x0", J0, "m0")                               \
+                         FGFA_PASSB_STEP("t1", "x1", J1, "m1") FGFA_PASSB_STEP("t0", "x2", J2, "m2")                 \
+                             FGFA_PASSB_STEP("t1", "x3", J3, "m3") FGFA_PASSB_STEP("t0", "x4", J4, "m4")             \
+                                 FGFA_PASSB_STEP("t1", "x5", J5, "m5") FGFA_PASSB_STEP("t0", "x6", J6, "m6")         \
+                                     FGFA_PASSB_STEP("t1", "x7", J7, "m7") "s_mov_b64 exec, %[sv]"                   \
+                     : [p] "+v"(P), [sv] "=&s"(sv_), [t0] "=&v"(t0_), [t1] "=&v"(t1_)                                \
+                     : [b16] "v"(B16), [x0] "v"(X0), [x1] "v"(X1), [x2] "v"(X2), [x3] "v"(X3), [x4] "v"(X4),         \
                        [x5] "v"(X5), [x6] "v"(X6), [x7] "v"(X7), [m0] "s"(M0), [m1] "s"(M1), [m2] "s"(M2),           \
                        [m3] "s"(M3), [m4] "s"(M4), [m5] "s"(M5), [m6] "s"(M6), [m7] "s"(M7)                          \
                      : "memory", "scc");                                                                             \
@@ -607,12 +615,13 @@ __device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen
 // steps 16l..16l+15, i.e. its own 64 bytes), so that fifteen of every sixteen run boundaries are
 // found with in-lane compares.  Only the first `nl` lanes hold steps.
 //
-// A run ends wherever the next one starts, and that is where its (start, length) is queued.
-// Pass A marks the starts and counts them per lane; a wave prefix sum gives every lane its own
-// stretch of the run queue.  Pass B then walks the sixteen steps again and each lane appends
-// its runs to its stretch: no ballot or lane ranking per step.  The run that is in progress when
-// a lane's first step arrives started in a lane below; its start id is fetched afterwards (one
-// ballot + ds_bpermute per block) and patched into the lane's first queue entry.
+// A run is queued where it STARTS, as (id, position in the block); it ends where the next entry
+// starts, which is all its length takes when it is emitted (drain).  Pass A marks the starts and
+// counts them per lane; a wave prefix sum gives every lane its own stretch of the run queue.  Pass
+// B then walks the sixteen steps again and each lane appends its starts to its stretch: no ballot
+// or lane ranking per step, nothing carried from step to step or from lane to lane.  A block is
+// walked on its own: its first step starts a run, and behind its last step the last lane queues
+// the entry that closes the last run.
 // When the block has more starts than the queue has room for (dense: few steps continue a run),
 // the steps are queued four at a time with the queue emitted in between.
 // A block may reach beyond its path at either end (it starts and ends on 64-byte boundaries):
@@ -645,80 +654,49 @@ __device__ __forceinline__ bool block16(const ScanArgs &A, Wave &w, uint32_t *se
 #pragma unroll
         for (int k = 0; k < 16; ++k) a[k] = (m16 >> k) & 1u ? a[k] : d0 | (uint32_t)k;
     }
-    // a block is walked on its own: its first step opens a run, its last step closes one
-    const uint32_t first = __builtin_amdgcn_readfirstlane(a[0]);
     const uint32_t prev = __builtin_amdgcn_update_dpp(0u, a[15], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     // pass A (lanes beyond `nl` compute garbage flags; they are kept out of `cnt` and of pass B)
     unsigned long long m[16];
     uint32_t cnt = 0;
     FGFA_PASSA8(kCutMask<UNIQ>, cnt, prev, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
     FGFA_PASSA8(kCutMask<UNIQ>, cnt, a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15]);
-    cnt -= (w.lane == 0) ? (uint32_t)(m[0] & 1ull) : 0u;  // nothing ends at the block's first step
-    m[0] &= ~1ull;
+    cnt += (w.lane == 0) ? 1u - (uint32_t)(m[0] & 1ull) : 0u;  // the block's first step starts a run whatever lies before it
+    m[0] |= 1ull;
     cnt = active ? cnt : 0u;
-    const uint32_t slots = cnt + (last_lane ? 1u : 0u);  // the last lane also queues the run that is open at the end
+    const uint32_t slots = cnt + (last_lane ? 1u : 0u);  // the last lane also queues the entry that closes the block's last run
     const uint32_t incl = wave_scan_incl(slots);
     const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
-    const unsigned long long below = __builtin_amdgcn_ballot_w64(cnt != 0u) & ((1ull << w.lane) - 1ull);
-    const int src = below ? 63 - __builtin_clzll(below) : w.lane;
+    const uint32_t b16 = 16u * (uint32_t)w.lane;
+    const uint32_t term = kTermEntry | ((16u * nl) & ((1u << kPosBits) - 1u));
     if (w.fill + total <= w.qcap) {
-        // pass B, lane-local: `cur` is the start of the run in progress, 0 standing in for the
-        // one that entered the lane (then the entry holds just the run's last id until patched)
-        uint32_t *const p0 = w.q + w.fill + (incl - slots);
-        uint32_t cur = 0u;
-        uint32_t p = lds_addr(p0);
+        uint32_t p = lds_addr(w.q + w.fill + (incl - slots));
         if (active) {
-            FGFA_PASSB8(cur, p, prev, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
-            FGFA_PASSB8(cur, p, a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15]);
+            FGFA_PASSB8(p, b16, "0", "1", "2", "3", "4", "5", "6", "7", a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
+            FGFA_PASSB8(p, b16, "8", "9", "10", "11", "12", "13", "14", "15", a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15]);
         }
-        // start id of the run in progress when this lane's first step arrived: the last start below
-        const uint32_t from_below = __shfl(cur, src, 64);
-        const uint32_t rs = below ? from_below : first;
-        if (cnt) {
-            const uint32_t last = *p0;
-            *p0 = (rs << kRunBits) | (last - rs);
-        } else {
-            cur = rs;
-        }
-        if (last_lane) *reinterpret_cast<lds_u32 *>((uintptr_t)p) = (cur << kRunBits) | (a[15] - cur);
+        if (last_lane) *reinterpret_cast<lds_u32 *>((uintptr_t)p) = term;
         w.fill += total;
         if (QONLY) return true;
         drain<UNIQ, HASH>(A, w, seen, bcur, mine, false);
     } else {
         if (QONLY) return false;
-        bool st[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            asm volatile("" : "+s"(m[k]));  // keeps this path's work from being hoisted above the branch
-            st[k] = __builtin_amdgcn_inverse_ballot_w64(m[k]) & active;
-        }
-        uint32_t last_start = a[0];
-#pragma unroll
-        for (int k = 1; k < 16; ++k) last_start = st[k] ? a[k] : last_start;
-        const uint32_t from_below = __shfl(last_start, src, 64);
-        const uint32_t rs = below ? from_below : first;
-        uint32_t cur = rs;
+        // Entries must lie in the order of their positions, so the block is queued sixteen lanes at a time (at most 256
+        // starts and the closing entry), the queue emitted down to at most 64 entries before each.
 #pragma unroll 1
-        for (int g = 0; g < 4; ++g) {
-            uint32_t pm, x0, x1, x2, x3;
-            bool s0, s1, s2, s3;
-            switch (g) {  // wave-uniform: one copy of the queueing and emitting code for all four groups
-                case 0: pm = prev, x0 = a[0], x1 = a[1], x2 = a[2], x3 = a[3], s0 = st[0], s1 = st[1], s2 = st[2], s3 = st[3]; break;
-                case 1: pm = a[3], x0 = a[4], x1 = a[5], x2 = a[6], x3 = a[7], s0 = st[4], s1 = st[5], s2 = st[6], s3 = st[7]; break;
-                case 2: pm = a[7], x0 = a[8], x1 = a[9], x2 = a[10], x3 = a[11], s0 = st[8], s1 = st[9], s2 = st[10], s3 = st[11]; break;
-                default: pm = a[11], x0 = a[12], x1 = a[13], x2 = a[14], x3 = a[15], s0 = st[12], s1 = st[13], s2 = st[14], s3 = st[15]; break;
-            }
-            enqueue(w, s0, (cur << kRunBits) | (pm - cur));
-            cur = s0 ? x0 : cur;
-            enqueue(w, s1, (cur << kRunBits) | (x0 - cur));
-            cur = s1 ? x1 : cur;
-            enqueue(w, s2, (cur << kRunBits) | (x1 - cur));
-            cur = s2 ? x2 : cur;
-            enqueue(w, s3, (cur << kRunBits) | (x2 - cur));
-            cur = s3 ? x3 : cur;
+        for (uint32_t grp = 0; grp < 4u; ++grp) {
             drain<UNIQ, HASH>(A, w, seen, bcur, mine, false);
+            const bool in_g = active && ((uint32_t)w.lane >> 4) == grp;
+            const uint32_t sl = in_g ? slots : 0u;
+            const uint32_t inc = wave_scan_incl(sl);
+            uint32_t p = lds_addr(w.q + w.fill + (inc - sl));
+            if (in_g) {
+                FGFA_PASSB8(p, b16, "0", "1", "2", "3", "4", "5", "6", "7", a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
+                FGFA_PASSB8(p, b16, "8", "9", "10", "11", "12", "13", "14", "15", a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], m[8], m[9], m[10], m[11], m[12], m[13], m[14], m[15]);
+                if (last_lane) *reinterpret_cast<lds_u32 *>((uintptr_t)p) = term;
+            }
+            w.fill += __builtin_amdgcn_readlane(inc, 63);
         }
-        enqueue(w, last_lane, (cur << kRunBits) | (a[15] - cur));
+        drain<UNIQ, HASH>(A, w, seen, bcur, mine, false);
     }
     return true;
 }

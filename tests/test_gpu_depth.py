@@ -902,3 +902,47 @@ def test_plan_says_how_many_steps_each_scan_kernel_walks(monkeypatch):
     for s, n in zip(starts, lens):
         seen[s:s + n] += 1
     assert (u.cpu().numpy() == seen).all()
+
+
+def test_medium_paths_whose_blocks_hold_more_runs_than_the_queue(monkeypatch):
+    """Paths of 2600 steps in runs of two (1300 runs: wave-per-path "medium" paths): a block of 1024 steps starts 512
+    runs, more than a wave's queue has room for, so k_scan_medium queues it sixteen lanes at a time (entries must lie
+    in the order of their positions: a run ends where the next entry starts).  Every other path walks downwards
+    (read from its reversed copy), and some revisit their own segments."""
+    import re
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    for v in ("FLATGFA_SHORT_MAX", "FLATGFA_NO_TINY", "FLATGFA_TAGGED", "FLATGFA_WB", "FLATGFA_PACKED", "FLATGFA_DENSE"):
+        monkeypatch.delenv(v, raising=False)
+    S = 200_000
+    rng = np.random.default_rng(23)
+    paths = []
+    for p in range(300):
+        starts = rng.integers(0, S - 2, 1300)
+        if p % 5 == 0:
+            starts[650:] = starts[:650]  # the second half walks the first half's segments again
+        ids = np.stack([starts, starts + 1], axis=1).reshape(-1)
+        if p % 2:
+            ids = ids[::-1]
+        paths.append(ids.astype(np.uint32))
+    lens = np.array([len(x) for x in paths])
+    ids = np.concatenate(paths)
+    steps = ((ids << 1) | (rng.integers(0, 2, len(ids)).astype(np.uint32))).astype(np.uint32)
+    pe = np.cumsum(lens).astype(np.uint32)
+    pb = (pe - lens).astype(np.uint32)
+    plan = DepthPlan(DeviceGraph(steps, pb, pe, S))
+    text = plan.describe()
+    assert int(re.search(r"medium_paths=(\d+)", text).group(1)) == 300, text
+    want_d = np.bincount(ids, minlength=S)
+    want_u = np.zeros(S, dtype=np.int64)
+    for x in paths:
+        want_u[np.unique(x)] += 1
+    for with_u in (True, False):
+        d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        plan.seg_depth(d, u if with_u else None)
+        plan.status()
+        assert (d.cpu().numpy() == want_d).all()
+        if with_u:
+            assert (u.cpu().numpy() == want_u).all()
