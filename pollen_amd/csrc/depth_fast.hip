@@ -850,16 +850,26 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
     if (slot[0].valid && !slot[0].skip) load_block_async<0>(w, FGFA_SPTR(slot[0]));
     slot[1] = next_own();
     if (slot[1].valid && !slot[1].skip) load_block_async<1>(w, FGFA_SPTR(slot[1]));
+    // -DFGFA_SHORT_PROF (tools/short_prof.py): cycles per phase of two workgroups' waves, printed when the kernel ends
+#ifdef FGFA_SHORT_PROF
+    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tl = __builtin_readcyclecounter();
+#define SP(i) do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = __builtin_readcyclecounter(); tp[i] += n_ - tl; tl = n_; } while (0)
+#else
+#define SP(i)
+#endif
 #define FGFA_SBLOCK(SET)                                                                                \
     if (slot[SET].valid) {                                                                              \
         const ShortBlk cur = slot[SET];                                                                 \
         uint32_t a[16];                                                                                 \
+        SP(0);                                                                                          \
         if (!cur.skip) {                                                                                \
             wait_block<SET>(w);                                                                         \
+            SP(1);                                                                                      \
             take_block<SET>(a);                                                                         \
         }                                                                                               \
         slot[SET] = next_own();                                                                         \
         if (slot[SET].valid && !slot[SET].skip) load_block_async<SET>(w, FGFA_SPTR(slot[SET]));         \
+        SP(2);                                                                                          \
         if (cur.skip) {                                                                                 \
         } else if (FGFA_SHORT_ABLATE & 1) {                                                             \
             uint32_t x_ = a[0];                                                                         \
@@ -873,6 +883,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
                 w.fill = 0;                                                                             \
             }                                                                                           \
         }                                                                                               \
+        SP(3);                                                                                          \
         if (cur.last) {                                                                                 \
             if (handed_back) {                                                                          \
                 if (lane == 0) {                                                                        \
@@ -892,6 +903,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
                 }                                                                                       \
             }                                                                                           \
         }                                                                                               \
+        SP(4);                                                                                          \
     }
 #pragma unroll 1
     while (slot[0].valid || slot[1].valid) {
@@ -900,6 +912,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
     }
 #undef FGFA_SBLOCK
 #undef FGFA_SPTR
+#ifdef FGFA_SHORT_PROF
+    if ((blockIdx.x == 0 || blockIdx.x == 100) && (threadIdx.x == 0 || threadIdx.x == 64 * 9)) printf("short wg %u wave %u: between %llu wait %llu take+next+issue %llu block16 %llu path-end %llu\n", blockIdx.x, threadIdx.x >> 6, tp[0], tp[1], tp[2], tp[3], tp[4]);
+#endif
     __syncthreads();
     for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThr)
         A.counts[(size_t)wdw * A.n_slots + blockIdx.x] = bcur[wdw];
