@@ -2453,6 +2453,40 @@ __device__ __forceinline__ void claim_step(uint32_t rec, uint32_t sb, unsigned l
         : "vcc", "memory");
 }
 
+// The same for records of one segment each (k_scan_dense's: ids without runs): two depth updates, one returning OR of
+// the segment's bit, and under the lanes that found it set the revisit's two updates.  Eleven vector instructions,
+// where the C++ rendering had two predicated regions with their exec bookkeeping.
+template <int WB>
+__device__ __forceinline__ void claim_point(uint32_t rec, uint32_t sb, unsigned long long vm, uint32_t dbase, uint32_t rbase, uint32_t one, uint32_t mone) {
+    constexpr uint32_t kRelMask = (1u << WB) - 1u;
+    uint32_t rel, a, w, k, bit, old;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[vm]\n\t"
+        "v_and_b32 %[rel], %[relmask], %[rec]\n\t"
+        "v_lshl_add_u32 %[a], %[rel], 2, %[dbase]\n\t"
+        "ds_add_u32 %[a], %[one]\n\t"
+        "ds_add_u32 %[a], %[mone] offset:4\n\t"
+        "v_bfe_u32 %[w], %[rec], 5, %[wb5]\n\t"
+        "v_lshl_add_u32 %[w], %[w], 2, %[sb]\n\t"
+        "v_and_b32 %[k], 31, %[rec]\n\t"
+        "v_lshlrev_b32 %[bit], %[k], 1\n\t"
+        "ds_or_rtn_b32 %[old], %[w], %[bit]\n\t"
+        "v_lshl_add_u32 %[a], %[rel], 2, %[rbase]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_and_b32 %[old], %[old], %[bit]\n\t"
+        "v_cmp_ne_u32 vcc, 0, %[old]\n\t"
+        "s_and_b64 exec, exec, vcc\n\t"
+        "ds_add_u32 %[a], %[one]\n\t"
+        "ds_add_u32 %[a], %[mone] offset:4\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [rel] "=&v"(rel), [a] "=&v"(a), [w] "=&v"(w), [k] "=&v"(k), [bit] "=&v"(bit), [old] "=&v"(old), [sv] "=&s"(sv)
+        : [rec] "v"(rec), [sb] "v"(sb), [vm] "s"(vm), [dbase] "s"(dbase), [rbase] "s"(rbase), [one] "v"(one), [mone] "v"(mone),
+          [relmask] "i"(kRelMask), [wb5] "i"(WB - 5)
+        : "vcc", "memory");
+}
+
 // Pass 2 of a tagged call: every record of k_scan says whose it is (see kTagShift), so a wave
 // walks whole sub-buckets, 64 consecutive records per step, three steps' records requested ahead
 // of their use, and needs no directory: nothing to fetch before the first record, no mapping of
@@ -2549,17 +2583,7 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
         uint32_t sb = priv_b + ((tag & (kSlots - 1u)) << (WB - 3));
         if (SHARED && any_shared) sb = tag >= shlo ? bits0 + ((kPriv + kTagCount - 1u - tag) << (WB - 3)) : sb;
         if (POINT) {  // every record is one segment (k_scan_dense)
-            const uint32_t rel = rec & (kW - 1u), bit = 1u << (rel & 31u);
-            uint32_t old = 0;
-            if ((act >> lane) & 1ull) {
-                atomicAdd(&D[rel], 1);
-                atomicAdd(&D[rel + 1u], -1);
-                old = atomicOr(bits + ((sb - bits0) >> 2) + (rel >> 5), bit);
-            }
-            if (old & bit) {
-                atomicAdd(&R[rel], 1);
-                atomicAdd(&R[rel + 1u], -1);
-            }
+            claim_point<WB>(rec, sb, act, dbase, rbase, one, mone);
         } else if (!(FGFA_TAG_ABLATE & 1)) {
             claim_step<WB>(rec, sb, act, dbase, rbase, one, mone);
         }
