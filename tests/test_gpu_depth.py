@@ -946,3 +946,28 @@ def test_medium_paths_whose_blocks_hold_more_runs_than_the_queue(monkeypatch):
         assert (d.cpu().numpy() == want_d).all()
         if with_u:
             assert (u.cpu().numpy() == want_u).all()
+
+
+@pytest.mark.parametrize("shape", [(300_000, 40, 30_000, "uniform"), (200_000, 300, 5_000, "pangenome"), (123_457, 7, 200_001, "uniform")])
+def test_dense_pass1_on_segment_ranges(shape, monkeypatch):
+    """k_scan_dense on a plan cut into segment ranges: a walk per range leaves out the steps outside it, so every phase takes
+    its general, predicated form (full tiles of plans without ranges take the plain one), tiles pipelined two deep all the same."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DENSE", "1")
+    monkeypatch.setenv("FLATGFA_RANGE_SEGS", "40960")
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.setenv("FLATGFA_BIG_GROUPS", "1")
+    for v in ("FLATGFA_SHORT_MAX", "FLATGFA_TAGGED", "FLATGFA_WB", "FLATGFA_PACKED"):
+        monkeypatch.delenv(v, raising=False)
+    S, P, L, model = shape
+    g = pa.synth(3, S, P, L, model, False)
+    steps, pb, pe, sl = g.soa()
+    plan = DepthPlan(DeviceGraph(steps, pb, pe, S, sl))
+    assert "k_scan_dense" in plan.describe() and "ranges=1 " not in plan.describe(), plan.describe()
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    plan.seg_depth(d, u)
+    plan.status()
+    want_d, want_u = fo.seg_depth_with_uniq(pools_of(g))
+    assert (d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all()
