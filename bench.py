@@ -112,6 +112,10 @@ def main():
                     help="who shards and reduces for N > 1: torch.distributed (one rank per GPU, RCCL through torch's nccl backend), or "
                          "the C ABI (flatgfa_sharded_*: rank 0 alone drives all N devices, RCCL inside libflatgfa.so; the other ranks only "
                          "keep the launcher's barrier)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="calls in flight: K plans of the rank's resident graph on K streams, called in turn, so that pass 2 of one "
+                         "call (bound by instruction issue) shares the chip with pass 1 of the next (bound by the memory system); every "
+                         "step is still a whole query into its own result buffer.  1 = strictly one call after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -170,18 +174,33 @@ def main():
     N_job = N if strong else world * N  # steps one step of the whole job walks
     graph = dev.DeviceGraph(l_steps, l_pb, l_pe, S, seg_len, device=str(device))
     plan = dev.DepthPlan(graph)
-    op = ShardedDepth(S, plan.seg_depth, device=device, with_uniq=True)
+    in_flight = max(1, args.in_flight)
+    plans = [plan] + [dev.DepthPlan(graph) for _ in range(in_flight - 1)]  # (a plan belongs to one stream; they share the graph image and its claim on the Infinity Cache)
+    side = [torch.cuda.Stream(device) for _ in plans] if in_flight > 1 else None
+    op = ShardedDepth(S, [p.seg_depth for p in plans], device=device, with_uniq=True, streams=side)
+    op1 = op if in_flight == 1 else ShardedDepth(S, plan.seg_depth, device=device, with_uniq=True)  # one call after the other, for the per-kernel samples
+
+    def status_all():
+        op.finish()
+        for k, p in enumerate(plans):
+            if side is not None:
+                with torch.cuda.stream(side[k]):
+                    p.status()
+            else:
+                p.status()
 
     def sync_all():
         op.finish()
+        if op1 is not op:
+            op1.finish()
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, len(op.bufs))):  # (every result buffer written at least once: all of them are verified below)
         op.run()
-    plan.status()
+    status_all()
     sync_all()
 
     # ---- verification of what is being timed: the REDUCED vector against the oracle, on every rank ----
@@ -198,6 +217,8 @@ def main():
             want = t.cpu().numpy()
         got = op.buf.cpu().numpy().view(np.uint32).astype(np.int64)
         ok = bool((got == want).all())
+        for b in op.bufs:  # (calls in flight: every plan's result, not only the last one's)
+            ok = ok and bool((b.cpu().numpy().view(np.uint32).astype(np.int64) == want).all())
         if world > 1:
             t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=coll_device)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -233,19 +254,30 @@ def main():
         dev.profile_enable(False)
         return t1 - t0, dev.profile_read()
 
-    elapsed, kernels_region = timed_loop(lambda i: op.run(), args.steps, True)
-    n_region_samples = len([i for i in range(args.steps) if i % EVENT_EVERY == EVENT_AT])
+    # Calls in flight (K > 1): the region is the pipelined loop and carries no event records -- a kernel's
+    # duration next to another call's kernel on the same chip is not that kernel's own -- and every per-kernel
+    # sample comes from the pass behind it, which runs one call after the other on the first plan alone.
+    elapsed, kernels_region = timed_loop(lambda i: op.run(), args.steps, in_flight == 1)
+    n_region_samples = len([i for i in range(args.steps) if i % EVENT_EVERY == EVENT_AT]) if in_flight == 1 else 0
+    if in_flight > 1:
+        SAMPLE_STEPS = 18
+    serial_elapsed = None
+    if in_flight > 1:  # the same loop with one call in flight (no event records either)
+        for _ in range(2):
+            op1.run()
+        serial_elapsed, _ = timed_loop(lambda i: op1.run(), args.steps, False)
     # the sampled pass behind the region
     for _ in range(2):
-        op.run()
+        op1.run()
     dev.profile_enable(True)
     for _ in range(SAMPLE_STEPS):
-        op.run()
+        op1.run()
     sync_all()
     dev.profile_enable(False)
     kernels_post = dev.profile_read()
     kernels = kernels_region + kernels_post
     n_timed_steps = n_region_samples + SAMPLE_STEPS
+    status_all()
     plan.status()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
@@ -326,6 +358,51 @@ def main():
                                    behind_region=stats([ms for n_, ms in kernels_post if n_ == dom]),
                                    frac_at_median=round(B_dom / (float(np.median(v)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5))
         roofline["n"] = int(len(v))
+        # the whole call as the timed region ran it (K calls in flight): SURVEY.md 8(d)'s bytes over ms_per_step
+        region_ms = elapsed / args.steps * 1e3
+        roofline["whole_call"]["timed_region"] = {
+            "calls_in_flight": in_flight, "ms_per_step": round(region_ms, 5),
+            "achieved": round(B_call / (region_ms * 1e-3) / 1e9, 2), "frac": round(B_call / (region_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "ms_per_step_one_call_in_flight": round(serial_elapsed / args.steps * 1e3, 5) if serial_elapsed else round(region_ms, 5)}
+        if in_flight > 1:
+            roofline["kernel_timing"] = (f"HIP events around each launch of {SAMPLE_STEPS} consecutive steps right behind the timed region, one call "
+                                         "after the other on the first plan's stream (the region itself keeps "
+                                         f"{in_flight} calls in flight and carries no event records); `achieved` uses the mean over all of them")
+        # Every step from HBM: the plan keeps the first cache_resident_mb of the steps in the 256 MiB Infinity Cache from
+        # call to call (they are read without the nt hint), which a loop over ONE resident graph profits from.  The same
+        # graph through a plan made with FLATGFA_MALL_MB=0, sampled the same way, is what a call costs when nothing of
+        # its steps is left in that cache (more graphs queried in turn than it holds: extras.rotate).
+        m_res = re.search(r"cache_resident_mb=(\d+)", plan.describe())
+        if world == 1 and dom.startswith("k_scan") and m_res and int(m_res.group(1)) > 0:
+            os.environ["FLATGFA_MALL_MB"] = "0"
+            try:
+                plan0 = dev.DepthPlan(graph)
+            finally:
+                del os.environ["FLATGFA_MALL_MB"]
+            cold = torch.zeros(2 * S, dtype=torch.int32, device=device)
+            for _ in range(3):
+                plan0.seg_depth(cold[:S], cold[S:])
+            plan0.status()
+            dev.profile_enable(True)
+            dev.profile_read()
+            for _ in range(SAMPLE_STEPS):
+                plan0.seg_depth(cold[:S], cold[S:])
+            plan0.status()
+            dev.profile_enable(False)
+            per0 = {}
+            for name, ms in dev.profile_read():
+                per0.setdefault(name, []).append(ms)
+            if dom in per0:
+                cold_ms = float(np.mean(per0[dom]))
+                roofline["frac_cold"] = round(B_dom / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                roofline["cold"] = {
+                    "what": f"the same graph through a plan made with FLATGFA_MALL_MB=0 (no step kept in the Infinity Cache: `frac` has "
+                            f"{m_res.group(1)} MB of them resident there from call to call), {len(per0[dom])} consecutive calls, HIP events",
+                    "kernel_avg_ms": round(cold_ms, 5), "achieved": round(B_dom / (cold_ms * 1e-3) / 1e9, 2), "n": len(per0[dom]),
+                    "kernels_avg_ms": {k: round(float(np.mean(v2)), 5) for k, v2 in per0.items()},
+                    "same_result": bool((cold.cpu().numpy() == op1.buf.cpu().numpy()).all()) if world == 1 else None}
+            plan0.close()
+            del plan0, cold
         # An event pair also contains the launch itself; what it reads around a kernel of k_scan's
         # shape that does nothing is reported beside the kernel times, not subtracted from them
         # (rocprofv3's dispatch durations, profiles/, do not contain it).
@@ -381,48 +458,11 @@ def main():
                     (cd.cpu().numpy().view(np.uint32) == want[0]).all() and (cu.cpu().numpy().view(np.uint32) == want[1]).all())}
             cplan.close()
             del gc, cs, cplan, cd, cu
-        # What the Infinity Cache contributes: a plan keeps the first so-many megabytes of the steps resident
-        # there (read without the nt hint; flatgfa_dev_plan_describe: cache_resident_mb).  The same graph
-        # through a plan made with that switched off, same loop, kernels by HIP events:
-        if args.workload == "cfgL":
-            os.environ["FLATGFA_MALL_MB"] = "0"
-            try:
-                plan0 = dev.DepthPlan(graph)
-            finally:
-                del os.environ["FLATGFA_MALL_MB"]
-            d0 = torch.zeros(S, dtype=torch.int32, device=device)
-            u0 = torch.zeros(S, dtype=torch.int32, device=device)
-            for _ in range(3):
-                plan0.seg_depth(d0, u0)
-            plan0.status()
-            dev.profile_enable(True)
-            dev.profile_read()
-            c0 = time.perf_counter()
-            for _ in range(16):
-                plan0.seg_depth(d0, u0)
-            plan0.status()
-            c1 = time.perf_counter()
-            dev.profile_enable(False)
-            per0 = {}
-            for name, ms in dev.profile_read():
-                per0.setdefault(name, []).append(ms)
-            same = bool((d0.cpu().numpy() == op.buf[:S].cpu().numpy()).all()) if hasattr(op, "buf") else None
-            extras["cache_residency"] = {
-                "what": "k_scan reads the first cache_resident_mb of the steps without the nt hint, so that they are still in the 256 MiB "
-                        "Infinity Cache at the next call; `without` = a plan of the same graph made with FLATGFA_MALL_MB=0 (every step read "
-                        "from HBM, as when more graphs are queried in turn than the cache holds: extras.rotate)",
-                "plan": plan.describe().split(" ")[-1],
-                "k_scan_ms": round(kern_avg_ms.get("k_scan", 0.0), 5),
-                "k_scan_ms_without": round(float(np.mean(per0.get("k_scan", [0.0]))), 5),
-                "frac_without": round(kernel_bytes("k_scan", N_local, P_local, S, 2) / (float(np.mean(per0.get("k_scan", [1.0]))) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "same_depth_vector": same}
-            plan0.close()
-            del plan0, d0, u0
         # The timed loop walks the same 400 MB image every step; MI355X has 256 MiB of Infinity
         # Cache and FETCH_SIZE counts its hits as fetches.  Cycle K resident images (> 1 GB): if
         # the cache helped, this is slower.
         if args.rotate >= 2:
-            ops = [op]
+            ops = [op1]  # (one call in flight in both loops)
             keep = []
             for seed in range(2, args.rotate + 1):
                 gk = pa.synth(seed, S, P, L, model, False)
@@ -435,7 +475,7 @@ def main():
                 o.run()
             torch.cuda.synchronize(device)
             rot_elapsed, _ = timed_loop(lambda i: ops[i % len(ops)].run(), args.steps, False)
-            same_elapsed, _ = timed_loop(lambda i: op.run(), args.steps, False)
+            same_elapsed, _ = timed_loop(lambda i: op1.run(), args.steps, False)
             for _, _, plk in keep:
                 plk.status()
             extras["rotate"] = {"images": len(ops), "resident_step_bytes": len(ops) * 4 * N,
@@ -596,6 +636,12 @@ def main():
             extras["cpu_all_cores"] = {"value": round(N / float(np.median(mts)), 1), "unit": "path-steps/s",
                                        "cores": nthr, "kind": "port, path-parallel (pthreads)"}
 
+    # how many ranks the collective really spans (an all-reduce of ones, on the data path's backend)
+    ranks_seen = 1
+    if world > 1:
+        t = torch.ones(1, dtype=torch.int32, device=coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ranks_seen = int(t.item())
     steps_all = [N_local]
     if world > 1:
         t = torch.zeros(world, dtype=torch.int64, device=coll_device)
@@ -625,7 +671,8 @@ def main():
                                    f"S={S}, P={P}, L={L}, model={model})" + (" per GPU" if world > 1 and not strong else ""),
                        "segments": S, "paths_per_gpu": P_local if strong else P,
                        "steps_per_gpu": N_local, "steps_per_gpu_all_ranks": steps_all, "steps_per_job_step": N_job, "sharding": sharding,
-                       "collective_bytes": 8 * S if world > 1 else 0},
+                       "collective_bytes": 8 * S if world > 1 else 0, "calls_in_flight": in_flight,
+                       "ranks_seen": ranks_seen, "uses_rccl": bool(world > 1 and backend == "nccl")},
             "bit_exact_vs_oracle": verified,
             "roofline": roofline, "cpu_baseline": cpu, "commit": git_head(),
         }
@@ -717,6 +764,7 @@ def main_host_c(args, torch, dist, pa, dev):
                        "segments": S, "steps_per_job_step": N, "host": "c", "steps_per_gpu": N_local,
                        "steps_per_gpu_all_ranks": [x["step_end"] - x["step_begin"] for x in lay],
                        "collective_bytes": sh.collective_bytes(True) if args.gpus > 1 or lay[0]["rccl"] else 0,
+                       "ranks_seen": sh.ranks_seen(), "uses_rccl": bool(lay[0]["rccl"]),
                        "sharding": f"flatgfa_sharded_* (C ABI, one process): {args.gpus} shards on devices {devices}, "
                                    f"{lay[0]['split_paths']} paths cut, exchange by " + ("RCCL ncclAllReduce inside libflatgfa.so" if lay[0]["rccl"] else "device-side adds (shards share a device)"),
                        "shards": [{k: x[k] for k in ("device", "step_begin", "step_end", "pieces")} for x in lay]},

@@ -227,6 +227,16 @@ int flatgfa_sharded_path_depth(flatgfa_sharded_t *sh, const uint32_t *path_ids, 
 int flatgfa_sharded_enqueue(flatgfa_sharded_t *sh, int with_uniq);
 int flatgfa_sharded_sync(flatgfa_sharded_t *sh);
 int flatgfa_sharded_fetch(flatgfa_sharded_t *sh, int shard, uint64_t *depth_out, uint64_t *uniq_out);
+/* How many ranks the handle's exchange really spans: every shard contributes a one to an all-reduce over the
+ * handle's communicator (RCCL), or -- shards that exchange by adds -- is counted as it answers.  Equals
+ * n_shards on a handle that works; negative = an error code. */
+int flatgfa_sharded_ranks_seen(flatgfa_sharded_t *sh);
+/* Where flatgfa_sharded_create would cut a graph whose paths, in path order, have path_steps[p] steps (host only: no
+ * device is touched).  cuts_out[r], r = 0 .. n_shards, counts path steps along the path order: shard r walks
+ * [cuts_out[r], cuts_out[r + 1]).  Cut r lies at the path boundary nearest to the even cut (total * r / n_shards) when
+ * that is within an eighth of a shard's share of it -- or always, with FLATGFA_SHARD_WHOLE_PATHS -- and inside the path
+ * otherwise. */
+int flatgfa_shard_cuts(const uint64_t *path_steps, uint32_t n_paths, int n_shards, unsigned flags, uint64_t *cuts_out);
 
 /* ------------------------------------------------------------------------ */
 /* Part 3 -- device-level entry points (caller-owned HBM buffers)           */

@@ -7,7 +7,7 @@ the multi-GPU path sharding.  All depth arithmetic runs in hand-written HIP kern
 (pollen_amd/csrc/depth_device.hip); the package has no CPU fallback.
 """
 from .flatgfa import (SHARD_NO_RCCL, SHARD_WHOLE_PATHS, FlatGFA, FlatGFAError, ShardedFlatGFA, device_count, format_float, load, parse, parse_bytes,
-                      parse_stream_bytes, synth, translate_prealloc)
+                      parse_stream_bytes, shard_cuts, synth, translate_prealloc)
 
 __all__ = ["SHARD_NO_RCCL", "SHARD_WHOLE_PATHS", "ShardedFlatGFA", "FlatGFA", "FlatGFAError", "device_count", "format_float", "load", "parse", "parse_bytes",
-           "parse_stream_bytes", "synth", "translate_prealloc"]
+           "parse_stream_bytes", "shard_cuts", "synth", "translate_prealloc"]

@@ -76,6 +76,8 @@ SIGNATURES = {
     "flatgfa_sharded_enqueue": (c_int, [c_void_p, c_int]),
     "flatgfa_sharded_sync": (c_int, [c_void_p]),
     "flatgfa_sharded_fetch": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "flatgfa_sharded_ranks_seen": (c_int, [c_void_p]),
+    "flatgfa_shard_cuts": (c_int, [c_void_p, c_uint32, c_int, ctypes.c_uint, c_void_p]),
     "flatgfa_dev_path_depth_all": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flatgfa_dev_path_overlaps": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_void_p]),
     "flatgfa_dev_plan_create": (c_void_p, [POINTER(flatgfa_dev_graph_t), c_void_p, c_void_p]),

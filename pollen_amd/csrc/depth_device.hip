@@ -271,12 +271,23 @@ struct flatgfa_dev_plan {
     uint32_t calls_since_status = 0;   // node-depth calls enqueued since the last flatgfa_dev_status: only the last can be completed there
     uint32_t *all_ids = nullptr;       // 0..n_paths-1 (path_depth_all without the bucketed path)
     int64_t cache_claim = 0;           // bytes of the device's Infinity Cache this plan's resident steps lay claim to (g_cache_claimed)
+    bool cache_claim_shared = false;   // ... a claim another plan over the same step array made first (g_cache_shares): counted once
 };
 
 // The Infinity Cache (256 MiB on MI355X) is one per device: what the plans of a process keep resident in it is
 // budgeted per device, first come first served, and given back when a plan is destroyed.
 static std::mutex g_cache_mu;
 static int64_t g_cache_claimed[64] = {};
+// Plans over the SAME resident step array (two plans of one graph on two streams, so that one call's pass 2 runs
+// beside the next call's pass 1; a plan per subset of paths) keep the same first megabytes of it resident: one
+// claim, counted once, held until the last of them is destroyed.
+struct CacheShare {
+    int device;
+    const uint32_t *steps;
+    int64_t bytes;
+    int users;
+};
+static std::vector<CacheShare> g_cache_shares;
 
 extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int n_cus, uint32_t **coarse_cache,
                                               uint32_t **qbits_cache, size_t *qbits_bytes, bool *qbits_all, const uint32_t *query_ids, uint32_t n_q, uint8_t *touch_out,
@@ -356,14 +367,29 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
         budget = std::min<int64_t>(budget, (int64_t)g->n_steps * 4);
         {
             std::lock_guard<std::mutex> lk(g_cache_mu);
-            if (pl->device >= 0 && pl->device < 64) {
-                if (!getenv("FLATGFA_MALL_MB")) budget = std::min<int64_t>(budget, (160ll << 20) - g_cache_claimed[pl->device]);
-                if (budget < (32ll << 20) || (int64_t)g->n_steps * 4 < (64ll << 20)) budget = 0;  // (not worth the L2 lines; graphs of a few million steps are launch-bound anyway)
+            const bool pinned = getenv("FLATGFA_MALL_MB") != nullptr;  // (the thresholds below are the plan's own rule: a pinned amount is taken as given)
+            CacheShare *share = nullptr;
+            for (CacheShare &c : g_cache_shares)
+                if (c.device == pl->device && c.steps == g->steps) share = &c;
+            if (pl->device < 0 || pl->device >= 64) {
+                budget = 0;
+            } else if (share && !pinned) {  // another plan keeps this array's first bytes resident already: the same stretch, no second claim
+                budget = std::min<int64_t>(share->bytes, (int64_t)g->n_steps * 4);
+                share->users += 1;
+                pl->cache_claim = share->bytes;
+                pl->cache_claim_shared = true;
+            } else {
+                if (!pinned) {
+                    budget = std::min<int64_t>(budget, (160ll << 20) - g_cache_claimed[pl->device]);
+                    if (budget < (32ll << 20) || (int64_t)g->n_steps * 4 < (64ll << 20)) budget = 0;  // (not worth the L2 lines; graphs of a few million steps are launch-bound anyway)
+                }
                 budget = std::max<int64_t>(budget, 0);
                 g_cache_claimed[pl->device] += budget;
                 pl->cache_claim = budget;
-            } else {
-                budget = 0;
+                if (budget && !pinned) {
+                    g_cache_shares.push_back(CacheShare{pl->device, g->steps, budget, 1});
+                    pl->cache_claim_shared = true;
+                }
             }
         }
         pl->fast.mall_steps = (uint64_t)budget / 4;
@@ -506,7 +532,17 @@ extern "C" void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *pl) {
     if (!pl) return;
     if (pl->cache_claim) {
         std::lock_guard<std::mutex> lk(g_cache_mu);
-        if (pl->device >= 0 && pl->device < 64) g_cache_claimed[pl->device] -= pl->cache_claim;
+        bool last = true;
+        if (pl->cache_claim_shared) {
+            for (size_t i = 0; i < g_cache_shares.size(); ++i) {
+                CacheShare &c = g_cache_shares[i];
+                if (c.device != pl->device || c.steps != pl->g.steps) continue;
+                last = --c.users == 0;
+                if (last) g_cache_shares.erase(g_cache_shares.begin() + (long)i);
+                break;
+            }
+        }
+        if (last && pl->device >= 0 && pl->device < 64) g_cache_claimed[pl->device] -= pl->cache_claim;
     }
     fast_plan_destroy(&pl->fast);
     if (pl->overlap_bits) (void)hipFree(pl->overlap_bits);

@@ -2484,7 +2484,7 @@ __device__ __forceinline__ void claim_point(uint32_t rec, uint32_t sb, unsigned 
         : [rel] "=&v"(rel), [a] "=&v"(a), [w] "=&v"(w), [k] "=&v"(k), [bit] "=&v"(bit), [old] "=&v"(old), [sv] "=&s"(sv)
         : [rec] "v"(rec), [sb] "v"(sb), [vm] "s"(vm), [dbase] "s"(dbase), [rbase] "s"(rbase), [one] "v"(one), [mone] "v"(mone),
           [relmask] "i"(kRelMask), [wb5] "i"(WB - 5)
-        : "vcc", "memory");
+        : "vcc", "scc", "memory");
 }
 
 // Pass 2 of a tagged call: every record of k_scan says whose it is (see kTagShift), so a wave

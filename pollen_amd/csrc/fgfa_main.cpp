@@ -106,8 +106,12 @@ int main(int argc, char **argv) {
     // the graph (and, for a mapped file, has the kernel map the step pool's pages in).
     const bool wants_device = cmd == "depth" || cmd == "window-depth" || cmd == "overlap";
     // (`fgfa` only ever uses device 0: on a node with several GPUs the runtime need not bring the others up.  Set
-    // before the first HIP call; a caller's own choice of visible devices is left alone.)
-    if (wants_device && !getenv("ROCR_VISIBLE_DEVICES") && !getenv("HIP_VISIBLE_DEVICES")) (void)setenv("ROCR_VISIBLE_DEVICES", "0", 0);
+    // before the first HIP call; a caller's or scheduler's own choice of visible devices -- by any of the variables the
+    // HIP runtime honours: CUDA_VISIBLE_DEVICES and GPU_DEVICE_ORDINAL index into what ROCr exposes, so narrowing
+    // ROCr to device 0 under them would hide the assigned GPU -- is left alone.)
+    bool pinned = false;
+    for (const char *v : {"ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"}) pinned = pinned || getenv(v) != nullptr;
+    if (wants_device && !pinned) (void)setenv("ROCR_VISIBLE_DEVICES", "0", 0);
     std::thread warm;
     if (wants_device && !getenv("FLATGFA_NO_WARM")) warm = std::thread([] { (void)flatgfa_warm_device(0); });
 

@@ -146,6 +146,8 @@ struct Shard {
     std::vector<Touch> touch;
     uint32_t *d_send = nullptr, *d_recv = nullptr, *d_tmp = nullptr;  // [(2 + W) * S] each (W words of packed touch counters per segment); 2 S scratch
     uint64_t *d_sums = nullptr;                                       // [2 * pieces]
+    uint32_t *d_ones = nullptr;                                       // [2] flatgfa_sharded_ranks_seen: this shard's one, and the sum
+    uint32_t ranks_seen = 0;
     ncclComm_t comm = nullptr;
     // the shard's host thread
     std::thread th;
@@ -157,7 +159,7 @@ struct Shard {
     std::string err;
 };
 
-enum { kCmdQuit = 1, kCmdLocal, kCmdExchange, kCmdSync, kCmdPathSums };
+enum { kCmdQuit = 1, kCmdLocal, kCmdExchange, kCmdSync, kCmdPathSums, kCmdCountRanks };
 
 }  // namespace
 
@@ -240,6 +242,45 @@ int shard_path_sums(flatgfa_sharded &h, Shard &s) {
     return shard_sync(h, s);
 }
 
+// Where the steps are cut (host only; flatgfa_shard_cuts exposes it to the CPU test suite).  `cum[p]` = path steps
+// before path p, counted along the path order.  Cut r lies at the path boundary nearest to the even cut
+// T * r / n when that is within an eighth of a shard's share of it -- or whenever paths must stay whole --
+// and inside the path otherwise.
+void shard_cuts(const std::vector<uint64_t> &cum, int n_shards, bool may_split, std::vector<uint64_t> *cut_out) {
+    const size_t P = cum.size() - 1;
+    const uint64_t T = cum[P];
+    std::vector<uint64_t> &cut = *cut_out;
+    cut.assign((size_t)n_shards + 1, 0);
+    cut[(size_t)n_shards] = T;
+    for (int r = 1; r < n_shards; ++r) {
+        const uint64_t target = (uint64_t)((__uint128_t)T * r / n_shards);
+        size_t p = (size_t)(std::upper_bound(cum.begin(), cum.end(), target) - cum.begin());  // cum[p - 1] <= target < cum[p]
+        p = p ? p - 1 : 0;
+        const uint64_t lo = cum[p], hi = cum[std::min(p + 1, P)];
+        const uint64_t near = target - lo <= hi - target ? lo : hi;
+        const uint64_t off = near > target ? near - target : target - near;
+        const uint64_t c = (!may_split || off * 8 * n_shards <= T) ? near : target;
+        cut[(size_t)r] = std::max(c, cut[(size_t)r - 1]);
+    }
+}
+
+// How many ranks the exchange really spans: every shard contributes a one.
+int shard_count_ranks(flatgfa_sharded &h, Shard &s) {
+    if (!s.d_ones) SH_HIP(hipMalloc(&s.d_ones, 8));
+    const uint32_t one[2] = {1u, 0u};
+    SH_HIP(hipMemcpyAsync(s.d_ones, one, 8, hipMemcpyHostToDevice, s.stream));
+    if (h.use_rccl) {
+        const Rccl *r = rccl(nullptr);
+        const ncclResult_t e = r->AllReduce(s.d_ones, s.d_ones + 1, 1, ncclUint32, ncclSum, s.comm, s.stream);
+        if (e != ncclSuccess) { s.err = std::string("ncclAllReduce: ") + r->GetErrorString(e); return FLATGFA_ERR_HIP; }
+    } else {
+        SH_HIP(hipMemcpyAsync(s.d_ones + 1, s.d_ones, 4, hipMemcpyDeviceToDevice, s.stream));
+    }
+    SH_HIP(hipMemcpyAsync(&s.ranks_seen, s.d_ones + 1, 4, hipMemcpyDeviceToHost, s.stream));
+    SH_HIP(hipStreamSynchronize(s.stream));
+    return FLATGFA_OK;
+}
+
 void shard_thread(flatgfa_sharded *h, Shard *s) {
     (void)hipSetDevice(s->device);
     for (;;) {
@@ -255,6 +296,7 @@ void shard_thread(flatgfa_sharded *h, Shard *s) {
         else if (cmd == kCmdExchange) rc = shard_exchange(*h, *s);
         else if (cmd == kCmdSync) rc = shard_sync(*h, *s);
         else if (cmd == kCmdPathSums) rc = shard_path_sums(*h, *s);
+        else if (cmd == kCmdCountRanks) rc = shard_count_ranks(*h, *s);
         {
             std::lock_guard<std::mutex> lk(s->mu);
             s->rc = rc;
@@ -360,7 +402,7 @@ void flatgfa_sharded_free(flatgfa_sharded_t *h) {
             if (t.d_span) (void)hipFree(t.d_span);
         }
         for (void *p : {(void *)s->d_steps, (void *)s->d_small, (void *)(s->d_recv != s->d_send ? s->d_recv : nullptr), (void *)s->d_send, (void *)s->d_tmp,
-                        (void *)s->d_sums})
+                        (void *)s->d_sums, (void *)s->d_ones})
             if (p) (void)hipFree(p);
         if (s->stream) (void)hipStreamDestroy(s->stream);
     }
@@ -409,20 +451,8 @@ flatgfa_sharded_t *flatgfa_sharded_create(flatgfa_t gfa, const int *devices, int
     }
     const uint64_t T = cum[P];
     const bool may_split = ordered && !(flags & FLATGFA_SHARD_WHOLE_PATHS);
-    // cut r, in path steps counted along the path order: at the path boundary nearest to the even
-    // cut when that is within an eighth of a shard's share of it, else inside the path
-    std::vector<uint64_t> cut(n_shards + 1, 0);
-    cut[n_shards] = T;
-    for (int r = 1; r < n_shards; ++r) {
-        const uint64_t target = (uint64_t)((__uint128_t)T * r / n_shards);
-        size_t p = (size_t)(std::upper_bound(cum.begin(), cum.end(), target) - cum.begin());  // cum[p - 1] <= target < cum[p]
-        p = p ? p - 1 : 0;
-        const uint64_t lo = cum[p], hi = cum[std::min(p + 1, P)];
-        const uint64_t near = target - lo <= hi - target ? lo : hi;
-        const uint64_t off = near > target ? near - target : target - near;
-        uint64_t c = (!may_split || off * 8 * n_shards <= T) ? near : target;
-        cut[r] = std::max(c, cut[r - 1]);
-    }
+    std::vector<uint64_t> cut;
+    shard_cuts(cum, n_shards, may_split, &cut);
     // ---- the shards' pieces ----
     std::vector<int> split_of(P, -1);
     {
@@ -556,6 +586,30 @@ int flatgfa_sharded_layout(flatgfa_sharded_t *h, int shard, int *device, uint64_
     if (n_split_paths) *n_split_paths = h->K;
     if (uses_rccl) *uses_rccl = h->use_rccl ? 1 : 0;
     return FLATGFA_OK;
+}
+
+int flatgfa_shard_cuts(const uint64_t *path_steps, uint32_t n_paths, int n_shards, unsigned flags, uint64_t *cuts_out) {
+    if ((n_paths && !path_steps) || n_shards < 1 || n_shards > 64 || !cuts_out) { set_error("flatgfa_shard_cuts: bad argument"); return FLATGFA_ERR_ARG; }
+    std::vector<uint64_t> cum((size_t)n_paths + 1, 0), cut;
+    for (uint32_t p = 0; p < n_paths; ++p) cum[p + 1] = cum[p] + path_steps[p];
+    shard_cuts(cum, n_shards, !(flags & FLATGFA_SHARD_WHOLE_PATHS), &cut);
+    for (int r = 0; r <= n_shards; ++r) cuts_out[r] = cut[(size_t)r];
+    return FLATGFA_OK;
+}
+
+int flatgfa_sharded_ranks_seen(flatgfa_sharded_t *h) {
+    if (!h) { set_error("flatgfa_sharded_ranks_seen: NULL handle"); return FLATGFA_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(h->op_mu);
+    const int rc = run_all(*h, kCmdCountRanks);
+    if (rc) return rc;
+    if (!h->use_rccl) {  // (shards that share a device exchange by adds: every shard is its own rank)
+        int n = 0;
+        for (auto &s : h->sh) n += (int)s->ranks_seen;
+        return n;
+    }
+    for (auto &s : h->sh)
+        if (s->ranks_seen != h->sh[0]->ranks_seen) { set_error("flatgfa_sharded_ranks_seen: the shards disagree"); return FLATGFA_ERR_HIP; }
+    return (int)h->sh[0]->ranks_seen;
 }
 
 int flatgfa_sharded_enqueue(flatgfa_sharded_t *h, int with_uniq) {

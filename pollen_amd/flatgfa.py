@@ -387,6 +387,13 @@ class ShardedFlatGFA:
                "sharded_path_depth")
         return ln, mean
 
+    def ranks_seen(self) -> int:
+        """How many ranks the handle's exchange really spans (an all-reduce of ones over its communicator)."""
+        n = int(_lib.lib().flatgfa_sharded_ranks_seen(self._h))
+        if n < 0:
+            _check(n, "sharded_ranks_seen")
+        return n
+
     def enqueue(self, with_uniq: bool = True) -> None:
         _check(_lib.lib().flatgfa_sharded_enqueue(self._h, 1 if with_uniq else 0), "sharded_enqueue")
 
@@ -399,6 +406,16 @@ class ShardedFlatGFA:
         u = np.zeros(S, dtype=np.uint64) if with_uniq else None
         _check(_lib.lib().flatgfa_sharded_fetch(self._h, int(shard), d.ctypes.data, u.ctypes.data if with_uniq else None), "sharded_fetch")
         return (d, u) if with_uniq else d
+
+
+def shard_cuts(path_steps, n_shards: int, flags: int = 0) -> np.ndarray:
+    """Where `ShardedFlatGFA` cuts a graph whose paths, in path order, have `path_steps[p]` steps
+    (flatgfa_shard_cuts: host only, no device needed): n_shards + 1 cut points counted in path steps along
+    the path order; shard r walks [cuts[r], cuts[r + 1])."""
+    ps = np.ascontiguousarray(path_steps, dtype=np.uint64)
+    out = np.zeros(int(n_shards) + 1, dtype=np.uint64)
+    _check(_lib.lib().flatgfa_shard_cuts(ps.ctypes.data if len(ps) else None, len(ps), int(n_shards), int(flags), out.ctypes.data), "shard_cuts")
+    return out
 
 
 def parse(filename: Union[str, os.PathLike]) -> FlatGFA:

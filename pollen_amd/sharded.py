@@ -68,22 +68,39 @@ class ShardedDepth:
     of a step into the next buffer and starts its all-reduce asynchronously (RCCL runs it on its
     own stream, after the kernels), so the collective of step i overlaps the kernels of step
     i + 1.  `finish()` waits for everything in flight; `depth` / `uniq` / `buf` refer to the most
-    recent step and are complete after `finish()`."""
+    recent step and are complete after `finish()`.
 
-    def __init__(self, n_segs: int, local_fn: Callable, device, with_uniq: bool = True, group=None,
-                 depth_of_pipeline: int = 2):
+    **Calls in flight.**  `local_fn` may be a LIST of K functions with a list of K `streams` (one
+    DepthPlan of the same resident graph per stream: a plan belongs to one stream): a step into buffer j runs
+    `local_fn[j % K]` on `streams[j % K]`, and the kernels of consecutive steps
+    share the chip -- pass 2 of one call (bound by instruction issue) runs on the CUs that pass 1
+    of the next (bound by the memory system) does not occupy, and neither kernel's tail leaves CUs
+    idle.  Every step is still a whole query into its own buffer."""
+
+    def __init__(self, n_segs: int, local_fn, device, with_uniq: bool = True, group=None,
+                 depth_of_pipeline: int = 2, streams=None):
         import torch
         self.torch = torch
         self.n_segs = int(n_segs)
-        self.local_fn = local_fn
+        self.local_fns = list(local_fn) if isinstance(local_fn, (list, tuple)) else [local_fn]
+        self.streams = list(streams) if streams else None
+        if self.streams is not None and len(self.streams) != len(self.local_fns):
+            raise ValueError("one stream per local_fn")
         self.with_uniq = with_uniq
         self.group = group
         k = 2 if with_uniq else 1
+        n_bufs = max(1, int(depth_of_pipeline))
+        if len(self.local_fns) > 1:  # a buffer per call in flight, and then some for the collectives behind them
+            n_bufs = -(-max(n_bufs, len(self.local_fns)) // len(self.local_fns)) * len(self.local_fns)
         # one fused buffer per step in flight, so that a single collective carries both vectors
-        self.bufs = [torch.zeros(k * self.n_segs, dtype=torch.int32, device=device)
-                     for _ in range(max(1, int(depth_of_pipeline)))]
+        self.bufs = [torch.zeros(k * self.n_segs, dtype=torch.int32, device=device) for _ in range(n_bufs)]
         self.works = [None] * len(self.bufs)
         self.cur = 0
+        self.step = 0
+
+    @property
+    def local_fn(self):
+        return self.local_fns[0]
 
     @property
     def buf(self):
@@ -97,25 +114,42 @@ class ShardedDepth:
     def uniq(self):
         return self.buf[self.n_segs:] if self.with_uniq else None
 
-    def run(self) -> None:
-        """One step: local partials into the next buffer, then its all-reduce (if world > 1)."""
+    def _enqueue(self, j: int, which: int) -> None:
         import torch.distributed as dist
-        j = (self.cur + 1) % len(self.bufs)
         if self.works[j] is not None:  # the collective that last used this buffer
             self.works[j].wait()
             self.works[j] = None
         b = self.bufs[j]
-        self.local_fn(b[: self.n_segs], b[self.n_segs:] if self.with_uniq else None)
+        self.local_fns[which](b[: self.n_segs], b[self.n_segs:] if self.with_uniq else None)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             self.works[j] = dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def run(self) -> None:
+        """One step: local partials into the next buffer, then its all-reduce (if world > 1)."""
+        j = (self.cur + 1) % len(self.bufs)
+        which = j % len(self.local_fns)  # (the buffers are a multiple of the functions: a buffer always meets the same plan and stream)
+        if self.streams is not None:
+            with self.torch.cuda.stream(self.streams[which]):
+                self._enqueue(j, which)
+        else:
+            self._enqueue(j, which)
         self.cur = j
+        self.step += 1
 
     def finish(self) -> None:
-        """Wait (the current stream, for RCCL) for every collective still in flight."""
+        """Wait (the current stream, for RCCL and for the side streams) for everything still in flight."""
         for k, w in enumerate(self.works):
             if w is not None:
-                w.wait()
+                if self.streams is not None:
+                    with self.torch.cuda.stream(self.streams[k % len(self.streams)]):
+                        w.wait()
+                else:
+                    w.wait()
                 self.works[k] = None
+        if self.streams is not None:
+            cur = self.torch.cuda.current_stream()
+            for s in self.streams:
+                cur.wait_stream(s)
 
 
 def gather_path_depth(local_lengths, local_weighted, group=None) -> Tuple[np.ndarray, np.ndarray]:

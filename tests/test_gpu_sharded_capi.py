@@ -48,6 +48,12 @@ def test_synthetic_graph_any_number_of_shards(n_shards):
     g = pa.synth(5, 30_000, 12, 20_000, "pangenome", True)
     lay, _ = check_sharded(g, n_shards)
     assert len(lay) == n_shards and all(not x["rccl"] for x in lay)  # (shards on one device exchange by adds)
+    with pa.ShardedFlatGFA(g, n_shards, devices=[0] * n_shards) as sh:
+        assert sh.ranks_seen() == n_shards
+        # the cuts the handle made are the ones the host-only function computes
+        lens = [20_000] * 12
+        cuts = pa.shard_cuts(lens, n_shards)
+        assert [x["step_begin"] for x in sh.layout()] == [int(c) for c in cuts[:-1]]
     # equal paths, twelve of them: 2 and 3 shards cut at path boundaries, 8 shards have to cut paths
     assert (lay[0]["split_paths"] > 0) == (n_shards == 8)
 
@@ -123,6 +129,7 @@ def test_rccl_route_on_one_device(monkeypatch):
     want_d, want_u = fo.seg_depth_with_uniq(pools)
     with pa.ShardedFlatGFA(g, 1, devices=[0]) as sh:
         assert sh.layout()[0]["rccl"]
+        assert sh.ranks_seen() == 1  # (an all-reduce of ones over the communicator)
         for _ in range(3):
             d, u = sh.seg_depth_with_uniq()
             assert (d == want_d).all() and (u == want_u).all()

@@ -37,6 +37,42 @@ def test_shard_paths_equal_paths_split_evenly():
         assert [hi - lo for lo, hi in cuts] == [1000 // world] * world
 
 
+def test_c_route_cuts_are_shard_paths_cuts():
+    """flatgfa_sharded_create's cut computation (flatgfa_shard_cuts: host only, no device) against the torch route's
+    shard_paths: with whole paths the two are the same rule; allowed to cut inside a path, a cut is the nearest path
+    boundary when that lies within an eighth of a shard's share of the even cut, and the even cut itself otherwise."""
+    import pollen_amd as pa
+    rng = np.random.default_rng(11)
+    for world in (1, 2, 3, 4, 8):
+        for P in (0, 1, 2, 7, 8, 100, 1000):
+            for hi_len in (1, 5000, 1_000_000):
+                lens = rng.integers(0, hi_len + 1, size=P).astype(np.uint64)
+                ends = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+                total = int(ends[-1])
+                pb = ends[:-1].astype(np.uint32)
+                pe = ends[1:].astype(np.uint32)
+                whole = pa.shard_cuts(lens, world, pa.SHARD_WHOLE_PATHS)
+                want = [int(ends[lo]) for lo, _ in shard_paths(pb, pe, world)] + [total]
+                assert whole.tolist() == want, (world, P, hi_len)
+                cuts = pa.shard_cuts(lens, world)
+                assert cuts[0] == 0 and cuts[-1] == total and (np.diff(cuts.astype(np.int64)) >= 0).all()
+                for r in range(1, world):
+                    target = total * r // world
+                    near = min((int(e) for e in ends), key=lambda e: (abs(e - target), e))
+                    if abs(near - target) * 8 * world <= total:
+                        assert int(cuts[r]) == max(near, int(cuts[r - 1])), (world, P, hi_len, r)
+                    else:
+                        assert int(cuts[r]) == max(target, int(cuts[r - 1])), (world, P, hi_len, r)
+
+
+def test_shard_cuts_rejects_bad_arguments():
+    import pollen_amd as pa
+    with pytest.raises(pa.FlatGFAError):
+        pa.shard_cuts([1, 2, 3], 0)
+    with pytest.raises(pa.FlatGFAError):
+        pa.shard_cuts([1, 2, 3], 65)
+
+
 def test_local_slice_rebases_spans():
     p = synth.pools(3, 200, 6, 50, "pangenome")
     pb, pe = p.paths["steps_start"], p.paths["steps_end"]
