@@ -179,6 +179,9 @@ def main():
     side = [torch.cuda.Stream(device) for _ in plans] if in_flight > 1 else None
     op = ShardedDepth(S, [p.seg_depth for p in plans], device=device, with_uniq=True, streams=side)
     op1 = op if in_flight == 1 else ShardedDepth(S, plan.seg_depth, device=device, with_uniq=True)  # one call after the other, for the per-kernel samples
+    op.prepare(plans)   # (N = 1: every step is one call through the C ABI, resolved here)
+    if op1 is not op:
+        op1.prepare([plan])
 
     def status_all():
         op.finish()

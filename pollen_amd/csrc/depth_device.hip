@@ -495,7 +495,10 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
         // (or any of the knobs that shape the bucketed path) skips the comparison.
         bool shaped = force != nullptr;
         for (const char *k : {"FLATGFA_PIECE_STEPS", "FLATGFA_SHORT_MAX", "FLATGFA_SHORT_ANY", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS",
-                              "FLATGFA_DEBUG_SKIP", "FLATGFA_WB", "FLATGFA_DENSE", "FLATGFA_TAGGED", "FLATGFA_PATH_GROUPS"})
+#ifdef FGFA_MEASURE
+                              "FLATGFA_DEBUG_SKIP",
+#endif
+                              "FLATGFA_WB", "FLATGFA_DENSE", "FLATGFA_TAGGED", "FLATGFA_PATH_GROUPS"})
             shaped = shaped || getenv(k) != nullptr;
         if (pl->fast.eligible && !shaped && g->n_steps <= (8u << 20)) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -772,7 +775,7 @@ extern "C" int flatgfa_dev_plan_describe(flatgfa_dev_plan_t *pl, char *out, int 
             " pass2=" + (f.tagged ? (f.n_shared ? "tagged(shared bitsets)" : f.acc_pair ? "tagged(two workgroups per window)" : "tagged") : (f.big_groups ? "directory(one-item shortcut)" : "directory")) +
             " windows=" + std::to_string(f.n_win) + "x" + std::to_string(1u << f.wb) + " ranges=" + std::to_string((f.n_more + 1) / f.n_groups) +
             (f.n_groups > 1 ? " path_groups=" + std::to_string(f.n_groups) : std::string()) +
-            " workgroups_per_window=" + std::to_string(f.acc_parts) + " items=" + std::to_string(f.n_items) + " split_paths=" + std::to_string(f.n_shared) +
+            " workgroups_per_window=" + std::to_string(f.acc_parts) + " items=" + std::to_string(f.n_items) + " no_claim_items=" + std::to_string(f.n_noclaim) + " split_paths=" + std::to_string(f.n_shared) +
             " short_paths=" + std::to_string(f.n_short) + " medium_paths=" + std::to_string(f.n_medium) + " tiny_paths=" + std::to_string(f.n_tiny) +
             " steps=" + std::to_string(f.class_steps[0]) + "/" + std::to_string(f.class_steps[1]) + "/" + std::to_string(f.class_steps[2]) + "/" + std::to_string(f.class_steps[3]) +  // (by k_scan / short / medium / tiny)
             " bucket_cap=" + std::to_string(f.cap);

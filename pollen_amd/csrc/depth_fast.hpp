@@ -59,6 +59,7 @@ struct FastPlan {
     void *items = nullptr;         // uint4[n_items + max_back] whole paths and pieces of long paths, longest first,
                                    // with room for the short paths k_scan_short hands back
     uint32_t n_items = 0;
+    uint32_t n_noclaim = 0;        // items whose path walks the segment ids strictly one way (their records skip pass 2's claim: depth_fast.hip kTagNoClaim)
     uint32_t max_back = 0;
     bool accumulate = false;       // a group of paths behind the first (see fast_plan_create): pass 2 adds to the outputs
     bool too_many_items = false;   // create_range's verdict: only the number of items (or of split paths) per k_scan workgroup stands between this range and a tagged plan

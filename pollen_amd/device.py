@@ -99,6 +99,30 @@ class DepthPlan:
                                                     uniq_out.data_ptr() if (uniq_out is not None and S) else None,
                                                     self._stream()), "dev_seg_depth")
 
+    def seg_depth_call(self, depth_out, uniq_out=None, stream=None):
+        """A prepared call: returns a function of no arguments that enqueues node depth (+ unique depth) into the given
+        tensors on `stream` (a torch.cuda.Stream; None = the stream that is current NOW).  Everything is checked and
+        resolved here, once; the function itself is one call through the C ABI -- what a loop that keeps several
+        calls in flight wants (the host has 60 us per kernel launch to stay ahead of the device)."""
+        torch = _torch()
+        S = self.graph.n_segs
+        for t in (depth_out, uniq_out):
+            if t is not None:
+                assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous() and t.numel() == S
+        fn = _lib.lib().flatgfa_dev_seg_depth
+        p = self._p
+        d = ctypes.c_void_p(depth_out.data_ptr() if S else None)
+        u = ctypes.c_void_p(uniq_out.data_ptr() if (uniq_out is not None and S) else None)
+        with torch.cuda.device(self.graph.device):
+            h = ctypes.c_void_p((stream if stream is not None else torch.cuda.current_stream(self.graph.device)).cuda_stream)
+        keep = (depth_out, uniq_out, stream)  # (the tensors live as long as the call does)
+
+        def call(_keep=keep):
+            rc = fn(p, d, u, h)
+            if rc:
+                _check(rc, "dev_seg_depth")
+        return call
+
     def path_sums(self, path_ids, depth, length_out, weighted_out) -> None:
         """Enqueue measure_path's integer sums for `path_ids` (int32 CUDA tensor); outputs are
         int64 CUDA tensors (u64 bits)."""

@@ -97,6 +97,20 @@ class ShardedDepth:
         self.works = [None] * len(self.bufs)
         self.cur = 0
         self.step = 0
+        self._prepared = None  # world 1: one prepared call per buffer (prepare())
+
+    def prepare(self, plans) -> None:
+        """World size 1 with DepthPlans (one per local_fn): resolve every buffer's call once (DepthPlan.seg_depth_call),
+        so that run() is a single call through the C ABI -- a loop that keeps calls in flight has to enqueue
+        two kernels in less time than the device takes to run them."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            return
+        k = len(self.local_fns)
+        assert len(plans) == k
+        self._prepared = [plans[j % k].seg_depth_call(b[: self.n_segs], b[self.n_segs:] if self.with_uniq else None,
+                                                       self.streams[j % k] if self.streams is not None else None)
+                          for j, b in enumerate(self.bufs)]
 
     @property
     def local_fn(self):
@@ -127,6 +141,11 @@ class ShardedDepth:
     def run(self) -> None:
         """One step: local partials into the next buffer, then its all-reduce (if world > 1)."""
         j = (self.cur + 1) % len(self.bufs)
+        if self._prepared is not None:
+            self._prepared[j]()
+            self.cur = j
+            self.step += 1
+            return
         which = j % len(self.local_fns)  # (the buffers are a multiple of the functions: a buffer always meets the same plan and stream)
         if self.streams is not None:
             with self.torch.cuda.stream(self.streams[which]):

@@ -19,7 +19,7 @@ FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
 @pytest.fixture(params=["auto", "bucketed", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3", "ranges", "dense",
-                        "untagged", "untagged_pieces", "untagged_noshort", "pair", "groups3", "packed", "slots8", "small11"])
+                        "untagged", "untagged_pieces", "untagged_noshort", "groups3", "packed", "slots8", "claim_all", "wb11"])
 def device_path(request, monkeypatch):
     """Runs a test once per device path: the default (up to 8 M steps the plan times the bucketed
     path against the atomic kernels on the graph at hand and keeps the faster), the bucketed path
@@ -47,15 +47,17 @@ def device_path(request, monkeypatch):
     monkeypatch.delenv("FLATGFA_DENSE", raising=False)
     monkeypatch.delenv("FLATGFA_BIG_GROUPS", raising=False)
     monkeypatch.delenv("FLATGFA_TAGGED", raising=False)
-    monkeypatch.delenv("FLATGFA_ACC_PAIR", raising=False)
+    monkeypatch.delenv("FLATGFA_NO_CLAIM", raising=False)
     monkeypatch.delenv("FLATGFA_PATH_GROUPS", raising=False)
     monkeypatch.delenv("FLATGFA_PACKED", raising=False)
     monkeypatch.delenv("FLATGFA_ACC_SLOTS", raising=False)
     monkeypatch.delenv("FLATGFA_WB", raising=False)
-    monkeypatch.delenv("FLATGFA_ACC_SMALL", raising=False)
-    if request.param == "small11":  # windows of 2048 segments, two pass-2 workgroups of 64 registers resident per CU (k_accum_small: a measurement's build, profiles/NOTES.md R4.9)
+    if request.param == "wb11":  # windows of 2048 segments (by default 4096, or 8192 beyond 4 M segments)
         monkeypatch.setenv("FLATGFA_WB", "11")
-        monkeypatch.setenv("FLATGFA_ACC_SMALL", "1")
+        monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
+        monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    if request.param == "claim_all":  # every item claims in a bitset, strictly monotone paths included (by default their records skip the claim: kTagNoClaim)
+        monkeypatch.setenv("FLATGFA_NO_CLAIM", "0")
         monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
         monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
     if request.param == "slots8":  # eight private bitsets per pass-2 wave wherever the plan allows them (by default only where a workgroup of pass 1 takes more than four items)
@@ -68,9 +70,6 @@ def device_path(request, monkeypatch):
         monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
     if request.param == "groups3":  # the paths walked in three groups, the second and third adding to the first's counts (by default only plans with more items per workgroup than a tag can name)
         monkeypatch.setenv("FLATGFA_PATH_GROUPS", "3")
-        monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
-    if request.param == "pair":  # two pass-2 workgroups per window, exchanging their halves (by default only where a window has 64 k records)
-        monkeypatch.setenv("FLATGFA_ACC_PAIR", "1")
         monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
     if request.param.startswith("untagged"):
         monkeypatch.setenv("FLATGFA_TAGGED", "0")
@@ -240,6 +239,8 @@ SHAPES = [
     (27, 200_000, 12, 40_000, "chromosome"),   # paths along the graph, every other one downwards (k_scan's step -1 runs)
     (28, 1_500_000, 7, 250_000, "chromosome"),
     (29, 30_000, 200, 900, "chromosome"),      # the wave-per-path kernels see downward paths as runs of one
+    (31, 300_000, 40, 60_000, "haplotype"),    # haplotype walks: strictly monotone but for those that wrap around the last segment (records that skip pass 2's claim)
+    (32, 2_000_000, 9, 500_000, "haplotype"),  # ... long ones, cut into pieces that are put together again by the plan
     (26, 17_000_000, 3, 4000, "uniform"),      # beyond 2048 windows of 8192 segments: two ranges, two walks of the steps
     (30, 40_000_000, 5, 60_000, "chromosome"), # three ranges; runs that straddle a range boundary are split between the walks
 ]
@@ -843,17 +844,25 @@ def test_steps_kept_in_the_infinity_cache_are_budgeted_per_device(monkeypatch):
     a = DepthPlan(graph)
     ra = resident(a)
     assert 90 <= ra <= 100, a.describe()       # all of its steps: they fit what a call's traffic leaves
-    b = DepthPlan(graph)
-    rb = resident(b)
-    assert rb <= 160 - ra and rb in (0, *range(32, 161)), b.describe()  # what the first left of the device's budget (nothing below 32 MB)
+    b = DepthPlan(graph)                       # a second plan over the SAME step array (two calls in flight): the same stretch, one claim
+    assert resident(b) == ra, b.describe()
+    graph2 = DeviceGraph(steps, pb, pe, S)     # another resident array: what the first left of the device's budget (nothing below 32 MB)
+    c = DepthPlan(graph2)
+    rc = resident(c)
+    assert rc <= 160 - ra and rc in (0, *range(32, 161)), c.describe()
     check(a)
     check(b)
-    a.close()
-    c = DepthPlan(graph)
-    assert resident(c) >= 32, c.describe()     # the first plan's share is free again
     check(c)
-    c.close()
+    a.close()
+    d2 = DepthPlan(graph)                      # b still holds the shared claim
+    assert resident(d2) == ra, d2.describe()
+    d2.close()
     b.close()
+    c.close()
+    e = DepthPlan(graph2)
+    assert resident(e) >= 90, e.describe()     # every share is free again
+    check(e)
+    e.close()
     monkeypatch.setenv("FLATGFA_MALL_MB", "0")
     z = DepthPlan(graph)
     assert resident(z) == 0
@@ -971,3 +980,101 @@ def test_dense_pass1_on_segment_ranges(shape, monkeypatch):
     plan.status()
     want_d, want_u = fo.seg_depth_with_uniq(pools_of(g))
     assert (d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all()
+
+
+def _monotone_graph(S, kinds, seed=0):
+    """Paths given as lists of segment ids per kind: 'up' a strictly increasing subset, 'down' strictly decreasing,
+    'up2' increasing in steps of two (no run longer than one step), 'loop' increasing with one stretch walked twice,
+    'flat' increasing but for one repeated id, 'wrap' increasing past the last segment and on from the first."""
+    rng = np.random.default_rng(seed)
+    walks = []
+    for k, (kind, n) in enumerate(kinds):
+        lo = int(rng.integers(0, max(1, S // 4)))
+        ids = lo + np.nonzero(rng.random(S - lo) < 0.6)[0][:n]
+        if kind == "down":
+            ids = ids[::-1]
+        elif kind == "up2":
+            ids = (lo + 2 * np.arange(min(n, (S - lo) // 2)))
+        elif kind == "loop":
+            ids = np.concatenate([ids, ids[len(ids) // 3: len(ids) // 3 + 50], ids[-1:] ])
+        elif kind == "flat":
+            ids = np.concatenate([ids[: len(ids) // 2], ids[len(ids) // 2 - 1:]])
+        elif kind == "wrap":
+            ids = np.concatenate([ids[len(ids) // 2:], ids[: len(ids) // 2]])
+        walks.append(ids.astype(np.uint32))
+    lens = np.array([len(x) for x in walks], dtype=np.uint32)
+    steps = (np.concatenate(walks) << 1) | rng.integers(0, 2, size=int(lens.sum())).astype(np.uint32)
+    pe = np.cumsum(lens).astype(np.uint32)
+    pb = (pe - lens).astype(np.uint32)
+    paths = np.zeros(len(lens), dtype=fo.PATH_DT)
+    paths["steps_start"], paths["steps_end"] = pb, pe
+    pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
+    pools.paths, pools.steps, pools.segs = paths, steps, np.zeros(S, dtype=fo.SEG_DT)
+    return steps, pb, pe, pools
+
+
+@pytest.mark.parametrize("pieces", [0, 4096])
+@pytest.mark.parametrize("n_segs", [200_000, 5_000_000])
+def test_strictly_monotone_paths_skip_the_claim(n_segs, pieces, monkeypatch):
+    """A path that walks the segment ids strictly one way never meets a segment twice: depth.rs:30-34's `seen` test is
+    always true for it, its records carry the no-claim tag and pass 2 applies them without a bitset.  The plan must find
+    exactly the paths that qualify -- upwards, downwards, in steps of two, cut into pieces -- and none that revisits
+    (a loop, one repeated id, a wrap around the last segment), alone or mixed in one workgroup's sub-buckets."""
+    import re
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
+    monkeypatch.delenv("FLATGFA_NO_CLAIM", raising=False)
+    if pieces:
+        monkeypatch.setenv("FLATGFA_PIECE_STEPS", str(pieces))
+    else:
+        monkeypatch.delenv("FLATGFA_PIECE_STEPS", raising=False)
+    kinds = [("up", 30_000), ("down", 30_000), ("loop", 20_000), ("up2", 9000), ("flat", 10_000), ("wrap", 12_000), ("up", 64), ("down", 1),
+             ("up", 50_000), ("loop", 300), ("down", 17_000)] * 3
+    steps, pb, pe, pools = _monotone_graph(n_segs, kinds, seed=n_segs + pieces)
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    plan = DepthPlan(DeviceGraph(steps, pb, pe, n_segs))
+    desc = plan.describe()
+    assert "pass2=tagged" in desc, desc
+    n_items = int(re.search(r" items=(\d+)", desc).group(1))
+    n_noclaim = int(re.search(r"no_claim_items=(\d+)", desc).group(1))
+    mono = sum(1 for k, _ in kinds if k in ("up", "down", "up2"))
+    assert 0 < n_noclaim < n_items, desc
+    if n_items == len(kinds):  # (no path was cut: exactly the paths that qualify)
+        assert n_noclaim == mono, desc
+    d = torch.zeros(n_segs, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(n_segs, dtype=torch.int32, device="cuda:0")
+    for _ in range(2):
+        plan.seg_depth(d, u)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == want_d).all()
+        assert (u.cpu().numpy().view(np.uint32) == want_u).all()
+    # all of them monotone: nothing but depth updates in pass 2, and uniq == depth where each segment is met by distinct paths
+    steps2, pb2, pe2, pools2 = _monotone_graph(n_segs, [("up", 40_000), ("down", 40_000), ("up2", 20_000)] * 8, seed=7)
+    want_d2, want_u2 = fo.seg_depth_with_uniq(pools2)
+    plan2 = DepthPlan(DeviceGraph(steps2, pb2, pe2, n_segs))
+    m = re.search(r" items=(\d+) no_claim_items=(\d+)", plan2.describe())
+    assert m and m.group(1) == m.group(2), plan2.describe()
+    plan2.seg_depth(d, u)
+    plan2.status()
+    assert (d.cpu().numpy().view(np.uint32) == want_d2).all() and (u.cpu().numpy().view(np.uint32) == want_u2).all()
+    assert (want_d2 == want_u2).all()
+
+
+def test_wrong_answer_switches_are_not_in_the_product_library(monkeypatch):
+    """FLATGFA_DEBUG_SKIP / FLATGFA_ACC_SKIP leave parts of the kernels' work out (measurements; results are then wrong
+    by construction): they exist in measurement builds only (-DFGFA_MEASURE, tools/variants.sh).  The product
+    library must not read them."""
+    monkeypatch.setenv("FLATGFA_DEBUG_SKIP", "1")
+    monkeypatch.setenv("FLATGFA_ACC_SKIP", "448")
+    monkeypatch.setenv("FLATGFA_ACC_PAIR", "1")
+    monkeypatch.setenv("FLATGFA_ACC_SMALL", "1")
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    for shape in [(3, 300_000, 60, 50_000, "pangenome"), (4, 50_000, 2000, 900, "chromosome")]:
+        g = pa.synth(*shape, False)
+        check_graph(g, pools_of(g))
+    with open(os.path.join(ROOT, "pollen_amd", "lib", "libflatgfa.so"), "rb") as f:
+        blob = f.read()
+    for name in (b"FLATGFA_DEBUG_SKIP", b"FLATGFA_ACC_SKIP", b"FLATGFA_ACC_PAIR", b"FLATGFA_ACC_SMALL", b"k_accum_pair", b"k_accum_small"):
+        assert name not in blob, name

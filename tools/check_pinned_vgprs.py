@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
-"""Build-time check for depth_fast.hip's pinned landing registers.
+"""Build-time check for the pinned landing registers of the depth kernels.
 
-k_scan keeps two 1024-step blocks in flight in the fixed VGPR sets v[80:95], v[96:111] and v[112:127]
-(see the comment above load_block_async in pollen_amd/csrc/depth_fast.hip).  That is only sound if
-nothing else in the kernel touches those registers.  This script compiles the file to gfx950
-assembly and checks, for every k_scan instantiation and every function it can call:
+k_scan keeps three 1024-step blocks in flight in the fixed VGPR sets v[80:95], v[96:111] and v[112:127]
+(see the comment above load_block_async in pollen_amd/csrc/depth_fast_kernels.hpp).  That is only sound if
+nothing else in the kernel touches those registers.  This script compiles the kernels' translation units
+(depth_scan.hip, depth_scan_paths.hip, depth_accum.hip) to gfx950 assembly and checks, for every k_scan
+instantiation and every function it can call:
 
   * the only instructions that mention v80..v127 are `global_load_dwordx4 v[Q:Q+3], ..., off`
     (as the destination) and `v_lshrrev_b32 vN, 1, vQ` (as the source);
   * the kernel's VGPR budget stays at or under 128 (a 1024-thread workgroup needs 4 waves/SIMD).
 
-Usage: check_pinned_vgprs.py [path/to/depth_fast.hip]      exit status 0 = ok
+Usage: check_pinned_vgprs.py [depth_scan.hip depth_scan_paths.hip depth_accum.hip]      exit status 0 = ok
 """
 import os
 import re
@@ -19,7 +20,8 @@ import sys
 import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "..", "pollen_amd", "csrc", "depth_fast.hip")
+CSRC = os.path.join(HERE, "..", "pollen_amd", "csrc")
+SRCS = sys.argv[1:] if len(sys.argv) > 1 else [os.path.join(CSRC, n) for n in ("depth_scan.hip", "depth_scan_paths.hip", "depth_accum.hip")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 PINNED = set(range(80, 128))
@@ -39,14 +41,22 @@ def regs_of(text):
 
 
 def main():
+    lines, text = [], ""
+    extra = os.environ.get("FGFA_CXXFLAGS", "").split()  # (the -D flags of a variant build, tools/variants.sh)
     with tempfile.TemporaryDirectory() as td:
-        asm = os.path.join(td, "depth_fast.s")
-        extra = os.environ.get("FGFA_CXXFLAGS", "").split()  # (the -D flags of a variant build, tools/tag_sweep.sh)
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                               SRC, "-o", asm] + extra, stderr=subprocess.DEVNULL)
-        lines = open(asm).read().splitlines()
+        procs = []
+        for k, src in enumerate(SRCS):
+            asm = os.path.join(td, f"tu{k}.s")
+            procs.append((asm, subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                                                 src, "-o", asm] + extra, stderr=subprocess.DEVNULL)))
+            text += open(src).read()
+        for asm, pr in procs:
+            if pr.wait() != 0:
+                print("pinned-VGPR check FAILED: hipcc -S failed")
+                return 1
+            lines += open(asm).read().splitlines()
     # the tagged walk's depth: FGFA_TAG_DEPTH steps are requested ahead, into v(123 - depth) .. v122
-    depth = int(re.search(r"#define FGFA_TAG_DEPTH (\d+)", open(SRC).read()).group(1))
+    depth = int(re.search(r"#define FGFA_TAG_DEPTH (\d+)", text).group(1))
     for f in extra:
         if f.startswith("-DFGFA_TAG_DEPTH="):
             depth = int(f.split("=")[1])
@@ -55,12 +65,21 @@ def main():
     n_acc_load = n_acc_take = 0
     n_tiny_load = n_tiny_take = 0
     n_dense_load = n_dense_take = 0
+    # k_scan_dense waits for its landing loads with `s_waitcnt vmcnt(8)`: sound only if the eight record stores of a
+    # plain tile are eight store INSTRUCTIONS.  Checked on the ISA: behind the kernel's first barrier some straight-line
+    # stretch holds exactly eight global_store_dword and no other vector-memory operation (merged or dropped stores
+    # would leave none).
+    dense_seen_barrier, dense_blk_stores, dense_blk_other, dense_blocks8, dense_wait8 = False, 0, 0, 0, 0
     budgets = {}
     for ln in lines:
         s = ln.split(";")[0].strip()
         if s.endswith(":") and not s.startswith("."):
             func = s[:-1]
             continue
+        if "k_scan_dense" in func and re.match(r"^\.LBB\d+_\d+:", s):  # (a label ends a straight-line stretch)
+            if dense_blk_stores == 8 and dense_blk_other == 0:
+                dense_blocks8 += 1
+            dense_blk_stores = dense_blk_other = 0
         m = re.match(r"\.amdhsa_next_free_vgpr\s+(\d+)", s)
         if m:
             budgets[func] = int(m.group(1))
@@ -94,6 +113,18 @@ def main():
                     bad.append(f"{func}: {s}")
             continue
         if "k_scan_dense" in func:  # a full tile's steps land in v112..v119 (two dwordx4 a thread), taken out by the shifts that drop the orientation bit
+            if s.startswith("s_barrier"):
+                dense_seen_barrier = True
+            if s.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_barrier")):
+                if dense_blk_stores == 8 and dense_blk_other == 0:
+                    dense_blocks8 += 1
+                dense_blk_stores = dense_blk_other = 0
+            elif s.startswith("global_store_dword ") and dense_seen_barrier:
+                dense_blk_stores += 1
+            elif s.startswith(("global_", "buffer_", "flat_", "scratch_")) and dense_seen_barrier:
+                dense_blk_other += 1
+            if s == "s_waitcnt vmcnt(8)":
+                dense_wait8 += 1
             pins = set(range(112, 120))
             if regs_of(s) & pins:
                 m = re.match(r"^global_load_dwordx4 v\[(112:115|116:119)\], v\[(\d+):(\d+)\], off nt$", s)
@@ -132,11 +163,14 @@ def main():
         bad.append("no pinned loads/takes found in k_scan_dense -- did the kernel change?")
     if n_load == 0 or n_take == 0:
         bad.append("no pinned loads/takes found -- did the kernel change?")
+    if dense_wait8 == 0 or dense_blocks8 == 0:  # (merged or dropped record stores would leave no stretch of exactly eight)
+        bad.append(f"k_scan_dense: vmcnt(8) waits {dense_wait8}, straight-line stretches of exactly eight record stores {dense_blocks8} "
+                   "-- the counted wait no longer matches the stores")
     if bad:
         print("pinned-VGPR check FAILED:\n  " + "\n  ".join(bad[:20]))
         return 1
-    print(f"pinned-VGPR check ok: k_accum {n_acc_load} record loads, {n_acc_take} takes, nothing else touches v120..v122 (tagged walk: v{123 - depth}..v122, k_accum_pair: v61..v63); "
-          f"k_scan_tiny {n_tiny_load} loads, {n_tiny_take} takes (v118..v123); k_scan_dense {n_dense_load} loads, {n_dense_take} takes (v112..v119); k_scan {n_load} loads, {n_take} takes, nothing else touches v80..v127; "
+    print(f"pinned-VGPR check ok: k_accum {n_acc_load} record loads, {n_acc_take} takes, nothing else touches v120..v122 (tagged walk: v{123 - depth}..v122; measurement builds' k_accum_pair / k_accum_small: v61..v63); "
+          f"k_scan_tiny {n_tiny_load} loads, {n_tiny_take} takes (v118..v123); k_scan_dense {n_dense_load} loads, {n_dense_take} takes (v112..v119), {dense_blocks8} stretches of eight record stores for {dense_wait8} vmcnt(8); k_scan {n_load} loads, {n_take} takes, nothing else touches v80..v127; "
           f"k_scan budgets {sorted(set(v for k, v in budgets.items() if 'k_scan' in k))}")
     return 0
 

@@ -5,6 +5,6 @@
 cd "$(dirname "$0")/../pollen_amd/csrc"
 while [ $# -ge 2 ]; do
   tag=$1; extra=$2; shift 2
-  make -j8 LIBDIR=../lib_$tag OBJDIR=../build_$tag BINDIR=../bin_$tag EXTRA="$extra" ../lib_$tag/libflatgfa.so 2>&1 | grep -E "error|warning: unused|Error" 
+  make -j8 LIBDIR=../lib_$tag OBJDIR=../build_$tag BINDIR=../bin_$tag EXTRA="$extra" ../lib_$tag/libflatgfa.so ../build_$tag/pinned.ok 2>&1 | grep -E "error|warning: unused|Error|FAILED" 
   ls -la ../lib_$tag/libflatgfa.so
 done
