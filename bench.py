@@ -442,6 +442,54 @@ def main():
         extras["path_depth_all_paths_ms"] = round(timed(lambda: plan.path_depth_all(d_only, len_out, wsum_out)), 5)
         extras["path_depth_all_paths_two_walks_ms"] = round(timed(path_depth_two_walks), 5)
         plan.status()
+
+        def sampled(fn, calls=SAMPLE_STEPS):  # per-kernel HIP-event times of `calls` consecutive calls, one after the other
+            fn()
+            plan.status()
+            dev.profile_enable(True)
+            dev.profile_read()
+            for _ in range(calls):
+                fn()
+            plan.status()
+            dev.profile_enable(False)
+            per_k = {}
+            for name, ms in dev.profile_read():
+                per_k.setdefault(name, []).append(ms)
+            return {k: float(np.sum(v)) / calls for k, v in per_k.items()}, {k: len(v) / calls for k, v in per_k.items()}
+
+        def hbm_row(bytes_, ms):
+            return {"bound": "hbm", "algorithmic_bytes": int(bytes_), "ms": round(ms, 5), "achieved": round(bytes_ / (ms * 1e-3) / 1e9, 2),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+        # ---- a3: path_depth of all paths (depth.rs:88-131; what bench/config.toml:30 times) as a measurement row of its own ----
+        # algorithmic bytes: every handle once, the spans, seg_len read and node depth written once, two u64 sums per path
+        pd_per_call, pd_launches = sampled(lambda: plan.path_depth_all(d_only, len_out, wsum_out))
+        pd_bytes = 4 * N + 8 * P + 8 * S + 16 * P
+        pd_ms = sum(pd_per_call.values())
+        pd_dom = max(pd_per_call, key=pd_per_call.get) if pd_per_call else None
+        pd_row = {"what": f"path_depth of all {P} paths (ops/depth.rs:88-131): node depth and the two sums of measure_path per path in ONE walk of the "
+                          "steps (flatgfa_dev_path_depth_all); the one f64 division per path is the host's",
+                  "ms_per_call": extras["path_depth_all_paths_ms"], "steps_per_s": round(N / (extras["path_depth_all_paths_ms"] * 1e-3), 1),
+                  "kernels_ms_per_call": {k: round(v, 5) for k, v in pd_per_call.items()}, "kernel_launches_per_call": pd_launches,
+                  "roofline": dict(hbm_row(pd_bytes, pd_ms), bytes_are="4 N + 8 P + 8 S + 16 P (steps, spans, seg_len in and depth out, the sums)",
+                                   ms_is="all kernels of a call, HIP events, one call after the other"),
+                  "dominant_kernel": None if not pd_dom else dict(hbm_row(4 * N + 8 * P, pd_per_call[pd_dom]), kernel=pd_dom, bytes_are="its step reads, 4 N + 8 P")}
+        if not args.no_cpu_baseline:
+            from oracle import flatgfa_oracle as fo
+            pools_a3 = fo.Pools(**{n: g.pool(n) for n in fo.POOL_ORDER})
+            fo.path_depth(pools_a3)
+            ts = []
+            for _ in range(3):
+                c0 = time.perf_counter()
+                want_len, want_mean = fo.path_depth(pools_a3)
+                ts.append(time.perf_counter() - c0)
+            got_len, got_mean = g.path_depth()
+            pd_row["cpu_baseline"] = {"value": round(N / float(np.median(ts)), 1), "unit": "path-steps/s", "cores": 1, "kind": "port",
+                                      "sample": f"oracle_path_depth (depth_oracle.c: seg_depth, then measure_path per path) on the full {args.workload} "
+                                                f"graph, median of {len(ts)} runs after 1 warm-up", "seconds_median": round(float(np.median(ts)), 4)}
+            pd_row["bit_exact_vs_oracle"] = bool((got_len == want_len).all() and got_mean.tobytes() == want_mean.tobytes())
+            del pools_a3
+        extras["path_depth"] = pd_row
         # The benchmark's walk continues 90 % of its steps (runs of 10).  The same shape with paths
         # that run along the graph, every other one downwards, 70 % continuing (0.3 records per
         # step): what a chromosome graph looks like to the kernels.
@@ -573,6 +621,66 @@ def main():
             extras["overlap_all_pairs"] = {"pairs": int(P) * int(P), "touching": int(touch.sum()),
                                            "ms": round((c6 - c5) * 1e3, 3), "note": "host API call incl. D2H of the P x P byte matrix"}
             g2.close()
+            # ... as a measurement row: on the device (inputs and the P x P result resident), a fresh plan's first call
+            # (it builds the per-path bitmaps: k_coarse_bits, k_handle_bits) and the calls after it (k_pair_touch alone)
+            if P * P <= (1 << 26):
+                oplan = dev.DepthPlan(graph)
+                q_all = torch.arange(P, dtype=torch.int32, device=device)
+                t_all = torch.zeros(P * P, dtype=torch.uint8, device=device)
+                torch.cuda.synchronize(device)
+                dev.profile_enable(True)
+                dev.profile_read()
+                c5 = time.perf_counter()
+                oplan.path_overlaps(q_all, t_all)
+                oplan.status()
+                first_ms = (time.perf_counter() - c5) * 1e3
+                dev.profile_enable(False)
+                build = {n_: ms for n_, ms in dev.profile_read()}
+                c5 = time.perf_counter()
+                for _ in range(5):
+                    oplan.path_overlaps(q_all, t_all)
+                oplan.status()
+                steady_ms = (time.perf_counter() - c5) / 5 * 1e3
+                dev.profile_enable(True)
+                dev.profile_read()
+                for _ in range(5):
+                    oplan.path_overlaps(q_all, t_all)
+                oplan.status()
+                dev.profile_enable(False)
+                pair_ms = float(np.mean([ms for n_, ms in dev.profile_read() if n_ == "k_pair_touch"] or [0.0]))
+                words = (((S + 31) // 32) + 3) & ~3
+                cwords = ((2 * S + 2047) // 2048 + 31) // 32
+                bitset_bytes = P * 2 * words * 4
+                # a pair reads both coarse bitmaps and, where they share a block, at least one block of both exact bitsets (one
+                # word per lane) before it can stop; one result byte per pair
+                pair_bytes = P * P * (2 * cwords * 4 + 1) + int(touch.sum()) * 2 * 256
+                orow = {"what": f"all {P} x {P} path pairs on {args.workload} (slow_odgi/overlap.py:6-32; BASELINE.json configs[4]); inputs and the P x P byte "
+                                "matrix resident in HBM", "pairs": int(P) * int(P), "touching": int(touch.sum()),
+                        "first_call_ms": round(first_ms, 4), "ms_per_call": round(steady_ms, 5), "pairs_per_s": round(P * P / (steady_ms * 1e-3), 1),
+                        "kernels_first_call_ms": {k: round(v, 5) for k, v in build.items()},
+                        "roofline": {
+                            "k_pair_touch": dict(hbm_row(pair_bytes, pair_ms) if pair_ms else {}, bytes_are="per pair both coarse bitmaps and one result byte; per "
+                                                 "touching pair one 2048-handle block of both exact bitsets (the least it must see before it stops)"),
+                            "k_coarse_bits": dict(hbm_row(4 * N + 8 * P + P * cwords * 4, build["k_coarse_bits"]) if build.get("k_coarse_bits") else {},
+                                                  bytes_are="4 N + 8 P + the bitmaps out (once per plan)"),
+                            "k_handle_bits": dict(hbm_row(4 * N + 8 * P + bitset_bytes, build["k_handle_bits"]) if build.get("k_handle_bits") else {},
+                                                  bytes_are="4 N + 8 P + the exact bitsets out (once per plan; the kernel reads the steps once per orientation: "
+                                                            "a window of one orientation's bits is what fits the LDS)")}}
+                t_dev = t_all.cpu().numpy().reshape(P, P)
+                orow["same_as_host_api"] = bool((t_dev == touch.reshape(P, P)).all())
+                if not args.no_cpu_baseline:
+                    pools_ov = fo.Pools(**{n: g.pool(n) for n in fo.POOL_ORDER})
+                    c5 = time.perf_counter()
+                    want_t = fo.path_touches(pools_ov, np.arange(P, dtype=np.uint32))
+                    cpu_s = time.perf_counter() - c5
+                    orow["cpu_baseline"] = {"value": round(P * P / cpu_s, 1), "unit": "path-pairs/s", "cores": 1, "kind": "port",
+                                            "sample": f"oracle_path_touches (overlap_oracle.c: a handle bitset per path, then word-wise ANDs with early exit) on the "
+                                                      f"full {args.workload} graph, all {P * P} pairs, one run (bitset build included)", "seconds": round(cpu_s, 3)}
+                    orow["bit_exact_vs_oracle"] = bool((want_t == t_dev).all())
+                    del pools_ov
+                extras["overlap"] = orow
+                oplan.close()
+                del oplan, q_all, t_all
             # The same query where few pairs touch: every path is folded into its own band of the
             # segments (two band widths wide, so that neighbours can share handles).  All pairs on
             # cfg-L touch after a handful of probes; here nearly every pair is settled by the

@@ -1078,3 +1078,68 @@ def test_wrong_answer_switches_are_not_in_the_product_library(monkeypatch):
         blob = f.read()
     for name in (b"FLATGFA_DEBUG_SKIP", b"FLATGFA_ACC_SKIP", b"FLATGFA_ACC_PAIR", b"FLATGFA_ACC_SMALL", b"k_accum_pair", b"k_accum_small"):
         assert name not in blob, name
+
+
+def test_more_than_two_to_the_31_steps():
+    """The format allows 2^32 - 1 steps (u32 spans, pool.rs:80-86).  Three thousand million steps on a million segments
+    (12 GB of handles): every step index in the upper half of the u32 range, bit for bit against the oracle -- node depth,
+    unique depth, and the sums of path depth for a few paths that lie beyond step 2^31."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    S, P, L = 1_000_000, 30_000, 100_000
+    assert 2**31 < P * L < 2**32
+    g = pa.synth(77, S, P, L, "pangenome", False)
+    pools = pools_of(g)
+    g.close()  # (one copy of the 12 GB on the host is enough)
+    steps = pools.steps
+    pb = np.ascontiguousarray(pools.paths["steps_start"], dtype=np.uint32)
+    pe = np.ascontiguousarray(pools.paths["steps_end"], dtype=np.uint32)
+    seg_len = pools.seg_lens()
+    assert int(pe[-1]) == P * L and int(pb[-1]) > 2**31
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    assert int(want_d.sum()) == P * L
+    graph = DeviceGraph(steps, pb, pe, S, seg_len)
+    plan = DepthPlan(graph)
+    assert "path=bucketed" in plan.describe(), plan.describe()
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    for _ in range(2):
+        plan.seg_depth(d, u)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == want_d).all(), "depth"
+        assert (u.cpu().numpy().view(np.uint32) == want_u).all(), "uniq"
+    ids = np.array([P - 1, P - 2, 21_475, 21_474, 0], dtype=np.uint32)  # (path 21 475 starts just beyond step 2^31)
+    want_len, want_mean = fo.path_depth(pools, ids)
+    ln = torch.zeros(len(ids), dtype=torch.int64, device="cuda:0")
+    ws = torch.zeros(len(ids), dtype=torch.int64, device="cuda:0")
+    plan.path_sums(torch.from_numpy(ids.view(np.int32)).to("cuda:0"), d, ln, ws)
+    plan.status()
+    got_len = ln.cpu().numpy().view(np.uint64)
+    got_mean = ws.cpu().numpy().view(np.uint64).astype(np.float64) / got_len.astype(np.float64)
+    assert (got_len == want_len).all() and got_mean.tobytes() == want_mean.tobytes()
+    plan.close()
+
+
+def test_more_steps_than_a_u32_can_index_is_an_error(tmp_path):
+    """One step more than the format's u32 spans can index (pool.rs:80-86): FLATGFA_ERR_TOO_LARGE when the graph is
+    made resident, not a truncated walk.  The file is sparse: a table of contents that announces 2^32 steps, and a hole."""
+    from oracle.flatgfa_oracle import MAGIC, POOL_DTYPES, POOL_ORDER, SEG_DT
+    n_steps = 2**32
+    seg = np.zeros(1, dtype=SEG_DT)
+    lens = {n: 0 for n in POOL_ORDER}
+    lens["segs"], lens["steps"] = 1, n_steps
+    toc = np.uint64(MAGIC).tobytes() + b"".join(np.array([lens[n], lens[n]], dtype="<u8").tobytes() for n in POOL_ORDER)
+    path = tmp_path / "too_large.flatgfa"
+    with open(path, "wb") as f:
+        f.write(toc + seg.tobytes())
+        f.truncate(len(toc) + sum(lens[n] * POOL_DTYPES[n].itemsize for n in POOL_ORDER))
+    assert os.stat(path).st_blocks * 512 < (1 << 24), "the file system does not keep the file sparse"
+    g = pa.load(str(path))
+    assert g.segment_count == 1 and g.path_count == 0
+    with pytest.raises(pa.FlatGFAError) as ei:
+        g.to_device(0)
+    assert ei.value.code == -6  # FLATGFA_ERR_TOO_LARGE
+    with pytest.raises(pa.FlatGFAError) as ei:
+        g.seg_depth_with_uniq()
+    assert ei.value.code == -6
+    g.close()

@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
-"""Per-basic-block instruction mix of one kernel in depth_fast.hip's gfx950 assembly.
-Usage: isa_blocks.py [substring of the mangled kernel name, default k_scanILb1ELb0E] [file.s]"""
+"""Per-basic-block instruction mix of one depth kernel's gfx950 assembly (k_scan*: depth_scan.hip / depth_scan_paths.hip,
+k_accum / k_path_reduce: depth_accum.hip).
+Usage: isa_blocks.py [substring of the mangled kernel name, default k_scanILi0ELb1E] [file.s]"""
 import re, subprocess, sys, os, tempfile
-want = sys.argv[1] if len(sys.argv) > 1 else "k_scanILb1ELb0E"
+want = sys.argv[1] if len(sys.argv) > 1 else "k_scanILi0ELb1E"
 asm = sys.argv[2] if len(sys.argv) > 2 else None
 if asm is None:
     here = os.path.dirname(os.path.abspath(__file__))
     asm = os.path.join(tempfile.gettempdir(), "depth_fast_isa.s")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                           os.path.join(here, "..", "pollen_amd", "csrc", "depth_fast.hip"), "-o", asm], stderr=subprocess.DEVNULL)
+                           os.path.join(here, "..", "pollen_amd", "csrc", "depth_accum.hip" if ("k_accum" in want or "k_path_reduce" in want) else
+                                        "depth_scan_paths.hip" if any(k in want for k in ("k_scan_short", "k_scan_tiny")) else "depth_scan.hip"),
+                           "-o", asm], stderr=subprocess.DEVNULL)
 lines = open(asm).read().splitlines()
 start = end = None
 for i, l in enumerate(lines):

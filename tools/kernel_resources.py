@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Registers, LDS and scratch of every kernel of depth_fast.hip (from the gfx950 assembly's
-.amdhsa metadata).  Usage: kernel_resources.py [file.hip]"""
+"""Registers, LDS and scratch of every depth kernel (depth_scan.hip, depth_scan_paths.hip, depth_accum.hip; from the gfx950
+assembly's .amdhsa metadata).  Usage: kernel_resources.py [file.hip [flags]]"""
 import os
 import re
 import subprocess
@@ -8,12 +8,14 @@ import sys
 import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "..", "pollen_amd", "csrc", "depth_fast.hip")
+SRCS = [sys.argv[1]] if len(sys.argv) > 1 else [os.path.join(HERE, "..", "pollen_amd", "csrc", n) for n in ("depth_scan.hip", "depth_scan_paths.hip", "depth_accum.hip")]
+txt = ""
 with tempfile.TemporaryDirectory() as td:
-    asm = os.path.join(td, "k.s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
-                           SRC, "-o", asm] + sys.argv[2:], stderr=subprocess.DEVNULL)
-    txt = open(asm).read()
+    for src in SRCS:
+        asm = os.path.join(td, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                               src, "-o", asm] + sys.argv[2:], stderr=subprocess.DEVNULL)
+        txt += open(asm).read()
 names = re.findall(r"\.amdhsa_kernel (\S+)", txt)
 dem = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.splitlines()
 for (m, d) in zip(re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", txt, re.S), dem):

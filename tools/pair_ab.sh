@@ -1,4 +1,6 @@
 #!/bin/bash
+# (FLATGFA_DEBUG_SKIP / FLATGFA_ACC_SKIP / FLATGFA_ACC_PAIR / FLATGFA_ACC_SMALL exist in measurement builds only:
+#  tools/variants.sh measure "-DFGFA_MEASURE" here, then FLATGFA_LIB=pollen_amd/lib_measure/libflatgfa.so on the GPU box)
 # A/B on one box: pass 2 with one workgroup per window against two (FLATGFA_ACC_PAIR), workloads in $WLS
 for w in ${WLS:-cfgL}; do
   for p in 1 0 1 0; do

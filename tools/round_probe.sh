@@ -1,4 +1,6 @@
 #!/bin/bash
+# (FLATGFA_DEBUG_SKIP / FLATGFA_ACC_SKIP / FLATGFA_ACC_PAIR / FLATGFA_ACC_SMALL exist in measurement builds only:
+#  tools/variants.sh measure "-DFGFA_MEASURE" here, then FLATGFA_LIB=pollen_amd/lib_measure/libflatgfa.so on the GPU box)
 # Quick look at a kernel change (run via gpurun): instruction mix, k_scan ablations, all workloads.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (FLATGFA_DEBUG_SKIP / FLATGFA_ACC_SKIP / FLATGFA_ACC_PAIR / FLATGFA_ACC_SMALL exist in measurement builds only:
+#  tools/variants.sh measure "-DFGFA_MEASURE" here, then FLATGFA_LIB=pollen_amd/lib_measure/libflatgfa.so on the GPU box)
 # k_scan with parts switched off (FLATGFA_DEBUG_SKIP: 1 no record stores, 2 no emission, 4 no pass B, 8 no tiles; the
 # diagnostic build of the kernel, results are wrong): what a workload's pass 1 spends where.   tools/scan_ablate.sh cfgL-chrom
 W=${1:-cfgL-chrom}
