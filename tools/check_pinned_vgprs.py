@@ -56,7 +56,8 @@ def main():
                 return 1
             lines += open(asm).read().splitlines()
     # the tagged walk's depth: FGFA_TAG_DEPTH steps are requested ahead, into v(123 - depth) .. v122
-    depth = int(re.search(r"#define FGFA_TAG_DEPTH (\d+)", text).group(1))
+    m_depth = re.search(r"#define FGFA_TAG_DEPTH (\d+)", text)  # (depth_accum.hip; absent when only other units are checked)
+    depth = int(m_depth.group(1)) if m_depth else 3
     for f in extra:
         if f.startswith("-DFGFA_TAG_DEPTH="):
             depth = int(f.split("=")[1])
@@ -167,7 +168,7 @@ def main():
         bad.append(f"k_scan_dense: vmcnt(8) waits {dense_wait8}, straight-line stretches of exactly eight record stores {dense_blocks8} "
                    "-- the counted wait no longer matches the stores")
     if bad:
-        print("pinned-VGPR check FAILED:\n  " + "\n  ".join(bad[:20]))
+        print("pinned-VGPR check FAILED (%d lines; kernels: %s):\n  " % (len(bad), sorted({b.split(":")[0][-40:] for b in bad})) + "\n  ".join(bad[:20]))
         return 1
     print(f"pinned-VGPR check ok: k_accum {n_acc_load} record loads, {n_acc_take} takes, nothing else touches v120..v122 (tagged walk: v{123 - depth}..v122; measurement builds' k_accum_pair / k_accum_small: v61..v63); "
           f"k_scan_tiny {n_tiny_load} loads, {n_tiny_take} takes (v118..v123); k_scan_dense {n_dense_load} loads, {n_dense_take} takes (v112..v119), {dense_blocks8} stretches of eight record stores for {dense_wait8} vmcnt(8); k_scan {n_load} loads, {n_take} takes, nothing else touches v80..v127; "
