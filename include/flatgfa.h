@@ -265,8 +265,14 @@ typedef struct flatgfa_dev_graph_t {
  * (flatgfa_last_error()); spans that are reversed or exceed n_steps are rejected here, where the
  * reference would panic on the slice index (pool.rs:341-347).  The plan is laid out for the path
  * spans and the step values it was created with (how many runs each path has decides which
- * kernel walks it): neither may change while it lives.  Every call still checks the step values
- * against n_segs, and reports an error rather than a wrong answer if they no longer fit the plan.
+ * kernel walks it; a path that walks the segment ids strictly one way is counted without the
+ * per-path "seen" set, flatgfa_dev_plan_describe: no_claim_items): neither may change while it
+ * lives.  Every call still checks the step values against n_segs and its scratch against what the
+ * steps need, and reports an error -- or completes the call through the simple kernels -- rather
+ * than a wrong answer when they no longer fit; what it does not re-check per step is that a path
+ * the plan found strictly monotone still is (a compare per step: 12-18 % of the step scan on a
+ * graph of such paths, profiles/NOTES.md R5.8): steps changed behind a plan that make such a path
+ * revisit a segment are outside the contract.
  * Creation runs the query a few times into scratch outputs: once to size the record buckets for
  * this graph (so that no later call runs out of room), and, up to 8 M steps, to time the bucketed
  * kernels against the atomic ones and keep the faster.  A graph beyond 16 M segments is walked in
