@@ -17,8 +17,8 @@ ENVS = [{}, {"FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0"}, {"FL
         {"FLATGFA_RANGE_SEGS": "65536"}, {"FLATGFA_RANGE_SEGS": "40960", "FLATGFA_PIECE_STEPS": "2048"},
         {"FLATGFA_ACC_PARTS": "2", "FLATGFA_PIECE_STEPS": "1024"}, {"FLATGFA_DENSE": "1", "FLATGFA_BIG_GROUPS": "1"}, {"FLATGFA_BIG_GROUPS": "1"}, {"FLATGFA_BIG_GROUPS": "0", "FLATGFA_PIECE_STEPS": "700"},
         {"FLATGFA_DENSE": "1", "FLATGFA_RANGE_SEGS": "65536", "FLATGFA_SHORT_MAX": "0"},
-        {"FLATGFA_TAGGED": "0"}, {"FLATGFA_TAGGED": "0", "FLATGFA_PIECE_STEPS": "900"}, {"FLATGFA_ACC_PAIR": "1", "FLATGFA_DEPTH_PATH": "bucketed"},
-        {"FLATGFA_ACC_PAIR": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_TAGGED": "0"}, {"FLATGFA_TAGGED": "0", "FLATGFA_PIECE_STEPS": "900"}, {"FLATGFA_NO_CLAIM": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_NO_CLAIM": "0", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
         {"FLATGFA_PIECE_STEPS": "4096", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
         {"FLATGFA_SCAN_ALWAYS": "1", "FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_WB": "12", "FLATGFA_DEPTH_PATH": "bucketed"},
         {"FLATGFA_WB": "11", "FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_PATH_GROUPS": "2", "FLATGFA_DEPTH_PATH": "bucketed"},
@@ -31,8 +31,8 @@ ENVS = [{}, {"FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0"}, {"FL
         {"FLATGFA_PACKED": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed", "FLATGFA_PIECE_STEPS": "3000"},
         {"FLATGFA_PACKED": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed", "FLATGFA_RANGE_SEGS": "65536"},
         {"FLATGFA_ACC_SLOTS": "8", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
-        {"FLATGFA_ACC_SLOTS": "4", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed", "FLATGFA_ACC_PAIR": "0"},
-        {"FLATGFA_WB": "11", "FLATGFA_ACC_SMALL": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"}]
+        {"FLATGFA_ACC_SLOTS": "4", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_WB": "11", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed", "FLATGFA_PIECE_STEPS": "5000"}]
 
 
 def random_graph(rng):
@@ -56,7 +56,15 @@ def random_graph(rng):
     steps = np.empty(N, dtype=np.uint32)
     pos = 0
     for L in lens:
-        if model == 0:  # locally monotone with jumps (wraps around S)
+        if L < S and rng.integers(0, 4) == 0:  # a strictly monotone walk, up or down (its records skip pass 2's claim); one in three of them with one segment visited twice after all
+            gaps = rng.integers(1, (S - 1) // L, size=L, endpoint=True).astype(np.int64)  # (strictly increasing, the last id below S)
+            ids = np.cumsum(gaps) - gaps[0]
+            if rng.integers(0, 2):
+                ids = ids[::-1].copy()
+            if rng.integers(0, 3) == 0 and L > 2:
+                k = int(rng.integers(1, L))
+                ids[k] = ids[k - 1]
+        elif model == 0:  # locally monotone with jumps (wraps around S)
             u = rng.integers(0, 100, size=L)
             j = rng.integers(0, 1 << 30, size=L)
             inc = np.where(u < 90, 1, np.where(u < 95, 2 + (j & 7), np.where(u < 99, -(1 + (j & 3)), 0))).astype(np.int64)
@@ -112,7 +120,7 @@ def main():
         pools.paths, pools.steps, pools.segs = paths, steps, segs
         want_d, want_u = fo.seg_depth_with_uniq(pools)
         env = ENVS[case % len(ENVS)]
-        for k in ("FLATGFA_SHORT_MAX", "FLATGFA_BUCKET_CAP", "FLATGFA_PIECE_STEPS", "FLATGFA_DEPTH_PATH", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS", "FLATGFA_DENSE", "FLATGFA_BIG_GROUPS", "FLATGFA_TAGGED", "FLATGFA_ACC_PAIR", "FLATGFA_SCAN_ALWAYS", "FLATGFA_WB", "FLATGFA_PATH_GROUPS", "FLATGFA_ACC_SMALL"):
+        for k in ("FLATGFA_SHORT_MAX", "FLATGFA_BUCKET_CAP", "FLATGFA_PIECE_STEPS", "FLATGFA_DEPTH_PATH", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS", "FLATGFA_DENSE", "FLATGFA_BIG_GROUPS", "FLATGFA_TAGGED", "FLATGFA_ACC_PAIR", "FLATGFA_SCAN_ALWAYS", "FLATGFA_WB", "FLATGFA_PATH_GROUPS", "FLATGFA_ACC_SMALL", "FLATGFA_NO_CLAIM", "FLATGFA_TAG_LIMIT", "FLATGFA_TAG_MEAN_ONLY", "FLATGFA_NO_PLAIN", "FLATGFA_NO_TINY", "FLATGFA_PACKED", "FLATGFA_ACC_SLOTS"):
             os.environ.pop(k, None)
         os.environ.update(env)
         graph = dev.DeviceGraph(steps, pb, pe, S, seg_len, device="cuda:0")
