@@ -26,7 +26,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 PINNED = set(range(80, 128))
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
-OK_LOAD = re.compile(r"^global_load_dwordx4 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], off( offset:(16|32|48|1024|2048|3072))?( nt)?$")
+OK_LOAD = re.compile(r"^global_load_dwordx4 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], off( offset:(16|32|48|1024|2048|3072))?( (nt|sc0|sc1))*$")
 OK_TAKE = re.compile(r"^v_lshrrev_b32(_e32)? v(\d+), 1, v(\d+)$")
 
 
@@ -42,7 +42,8 @@ def regs_of(text):
 
 def main():
     lines, text = [], ""
-    extra = os.environ.get("FGFA_CXXFLAGS", "").split()  # (the -D flags of a variant build, tools/variants.sh)
+    import shlex
+    extra = shlex.split(os.environ.get("FGFA_CXXFLAGS", ""))  # (the -D flags of a variant build, tools/variants.sh; quoted as for a shell)
     with tempfile.TemporaryDirectory() as td:
         procs = []
         for k, src in enumerate(SRCS):
