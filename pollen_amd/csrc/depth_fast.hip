@@ -203,6 +203,17 @@ int alloc_buckets(FastPlan *fp, uint64_t want_cap) {
 static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
                      uint32_t *status, hipStream_t stream, const PathSums *ps, bool count_only);
 
+// The A/B switches of past measurements (which policy a plan takes: NOTES.md) read the environment in measurement
+// builds only (-DFGFA_MEASURE, tools/variants.sh); the product library takes the policy that won.
+static inline bool measure_switch(const char *name) {
+#ifdef FGFA_MEASURE
+    return getenv(name) != nullptr;
+#else
+    (void)name;
+    return false;
+#endif
+}
+
 // The plan of one range of segments, [seg_base, seg_base + n_range): the whole graph, or one of
 // the ranges of a graph beyond 16 M segments.
 static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp, uint32_t seg_base,
@@ -256,7 +267,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         FAST_TRY(e);
     }
     const bool short_any = getenv("FLATGFA_SHORT_ANY") != nullptr;  // tests: let k_scan_short find out and hand back
-    const bool no_rev = getenv("FLATGFA_NO_REVERSED_COPIES") != nullptr;  // (measurements)
+    const bool no_rev = measure_switch("FLATGFA_NO_REVERSED_COPIES");
     // A wave-per-path kernel only knows runs that go up.  A path that walks the ids downwards (a
     // contig on the reverse strand) has far fewer runs when it is read backwards, and the order of a
     // path's steps does not matter to the counts: such a path is walked from a reversed copy of its
@@ -293,7 +304,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // different workgroups, and it is the paths that start near each other that meet in a window.  A
     // sub-bucket then holds one path's records of its window, not those of the five or six that
     // chance gave one workgroup (the capacity every sub-bucket gets is the fullest one's, §2).
-    if (whole.size() > 1 && !getenv("FLATGFA_KEEP_PATH_ORDER")) {
+    if (whole.size() > 1 && !measure_switch("FLATGFA_KEEP_PATH_ORDER")) {
         std::vector<uint32_t> at(whole.size()), first(whole.size(), 0u);
         for (size_t i = 0; i < whole.size(); ++i) at[i] = whole[i].x;
         uint32_t *d_at = nullptr;
@@ -381,7 +392,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         // graph of thousands of paths rarely needs its long ones cut: k_scan's workgroups take the
         // items longest first as they get to them, and if whole paths dealt that way (to the least
         // loaded workgroup each) leave the longest hand within a tenth of the best cut's, they stay whole.
-        if (piece && !getenv("FLATGFA_KEEP_CUTS")) {
+        if (piece && !measure_switch("FLATGFA_KEEP_CUTS")) {
             std::vector<uint4> trial;
             const uint32_t n_split = cut(piece, &trial);
             if (n_split > (wb <= 12 ? kMaxShared : 0u)) {
@@ -524,7 +535,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         std::vector<std::vector<uint32_t>> per_wave(acc_waves), fat_of_part(fp->acc_parts);
         std::vector<uint64_t> load(acc_waves, 0), part_load(fp->acc_parts, 0);
         for (uint32_t gi : order) {
-            if (path_steps[gi] < fat_min || by_path[gi].size() < kAccWaves / 2 || getenv("FLATGFA_NO_FAT_PATHS")) continue;  // (fewer pieces than half the waves: better one wave busy all the time than three)
+            if (path_steps[gi] < fat_min || by_path[gi].size() < kAccWaves / 2 || measure_switch("FLATGFA_NO_FAT_PATHS")) continue;  // (fewer pieces than half the waves: better one wave busy all the time than three)
             const uint32_t q = (uint32_t)(std::min_element(part_load.begin(), part_load.end()) - part_load.begin());
             part_load[q] += path_steps[gi];
             fat_of_part[q].push_back(gi);
@@ -625,7 +636,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipMalloc(&fp->items, (items.size() + fp->max_back + 1) * sizeof(uint4)));
     if (!items.empty()) {
         FAST_TRY(hipMemcpy(fp->items, items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
-        if (!getenv("FLATGFA_NO_ITEM_DIRS")) {  // (knob for measurements: every item taken as running upwards)
+        if (!measure_switch("FLATGFA_NO_ITEM_DIRS")) {  // (measurement builds: every item taken as running upwards)
             unsigned long long *d_runs64 = nullptr, runs64 = 0, item_steps = 0;
             FAST_TRY(hipMalloc(&d_runs64, 8));
             FAST_TRY(hipMemset(d_runs64, 0, 8));
