@@ -175,16 +175,53 @@ def main():
     graph = dev.DeviceGraph(l_steps, l_pb, l_pe, S, seg_len, device=str(device))
     plan = dev.DepthPlan(graph)
     in_flight = max(1, args.in_flight)
-    plans = [plan] + [dev.DepthPlan(graph) for _ in range(in_flight - 1)]  # (a plan belongs to one stream; they share the graph image and its claim on the Infinity Cache)
-    side = [torch.cuda.Stream(device) for _ in plans] if in_flight > 1 else None
-    op = ShardedDepth(S, [p.seg_depth for p in plans], device=device, with_uniq=True, streams=side)
+
+    class PipelinedDepth:
+        """N = 1 with calls in flight: the library's own pipeline (flatgfa_dev_pipeline_*: K plans of the resident graph
+        on K internal streams), one result buffer per lane.  Same interface as ShardedDepth."""
+
+        def __init__(self, k):
+            import ctypes
+            self.pipe = dev.DepthPipeline(graph, k)
+            self.bufs = [torch.zeros(2 * S, dtype=torch.int32, device=device) for _ in range(k)]
+            self.cur = 0
+            fn = dev._lib.lib().flatgfa_dev_pipeline_seg_depth
+            none = ctypes.c_void_p(-1)  # (nothing to wait for: the buffers are this loop's own, a lane's calls are in order)
+            self._calls = [(lambda f=fn, p=self.pipe._p, d=ctypes.c_void_p(b[:S].data_ptr()), u=ctypes.c_void_p(b[S:].data_ptr()): f(p, d, u, none))
+                           for b in self.bufs]
+
+        @property
+        def buf(self):
+            return self.bufs[self.cur]
+
+        def run(self):
+            j = (self.cur + 1) % len(self.bufs)  # (call n goes to lane n mod K inside the library: warm-up and region keep in step with it)
+            if self._calls[j]():
+                raise SystemExit("flatgfa_dev_pipeline_seg_depth failed: " + dev._lib.last_error())
+            self.cur = j
+
+        def finish(self):
+            self.pipe.join()
+
+    plans = [plan]
+    side = None
+    if world == 1 and in_flight > 1:
+        op = PipelinedDepth(in_flight)
+        op.cur = len(op.bufs) - 1  # (the first call: buffer 0, lane 0)
+    else:
+        plans = [plan] + [dev.DepthPlan(graph) for _ in range(in_flight - 1)]  # (a plan belongs to one stream; they share the graph image and its claim on the Infinity Cache)
+        side = [torch.cuda.Stream(device) for _ in plans] if in_flight > 1 else None
+        op = ShardedDepth(S, [p.seg_depth for p in plans], device=device, with_uniq=True, streams=side)
+        op.prepare(plans)   # (N = 1: every step is one call through the C ABI, resolved here)
     op1 = op if in_flight == 1 else ShardedDepth(S, plan.seg_depth, device=device, with_uniq=True)  # one call after the other, for the per-kernel samples
-    op.prepare(plans)   # (N = 1: every step is one call through the C ABI, resolved here)
     if op1 is not op:
         op1.prepare([plan])
 
     def status_all():
         op.finish()
+        if isinstance(op, PipelinedDepth):
+            op.pipe.status()
+            return
         for k, p in enumerate(plans):
             if side is not None:
                 with torch.cuda.stream(side[k]):
@@ -783,6 +820,7 @@ def main():
                        "segments": S, "paths_per_gpu": P_local if strong else P,
                        "steps_per_gpu": N_local, "steps_per_gpu_all_ranks": steps_all, "steps_per_job_step": N_job, "sharding": sharding,
                        "collective_bytes": 8 * S if world > 1 else 0, "calls_in_flight": in_flight,
+                       "in_flight_through": ("flatgfa_dev_pipeline_* (C ABI)" if world == 1 and in_flight > 1 else "one plan per torch stream" if in_flight > 1 else None),
                        "ranks_seen": ranks_seen, "uses_rccl": bool(world > 1 and backend == "nccl")},
             "bit_exact_vs_oracle": verified,
             "roofline": roofline, "cpu_baseline": cpu, "commit": git_head(),

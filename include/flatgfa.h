@@ -321,6 +321,28 @@ int flatgfa_dev_path_overlaps(flatgfa_dev_plan_t *plan, const uint32_t *query_id
  * stream (this call may release and reallocate the plan's scratch once that stream is idle). */
 int flatgfa_dev_status(flatgfa_dev_plan_t *plan, void *stream);
 
+/* Calls in flight.  A plan's calls run one after the other on its one stream, and a call is two kernels with
+ * opposite needs: pass 1 is bound by the memory system, pass 2 by instruction issue, each wants the whole chip, and
+ * each leaves compute units idle at its end.  A pipeline is `calls_in_flight` plans of ONE resident graph (they share
+ * the graph image and its claim on the Infinity Cache; each has its own record scratch) on as many internal streams,
+ * taken in turn: pass 2 of one call then shares the chip with pass 1 of the next (1 M segments / 100 M steps: 0.133 ->
+ * 0.114 ms per call with two in flight; a third adds nothing).  Every call is a whole query into the caller's buffers,
+ * which must not be reused before the call that wrote them is known to be done (join, or status).
+ *   flatgfa_dev_pipeline_seg_depth   as flatgfa_dev_seg_depth, on the pipeline's next lane; returns without waiting.
+ *                                    The call first waits for everything enqueued so far on `after_stream` (the
+ *                                    stream that filled the graph image or consumed the buffers' previous contents;
+ *                                    NULL = the default stream), or for nothing when after_stream is (void *)-1.
+ *   flatgfa_dev_pipeline_join        makes `stream` wait for every call enqueued so far (events; no host wait).
+ *   flatgfa_dev_pipeline_status      waits for every lane; FLATGFA_ERR_BOUNDS etc. as flatgfa_dev_status. */
+typedef struct flatgfa_dev_pipeline flatgfa_dev_pipeline_t;
+flatgfa_dev_pipeline_t *flatgfa_dev_pipeline_create(const flatgfa_dev_graph_t *g, const uint32_t *host_path_begin,
+                                                    const uint32_t *host_path_end, int calls_in_flight);
+void flatgfa_dev_pipeline_destroy(flatgfa_dev_pipeline_t *p);
+int flatgfa_dev_pipeline_seg_depth(flatgfa_dev_pipeline_t *p, uint32_t *depth_out, uint32_t *uniq_out, void *after_stream);
+int flatgfa_dev_pipeline_join(flatgfa_dev_pipeline_t *p, void *stream);
+int flatgfa_dev_pipeline_status(flatgfa_dev_pipeline_t *p);
+int flatgfa_dev_pipeline_describe(flatgfa_dev_pipeline_t *p, char *out, int cap);
+
 /* Which kernels this plan's calls run -- the choices made when it was created, some of them by
  * timing on the graph -- as a line of `key=value` words; returns the bytes written (NUL excluded). */
 int flatgfa_dev_plan_describe(flatgfa_dev_plan_t *plan, char *out, int cap);

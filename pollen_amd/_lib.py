@@ -83,6 +83,12 @@ SIGNATURES = {
     "flatgfa_dev_plan_create": (c_void_p, [POINTER(flatgfa_dev_graph_t), c_void_p, c_void_p]),
     "flatgfa_dev_plan_destroy": (None, [c_void_p]),
     "flatgfa_dev_plan_describe": (c_int, [c_void_p, c_char_p, c_int]),
+    "flatgfa_dev_pipeline_create": (c_void_p, [POINTER(flatgfa_dev_graph_t), c_void_p, c_void_p, c_int]),
+    "flatgfa_dev_pipeline_destroy": (None, [c_void_p]),
+    "flatgfa_dev_pipeline_seg_depth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "flatgfa_dev_pipeline_join": (c_int, [c_void_p, c_void_p]),
+    "flatgfa_dev_pipeline_status": (c_int, [c_void_p]),
+    "flatgfa_dev_pipeline_describe": (c_int, [c_void_p, c_char_p, c_int]),
     "flatgfa_dev_seg_depth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "flatgfa_dev_path_sums": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flatgfa_dev_status": (c_int, [c_void_p, c_void_p]),

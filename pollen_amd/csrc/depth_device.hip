@@ -862,6 +862,94 @@ extern "C" float flatgfa_dev_profile_overhead_ms(int n_workgroups, int lds_bytes
     return ts[ts.size() / 2];
 }
 
+// ---- calls in flight: K plans of one resident graph on K internal streams ----
+struct flatgfa_dev_pipeline {
+    int device = 0;
+    std::vector<flatgfa_dev_plan_t *> plans;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> joined;   // one per lane: recorded when a caller's stream joins (not per call: an event behind every call costs tens of microseconds)
+    hipEvent_t after = nullptr;       // recorded on a caller's stream whose work a call has to wait for
+    uint64_t n_calls = 0;
+};
+
+extern "C" void flatgfa_dev_pipeline_destroy(flatgfa_dev_pipeline_t *p) {
+    if (!p) return;
+    for (size_t k = 0; k < p->streams.size(); ++k)
+        if (p->streams[k]) (void)hipStreamSynchronize(p->streams[k]);
+    for (flatgfa_dev_plan_t *pl : p->plans) flatgfa_dev_plan_destroy(pl);
+    for (hipEvent_t e : p->joined)
+        if (e) (void)hipEventDestroy(e);
+    if (p->after) (void)hipEventDestroy(p->after);
+    for (hipStream_t st : p->streams)
+        if (st) (void)hipStreamDestroy(st);
+    delete p;
+}
+
+extern "C" flatgfa_dev_pipeline_t *flatgfa_dev_pipeline_create(const flatgfa_dev_graph_t *g, const uint32_t *hb, const uint32_t *he, int calls_in_flight) {
+    if (!g || calls_in_flight < 1 || calls_in_flight > 8) { set_error("dev_pipeline_create: bad argument (1 .. 8 calls in flight)"); return nullptr; }
+    auto *p = new flatgfa_dev_pipeline();
+    HIP_TRY(hipGetDevice(&p->device), { delete p; return nullptr; });
+    for (int k = 0; k < calls_in_flight; ++k) {
+        hipStream_t st = nullptr;
+        hipEvent_t ev = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            set_error("dev_pipeline_create: cannot create a stream");
+            if (st) (void)hipStreamDestroy(st);
+            flatgfa_dev_pipeline_destroy(p);
+            return nullptr;
+        }
+        p->streams.push_back(st);
+        p->joined.push_back(ev);
+        flatgfa_dev_plan_t *pl = flatgfa_dev_plan_create(g, hb, he);  // (plans of one step array share the graph image and one claim on the Infinity Cache)
+        if (!pl) { flatgfa_dev_pipeline_destroy(p); return nullptr; }
+        p->plans.push_back(pl);
+    }
+    if (hipEventCreateWithFlags(&p->after, hipEventDisableTiming) != hipSuccess) { set_error("dev_pipeline_create: cannot create an event"); flatgfa_dev_pipeline_destroy(p); return nullptr; }
+    return p;
+}
+
+extern "C" int flatgfa_dev_pipeline_seg_depth(flatgfa_dev_pipeline_t *p, uint32_t *depth_out, uint32_t *uniq_out, void *after_stream) {
+    if (!p || p->plans.empty()) { set_error("dev_pipeline_seg_depth: NULL pipeline"); return FLATGFA_ERR_ARG; }
+    const size_t lane = (size_t)(p->n_calls % p->plans.size());
+    if (after_stream != (void *)-1) {  // (-1: nothing to wait for)
+        HIP_TRY(hipEventRecord(p->after, (hipStream_t)after_stream), return FLATGFA_ERR_HIP);
+        HIP_TRY(hipStreamWaitEvent(p->streams[lane], p->after, 0), return FLATGFA_ERR_HIP);
+    }
+    p->n_calls += 1;
+    return flatgfa_dev_seg_depth(p->plans[lane], depth_out, uniq_out, p->streams[lane]);
+}
+
+extern "C" int flatgfa_dev_pipeline_join(flatgfa_dev_pipeline_t *p, void *stream) {
+    if (!p) { set_error("dev_pipeline_join: NULL pipeline"); return FLATGFA_ERR_ARG; }
+    for (size_t k = 0; k < p->streams.size(); ++k) {
+        HIP_TRY(hipEventRecord(p->joined[k], p->streams[k]), return FLATGFA_ERR_HIP);
+        HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, p->joined[k], 0), return FLATGFA_ERR_HIP);
+    }
+    return FLATGFA_OK;
+}
+
+extern "C" int flatgfa_dev_pipeline_status(flatgfa_dev_pipeline_t *p) {
+    if (!p) { set_error("dev_pipeline_status: NULL pipeline"); return FLATGFA_ERR_ARG; }
+    int rc = FLATGFA_OK;
+    for (size_t k = 0; k < p->plans.size(); ++k) {
+        const int r = flatgfa_dev_status(p->plans[k], p->streams[k]);  // (synchronizes the lane; completes its last call if that ran out of room)
+        if (r != FLATGFA_OK && rc == FLATGFA_OK) rc = r;
+    }
+    return rc;
+}
+
+extern "C" int flatgfa_dev_pipeline_describe(flatgfa_dev_pipeline_t *p, char *out, int cap) {
+    if (!p || p->plans.empty() || !out || cap <= 0) return 0;
+    std::string s = "calls_in_flight=" + std::to_string(p->plans.size()) + " ";
+    char buf[768] = "";
+    (void)flatgfa_dev_plan_describe(p->plans[0], buf, (int)sizeof buf);
+    s += buf;
+    const int n = (int)std::min<size_t>(s.size(), (size_t)cap - 1);
+    memcpy(out, s.data(), (size_t)n);
+    out[n] = 0;
+    return n;
+}
+
 extern "C" int flatgfa_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

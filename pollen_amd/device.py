@@ -175,6 +175,66 @@ class DepthPlan:
             _check(_lib.lib().flatgfa_dev_status(self._p, self._stream()), "dev_status")
 
 
+class DepthPipeline:
+    """Calls in flight (flatgfa_dev_pipeline_t): K plans of one resident graph on K internal streams, taken in turn, so
+    that pass 2 of one call shares the chip with pass 1 of the next.  `seg_depth` enqueues and returns; the buffers of a
+    call may be read after `join()` (torch's current stream then waits for every call so far) or `status()`."""
+
+    def __init__(self, graph: DeviceGraph, calls_in_flight: int = 2):
+        torch = _torch()
+        self.graph = graph
+        self.calls_in_flight = int(calls_in_flight)
+        with torch.cuda.device(graph.device):
+            g = graph.c_struct()
+            self._p = ctypes.c_void_p(_lib.lib().flatgfa_dev_pipeline_create(
+                ctypes.byref(g), graph.h_path_begin.ctypes.data if graph.n_paths else None,
+                graph.h_path_end.ctypes.data if graph.n_paths else None, self.calls_in_flight))
+        if not self._p.value:
+            raise FlatGFAError("dev_pipeline_create", -2)
+
+    def close(self) -> None:
+        if getattr(self, "_p", None) is not None and self._p.value:
+            _lib.lib().flatgfa_dev_pipeline_destroy(self._p)
+            self._p = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def seg_depth(self, depth_out, uniq_out=None, after_current_stream: bool = True) -> None:
+        """Enqueue node depth (+ unique depth) on the pipeline's next lane.  With `after_current_stream` the call first
+        waits for what torch's current stream holds so far (whoever filled the inputs or read these buffers last)."""
+        torch = _torch()
+        S = self.graph.n_segs
+        for t in (depth_out, uniq_out):
+            if t is not None:
+                assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous() and t.numel() == S
+        with torch.cuda.device(self.graph.device):
+            after = ctypes.c_void_p(torch.cuda.current_stream(self.graph.device).cuda_stream) if after_current_stream else ctypes.c_void_p(-1)
+            _check(_lib.lib().flatgfa_dev_pipeline_seg_depth(self._p, depth_out.data_ptr() if S else None,
+                                                             uniq_out.data_ptr() if (uniq_out is not None and S) else None, after),
+                   "dev_pipeline_seg_depth")
+
+    def join(self) -> None:
+        """torch's current stream waits for every call enqueued so far (no host wait)."""
+        torch = _torch()
+        with torch.cuda.device(self.graph.device):
+            _check(_lib.lib().flatgfa_dev_pipeline_join(self._p, ctypes.c_void_p(torch.cuda.current_stream(self.graph.device).cuda_stream)),
+                   "dev_pipeline_join")
+
+    def status(self) -> None:
+        """Wait for every lane and raise if a kernel saw an out-of-range id."""
+        with _torch().cuda.device(self.graph.device):
+            _check(_lib.lib().flatgfa_dev_pipeline_status(self._p), "dev_pipeline_status")
+
+    def describe(self) -> str:
+        buf = ctypes.create_string_buffer(1024)
+        _lib.lib().flatgfa_dev_pipeline_describe(self._p, buf, 1024)
+        return buf.value.decode()
+
+
 def profile_enable(on: bool) -> None:
     _lib.lib().flatgfa_dev_profile_enable(1 if on else 0)
 

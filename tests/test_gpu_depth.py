@@ -1143,3 +1143,47 @@ def test_more_steps_than_a_u32_can_index_is_an_error(tmp_path):
         g.seg_depth_with_uniq()
     assert ei.value.code == -6
     g.close()
+
+
+@pytest.mark.parametrize("calls_in_flight", [1, 2, 3])
+def test_calls_in_flight_through_the_pipeline(calls_in_flight, monkeypatch):
+    """flatgfa_dev_pipeline_*: K plans of one resident graph on K internal streams, taken in turn (pass 2 of one call beside
+    pass 1 of the next).  Every call is a whole query: each lane's result, of many calls enqueued without waiting, is the
+    oracle's; join() orders the caller's stream behind them; an out-of-range step is an error from status(), not a count."""
+    from pollen_amd.device import DepthPipeline, DeviceGraph
+    import torch
+    for v in ("FLATGFA_DEPTH_PATH", "FLATGFA_TAGGED", "FLATGFA_SHORT_MAX", "FLATGFA_PIECE_STEPS"):
+        monkeypatch.delenv(v, raising=False)
+    S = 700_000
+    g = pa.synth(61, S, 400, 30_000, "chromosome", False)
+    steps, pb, pe, _ = g.soa()
+    want_d, want_u = fo.seg_depth_with_uniq(pools_of(g))
+    graph = DeviceGraph(steps, pb, pe, S)
+    pipe = DepthPipeline(graph, calls_in_flight)
+    assert f"calls_in_flight={calls_in_flight} " in pipe.describe() and "path=bucketed" in pipe.describe(), pipe.describe()
+    bufs = [torch.full((2 * S,), -3, dtype=torch.int32, device="cuda:0") for _ in range(calls_in_flight)]
+    for n in range(5 * calls_in_flight + 1):
+        b = bufs[n % calls_in_flight]
+        pipe.seg_depth(b[:S], b[S:], after_current_stream=(n % 2 == 0))
+    pipe.join()  # torch's current stream now waits for all of them: the copies below are ordered behind the kernels
+    got = [b.cpu().numpy().view(np.uint32) for b in bufs]
+    pipe.status()
+    for k, x in enumerate(got):
+        assert (x[:S] == want_d).all() and (x[S:] == want_u).all(), f"lane {k}"
+    # depth only, and the buffers reused
+    for n in range(calls_in_flight):
+        bufs[n][:S].fill_(7)
+        pipe.seg_depth(bufs[n][:S], None)
+    pipe.status()
+    for b in bufs:
+        assert (b[:S].cpu().numpy().view(np.uint32) == want_d).all()
+    # a step that names a segment beyond the graph: an error, on whichever lane meets it
+    bad = steps.copy()
+    bad[int(pb[3]) + 17] = np.uint32((S + 5) << 1)
+    graph.steps.copy_(torch.from_numpy(bad.view(np.int32)))
+    torch.cuda.synchronize()
+    pipe.seg_depth(bufs[0][:S], bufs[0][S:])
+    with pytest.raises(pa.FlatGFAError) as ei:
+        pipe.status()
+    assert ei.value.code == -2  # FLATGFA_ERR_BOUNDS
+    pipe.close()
