@@ -526,6 +526,24 @@ def main():
                                                 f"graph, median of {len(ts)} runs after 1 warm-up", "seconds_median": round(float(np.median(ts)), 4)}
             pd_row["bit_exact_vs_oracle"] = bool((got_len == want_len).all() and got_mean.tobytes() == want_mean.tobytes())
             del pools_a3
+        if in_flight > 1:  # the same query with calls in flight (flatgfa_dev_pipeline_path_depth_all), every lane its own outputs
+            ppipe = dev.DepthPipeline(graph, in_flight)
+            outs = [(torch.zeros(S, dtype=torch.int32, device=device), torch.zeros(P, dtype=torch.int64, device=device),
+                     torch.zeros(P, dtype=torch.int64, device=device)) for _ in range(in_flight)]
+            for k in range(2 * in_flight):
+                ppipe.path_depth_all(*outs[k % in_flight], after_current_stream=False)
+            ppipe.status()
+            torch.cuda.synchronize(device)
+            c0 = time.perf_counter()
+            for k in range(args.steps):
+                ppipe.path_depth_all(*outs[k % in_flight], after_current_stream=False)
+            ppipe.status()
+            pip_ms = (time.perf_counter() - c0) / args.steps * 1e3
+            same = all(bool((o[1].cpu().numpy() == len_out.cpu().numpy()).all() and (o[2].cpu().numpy() == wsum_out.cpu().numpy()).all()) for o in outs)
+            pd_row["calls_in_flight"] = {"n": in_flight, "ms_per_call": round(pip_ms, 5), "steps_per_s": round(N / (pip_ms * 1e-3), 1),
+                                         "frac": round(pd_bytes / (pip_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "same_sums_as_one_at_a_time": same}
+            ppipe.close()
+            del ppipe, outs
         extras["path_depth"] = pd_row
         # The benchmark's walk continues 90 % of its steps (runs of 10).  The same shape with paths
         # that run along the graph, every other one downwards, 70 % continuing (0.3 records per

@@ -332,6 +332,7 @@ int flatgfa_dev_status(flatgfa_dev_plan_t *plan, void *stream);
  *                                    The call first waits for everything enqueued so far on `after_stream` (the
  *                                    stream that filled the graph image or consumed the buffers' previous contents;
  *                                    NULL = the default stream), or for nothing when after_stream is (void *)-1.
+ *   flatgfa_dev_pipeline_path_depth_all   as flatgfa_dev_path_depth_all (what `fgfa depth` prints), likewise.
  *   flatgfa_dev_pipeline_join        makes `stream` wait for every call enqueued so far (events; no host wait).
  *   flatgfa_dev_pipeline_status      waits for every lane; FLATGFA_ERR_BOUNDS etc. as flatgfa_dev_status. */
 typedef struct flatgfa_dev_pipeline flatgfa_dev_pipeline_t;
@@ -339,6 +340,8 @@ flatgfa_dev_pipeline_t *flatgfa_dev_pipeline_create(const flatgfa_dev_graph_t *g
                                                     const uint32_t *host_path_end, int calls_in_flight);
 void flatgfa_dev_pipeline_destroy(flatgfa_dev_pipeline_t *p);
 int flatgfa_dev_pipeline_seg_depth(flatgfa_dev_pipeline_t *p, uint32_t *depth_out, uint32_t *uniq_out, void *after_stream);
+int flatgfa_dev_pipeline_path_depth_all(flatgfa_dev_pipeline_t *p, uint32_t *depth_out, uint64_t *length_out, uint64_t *weighted_out,
+                                        void *after_stream);
 int flatgfa_dev_pipeline_join(flatgfa_dev_pipeline_t *p, void *stream);
 int flatgfa_dev_pipeline_status(flatgfa_dev_pipeline_t *p);
 int flatgfa_dev_pipeline_describe(flatgfa_dev_pipeline_t *p, char *out, int cap);

@@ -86,6 +86,7 @@ SIGNATURES = {
     "flatgfa_dev_pipeline_create": (c_void_p, [POINTER(flatgfa_dev_graph_t), c_void_p, c_void_p, c_int]),
     "flatgfa_dev_pipeline_destroy": (None, [c_void_p]),
     "flatgfa_dev_pipeline_seg_depth": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "flatgfa_dev_pipeline_path_depth_all": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "flatgfa_dev_pipeline_join": (c_int, [c_void_p, c_void_p]),
     "flatgfa_dev_pipeline_status": (c_int, [c_void_p]),
     "flatgfa_dev_pipeline_describe": (c_int, [c_void_p, c_char_p, c_int]),

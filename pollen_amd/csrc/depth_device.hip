@@ -919,6 +919,18 @@ extern "C" int flatgfa_dev_pipeline_seg_depth(flatgfa_dev_pipeline_t *p, uint32_
     return flatgfa_dev_seg_depth(p->plans[lane], depth_out, uniq_out, p->streams[lane]);
 }
 
+extern "C" int flatgfa_dev_pipeline_path_depth_all(flatgfa_dev_pipeline_t *p, uint32_t *depth_out, uint64_t *length_out, uint64_t *weighted_out,
+                                                    void *after_stream) {
+    if (!p || p->plans.empty()) { set_error("dev_pipeline_path_depth_all: NULL pipeline"); return FLATGFA_ERR_ARG; }
+    const size_t lane = (size_t)(p->n_calls % p->plans.size());
+    if (after_stream != (void *)-1) {
+        HIP_TRY(hipEventRecord(p->after, (hipStream_t)after_stream), return FLATGFA_ERR_HIP);
+        HIP_TRY(hipStreamWaitEvent(p->streams[lane], p->after, 0), return FLATGFA_ERR_HIP);
+    }
+    p->n_calls += 1;
+    return flatgfa_dev_path_depth_all(p->plans[lane], depth_out, length_out, weighted_out, p->streams[lane]);
+}
+
 extern "C" int flatgfa_dev_pipeline_join(flatgfa_dev_pipeline_t *p, void *stream) {
     if (!p) { set_error("dev_pipeline_join: NULL pipeline"); return FLATGFA_ERR_ARG; }
     for (size_t k = 0; k < p->streams.size(); ++k) {

@@ -217,6 +217,18 @@ class DepthPipeline:
                                                              uniq_out.data_ptr() if (uniq_out is not None and S) else None, after),
                    "dev_pipeline_seg_depth")
 
+    def path_depth_all(self, depth_out, length_out, weighted_out, after_current_stream: bool = True) -> None:
+        """Enqueue node depth and measure_path's two sums for every path (what `fgfa depth` needs) on the next lane."""
+        torch = _torch()
+        S, P = self.graph.n_segs, self.graph.n_paths
+        assert depth_out.dtype == torch.int32 and depth_out.numel() == S and depth_out.is_contiguous()
+        for t in (length_out, weighted_out):
+            assert t.dtype == torch.int64 and t.is_cuda and t.is_contiguous() and t.numel() == P
+        with torch.cuda.device(self.graph.device):
+            after = ctypes.c_void_p(torch.cuda.current_stream(self.graph.device).cuda_stream) if after_current_stream else ctypes.c_void_p(-1)
+            _check(_lib.lib().flatgfa_dev_pipeline_path_depth_all(self._p, depth_out.data_ptr() if S else None, length_out.data_ptr() if P else None,
+                                                                  weighted_out.data_ptr() if P else None, after), "dev_pipeline_path_depth_all")
+
     def join(self) -> None:
         """torch's current stream waits for every call enqueued so far (no host wait)."""
         torch = _torch()

@@ -1177,6 +1177,23 @@ def test_calls_in_flight_through_the_pipeline(calls_in_flight, monkeypatch):
     pipe.status()
     for b in bufs:
         assert (b[:S].cpu().numpy().view(np.uint32) == want_d).all()
+    # path depth of all paths (what `fgfa depth` prints) through the lanes
+    _, _, _, seg_len = g.soa()
+    graph2 = DeviceGraph(steps, pb, pe, S, seg_len)
+    pipe2 = DepthPipeline(graph2, calls_in_flight)
+    P = len(pb)
+    outs = [(torch.zeros(S, dtype=torch.int32, device="cuda:0"), torch.zeros(P, dtype=torch.int64, device="cuda:0"),
+             torch.zeros(P, dtype=torch.int64, device="cuda:0")) for _ in range(calls_in_flight)]
+    for n in range(3 * calls_in_flight):
+        pipe2.path_depth_all(*outs[n % calls_in_flight])
+    pipe2.status()
+    want_len, want_mean = fo.path_depth(pools_of(g))
+    for o in outs:
+        assert (o[0].cpu().numpy().view(np.uint32) == want_d).all()
+        got_len = o[1].cpu().numpy().view(np.uint64)
+        got_mean = o[2].cpu().numpy().view(np.uint64).astype(np.float64) / got_len.astype(np.float64)
+        assert (got_len == want_len).all() and got_mean.tobytes() == want_mean.tobytes()
+    pipe2.close()
     # a step that names a segment beyond the graph: an error, on whichever lane meets it
     bad = steps.copy()
     bad[int(pb[3]) + 17] = np.uint32((S + 5) << 1)
