@@ -112,7 +112,7 @@ def main():
                     help="who shards and reduces for N > 1: torch.distributed (one rank per GPU, RCCL through torch's nccl backend), or "
                          "the C ABI (flatgfa_sharded_*: rank 0 alone drives all N devices, RCCL inside libflatgfa.so; the other ranks only "
                          "keep the launcher's barrier)")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="calls in flight: K plans of the rank's resident graph on K streams, called in turn, so that pass 2 of one "
                          "call (bound by instruction issue) shares the chip with pass 1 of the next (bound by the memory system); every "
                          "step is still a whole query into its own result buffer.  1 = strictly one call after the other")
@@ -839,6 +839,7 @@ def main():
                        "steps_per_gpu": N_local, "steps_per_gpu_all_ranks": steps_all, "steps_per_job_step": N_job, "sharding": sharding,
                        "collective_bytes": 8 * S if world > 1 else 0, "calls_in_flight": in_flight,
                        "in_flight_through": ("flatgfa_dev_pipeline_* (C ABI)" if world == 1 and in_flight > 1 else "one plan per torch stream" if in_flight > 1 else None),
+                       "pipeline": op.pipe.describe() if isinstance(op, PipelinedDepth) else None,
                        "ranks_seen": ranks_seen, "uses_rccl": bool(world > 1 and backend == "nccl")},
             "bit_exact_vs_oracle": verified,
             "roofline": roofline, "cpu_baseline": cpu, "commit": git_head(),

@@ -304,8 +304,13 @@ extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int 
 
 static int atomic_seg_depth(flatgfa_dev_plan_t *pl, uint32_t *depth_out, uint32_t *uniq_out, hipStream_t stream);
 
+static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const uint32_t *hb, const uint32_t *he, uint32_t scan_workgroups);
 extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t *g, const uint32_t *hb,
                                                         const uint32_t *he) {
+    return plan_create_impl(g, hb, he, 0u);
+}
+// (scan_workgroups: pass 1's persistent workgroups, 0 = one per CU; a pipeline's lanes take fewer)
+static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const uint32_t *hb, const uint32_t *he, uint32_t scan_workgroups) {
     if (!g) { set_error("plan_create: NULL graph"); return nullptr; }
     std::vector<uint32_t> cb, ce;
     if (g->n_paths && (!hb || !he)) {
@@ -347,7 +352,7 @@ extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t
     // cover both device paths); anything else lets eligibility decide.
     const char *force = getenv("FLATGFA_DEPTH_PATH");
     if (!(force && std::string(force) == "atomic")) {
-        if (!fast_plan_create(pl->g, hb, he, &pl->fast)) { flatgfa_dev_plan_destroy(pl); return nullptr; }
+        if (!fast_plan_create(pl->g, hb, he, &pl->fast, scan_workgroups)) { flatgfa_dev_plan_destroy(pl); return nullptr; }
     }
     // Steps kept in the Infinity Cache.  k_scan streams the steps past the caches (nt: whole lines read once),
     // which is right for what does not fit them -- but a resident graph is queried again and again, and the
@@ -775,7 +780,7 @@ extern "C" int flatgfa_dev_plan_describe(flatgfa_dev_plan_t *pl, char *out, int 
             " pass2=" + (f.tagged ? (f.n_shared ? "tagged(shared bitsets)" : f.acc_pair ? "tagged(two workgroups per window)" : "tagged") : (f.big_groups ? "directory(one-item shortcut)" : "directory")) +
             " windows=" + std::to_string(f.n_win) + "x" + std::to_string(1u << f.wb) + " ranges=" + std::to_string((f.n_more + 1) / f.n_groups) +
             (f.n_groups > 1 ? " path_groups=" + std::to_string(f.n_groups) : std::string()) +
-            " workgroups_per_window=" + std::to_string(f.acc_parts) + " items=" + std::to_string(f.n_items) + " no_claim_items=" + std::to_string(f.n_noclaim) + " split_paths=" + std::to_string(f.n_shared) +
+            " scan_workgroups=" + std::to_string(f.n_slots) + " workgroups_per_window=" + std::to_string(f.acc_parts) + " items=" + std::to_string(f.n_items) + " no_claim_items=" + std::to_string(f.n_noclaim) + " split_paths=" + std::to_string(f.n_shared) +
             " short_paths=" + std::to_string(f.n_short) + " medium_paths=" + std::to_string(f.n_medium) + " tiny_paths=" + std::to_string(f.n_tiny) +
             " steps=" + std::to_string(f.class_steps[0]) + "/" + std::to_string(f.class_steps[1]) + "/" + std::to_string(f.class_steps[2]) + "/" + std::to_string(f.class_steps[3]) +  // (by k_scan / short / medium / tiny)
             " bucket_cap=" + std::to_string(f.cap);
@@ -900,7 +905,17 @@ extern "C" flatgfa_dev_pipeline_t *flatgfa_dev_pipeline_create(const flatgfa_dev
         }
         p->streams.push_back(st);
         p->joined.push_back(ev);
-        flatgfa_dev_plan_t *pl = flatgfa_dev_plan_create(g, hb, he);  // (plans of one step array share the graph image and one claim on the Infinity Cache)
+        // Plans of one step array share the graph image and one claim on the Infinity Cache.  A lane's pass 1 runs fewer
+        // persistent workgroups than there are CUs -- half of them with three calls in flight or more, eleven sixteenths
+        // with two -- so that the kernels of the other calls share the chip with it all the time, not only at its tail
+        // (cfg-L, three in flight: 0.116 -> 0.107 ms per call; 4 M segments 0.165 -> 0.141; a call alone would be slower:
+        // 0.133 -> 0.168).  Graphs whose kernels run for milliseconds keep one per CU: their pass 1 is bound by
+        // instruction issue as much as by memory and wants every CU (profiles/NOTES.md R5.10).
+        int n_cus = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
+        const uint32_t wgs = calls_in_flight >= 2 && g->n_steps <= (1ull << 28) ? (uint32_t)(calls_in_flight >= 3 ? n_cus / 2 : n_cus * 11 / 16) : 0u;
+        flatgfa_dev_plan_t *pl = plan_create_impl(g, hb, he, wgs);
         if (!pl) { flatgfa_dev_pipeline_destroy(p); return nullptr; }
         p->plans.push_back(pl);
     }

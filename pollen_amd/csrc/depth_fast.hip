@@ -202,6 +202,7 @@ int alloc_buckets(FastPlan *fp, uint64_t want_cap) {
 
 static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
                      uint32_t *status, hipStream_t stream, const PathSums *ps, bool count_only);
+static thread_local uint32_t t_scan_workgroups = 0;  // fast_plan_create's `scan_workgroups`, for the ranges it makes
 
 // The A/B switches of past measurements (which policy a plan takes: NOTES.md) read the environment in measurement
 // builds only (-DFGFA_MEASURE, tools/variants.sh); the product library takes the policy that won.
@@ -235,6 +236,10 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipGetDeviceProperties(&prop, dev));
     fp->n_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     fp->n_slots = fp->n_cus;
+    // Pass 1's persistent workgroups: one per CU -- or fewer for a plan that is one lane of a pipeline (calls in flight:
+    // flatgfa_dev_pipeline_create), where the CUs it leaves are another call's.  FLATGFA_SCAN_WGS=n: tests, measurements.
+    if (t_scan_workgroups) fp->n_slots = std::max(8u, std::min<uint32_t>(fp->n_cus, t_scan_workgroups));
+    if (const char *f = getenv("FLATGFA_SCAN_WGS")) fp->n_slots = std::max(8u, std::min<uint32_t>(fp->n_cus, (uint32_t)strtoul(f, nullptr, 10)));
     if (fp->n_slots > kMaxSlots) return true;
     fp->n_win = n_win;
     fp->wb = wb;
@@ -902,7 +907,14 @@ static void adopt_plans(std::vector<FastPlan> *plans, FastPlan *fp) {
     plans->clear();
 }
 
-bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp) {
+static bool fast_plan_create_impl(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp);
+bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp, uint32_t scan_workgroups) {
+    t_scan_workgroups = scan_workgroups;
+    const bool ok = fast_plan_create_impl(g, hb, he, fp);
+    t_scan_workgroups = 0;
+    return ok;
+}
+static bool fast_plan_create_impl(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp) {
     *fp = FastPlan();
     if (g.n_segs == 0 || g.n_paths == 0 || g.n_steps == 0) return true;
     if ((reinterpret_cast<uintptr_t>(g.steps) & 15u) != 0) return true;  // 16-byte step loads

@@ -19,7 +19,7 @@ FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
 @pytest.fixture(params=["auto", "bucketed", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3", "ranges", "dense",
-                        "untagged", "untagged_pieces", "untagged_noshort", "groups3", "packed", "slots8", "claim_all", "wb11"])
+                        "untagged", "untagged_pieces", "untagged_noshort", "groups3", "packed", "slots8", "claim_all", "wb11", "wgs96"])
 def device_path(request, monkeypatch):
     """Runs a test once per device path: the default (up to 8 M steps the plan times the bucketed
     path against the atomic kernels on the graph at hand and keeps the faster), the bucketed path
@@ -48,6 +48,7 @@ def device_path(request, monkeypatch):
     monkeypatch.delenv("FLATGFA_BIG_GROUPS", raising=False)
     monkeypatch.delenv("FLATGFA_TAGGED", raising=False)
     monkeypatch.delenv("FLATGFA_NO_CLAIM", raising=False)
+    monkeypatch.delenv("FLATGFA_SCAN_WGS", raising=False)
     monkeypatch.delenv("FLATGFA_PATH_GROUPS", raising=False)
     monkeypatch.delenv("FLATGFA_PACKED", raising=False)
     monkeypatch.delenv("FLATGFA_ACC_SLOTS", raising=False)
@@ -55,6 +56,9 @@ def device_path(request, monkeypatch):
     if request.param == "wb11":  # windows of 2048 segments (by default 4096, or 8192 beyond 4 M segments)
         monkeypatch.setenv("FLATGFA_WB", "11")
         monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
+        monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    if request.param == "wgs96":  # pass 1 with 96 persistent workgroups, hence 96 sub-buckets per window (by default one per CU; a pipeline's lanes take 128 or 176)
+        monkeypatch.setenv("FLATGFA_SCAN_WGS", "96")
         monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
     if request.param == "claim_all":  # every item claims in a bitset, strictly monotone paths included (by default their records skip the claim: kTagNoClaim)
         monkeypatch.setenv("FLATGFA_NO_CLAIM", "0")
