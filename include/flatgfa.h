@@ -325,8 +325,11 @@ int flatgfa_dev_status(flatgfa_dev_plan_t *plan, void *stream);
  * opposite needs: pass 1 is bound by the memory system, pass 2 by instruction issue, each wants the whole chip, and
  * each leaves compute units idle at its end.  A pipeline is `calls_in_flight` plans of ONE resident graph (they share
  * the graph image and its claim on the Infinity Cache; each has its own record scratch) on as many internal streams,
- * taken in turn: pass 2 of one call then shares the chip with pass 1 of the next (1 M segments / 100 M steps: 0.133 ->
- * 0.114 ms per call with two in flight; a third adds nothing).  Every call is a whole query into the caller's buffers,
+ * taken in turn, and -- on graphs of up to 2^28 steps -- each lane's pass 1 runs on fewer persistent workgroups than
+ * there are compute units (half of them with three calls in flight or more, eleven sixteenths with two), so that the
+ * other calls' kernels share the chip with it all the time, not only at its tail (1 M segments / 100 M steps: 0.133 ms
+ * per call one at a time, 0.114 with two in flight, 0.107 with three; a fourth loses).  A lane's plan alone would be
+ * slower than flatgfa_dev_plan_create's.  Every call is a whole query into the caller's buffers,
  * which must not be reused before the call that wrote them is known to be done (join, or status).
  *   flatgfa_dev_pipeline_seg_depth   as flatgfa_dev_seg_depth, on the pipeline's next lane; returns without waiting.
  *                                    The call first waits for everything enqueued so far on `after_stream` (the

@@ -21,9 +21,9 @@ done
 # 2. kernel trace + stats of the same command (csv)
 rm -rf $OUT/_trace; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_trace -o t -- python3 $CMD --no-cpu-baseline --no-extras > $OUT/_trace.log 2>&1
 f=$(find $OUT/_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_rocprofv3_kernel_stats.csv
-# 2b. ... with two calls in flight, as the timed region runs (the kernels of consecutive calls overlap: their durations are longer, the calls shorter)
-rm -rf $OUT/_trace; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_trace -o t -- python3 bench.py --steps 40 --warmup 3 --in-flight 2 --no-cpu-baseline --no-extras > $OUT/_trace2.log 2>&1
-f=$(find $OUT/_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_rocprofv3_kernel_stats_in_flight2.csv
+# 2b. ... with calls in flight (the default: three lanes of the pipeline), as the timed region runs (the kernels of consecutive calls overlap: their durations are longer, the calls shorter)
+rm -rf $OUT/_trace; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_trace -o t -- python3 bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-extras > $OUT/_trace2.log 2>&1
+f=$(find $OUT/_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_rocprofv3_kernel_stats_in_flight.csv
 # 2c. ... with no step kept in the Infinity Cache (FLATGFA_MALL_MB=0: what roofline.frac_cold is measured on)
 rm -rf $OUT/_trace; FLATGFA_MALL_MB=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_trace -o t -- python3 $CMD --no-cpu-baseline --no-extras > $OUT/_trace3.log 2>&1
 f=$(find $OUT/_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_rocprofv3_kernel_stats_mall0.csv
