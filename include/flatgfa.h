@@ -325,8 +325,8 @@ int flatgfa_dev_status(flatgfa_dev_plan_t *plan, void *stream);
  * opposite needs: pass 1 is bound by the memory system, pass 2 by instruction issue, each wants the whole chip, and
  * each leaves compute units idle at its end.  A pipeline is `calls_in_flight` plans of ONE resident graph (they share
  * the graph image and its claim on the Infinity Cache; each has its own record scratch) on as many internal streams,
- * taken in turn, and -- on graphs of up to 2^28 steps -- each lane's pass 1 runs on fewer persistent workgroups than
- * there are compute units (half of them with three calls in flight or more, eleven sixteenths with two), so that the
+ * taken in turn, and each lane's pass 1 runs on fewer persistent workgroups than there are compute units (half of
+ * them with three calls in flight or more on graphs of up to 2^28 steps, eleven sixteenths otherwise), so that the
  * other calls' kernels share the chip with it all the time, not only at its tail (1 M segments / 100 M steps: 0.133 ms
  * per call one at a time, 0.114 with two in flight, 0.107 with three; a fourth loses).  A lane's plan alone would be
  * slower than flatgfa_dev_plan_create's.  Every call is a whole query into the caller's buffers,

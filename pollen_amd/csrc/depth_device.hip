@@ -909,12 +909,13 @@ extern "C" flatgfa_dev_pipeline_t *flatgfa_dev_pipeline_create(const flatgfa_dev
         // persistent workgroups than there are CUs -- half of them with three calls in flight or more, eleven sixteenths
         // with two -- so that the kernels of the other calls share the chip with it all the time, not only at its tail
         // (cfg-L, three in flight: 0.116 -> 0.107 ms per call; 4 M segments 0.165 -> 0.141; a call alone would be slower:
-        // 0.133 -> 0.168).  Graphs whose kernels run for milliseconds keep one per CU: their pass 1 is bound by
-        // instruction issue as much as by memory and wants every CU (profiles/NOTES.md R5.10).
+        // 0.133 -> 0.168).  Graphs beyond 2^28 steps, whose pass 1 is bound by instruction issue as much as by memory, take
+        // eleven sixteenths whatever is in flight (ninety paths of ten million steps 2.17 -> 1.89 ms; sixteen thousand
+        // haplotype walks even; half the chip loses there: profiles/NOTES.md R5.10).
         int n_cus = 256;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
-        const uint32_t wgs = calls_in_flight >= 2 && g->n_steps <= (1ull << 28) ? (uint32_t)(calls_in_flight >= 3 ? n_cus / 2 : n_cus * 11 / 16) : 0u;
+        const uint32_t wgs = calls_in_flight < 2 ? 0u : (uint32_t)(calls_in_flight >= 3 && g->n_steps <= (1ull << 28) ? n_cus / 2 : n_cus * 11 / 16);
         flatgfa_dev_plan_t *pl = plan_create_impl(g, hb, he, wgs);
         if (!pl) { flatgfa_dev_pipeline_destroy(p); return nullptr; }
         p->plans.push_back(pl);
