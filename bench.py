@@ -7,10 +7,13 @@ synthetic graph (BASELINE.json metric; configs[2] at N=1, configs[3] at N>1).
 
 One "step" = one pass of the hot path (seg_depth_with_uniq, ops/depth.rs:15-39) over the rank's
 resident graph image: run the HIP kernels, and -- for N > 1 -- one RCCL sum all-reduce of the
-fused [depth | uniq] vector.  Steps alternate between two result buffers, so the all-reduce of
-one step overlaps the kernels of the next (pollen_amd/sharded.py); the timed region ends when
-every kernel and every collective of its K steps has finished.  Inputs are in HBM before the
-timed region starts.
+fused [depth | uniq] vector.  The timed region keeps `--in-flight` (3) calls in flight: at one GPU through the
+library's pipeline (flatgfa_dev_pipeline_*: that many plans of the resident graph on as many internal streams, each
+lane's pass 1 on part of the chip, so that pass 2 of one call runs beside pass 1 of another); with a collective per
+step (N > 1) one plan per torch stream, the all-reduce of one step overlapping the kernels of the next
+(pollen_amd/sharded.py).  Every step is a whole query into its own result buffer, all of them checked against the
+oracle before anything is timed; the region ends when every kernel and every collective of its K steps has
+finished.  Inputs are in HBM before the timed region starts.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU):
   --scaling strong (default)  BASELINE.json configs[3]: the SAME graph, its paths cut into N
@@ -23,9 +26,10 @@ Before anything is timed the REDUCED vector is checked against the oracle on eve
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel: its own algorithmic bytes
 (k_scan reads every step once: 4N + 8P; k_accum writes the result vectors: 4Sk) over its average
-duration from HIP events recorded around each launch on the launch stream inside the timed
-region; `roofline.whole_call` is the whole call's algorithmic bytes (4N + 8P + 4Sk, SURVEY.md
-8(d)) over all its kernels.  `cpu_baseline` is the single-threaded C oracle (the reference's loop
+duration from HIP events recorded around each launch on the launch stream, eighteen consecutive calls
+that run one after the other on a plan of its own right behind the timed region (`frac`; `frac_cold`: the
+same with no step kept in the Infinity Cache); `roofline.whole_call` is the whole call's algorithmic bytes
+(4N + 8P + 4Sk) over the sum of its kernels, and -- `timed_region` -- over the region's ms_per_step.  `cpu_baseline` is the single-threaded C oracle (the reference's loop
 is single-threaded) timed on this host.
 """
 import argparse
@@ -406,8 +410,9 @@ def main():
             "ms_per_step_one_call_in_flight": round(serial_elapsed / args.steps * 1e3, 5) if serial_elapsed else round(region_ms, 5)}
         if in_flight > 1:
             roofline["kernel_timing"] = (f"HIP events around each launch of {SAMPLE_STEPS} consecutive steps right behind the timed region, one call "
-                                         "after the other on the first plan's stream (the region itself keeps "
-                                         f"{in_flight} calls in flight and carries no event records); `achieved` uses the mean over all of them")
+                                         "after the other on a plan of its own (flatgfa_dev_plan_create: one pass-1 workgroup per CU); the region itself keeps "
+                                         f"{in_flight} calls in flight through flatgfa_dev_pipeline_* -- whose lanes run pass 1 on fewer workgroups, "
+                                         "config.pipeline: scan_workgroups -- and carries no event records; `achieved` uses the mean over all of them")
         # Every step from HBM: the plan keeps the first cache_resident_mb of the steps in the 256 MiB Infinity Cache from
         # call to call (they are read without the nt hint), which a loop over ONE resident graph profits from.  The same
         # graph through a plan made with FLATGFA_MALL_MB=0, sampled the same way, is what a call costs when nothing of
