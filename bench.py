@@ -60,6 +60,9 @@ WORKLOADS = {
     "chrom-10k": (1_000_000, 10_000, 10_000, "chromosome"),   # ten thousand contigs of ten blocks each, half of them downwards
     "chrom-1k": (1_000_000, 100_000, 1000, "chromosome"),     # a hundred thousand short ones
     "tiny-paths": (1_000_000, 1_000_000, 100, "pangenome"),   # a million paths of a hundred steps
+    "hap-1k": (1_000_000, 100_000, 1000, "haplotype"),        # a hundred thousand contigs that stay in order, half of them downwards: no segment twice, no claims
+    "hap-10k": (1_000_000, 10_000, 10_000, "haplotype"),
+    "hap-100": (1_000_000, 1_000_000, 100, "haplotype"),
     "cfgL-100kseg": (100_000, 1000, 100_000, "pangenome"),    # deep coverage of a small graph: 25 windows
     "cfgL-4Mseg": (4_000_000, 1000, 100_000, "pangenome"),
     "cfgL-16Mseg": (16_000_000, 1000, 100_000, "pangenome"),

@@ -58,33 +58,43 @@ namespace fgfa_dev {
 namespace {
 
 // Plan time: how many runs (as k_scan_short cuts them: +1 continuations, cut at multiples of 32)
-// each path has.  One workgroup per path at a time.
+// each path has, and whether it walks the segment ids strictly upwards or strictly downwards from its first
+// step to its last (mono[p] = 1: it never meets a segment twice, so a wave-per-path kernel need not look).
+// One workgroup per path at a time.
 __global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__ steps, const uint32_t *__restrict__ pb,
                                                      const uint32_t *__restrict__ pe, uint32_t n_paths,
-                                                     uint32_t *__restrict__ runs, uint32_t *__restrict__ runs_down) {
-    __shared__ uint32_t total, total_down;
+                                                     uint32_t *__restrict__ runs, uint32_t *__restrict__ runs_down, uint32_t *__restrict__ mono) {
+    __shared__ uint32_t total, total_down, asc, desc;
     for (uint32_t p = blockIdx.x; p < n_paths; p += gridDim.x) {
-        if (threadIdx.x == 0) total = total_down = 0;
+        if (threadIdx.x == 0) total = total_down = asc = desc = 0;
         __syncthreads();
         const uint64_t b = pb[p], e = pe[p];
-        uint32_t mine = 0, down = 0;  // (down: the runs the path has when it is read backwards)
+        uint32_t mine = 0, down = 0, a = 0, c = 0;  // (down: the runs the path has when it is read backwards)
         for (uint64_t i = b + threadIdx.x; i < e; i += 256) {
             const uint32_t id = steps[i] >> 1, before = i == b ? 0u : steps[i - 1] >> 1;
             mine += (i == b || id != before + 1u || (id & 31u) == 0u) ? 1u : 0u;
             down += (i == b || id + 1u != before || (before & 31u) == 0u) ? 1u : 0u;
+            a += (i != b && id > before) ? 1u : 0u;
+            c += (i != b && id < before) ? 1u : 0u;
         }
         for (int off = 32; off > 0; off >>= 1) {
             mine += __shfl_down(mine, off, 64);
             down += __shfl_down(down, off, 64);
+            a += __shfl_down(a, off, 64);
+            c += __shfl_down(c, off, 64);
         }
         if ((threadIdx.x & 63) == 0) {
             atomicAdd(&total, mine);
             atomicAdd(&total_down, down);
+            atomicAdd(&asc, a);
+            atomicAdd(&desc, c);
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             runs[p] = total;
             runs_down[p] = total_down;
+            const uint32_t pairs = e > b ? (uint32_t)(e - b - 1) : 0u;
+            mono[p] = (e > b && (asc == pairs || desc == pairs)) ? 1u : 0u;
         }
         __syncthreads();
     }
@@ -258,18 +268,30 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // Which kernel walks a path depends on how many runs it has: short paths must fit the run queue,
     // paths with at most kMediumRuns runs are walked wave by wave too, by pairs of waves that share a
     // bigger hash set (k_scan_short's medium variant).  The counts come from a one-off kernel.
-    std::vector<uint32_t> runs, runs_down;
+    std::vector<uint32_t> runs, runs_down, mono;
     if (short_max) {
+        // (counted over the spans this plan walks -- a plan may be given others than the graph's own)
         uint32_t *d_runs = nullptr;
-        FAST_TRY(hipMalloc(&d_runs, (size_t)g.n_paths * 8));
+        const size_t np = g.n_paths;
+        FAST_TRY(hipMalloc(&d_runs, np * 20));
+        hipError_t e = hipMemcpy(d_runs + 3 * np, hb, np * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_runs + 4 * np, he, np * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d_runs);
+            FAST_TRY(e);
+        }
         hipLaunchKernelGGL(k_count_runs, dim3(std::min<uint32_t>(g.n_paths, fp->n_cus * 8u)), dim3(256), 0, nullptr, g.steps,
-                           g.path_begin, g.path_end, g.n_paths, d_runs, d_runs + g.n_paths);
+                           d_runs + 3 * np, d_runs + 4 * np, g.n_paths, d_runs, d_runs + np, d_runs + 2 * np);
         runs.resize(g.n_paths);
         runs_down.resize(g.n_paths);
-        hipError_t e = hipMemcpy(runs.data(), d_runs, (size_t)g.n_paths * 4, hipMemcpyDeviceToHost);
+        mono.resize(g.n_paths);
+        e = hipMemcpy(runs.data(), d_runs, (size_t)g.n_paths * 4, hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipMemcpy(runs_down.data(), d_runs + g.n_paths, (size_t)g.n_paths * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(mono.data(), d_runs + 2 * (size_t)g.n_paths, (size_t)g.n_paths * 4, hipMemcpyDeviceToHost);
         (void)hipFree(d_runs);
         FAST_TRY(e);
+        // (FLATGFA_NO_CLAIM=0: every path claims, monotone or not -- tests and measurements)
+        if (const char *nc = getenv("FLATGFA_NO_CLAIM"); nc && nc[0] == '0') std::fill(mono.begin(), mono.end(), 0u);
     }
     const bool short_any = getenv("FLATGFA_SHORT_ANY") != nullptr;  // tests: let k_scan_short find out and hand back
     const bool no_rev = measure_switch("FLATGFA_NO_REVERSED_COPIES");
@@ -277,7 +299,9 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // contig on the reverse strand) has far fewer runs when it is read backwards, and the order of a
     // path's steps does not matter to the counts: such a path is walked from a reversed copy of its
     // steps, made here once (rev_steps; every copy starts at a multiple of 16).
+    // (the *_mono lists: paths that walk the ids strictly one way -- the wave-per-path kernels skip their claims)
     std::vector<uint4> items, short_items, medium_items, short_rev, medium_rev, whole, rev_list, tiny_items;
+    std::vector<uint4> short_mono, medium_mono, short_rev_mono, medium_rev_mono, tiny_mono;
     const bool no_tiny = getenv("FLATGFA_NO_TINY") != nullptr;  // (measurements, tests: tiny paths go to k_scan_short as before)
     uint64_t rev_len = 0;
     for (uint32_t p = 0; p < g.n_paths; ++p) {
@@ -289,17 +313,18 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         const bool is_tiny = n <= std::min<uint64_t>(short_max, kTinyMax) && !no_tiny;  // (k_scan_tiny: a wave holds the whole path)
         const bool is_short = !is_tiny && n <= short_max && (down || in_reach) && (rn + 16 <= kQCap || short_any);
         const bool is_medium = !is_tiny && !is_short && short_max && (down || in_reach) && rn <= kMediumRuns;
+        const bool mn = short_max && mono[p] != 0u;
         if (is_tiny) {
-            tiny_items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
+            (mn ? tiny_mono : tiny_items).push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
         } else if ((is_short || is_medium) && down) {
             const uint32_t at = (uint32_t)rev_len;
             rev_list.push_back(make_uint4((uint32_t)b, (uint32_t)e, at, p));
-            (is_short ? short_rev : medium_rev).push_back(make_uint4(at, at + (uint32_t)n, kNoSlot, p));
+            (is_short ? (mn ? short_rev_mono : short_rev) : (mn ? medium_rev_mono : medium_rev)).push_back(make_uint4(at, at + (uint32_t)n, kNoSlot, p));
             rev_len += (n + 15) & ~15ull;
         } else if (is_short) {
-            short_items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
+            (mn ? short_mono : short_items).push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
         } else if (is_medium) {
-            medium_items.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
+            (mn ? medium_mono : medium_items).push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
         } else {
             whole.push_back(make_uint4((uint32_t)b, (uint32_t)e, kNoSlot, p));
         }
@@ -419,14 +444,22 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     }
     fp->n_shared = cut(piece ? piece : 32768, &items);
     std::stable_sort(items.begin(), items.end(), longer);
-    std::stable_sort(short_items.begin(), short_items.end(), longer);
-    std::stable_sort(medium_items.begin(), medium_items.end(), longer);
-    std::stable_sort(short_rev.begin(), short_rev.end(), longer);
-    std::stable_sort(medium_rev.begin(), medium_rev.end(), longer);
-    fp->n_short_rev = (uint32_t)short_rev.size();
-    fp->n_medium_rev = (uint32_t)medium_rev.size();
-    short_items.insert(short_items.end(), short_rev.begin(), short_rev.end());      // (the reversed ones behind the others)
-    medium_items.insert(medium_items.end(), medium_rev.begin(), medium_rev.end());
+    // A wave-per-path list: the paths read from the graph's steps, then those read from their reversed copies; of
+    // either kind the ones that need no claim lie next to the boundary, so that one stretch of the list names them
+    // all: [claim][no claim | no claim, reversed][claim, reversed], each part longest first.
+    const auto lay_out = [&](std::vector<uint4> *fwd, std::vector<uint4> *fwd_mono, std::vector<uint4> *rev_mono, std::vector<uint4> *rev,
+                             uint32_t *n_rev, uint32_t *mono_lo, uint32_t *mono_n) {
+        for (std::vector<uint4> *v : {fwd, fwd_mono, rev_mono, rev}) std::stable_sort(v->begin(), v->end(), longer);
+        *mono_lo = (uint32_t)fwd->size();
+        *mono_n = (uint32_t)(fwd_mono->size() + rev_mono->size());
+        *n_rev = (uint32_t)(rev_mono->size() + rev->size());
+        for (std::vector<uint4> *v : {fwd_mono, rev_mono, rev}) fwd->insert(fwd->end(), v->begin(), v->end());
+    };
+    lay_out(&short_items, &short_mono, &short_rev_mono, &short_rev, &fp->n_short_rev, &fp->short_mono_lo, &fp->short_mono_n);
+    lay_out(&medium_items, &medium_mono, &medium_rev_mono, &medium_rev, &fp->n_medium_rev, &fp->medium_mono_lo, &fp->medium_mono_n);
+    fp->tiny_mono_lo = (uint32_t)tiny_items.size();
+    fp->tiny_mono_n = (uint32_t)tiny_mono.size();
+    tiny_items.insert(tiny_items.end(), tiny_mono.begin(), tiny_mono.end());
     fp->n_items = (uint32_t)items.size();
     fp->n_short = (uint32_t)short_items.size();
     fp->n_medium = (uint32_t)medium_items.size();
@@ -1124,6 +1157,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     sa.path_begin = sa.path_end = nullptr;
     sa.rev_steps = nullptr;
     sa.n_fwd = ~0u;
+    sa.mono_lo = sa.mono_n = 0u;
     sa.steps = g.steps;
     sa.n_steps = g.n_steps;
     sa.items = reinterpret_cast<uint4 *>(fp.items);
@@ -1184,6 +1218,8 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
         ScanArgs sk = sa;
         sk.short_items = reinterpret_cast<const uint4 *>(fp.tiny_items);
         sk.n_short = fp.n_tiny;
+        sk.mono_lo = fp.tiny_mono_lo;
+        sk.mono_n = fp.tiny_mono_n;
         const uint32_t kgrid = std::min<uint32_t>((fp.n_tiny + kWaves - 1) / kWaves, fp.n_slots);
         ProfScope pscope(uniq_out ? "k_scan_tiny<uniq>" : "k_scan_tiny<depth>", stream);
         launch_scan_tiny(fp, sk, uniq_out != nullptr, kgrid, stream);
@@ -1198,6 +1234,8 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
             sk.short_items = list;
             sk.n_short = n;
             sk.n_fwd = n_all - n_rev;  // (the reversed ones lie behind the others in the list)
+            sk.mono_lo = medium ? fp.medium_mono_lo : fp.short_mono_lo;
+            sk.mono_n = medium ? fp.medium_mono_n : fp.short_mono_n;
             sk.rev_steps = fp.rev_steps;
             sk.path_begin = g.path_begin;
             sk.path_end = g.path_end;

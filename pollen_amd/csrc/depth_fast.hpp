@@ -70,6 +70,9 @@ struct FastPlan {
                                    // steps, then n_short_rev paths that walk the ids downwards, read from rev_steps (their
                                    // steps in reverse order: a wave-per-path kernel only knows runs that go up)
     uint32_t n_short = 0, n_short_rev = 0;
+    // the paths of a wave-per-path list that walk the segment ids strictly one way -- no segment twice, so no claim --
+    // lie at [mono_lo, mono_lo + mono_n) of their list, on both sides of the boundary to the reversed ones
+    uint32_t short_mono_lo = 0, short_mono_n = 0, medium_mono_lo = 0, medium_mono_n = 0, tiny_mono_lo = 0, tiny_mono_n = 0;
     uint32_t *rev_steps = nullptr; // the reversed copies, every path at a multiple of 16
     uint32_t n_rev_steps = 0;
     uint32_t lds_bytes_short = 0;

@@ -99,6 +99,7 @@ struct ScanArgs {
     const uint32_t *path_begin, *path_end;  // the graph's spans: a handed-back path that was read from its reversed copy is walked by k_scan from the graph's own steps
     const uint32_t *rev_steps;  // the wave-per-path kernels: the reversed copies, which the paths from n_fwd on in the list are read from (one launch for both)
     uint32_t n_fwd;
+    uint32_t mono_lo, mono_n;   // the wave-per-path kernels: the paths [mono_lo, mono_lo + mono_n) of the list never meet a segment twice (the plan looked): no claims
     uint32_t seg_base, n_total, ranged;  // ranged: this walk keeps what falls into [seg_base, seg_base + n_segs) of the graph's n_total segments
     uint32_t *zero_a, *zero_b;  // k_scan clears these vectors of n_segs counts first (pass 2 adds to them when windows are shared); or null
     unsigned long long *zero_c, *zero_d;  // ... and these two of n_zero64 sums (the paths' sums k_path_reduce adds to); or null

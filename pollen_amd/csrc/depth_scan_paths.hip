@@ -90,14 +90,15 @@ __device__ __forceinline__ uint32_t claim_hashed(const ScanArgs &A, uint32_t *ta
 // into uniq records 32..64 entries at a time, so its bit-stretch loop runs with most lanes busy.
 template <bool UNIQ, int HASH>
 __device__ __forceinline__ void emit_chunk(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
-                                           bool valid, uint32_t ent, uint32_t next) {
+                                           bool valid, uint32_t ent, uint32_t next, bool mono) {
     // a run lasts until the next entry's position (positions start over with every block: modulo 1024)
     const uint32_t id = ent >> kPosBits, lenm1 = (next - ent - 1u) & ((1u << kPosBits) - 1u), win = id >> kShortWinBits;
     valid = valid && id < kDummyBase;  // runs of placeholder ids and the entries that only close a run are dropped here
     uint32_t kind = 0, pos;
     if (UNIQ) {
         const uint32_t mask = valid ? (0xFFFFFFFFu >> (31u - lenm1)) << (id & 31u) : 0u;
-        const uint32_t old = (FGFA_SHORT_ABLATE & 4) ? 0u : claim_hashed<HASH>(A, seen, w.dummy, w.lane, valid, id >> 5, mask);
+        // (mono, uniform: the path never meets a segment twice -- every run is all first visits, and the set stays empty)
+        const uint32_t old = ((FGFA_SHORT_ABLATE & 4) || mono) ? 0u : claim_hashed<HASH>(A, seen, w.dummy, w.lane, valid, id >> 5, mask);
         pos = take_slots(bcur, w.lane, valid, win);
         const uint32_t nb = mask & ~old;
         kind = (nb == mask) ? 2u : 0u;
@@ -137,14 +138,14 @@ __device__ __forceinline__ void drain_partial(const ScanArgs &A, Wave &w, uint32
 // where its run ends), then move what is left to the front of the queue.  With `all` the newest entry closes a
 // block, and everything is emitted.
 template <bool UNIQ, int HASH>
-__device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine, bool all) {
+__device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine, bool all, bool mono) {
     uint32_t base = 0;
     while (w.fill - base >= 65u || (all && w.fill - base >= 2u)) {
         const uint32_t n = min(64u, w.fill - 1u - base);
         const bool valid = (uint32_t)w.lane < n;
         const uint32_t at = base + (valid ? (uint32_t)w.lane : 0u);
         const uint32_t ent = w.q[at], next = w.q[at + 1u];
-        emit_chunk<UNIQ, HASH>(A, w, seen, bcur, mine, valid, ent, next);
+        emit_chunk<UNIQ, HASH>(A, w, seen, bcur, mine, valid, ent, next, mono);
         base += n;
         if (UNIQ) drain_partial(A, w, bcur, mine, false);
     }
@@ -231,7 +232,7 @@ __device__ __forceinline__ void drain(const ScanArgs &A, Wave &w, uint32_t *seen
 // emitted; the return value says whether they fitted the queue.
 template <bool UNIQ, int HASH, bool QONLY>
 __device__ __forceinline__ bool block16(const ScanArgs &A, Wave &w, uint32_t *seen, uint32_t *bcur, uint32_t *mine,
-                                        uint32_t (&a)[16], uint32_t nl, uint32_t rel_lo, uint32_t rel_hi, uint32_t blk_pos) {
+                                        uint32_t (&a)[16], uint32_t nl, uint32_t rel_lo, uint32_t rel_hi, uint32_t blk_pos, bool mono) {
     const bool active = (uint32_t)w.lane < nl;
     const bool last_lane = (uint32_t)w.lane + 1u == nl;
     const bool partial = rel_lo > 0u || rel_hi < 16u * nl;
@@ -278,14 +279,14 @@ __device__ __forceinline__ bool block16(const ScanArgs &A, Wave &w, uint32_t *se
         if (last_lane) *reinterpret_cast<lds_u32 *>((uintptr_t)p) = term;
         w.fill += total;
         if (QONLY) return true;
-        drain<UNIQ, HASH>(A, w, seen, bcur, mine, false);
+        drain<UNIQ, HASH>(A, w, seen, bcur, mine, false, mono);
     } else {
         if (QONLY) return false;
         // Entries must lie in the order of their positions, so the block is queued sixteen lanes at a time (at most 256
         // starts and the closing entry), the queue emitted down to at most 64 entries before each.
 #pragma unroll 1
         for (uint32_t grp = 0; grp < 4u; ++grp) {
-            drain<UNIQ, HASH>(A, w, seen, bcur, mine, false);
+            drain<UNIQ, HASH>(A, w, seen, bcur, mine, false, mono);
             const bool in_g = active && ((uint32_t)w.lane >> 4) == grp;
             const uint32_t sl = in_g ? slots : 0u;
             const uint32_t inc = wave_scan_incl(sl);
@@ -297,7 +298,7 @@ __device__ __forceinline__ bool block16(const ScanArgs &A, Wave &w, uint32_t *se
             }
             w.fill += __builtin_amdgcn_readlane(inc, 63);
         }
-        drain<UNIQ, HASH>(A, w, seen, bcur, mine, false);
+        drain<UNIQ, HASH>(A, w, seen, bcur, mine, false, mono);
     }
     return true;
 }
@@ -380,7 +381,9 @@ __device__ __forceinline__ void pair_meet(uint32_t *ctr, int lane, uint32_t &tar
     asm volatile("" ::: "memory");
 }
 
-template <bool UNIQ, int WAVES, int HASH, bool QONLY, bool PAIRED = false>
+// MONO: the list has paths that need no claims (ScanArgs::mono_lo / mono_n) -- a build of its own: the test costs the
+// lists without any 1-3 %.
+template <bool UNIQ, int WAVES, int HASH, bool QONLY, bool PAIRED = false, bool MONO = false>
 __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
     static_assert(!PAIRED || (!QONLY && WAVES % 2 == 0), "pairs walk medium paths");
     constexpr uint32_t kTab = 1u << HASH;
@@ -461,6 +464,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
 #define FGFA_SBLOCK(SET)                                                                                \
     if (slot[SET].valid) {                                                                              \
         const ShortBlk cur = slot[SET];                                                                 \
+        const bool mono = MONO && UNIQ && cur.item - A.mono_lo < A.mono_n;  /* (uniform) this path needs no claims */ \
         uint32_t a[16];                                                                                 \
         SP(0);                                                                                          \
         if (!cur.skip) {                                                                                \
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
         } else if (!handed_back) {                                                                      \
             const uint32_t lo = cur.b > cur.pos ? cur.b - cur.pos : 0u;                                 \
             const uint32_t hi = cur.e - cur.pos < 1024u ? cur.e - cur.pos : 1024u;                      \
-            if (!block16<UNIQ, HASH, QONLY>(A, w, tab, bcur, mine, a, cur.nl, lo, hi, cur.pos)) {       \
+            if (!block16<UNIQ, HASH, QONLY>(A, w, tab, bcur, mine, a, cur.nl, lo, hi, cur.pos, mono)) { \
                 handed_back = true;                                                                     \
                 w.fill = 0;                                                                             \
             }                                                                                           \
@@ -496,8 +500,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
                 handed_back = false;                                                                    \
             } else {                                                                                    \
                 if (FGFA_SHORT_ABLATE & 2) w.fill = 0;                                                  \
-                drain<UNIQ, HASH>(A, w, tab, bcur, mine, true);                                         \
-                if (UNIQ && !(FGFA_SHORT_ABLATE & 16)) {                                                \
+                drain<UNIQ, HASH>(A, w, tab, bcur, mine, true, mono);                                   \
+                if (UNIQ && !mono && !(FGFA_SHORT_ABLATE & 16)) {  /* (both waves of a pair see the same path) */ \
                     pair_meet<PAIRED>(meet, lane, met);  /* both are through with the path's claims */  \
                     wipe();                                                                             \
                     pair_meet<PAIRED>(meet, lane, met);  /* ... and the set is empty for the next */    \
@@ -521,10 +525,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_scan_short(const ScanArgs A) {
         A.counts[(size_t)wdw * A.n_slots + blockIdx.x] = bcur[wdw];
 }
 
-template <bool UNIQ>
-constexpr auto k_walk_short = k_scan_short<UNIQ, kShortWaves, kShortHash, true>;
-template <bool UNIQ>
-constexpr auto k_walk_medium = k_scan_short<UNIQ, kMediumWaves, kMediumHash, false, kMediumPaired>;
+template <bool UNIQ, bool MONO = false>
+constexpr auto k_walk_short = k_scan_short<UNIQ, kShortWaves, kShortHash, true, false, MONO>;
+template <bool UNIQ, bool MONO = false>
+constexpr auto k_walk_medium = k_scan_short<UNIQ, kMediumWaves, kMediumHash, false, kMediumPaired, MONO>;
 
 // ------------------------------------------------------------ pass 1, tiny paths ---
 //
@@ -568,7 +572,7 @@ __device__ __forceinline__ void tiny_take(uint32_t n_since, uint32_t &a0, uint32
 #undef FGFA_TTAKE
 }
 
-template <bool UNIQ>
+template <bool UNIQ, bool MONO = false>
 __global__ __launch_bounds__(kThreads) void k_scan_tiny(const ScanArgs A) {
     extern __shared__ uint32_t lds[];
     // layout: [bcur: kShortMaxWin][id sets: kWaves * kTinyTab][record queues: kWaves * kTinyQueue entries of 8 bytes][dummy: 128]
@@ -595,11 +599,14 @@ __global__ __launch_bounds__(kThreads) void k_scan_tiny(const ScanArgs A) {
     uint32_t gi = blockIdx.x * kWaves + (uint32_t)wave;  // the path whose steps are requested next
     uint32_t bx = 0, by = 0, bk = 64u;                   // (per lane) the batch; how many of it are handed out
     uint32_t pb[3] = {0u, 0u, 0u}, pn[3] = {0u, 0u, 0u};  // the paths in flight: first step, number of steps (0: none)
+    uint32_t pm[3] = {0u, 0u, 0u};                        // ... and whether the plan found them to walk the ids strictly one way (no first-visit test)
     uint32_t since[3] = {0u, 0u, 0u};                     // memory operations issued behind each slot's loads
-    const auto next_path = [&](uint32_t &b, uint32_t &n) {
+    const auto next_path = [&](uint32_t &b, uint32_t &n, uint32_t &m) {
         n = 0u;
         b = 0u;
+        m = 0u;
         if (gi >= A.n_short) return;
+        m = MONO && gi - A.mono_lo < A.mono_n ? 1u : 0u;
         if (bk >= 64u) {
             const uint64_t idx = (uint64_t)gi + (uint64_t)lane * stride;
             uint2 d = make_uint2(0u, 0u);
@@ -615,7 +622,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_tiny(const ScanArgs A) {
     };
 #define FGFA_TINY_REQ(D)                                                                            \
     do {                                                                                            \
-        next_path(pb[D], pn[D]);                                                                    \
+        next_path(pb[D], pn[D], pm[D]);                                                             \
         if (pn[D]) {                                                                                \
             /* lanes beyond the path re-read its first step */                                      \
             const uint32_t o0 = (uint32_t)lane < pn[D] ? 4u * (uint32_t)lane : 0u;                  \
@@ -634,6 +641,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_tiny(const ScanArgs A) {
         uint32_t a0, a1;                                                                                               \
         tiny_take<D>(since[D], a0, a1);                                                                                \
         const uint32_t n = pn[D];                                                                                      \
+        const bool mono_##D = pm[D] != 0u;                                                                             \
         FGFA_TINY_REQ(D);                                                                                              \
         const bool v0 = (uint32_t)lane < n, v1 = 64u + (uint32_t)lane < n;                                             \
         uint32_t x0 = a0 >> 1, x1 = a1 >> 1;                                                                           \
@@ -641,7 +649,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_tiny(const ScanArgs A) {
         x0 = x0 < A.n_segs ? x0 : 0u;                                                                                  \
         x1 = x1 < A.n_segs ? x1 : 0u;                                                                                  \
         bool f0 = true, f1 = true;  /* first visits */                                                                 \
-        if (UNIQ && !(FGFA_TINY_ABLATE & 1)) {                                                                         \
+        if (UNIQ && !(FGFA_TINY_ABLATE & 1) && !mono_##D) {  /* (a path that walks the ids strictly one way: all first visits) */ \
             uint32_t h0 = (x0 * 0x9E3779B1u) >> (32 - kTinyBits), h1 = (x1 * 0x9E3779B1u) >> (32 - kTinyBits);                                     \
             /* the first probe -- nearly always the last -- by all lanes, nothing predicated (a lane without a step */   \
             /* probes a word of its own in `dummy`): as `if (t0) CAS` the loop was mostly scalar exec-mask traffic  */   \
@@ -727,7 +735,7 @@ bool path_kernels_setup() {
     static const bool ok = [] {
         bool good = true;
         for (const void *k : {(const void *)k_walk_short<true>, (const void *)k_walk_short<false>, (const void *)k_walk_medium<true>,
-                              (const void *)k_walk_medium<false>})
+                              (const void *)k_walk_medium<false>, (const void *)k_walk_short<true, true>, (const void *)k_walk_medium<true, true>})
             good = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) == hipSuccess && good;
         return good;
     }();
@@ -738,7 +746,8 @@ bool path_kernels_setup() {
 // (dynamic LDS: the cursor table, per wave its run queue, parked claims and hash set -- a medium pair shares one set --, the dummies)
 void launch_scan_tiny(const FastPlan &fp, const ScanArgs &sk, bool uniq, uint32_t grid, hipStream_t stream) {
     const uint32_t lds = (kShortMaxWin + kWaves * kTinyTab + kWaves * kTinyQueue * 2u + 128u) * 4u;
-    if (uniq) hipLaunchKernelGGL(k_scan_tiny<true>, dim3(grid), dim3(kThreads), lds, stream, sk);
+    if (uniq && sk.mono_n) hipLaunchKernelGGL((k_scan_tiny<true, true>), dim3(grid), dim3(kThreads), lds, stream, sk);
+    else if (uniq) hipLaunchKernelGGL(k_scan_tiny<true>, dim3(grid), dim3(kThreads), lds, stream, sk);
     else hipLaunchKernelGGL(k_scan_tiny<false>, dim3(grid), dim3(kThreads), lds, stream, sk);
 }
 
@@ -747,10 +756,12 @@ void launch_scan_short(const FastPlan &fp, const ScanArgs &sk, bool medium, bool
     const uint32_t lds_medium = kMediumPaired ? (kShortMaxWin + kMediumWaves * (kQPaired + 2 * kPCap) + (kMediumWaves / 2) * (2u << kMediumHash) + 128u + 16u) * 4u
                                               : (kShortMaxWin + kMediumWaves * (kQCap + 2 * kPCap + (2u << kMediumHash)) + 128u + 16u) * 4u;
     if (medium) {
-        if (uniq) hipLaunchKernelGGL(k_walk_medium<true>, dim3(grid), dim3(kMediumWaves * 64), lds_medium, stream, sk);
+        if (uniq && sk.mono_n) hipLaunchKernelGGL((k_walk_medium<true, true>), dim3(grid), dim3(kMediumWaves * 64), lds_medium, stream, sk);
+        else if (uniq) hipLaunchKernelGGL(k_walk_medium<true>, dim3(grid), dim3(kMediumWaves * 64), lds_medium, stream, sk);
         else hipLaunchKernelGGL(k_walk_medium<false>, dim3(grid), dim3(kMediumWaves * 64), lds_medium, stream, sk);
     } else {
-        if (uniq) hipLaunchKernelGGL(k_walk_short<true>, dim3(grid), dim3(kShortWaves * 64), lds_short, stream, sk);
+        if (uniq && sk.mono_n) hipLaunchKernelGGL((k_walk_short<true, true>), dim3(grid), dim3(kShortWaves * 64), lds_short, stream, sk);
+        else if (uniq) hipLaunchKernelGGL(k_walk_short<true>, dim3(grid), dim3(kShortWaves * 64), lds_short, stream, sk);
         else hipLaunchKernelGGL(k_walk_short<false>, dim3(grid), dim3(kShortWaves * 64), lds_short, stream, sk);
     }
 }

@@ -1066,6 +1066,79 @@ def test_strictly_monotone_paths_skip_the_claim(n_segs, pieces, monkeypatch):
     assert (want_d2 == want_u2).all()
 
 
+def _walks_graph(S, walks, seed=0):
+    rng = np.random.default_rng(seed)
+    lens = np.array([len(x) for x in walks], dtype=np.uint32)
+    steps = (np.concatenate(walks).astype(np.uint32) << 1) | rng.integers(0, 2, size=int(lens.sum())).astype(np.uint32)
+    pe = np.cumsum(lens).astype(np.uint32)
+    pb = (pe - lens).astype(np.uint32)
+    paths = np.zeros(len(lens), dtype=fo.PATH_DT)
+    paths["steps_start"], paths["steps_end"] = pb, pe
+    pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
+    pools.paths, pools.steps, pools.segs = paths, steps, np.zeros(S, dtype=fo.SEG_DT)
+    return steps, pb, pe, pools
+
+
+@pytest.mark.parametrize("no_claim", ["", "0"])
+def test_strictly_monotone_short_paths_skip_the_claim(no_claim, monkeypatch):
+    """The same for the paths single waves walk (k_scan_tiny, k_scan_short, its medium build): the plan lists the
+    paths that walk the ids strictly one way in a stretch of their own, and the kernels neither probe nor wipe the
+    per-path set for them.  Tiny, short and medium paths, upwards and downwards (the latter read from reversed
+    copies), next to paths of the same lengths that do meet a segment twice -- a stretch walked again, one id
+    repeated in place -- whose first visits must still be found; FLATGFA_NO_CLAIM=0 lists none and counts the same."""
+    import re
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    for v in ("FLATGFA_SHORT_MAX", "FLATGFA_NO_TINY", "FLATGFA_SHORT_ANY"):
+        monkeypatch.delenv(v, raising=False)
+    if no_claim:
+        monkeypatch.setenv("FLATGFA_NO_CLAIM", no_claim)
+    else:
+        monkeypatch.delenv("FLATGFA_NO_CLAIM", raising=False)
+    S = 600_000
+    rng = np.random.default_rng(5)
+    shapes = [("up", 100, 0.6), ("down", 128, 0.6), ("up2", 60, 1.0), ("loop", 90, 0.6), ("flat", 70, 0.6), ("up", 1, 1.0), ("up", 2, 0.5),
+              ("up", 1500, 0.6), ("down", 2000, 0.7), ("loop", 1200, 0.6), ("flat", 900, 0.6), ("up2", 700, 1.0), ("down", 129, 0.9),
+              ("up", 8000, 0.93), ("down", 9000, 0.95), ("loop", 7000, 0.93), ("flat", 6000, 0.95), ("up", 2049, 0.9)]
+    walks, n_mono = [], 0
+    for rep in range(24):
+        for kind, n, dens in shapes:
+            lo = int(rng.integers(0, S - 3 * n - 64))
+            ids = lo + (np.nonzero(rng.random(int(1.2 * n / dens) + 64) < dens)[0][:n] if kind != "up2" else 2 * np.arange(n))
+            assert len(ids) == n
+            if kind == "down":
+                ids = ids[::-1]
+            elif kind == "loop":
+                ids = np.concatenate([ids, ids[n // 3: n // 3 + 20]])
+            elif kind == "flat":
+                ids = np.concatenate([ids[: n // 2], ids[n // 2 - 1:]])
+            n_mono += kind in ("up", "down", "up2")
+            walks.append(ids)
+    steps, pb, pe, pools = _walks_graph(S, walks, seed=11)
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    plan = DepthPlan(DeviceGraph(steps, pb, pe, S))
+    desc = plan.describe()
+    assert "k_scan_tiny" in desc and "k_scan_short" in desc and "k_scan_medium" in desc, desc
+    got = int(re.search(r"no_claim_paths=(\d+)", desc).group(1))
+    if no_claim:
+        assert got == 0, desc
+    elif re.search(r" items=0 ", desc):  # (every path went to a wave-per-path kernel: exactly the ones that qualify)
+        assert got == n_mono, desc
+    else:
+        assert 0 < got <= n_mono, desc
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    for _ in range(2):
+        plan.seg_depth(d, u)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == want_d).all()
+        assert (u.cpu().numpy().view(np.uint32) == want_u).all()
+    plan.seg_depth(d, None)
+    plan.status()
+    assert (d.cpu().numpy().view(np.uint32) == want_d).all()
+
+
 def test_wrong_answer_switches_are_not_in_the_product_library(monkeypatch):
     """FLATGFA_DEBUG_SKIP / FLATGFA_ACC_SKIP leave parts of the kernels' work out (measurements; results are then wrong
     by construction): they exist in measurement builds only (-DFGFA_MEASURE, tools/variants.sh).  The product
