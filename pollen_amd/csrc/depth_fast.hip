@@ -1009,6 +1009,31 @@ static bool fast_plan_create_impl(const flatgfa_dev_graph_t &g, const uint32_t *
                 continue;
             }
             if (all && !(many && groups_ok)) {
+                // 4096-segment windows on a graph that would get 8192-segment ones, where pass 2 has use for the LDS they
+                // free: a pass-1 workgroup that takes dozens of claiming items leaves every sub-bucket with dozens of
+                // tags, and pass 2 hands its four private bitsets on all the time -- with the smaller windows it has
+                // eight (16 000 paths of 100 k steps on 16 M segments: pass 2 2.14 -> 1.81 ms, pass 1 pays 0.1 for twice
+                // the windows; with eight items per workgroup, or items that claim nothing, it is a loss: NOTES R5.12).
+                const auto wants_small_windows = [&](const FastPlan &q) {
+                    return q.eligible && q.tagged && q.wb == 13 && !q.n_more && g.n_segs <= (uint64_t)kMaxWinTagged << 12 && !getenv("FLATGFA_WB") &&
+                           !getenv("FLATGFA_RANGE_SEGS") && q.n_items >= 16ull * q.n_slots && 2ull * q.n_noclaim < q.n_items && q.n_shared <= 64 &&
+                           q.est_records / q.n_win >= 32768;
+                };
+                if (!force_wb && plans.size() == 1 && wants_small_windows(plans[0])) {
+                    std::vector<FastPlan> alt;
+                    bool a_all = true, a_many = false;
+                    if (!append_ranges(g, hb, he, kMaxWinTagged, 12u, &alt, &a_all, &a_many)) {
+                        destroy_plans(&alt);
+                        destroy_plans(&plans);
+                        return false;
+                    }
+                    if (a_all && !a_many && alt.size() == 1 && alt[0].eligible && alt[0].tagged && alt[0].acc_slots == 8) {
+                        destroy_plans(&plans);
+                        plans.swap(alt);
+                    } else {
+                        destroy_plans(&alt);
+                    }
+                }
                 adopt_plans(&plans, fp);
                 return true;
             }

@@ -1139,6 +1139,31 @@ def test_strictly_monotone_short_paths_skip_the_claim(no_claim, monkeypatch):
     assert (d.cpu().numpy().view(np.uint32) == want_d).all()
 
 
+def test_small_windows_where_workgroups_take_dozens_of_items(monkeypatch):
+    """A graph beyond 4 M segments gets 8192-segment windows -- unless a pass-1 workgroup takes so many claiming items
+    that pass 2 is better off with eight private bitsets per wave, which only 4096-segment windows leave LDS for
+    (fast_plan_create; NOTES R5.12).  The plan's description says which it took; the counts are the oracle's either way."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.setenv("FLATGFA_SCAN_WGS", "64")
+    for v in ("FLATGFA_WB", "FLATGFA_RANGE_SEGS", "FLATGFA_ACC_SLOTS"):
+        monkeypatch.delenv(v, raising=False)
+    S = 4_200_000
+    for P, L, want in [(1500, 40_000, "x4096"), (640, 80_000, "x8192")]:
+        g = pa.synth(9, S, P, L, "chromosome", False)
+        steps, pb, pe, _ = g.soa()
+        wd, wu = fo.seg_depth_with_uniq(pools_of(g))
+        plan = DepthPlan(DeviceGraph(steps, pb, pe, S))
+        desc = plan.describe()
+        assert "pass2=tagged" in desc and want in desc, desc
+        d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        plan.seg_depth(d, u)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == wd).all() and (u.cpu().numpy().view(np.uint32) == wu).all(), desc
+
+
 def test_wrong_answer_switches_are_not_in_the_product_library(monkeypatch):
     """FLATGFA_DEBUG_SKIP / FLATGFA_ACC_SKIP leave parts of the kernels' work out (measurements; results are then wrong
     by construction): they exist in measurement builds only (-DFGFA_MEASURE, tools/variants.sh).  The product
