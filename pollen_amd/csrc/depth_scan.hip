@@ -7,6 +7,10 @@
 
 #include "depth_fast_kernels.hpp"
 
+#ifndef FGFA_TPROF_ALL
+#define FGFA_TPROF_ALL 0  /* measurement builds: FLATGFA_SCAN_TIME's timeline from every build of k_scan, not the plain one alone */
+#endif
+
 namespace fgfa_dev {
 namespace {
 
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the span math on the scalar unit
     uint32_t *mine = PACKED ? A.buckets + A.pk_base[blockIdx.x] : A.buckets + (size_t)blockIdx.x * A.cap;  // this workgroup's sub-bucket of window 0 (packed: its region)
-    if (TAGGED && MODE == kModePlain && A.tprof && threadIdx.x == 0) {
+    if (TAGGED && (MODE == kModePlain || FGFA_TPROF_ALL) && A.tprof && threadIdx.x == 0) {
         A.tprof[kTprofRow * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
         // where it runs: HW_ID (wave, SIMD, CU, shader array and engine) and XCC_ID
         A.tprof[kTprofRow * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
 #undef FGFA_LOAD_BLOCK
 #undef FGFA_ITEM_TAG
     // publish how many records this workgroup left in each window's sub-bucket
-    if (TAGGED && MODE == kModePlain && A.tprof && lane == 0) A.tprof[kTprofRow * blockIdx.x + 4 + wave] = __builtin_amdgcn_s_memrealtime();
+    if (TAGGED && (MODE == kModePlain || FGFA_TPROF_ALL) && A.tprof && lane == 0) A.tprof[kTprofRow * blockIdx.x + 4 + wave] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads)
         A.counts[(size_t)wdw * A.n_slots + blockIdx.x] = bcur[wdw];
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             A.work_counter[2] = 0u;
         }
     }
-    if (TAGGED && MODE == kModePlain && A.tprof && threadIdx.x == 0) {
+    if (TAGGED && (MODE == kModePlain || FGFA_TPROF_ALL) && A.tprof && threadIdx.x == 0) {
         A.tprof[kTprofRow * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         A.tprof[kTprofRow * blockIdx.x + 3] = rr;  // the items it took
     }
