@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/profiles; mkdir -p $OUT; cd $R
 #  its per-kernel samples, like these traces, are taken one call after the other)
 CMD="bench.py --steps 40 --warmup 3 --in-flight 1"
 # 1. the bench line itself (all workloads; cfgL is the headline)
-for w in cfgL cfgL-uniform cfgL-chrom cfgL-short cfgL-fewlong cfgL-4paths cfgL-medium cfgL-32k chrom-10k chrom-1k tiny-paths cfgL-100kseg cfgL-4Mseg cfgL-16Mseg cfgL-64Mseg cfgM cfgS; do
+for w in cfgL cfgL-uniform cfgL-chrom cfgL-short cfgL-fewlong cfgL-4paths cfgL-medium cfgL-32k chrom-10k chrom-1k tiny-paths hap-1k hap-10k hap-100 cfgL-100kseg cfgL-4Mseg cfgL-16Mseg cfgL-64Mseg cfgM cfgS; do
   timeout 600 python3 bench.py --steps 40 --warmup 3 --workload $w 2>$OUT/_bench_$w.err | tail -1 > $OUT/${TAG}_bench_$w.json
   # (a workload whose secondary measurements do not apply -- a million tiny paths -- still gets its line)
   [ -s $OUT/${TAG}_bench_$w.json ] || timeout 600 python3 bench.py --steps 40 --warmup 3 --workload $w --no-extras 2>>$OUT/_bench_$w.err | tail -1 > $OUT/${TAG}_bench_$w.json
