@@ -125,6 +125,9 @@ def main():
                          "step is still a whole query into its own result buffer.  1 = strictly one call after the other")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-cold", action="store_true",
+                    help="skip roofline.frac_cold's second plan (FLATGFA_MALL_MB=0) and its calls: a kernel trace of the run then holds "
+                         "the warm plan's launches alone (tools/profile_round.sh)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements (depth-only, path depth, rotation, end-to-end, copy bandwidth)")
     args = ap.parse_args()
@@ -421,7 +424,7 @@ def main():
         # graph through a plan made with FLATGFA_MALL_MB=0, sampled the same way, is what a call costs when nothing of
         # its steps is left in that cache (more graphs queried in turn than it holds: extras.rotate).
         m_res = re.search(r"cache_resident_mb=(\d+)", plan.describe())
-        if world == 1 and dom.startswith("k_scan") and m_res and int(m_res.group(1)) > 0:
+        if world == 1 and dom.startswith("k_scan") and m_res and int(m_res.group(1)) > 0 and not args.no_cold:
             os.environ["FLATGFA_MALL_MB"] = "0"
             try:
                 plan0 = dev.DepthPlan(graph)

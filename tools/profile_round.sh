@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/profiles; mkdir -p $OUT; cd $R
 # (the kernels' own durations: one call in flight -- bench.py's timed region keeps two, whose kernels share the chip;
 #  its per-kernel samples, like these traces, are taken one call after the other)
-CMD="bench.py --steps 40 --warmup 3 --in-flight 1"
+CMD="bench.py --steps 40 --warmup 3 --in-flight 1 --no-cold"  # (--no-cold: roofline.frac_cold's plan has a trace of its own, 2c)
 # 1. the bench line itself (all workloads; cfgL is the headline)
 for w in cfgL cfgL-uniform cfgL-chrom cfgL-short cfgL-fewlong cfgL-4paths cfgL-medium cfgL-32k chrom-10k chrom-1k tiny-paths hap-1k hap-10k hap-100 cfgL-100kseg cfgL-4Mseg cfgL-16Mseg cfgL-64Mseg cfgM cfgS; do
   timeout 600 python3 bench.py --steps 40 --warmup 3 --workload $w 2>$OUT/_bench_$w.err | tail -1 > $OUT/${TAG}_bench_$w.json
@@ -22,7 +22,7 @@ done
 rm -rf $OUT/_trace; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_trace -o t -- python3 $CMD --no-cpu-baseline --no-extras > $OUT/_trace.log 2>&1
 f=$(find $OUT/_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_rocprofv3_kernel_stats.csv
 # 2b. ... with calls in flight (the default: three lanes of the pipeline), as the timed region runs (the kernels of consecutive calls overlap: their durations are longer, the calls shorter)
-rm -rf $OUT/_trace; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_trace -o t -- python3 bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-extras > $OUT/_trace2.log 2>&1
+rm -rf $OUT/_trace; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_trace -o t -- python3 bench.py --steps 40 --warmup 3 --no-cold --no-cpu-baseline --no-extras > $OUT/_trace2.log 2>&1
 f=$(find $OUT/_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_rocprofv3_kernel_stats_in_flight.csv
 # 2c. ... with no step kept in the Infinity Cache (FLATGFA_MALL_MB=0: what roofline.frac_cold is measured on)
 rm -rf $OUT/_trace; FLATGFA_MALL_MB=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/_trace -o t -- python3 $CMD --no-cpu-baseline --no-extras > $OUT/_trace3.log 2>&1
