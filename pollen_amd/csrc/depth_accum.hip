@@ -699,7 +699,10 @@ __device__ __forceinline__ void claim_point(uint32_t rec, uint32_t sb, unsigned 
 #ifndef FGFA_TAG_ABLATE
 #define FGFA_TAG_ABLATE 0  /* measurements only (results are then wrong): 1 = no claims, 2 = no bitset hand-overs, 4 = claims stop behind the depth updates, 8 = behind the first word's OR, 16 = no further words */
 #endif
-template <int WB, bool POINT, bool SHARED, bool LOW = false, int SLOTS = (int)kTagSlots, bool NC = false>  // (NC: the plan has items whose records need no claim, kTagNoClaim -- a build of its own: the test costs cfg-L 4 %)
+// OWN: the wave keeps track of which tag owns each of its bitsets (see FGFA_TAG_MISS_OWN below) instead of taking them for the tags of
+// (hmax - kSlots, hmax]: for sub-buckets whose tags lie far apart -- a workgroup of pass 1 that took hundreds of items few of which
+// visit any one window -- where a step of 64 records holds three tags twenty apart and the other build claims them one after the other.
+template <int WB, bool POINT, bool SHARED, bool LOW = false, int SLOTS = (int)kTagSlots, bool NC = false, bool OWN = false>  // (NC: the plan has items whose records need no claim, kTagNoClaim -- a build of its own: the test costs cfg-L 4 %)
 __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, uint32_t *bits, const uint2 *scnt2, const uint32_t *wbase,
                                              uint32_t *grab) {
     constexpr uint32_t kW = 1u << WB, kNW = kW / 32u;
@@ -767,6 +770,11 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
         left -= NV;                                              \
     } while (0)
     int hmax = -1;  // (uniform) the highest private tag met in the open sub-bucket (the wave's first one is walked the general way: nothing says it is new)
+    // OWN: (lane s < kSlots) the tag whose bits slot s holds, or kFree; `hmax` is then the highest tag that owns a slot, and
+    // `dense` says that slot s is owned by the tag of (hmax - kSlots, hmax] congruent to s, for every s (or that no slot is owned at all)
+    constexpr uint32_t kFree = ~0u;
+    uint32_t ownv = kFree;
+    bool dense = true;
     const auto clear_slots = [&](int from, int to) {  // the bitsets of the tags from .. to change hands
         for (int t = from; t <= to; ++t) {
             uint32_t *bs = bits + (wv * kSlots + ((uint32_t)t & (kSlots - 1u))) * kNW;
@@ -793,6 +801,68 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
     if (kDepth > 5) FGFA_TAG_GEN((kDepth > 5 ? 5 : 0), nv5, f5);
     if (kDepth > 6) FGFA_TAG_GEN((kDepth > 6 ? 6 : 0), nv6, f6);
     if (kDepth > 7) FGFA_TAG_GEN((kDepth > 7 ? 7 : 0), nv7, f7);
+    // OWN: the records of a step whose tag does not own its bitset (slot = tag mod kSlots, as ever) are taken a BURST at a time -- the
+    // lowest such tag T and every other one within kSlots of it, up to T2: the slots of T .. T2 change hands (cleared; tags
+    // of that stretch without a record get theirs too, as in the other build), and all of the step's records claim at once.  k_scan's
+    // gate (a tag's records all lie before those of a tag kTagSlots beyond it) says the bitsets' previous owners are finished -- unless
+    // their last records are in this very step, unclaimed: those claim first.  Tags twenty apart share a slot one
+    // time in kSlots, where the other build takes every such step in as many claims as it has tags.
+#define FGFA_TAG_MISS_OWN(REC, TAG, VM, CVM, SHM, PVM)                                                                 \
+    do {                                                                                                               \
+        constexpr uint32_t kMask_ = kSlots - 1u;                                                                       \
+        unsigned long long miss_;                                                                                      \
+        if (dense) {                                                                                                   \
+            miss_ = PVM & ~__builtin_amdgcn_ballot_w64((uint32_t)(hmax - (int)TAG) < kSlots);                          \
+            if (miss_) {                                                                                               \
+                /* the common hand-over, as in the other build: the step's tags end with its highest and span fewer than */ \
+                /* kSlots -- the bitsets of (hmax, c] change hands, and the owners are those of c's stretch            */ \
+                const int c_ = (int)__builtin_amdgcn_readlane(TAG, 63 - (int)__builtin_clzll(PVM));                    \
+                if ((__builtin_amdgcn_ballot_w64((int)TAG > c_ || (int)(TAG + kSlots) <= c_) & PVM) == 0ull) {         \
+                    clear_slots(max(hmax + 1, c_ - (int)(kSlots - 1u)), c_);                                           \
+                    hmax = c_;                                                                                         \
+                    ownv = (uint32_t)c_ - (((uint32_t)c_ - (uint32_t)lane) & kMask_);                                  \
+                    miss_ = 0ull;                                                                                      \
+                }                                                                                                      \
+            }                                                                                                          \
+        } else {                                                                                                       \
+            const uint32_t o_ = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((TAG & kMask_) << 2), (int)ownv);          \
+            miss_ = PVM & ~__builtin_amdgcn_ballot_w64(o_ == TAG);                                                     \
+        }                                                                                                              \
+        unsigned long long todo_ = VM;                                                                                 \
+        while (miss_) {                                                                                                \
+            /* the lowest tag without a bitset first (not the first lane's: neighbouring items interleave) */          \
+            const uint32_t t_ = wave_min_u32((miss_ >> lane) & 1ull ? TAG : ~0u);                                      \
+            const uint32_t rel_ = TAG - t_;                                                                            \
+            const unsigned long long bm_ = __builtin_amdgcn_ballot_w64(rel_ < kSlots) & miss_;                         \
+            uint32_t t2_ = t_;                                                                                         \
+            if (__builtin_amdgcn_ballot_w64(rel_ != 0u) & bm_) t2_ = wave_max_u32((bm_ >> lane) & 1ull ? TAG : 0u);    \
+            const uint32_t n_ = t2_ - t_ + 1u;  /* 1 .. kSlots */                                                      \
+            /* unclaimed records of older tags whose bitset the burst takes (their last: k_scan's gate): they claim first */ \
+            const unsigned long long busy_ = __builtin_amdgcn_ballot_w64((int)TAG < (int)t_ && (rel_ & kMask_) < n_) & todo_ & PVM; \
+            if (busy_) {                                                                                               \
+                claim(REC, TAG, busy_, busy_ & CVM, false);                                                            \
+                todo_ &= ~busy_;                                                                                       \
+            }                                                                                                          \
+            const uint32_t off_ = ((uint32_t)lane - t_) & kMask_;  /* (lane s stands for slot s) */                     \
+            const uint32_t nt_ = t_ + off_;                                                                            \
+            /* (a tag of the stretch that owns its slot already -- its records came first: waves of k_scan that ran ahead -- keeps it) */ \
+            const bool upd_ = off_ < n_ && (uint32_t)lane < kSlots && ownv != nt_;                                     \
+            unsigned long long um_ = __builtin_amdgcn_ballot_w64(upd_);                                                \
+            if (__builtin_amdgcn_ballot_w64(upd_ && ownv != kFree && (int)(ownv + kTagSlots) > (int)nt_))              \
+                atomicOr(A.status, kStInternal);  /* cannot happen: k_scan's gate */                                   \
+            ownv = upd_ ? nt_ : ownv;                                                                                  \
+            while (um_) {                                                                                              \
+                uint32_t *bs_ = bits + (wv * kSlots + (uint32_t)__builtin_ctzll(um_)) * kNW;                           \
+                um_ &= um_ - 1ull;                                                                                     \
+                for (uint32_t i_ = lane; i_ < kNW / 2u; i_ += 64) reinterpret_cast<uint2 *>(bs_)[i_] = make_uint2(0u, 0u); \
+            }                                                                                                          \
+            hmax = max(hmax, (int)t2_);                                                                                \
+            const uint32_t wt_ = (uint32_t)hmax - (((uint32_t)hmax - (uint32_t)lane) & kMask_);                        \
+            dense = (__builtin_amdgcn_ballot_w64(ownv == wt_) & ((1ull << kSlots) - 1ull)) == ((1ull << kSlots) - 1ull); \
+            miss_ &= ~bm_;                                                                                             \
+        }                                                                                                              \
+        claim(REC, TAG, todo_, todo_ & CVM, SHM != 0ull);                                                              \
+    } while (0)
 #define FGFA_TAG_STEP(K, NV, FR)                                                                                       \
     if (NV == 0u) break;                                                                                               \
     {                                                                                                                  \
@@ -805,14 +875,25 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
             if (cvm) {                                                                                                 \
                 for (uint32_t i = lane; i < kSlots * kNW / 4u; i += 64) reinterpret_cast<uint4 *>(bits + wv * kSlots * kNW)[i] = make_uint4(0u, 0u, 0u, 0u); \
                 hmax = (int)kSlots - 1;                                                                                \
-            } else hmax = -1;  /* (nothing to claim in its first step: the slots are cleared as their tags show up) */ \
-        } else if (FR) hmax = -1;  /* the private slots start over with this sub-bucket */                             \
+                if (OWN) ownv = (uint32_t)lane;                                                                        \
+            } else {                                                                                                   \
+                hmax = -1;  /* (nothing to claim in its first step: the slots are cleared as their tags show up) */    \
+                if (OWN) ownv = kFree;                                                                                 \
+            }                                                                                                          \
+            if (OWN) dense = true;                                                                                     \
+        } else if (FR) {                                                                                               \
+            hmax = -1;  /* the private slots start over with this sub-bucket */                                        \
+            if (OWN) ownv = kFree, dense = true;                                                                       \
+        }                                                                                                              \
         FGFA_TAG_GEN(K, NV, FR);                                                                                       \
         if (NC && cvm == 0ull) {                                                                                       \
             depth_step<WB>(rec, vm, dbase, one, mone);                                                                 \
         } else {                                                                                                       \
         const unsigned long long shm = SHARED ? __builtin_amdgcn_ballot_w64(tag >= shlo) & cvm : 0ull;                 \
         const unsigned long long pvm = cvm & ~shm;  /* the lanes whose tag names an item of their own */               \
+        if constexpr (OWN) {                                                                                           \
+            FGFA_TAG_MISS_OWN(rec, tag, vm, cvm, shm, pvm);                                                            \
+        } else {                                                                                                       \
         bool general = false;                                                                                          \
         if (!(FGFA_TAG_ABLATE & 2) && (__builtin_amdgcn_ballot_w64((uint32_t)hmax - tag >= kSlots) & pvm)) {        \
             /* tags beyond those met so far (or, which cannot be, kSlots behind): their bitsets change hands. */     \
@@ -850,6 +931,7 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
             } while (todo);                                                                                            \
         }                                                                                                              \
         }                                                                                                              \
+        }                                                                                                              \
     }
     while (true) {
         FGFA_TAG_STEP(0, nv0, f0)
@@ -862,6 +944,7 @@ __device__ __forceinline__ void apply_tagged(const AccArgs &A, int *D, int *R, u
         if (kDepth > 7) { FGFA_TAG_STEP((kDepth > 7 ? 7 : 0), nv7, f7) }
     }
 #undef FGFA_TAG_STEP
+#undef FGFA_TAG_MISS_OWN
 #undef FGFA_TAG_GEN
 #undef FGFA_TAG_GRAB
 #undef FGFA_TAG_TAKEN
@@ -1002,7 +1085,7 @@ extern __shared__ __attribute__((aligned(16))) uint32_t tag_bits[];
 // one instruction per cycle and CU where two are possible, and eight waves per SIMD hide more of its
 // LDS round trips than four.  Both leave their partial vectors in scratch; the second one to
 // finish adds the other's to its own and writes the results.
-template <bool UNIQ, int WB, bool PSUM, bool POINT, bool BIG, bool TAGGED, bool PAIR, int SLOTS = (int)kTagSlots, bool LOWREG = PAIR, bool NC = false>
+template <bool UNIQ, int WB, bool PSUM, bool POINT, bool BIG, bool TAGGED, bool PAIR, int SLOTS = (int)kTagSlots, bool LOWREG = PAIR, bool NC = false, bool OWN = false>
 __device__ __forceinline__ void accum_body(const AccArgs &A) {
     constexpr uint32_t kW = 1u << WB;
     constexpr int kPer = kW / kAccThreads;  // cells per thread: 4 or 8
@@ -1091,8 +1174,8 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
         if (PAIR) apply_tagged<WB, POINT, false, true, (int)kTagSlots, NC>(A, D, R, tag_bits, scnt2, wbase, &grab);
         else if (LOWREG && A.n_shared) apply_tagged<WB, POINT, true, true, SLOTS, NC>(A, D, R, tag_bits, scnt2, wbase, &grab);
         else if (LOWREG) apply_tagged<WB, POINT, false, true, SLOTS, NC>(A, D, R, tag_bits, scnt2, wbase, &grab);
-        else if (A.n_shared) apply_tagged<WB, POINT, true, false, SLOTS, NC>(A, D, R, tag_bits, scnt2, wbase, &grab);
-        else apply_tagged<WB, POINT, false, false, SLOTS, NC>(A, D, R, tag_bits, scnt2, wbase, &grab);
+        else if (A.n_shared) apply_tagged<WB, POINT, true, false, SLOTS, NC, OWN>(A, D, R, tag_bits, scnt2, wbase, &grab);
+        else apply_tagged<WB, POINT, false, false, SLOTS, NC, OWN>(A, D, R, tag_bits, scnt2, wbase, &grab);
     } else if (UNIQ) {
         apply_groups<WB, false, POINT, BIG>(A, D, R, bits + wave * (kSlots * (kW / 32)), marks + wave * 64, pend + wave * (3 * kPend), wbase, win,
                                 ge0, ge1, true, be_first, slf_first);
@@ -1204,9 +1287,9 @@ __device__ __forceinline__ void accum_body(const AccArgs &A) {
     }
 }
 
-template <bool UNIQ, int WB, bool PSUM = false, bool POINT = false, bool BIG = false, bool TAGGED = false, int SLOTS = (int)kTagSlots, bool NC = false>
+template <bool UNIQ, int WB, bool PSUM = false, bool POINT = false, bool BIG = false, bool TAGGED = false, int SLOTS = (int)kTagSlots, bool NC = false, bool OWN = false>
 __global__ __launch_bounds__(kAccThreads) void k_accum(const AccArgs A) {
-    accum_body<UNIQ, WB, PSUM, POINT, BIG, TAGGED, false, SLOTS, false, NC>(A);
+    accum_body<UNIQ, WB, PSUM, POINT, BIG, TAGGED, false, SLOTS, false, NC, OWN>(A);
 }
 #ifdef FGFA_MEASURE  // (measurement builds only, tools/variants.sh: profiles/NOTES.md R4.6, R4.9 -- no plan of the product library picks them)
 template <int WB, bool POINT>
@@ -1241,6 +1324,13 @@ bool accum_kernels_setup() {
         set((const void *)k_accum<true, 12, false, false, false, true, 8, true>, tagged_lds_bytes(12, 64, 8));
         set((const void *)k_accum<true, 13, false, false, false, true, (int)kTagSlots, true>, tagged_lds_bytes(13, 0));
         set((const void *)k_accum<true, 13, false, true, false, true, (int)kTagSlots, true>, tagged_lds_bytes(13, 0));
+        // (... and the builds that keep track of the bitsets' owners, for sub-buckets of sparse tags: FastPlan::acc_own)
+        set((const void *)k_accum<true, 12, false, false, false, true, (int)kTagSlots, false, true>, tagged_lds_bytes(12, kMaxShared));
+        set((const void *)k_accum<true, 12, false, false, false, true, 8, false, true>, tagged_lds_bytes(12, 64, 8));
+        set((const void *)k_accum<true, 13, false, false, false, true, (int)kTagSlots, false, true>, tagged_lds_bytes(13, 0));
+        set((const void *)k_accum<true, 12, false, false, false, true, (int)kTagSlots, true, true>, tagged_lds_bytes(12, kMaxShared));
+        set((const void *)k_accum<true, 12, false, false, false, true, 8, true, true>, tagged_lds_bytes(12, 64, 8));
+        set((const void *)k_accum<true, 13, false, false, false, true, (int)kTagSlots, true, true>, tagged_lds_bytes(13, 0));
 #ifdef FGFA_MEASURE
         set((const void *)k_accum_small<11>, tagged_lds_bytes(11, kMaxShared));
         set((const void *)k_accum_pair<12, false>, tagged_lds_bytes(12, 0));
@@ -1257,6 +1347,12 @@ bool accum_kernels_setup() {
     do {                                                                                                                       \
         if (nc) hipLaunchKernelGGL((k_accum<true, WB_, false, POINT_, false, true, SLOTS_, true>), GRID, dim3(kAccThreads), LDS, stream, aa);  \
         else hipLaunchKernelGGL((k_accum<true, WB_, false, POINT_, false, true, SLOTS_, false>), GRID, dim3(kAccThreads), LDS, stream, aa);    \
+    } while (0)
+// (... that keeps track of the bitsets' owners: plans whose sub-buckets hold sparse tags, FastPlan::acc_own)
+#define FGFA_OWN_LAUNCH(GRID, LDS, WB_, SLOTS_)                                                                                \
+    do {                                                                                                                       \
+        if (nc) hipLaunchKernelGGL((k_accum<true, WB_, false, false, false, true, SLOTS_, true, true>), GRID, dim3(kAccThreads), LDS, stream, aa);  \
+        else hipLaunchKernelGGL((k_accum<true, WB_, false, false, false, true, SLOTS_, false, true>), GRID, dim3(kAccThreads), LDS, stream, aa);    \
     } while (0)
 void launch_accum(const FastPlan &fp, AccArgs &aa, bool uniq, bool tagged, bool psum, hipStream_t stream) {
     const dim3 agrid(fp.n_win, fp.acc_parts);
@@ -1281,6 +1377,9 @@ void launch_accum(const FastPlan &fp, AccArgs &aa, bool uniq, bool tagged, bool 
         else if (fp.wb == 11 && getenv("FLATGFA_ACC_SMALL")) hipLaunchKernelGGL((k_accum_small<11>), agrid, dim3(kAccThreads), tl, stream, aa);
 #endif
         else if (fp.wb == 11) FGFA_TAGGED_LAUNCH(agrid, tl, 11, false, (int)kTagSlots);
+        else if (fp.acc_own && fp.wb == 12 && fp.acc_slots == 8 && fp.n_shared <= 64) FGFA_OWN_LAUNCH(agrid, tagged_lds_bytes(12, fp.n_shared, 8), 12, 8);
+        else if (fp.acc_own && fp.wb == 12) FGFA_OWN_LAUNCH(agrid, tl, 12, (int)kTagSlots);
+        else if (fp.acc_own && fp.wb == 13) FGFA_OWN_LAUNCH(agrid, tl, 13, (int)kTagSlots);
         else if (fp.wb == 12 && fp.acc_slots == 8 && fp.n_shared <= 64) FGFA_TAGGED_LAUNCH(agrid, tagged_lds_bytes(12, fp.n_shared, 8), 12, false, 8);
         else if (fp.wb == 12) FGFA_TAGGED_LAUNCH(agrid, tl, 12, false, (int)kTagSlots);
         else FGFA_TAGGED_LAUNCH(agrid, tl, 13, false, (int)kTagSlots);
@@ -1303,6 +1402,7 @@ void launch_accum(const FastPlan &fp, AccArgs &aa, bool uniq, bool tagged, bool 
     }
 }
 #undef FGFA_TAGGED_LAUNCH
+#undef FGFA_OWN_LAUNCH
 
 void launch_path_reduce(const FastPlan &fp, unsigned long long *len_out, unsigned long long *weighted_out, hipStream_t stream) {
     hipLaunchKernelGGL(k_path_reduce, dim3((fp.n_items + 3) / 4), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(fp.items), fp.elist, fp.n_items,

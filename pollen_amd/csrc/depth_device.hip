@@ -494,6 +494,43 @@ static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const 
             pl->fast.big_groups = strtol(f, nullptr, 10) != 0;
             for (uint32_t r = 0; r < pl->fast.n_more; ++r) pl->fast.more[r].big_groups = pl->fast.big_groups;
         }
+        // Pass 2 of a tagged call can keep track of which tag owns each of a wave's bitsets (k_accum<..., OWN>): where a pass-1
+        // workgroup takes hundreds of items of which a window sees a few -- tags twenty apart in a sub-bucket -- every step of
+        // 64 records holds several, and the plain walk claims them one stretch after the other (160 000 contigs on 16 M
+        // segments: pass 2 2.48 -> 1.62 ms); where the tags are dense it costs 4-9 %.  Timed on this graph, both ways, when
+        // the workgroups take more items than a wave has bitsets.
+        {
+            const auto many_items = [](const FastPlan &q) {
+                return q.tagged && !q.dense && (q.wb == 12 || q.wb == 13) && (uint64_t)q.n_items + q.max_back > 2ull * q.acc_slots * std::min<uint32_t>(std::max(q.n_items, 1u), q.n_slots);
+            };
+            bool any = pl->fast.eligible && many_items(pl->fast);
+            for (uint32_t r = 0; r < pl->fast.n_more; ++r) any = any || (pl->fast.eligible && many_items(pl->fast.more[r]));
+            const auto set_own = [&](bool on) {
+                pl->fast.acc_own = on;
+                for (uint32_t r = 0; r < pl->fast.n_more; ++r) pl->fast.more[r].acc_own = on;
+            };
+            if (any && !getenv("FLATGFA_ACC_OWN")) {
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                float best[2] = {1e30f, 1e30f};
+                bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+                for (int rep = 0; rep < 3 && ok; ++rep) {
+                    for (int which = 0; which < 2 && ok; ++which) {
+                        set_own(which != 0);
+                        ok = hipEventRecord(e0, nullptr) == hipSuccess;
+                        const int rc = fast_seg_depth(pl->fast, pl->g, tmp, tmp + g->n_segs, pl->status, nullptr);
+                        float ms = 0;
+                        ok = ok && rc == FLATGFA_OK && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+                             hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+                        if (ok && rep) best[which] = std::min(best[which], ms);
+                    }
+                }
+                if (e0) (void)hipEventDestroy(e0);
+                if (e1) (void)hipEventDestroy(e1);
+                (void)hipMemset(pl->status, 0, 4);
+                set_own(ok && best[1] * 1.02f < best[0]);  // (it has to win by more than the noise of two runs)
+                if (getenv("FLATGFA_TIMING")) fprintf(stderr, "plan: pass 2 with bitsets by tag %.1f us, by owner %.1f us\n", best[0] * 1e3, best[1] * 1e3);
+            }
+        }
         // Small graphs are launch-bound: three kernels of the bucketed path against one of the
         // atomic path (10 k segments / 1 M steps: 76 us against 26).  Up to 8 M steps both are
         // timed here, on this graph, and the plan keeps the faster one.  FLATGFA_DEPTH_PATH=bucketed
@@ -780,7 +817,7 @@ extern "C" int flatgfa_dev_plan_describe(flatgfa_dev_plan_t *pl, char *out, int 
             " pass2=" + (f.tagged ? (f.n_shared ? "tagged(shared bitsets)" : f.acc_pair ? "tagged(two workgroups per window)" : "tagged") : (f.big_groups ? "directory(one-item shortcut)" : "directory")) +
             " windows=" + std::to_string(f.n_win) + "x" + std::to_string(1u << f.wb) + " ranges=" + std::to_string((f.n_more + 1) / f.n_groups) +
             (f.n_groups > 1 ? " path_groups=" + std::to_string(f.n_groups) : std::string()) +
-            " scan_workgroups=" + std::to_string(f.n_slots) + " workgroups_per_window=" + std::to_string(f.acc_parts) + " items=" + std::to_string(f.n_items) + " no_claim_items=" + std::to_string(f.n_noclaim) + " no_claim_paths=" + std::to_string(f.short_mono_n + f.medium_mono_n + f.tiny_mono_n) + " split_paths=" + std::to_string(f.n_shared) +
+            " scan_workgroups=" + std::to_string(f.n_slots) + " workgroups_per_window=" + std::to_string(f.acc_parts) + " items=" + std::to_string(f.n_items) + (f.acc_own ? " bitset_owners=tracked" : "") + " no_claim_items=" + std::to_string(f.n_noclaim) + " no_claim_paths=" + std::to_string(f.short_mono_n + f.medium_mono_n + f.tiny_mono_n) + " split_paths=" + std::to_string(f.n_shared) +
             " short_paths=" + std::to_string(f.n_short) + " medium_paths=" + std::to_string(f.n_medium) + " tiny_paths=" + std::to_string(f.n_tiny) +
             " steps=" + std::to_string(f.class_steps[0]) + "/" + std::to_string(f.class_steps[1]) + "/" + std::to_string(f.class_steps[2]) + "/" + std::to_string(f.class_steps[3]) +  // (by k_scan / short / medium / tiny)
             " bucket_cap=" + std::to_string(f.cap);

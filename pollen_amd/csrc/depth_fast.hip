@@ -803,6 +803,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         fp->acc_slots = can8 && (uint64_t)fp->n_items + fp->max_back > 4ull * grid ? 8u : kTagSlots;
         if (const char *f = getenv("FLATGFA_ACC_SLOTS")) fp->acc_slots = can8 && strtol(f, nullptr, 10) == 8 ? 8u : kTagSlots;
         if (fp->acc_slots == 8) fp->acc_pair = false;
+        if (const char *f = getenv("FLATGFA_ACC_OWN")) fp->acc_own = strtol(f, nullptr, 10) != 0;  // tests, measurements
     }
     if (fp->acc_pair) {
         FAST_TRY(hipMalloc(&fp->pair_part, (size_t)n_win * 2 * 2 * (1u << wb) * 4));

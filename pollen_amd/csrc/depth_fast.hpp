@@ -28,6 +28,7 @@ struct FastPlan {
     uint64_t est_records = 0;  // records k_scan will make of its items (counted when the plan is made)
     bool acc_pair = false;     // tagged calls with unique depth run two workgroups per window, both resident on a CU (k_accum_pair)
     uint32_t acc_slots = 4;    // private bitsets per wave of the tagged walk
+    bool acc_own = false;      // ... which keeps track of their owners (k_accum<..., OWN>): sub-buckets of sparse tags
     uint32_t *pair_part = nullptr, *pair_flag = nullptr;  // their halves of the result vectors, and how many are there
     // Packed buckets: every (window, workgroup) sub-bucket has exactly the room its records need (counted once when the
     // plan is made, k_scan dealing its items in a fixed order from then on), a workgroup's sub-buckets back to back.

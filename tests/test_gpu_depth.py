@@ -19,7 +19,8 @@ FGFA = os.path.join(ROOT, "pollen_amd", "bin", "fgfa")
 
 
 @pytest.fixture(params=["auto", "bucketed", "atomic", "tinycap", "pieces", "noshort", "handback", "parts3", "ranges", "dense",
-                        "untagged", "untagged_pieces", "untagged_noshort", "groups3", "packed", "slots8", "claim_all", "wb11", "wgs96"])
+                        "untagged", "untagged_pieces", "untagged_noshort", "groups3", "packed", "slots8", "claim_all", "wb11", "wgs96",
+                        "owners", "owners8", "owners_pieces"])
 def device_path(request, monkeypatch):
     """Runs a test once per device path: the default (up to 8 M steps the plan times the bucketed
     path against the atomic kernels on the graph at hand and keeps the faster), the bucketed path
@@ -53,6 +54,18 @@ def device_path(request, monkeypatch):
     monkeypatch.delenv("FLATGFA_PACKED", raising=False)
     monkeypatch.delenv("FLATGFA_ACC_SLOTS", raising=False)
     monkeypatch.delenv("FLATGFA_WB", raising=False)
+    monkeypatch.delenv("FLATGFA_ACC_OWN", raising=False)
+    monkeypatch.delenv("FLATGFA_TAG_LIMIT", raising=False)
+    if request.param.startswith("owners"):
+        # the tagged walk that keeps track of which tag owns each of a wave's bitsets (k_accum<..., OWN>: by default only plans whose
+        # sub-buckets hold sparse tags), on every plan: four bitsets, eight, and next to the shared ones of paths cut into pieces
+        monkeypatch.setenv("FLATGFA_ACC_OWN", "1")
+        monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
+        monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+        if request.param == "owners8":
+            monkeypatch.setenv("FLATGFA_ACC_SLOTS", "8")
+        elif request.param == "owners_pieces":
+            monkeypatch.setenv("FLATGFA_PIECE_STEPS", "4096")
     if request.param == "wb11":  # windows of 2048 segments (by default 4096, or 8192 beyond 4 M segments)
         monkeypatch.setenv("FLATGFA_WB", "11")
         monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
