@@ -76,6 +76,7 @@ WORKLOADS = {
     "chr-like": (16_000_000, 90, 10_000_000, "chromosome"),    # a chromosome graph as the HPRC ones are shaped: ninety haplotype paths of ten million steps each
     "chr-like-40M": (40_000_000, 90, 20_000_000, "chromosome"),  # ... on forty million segments: beyond one range of 4096-segment windows
     "chr-like-2k": (16_000_000, 2000, 500_000, "chromosome"),     # ... walked by two thousand paths of half a million steps
+    "hap-chr20": (4_000_000, 2000, 100_000, "haplotype"),     # the size of one chromosome's graph (a few million segments, a couple of thousand contigs of ~100 k steps that stay in order): 200 M steps
     "hap-16M": (16_000_000, 16_000, 100_000, "haplotype"),    # sixteen thousand haplotype walks of a hundred thousand steps that stay in their neighbourhood
     "hap-chr": (16_000_000, 90, 10_000_000, "haplotype"),      # ninety of ten million steps
     "cfgS": (10_000, 100, 10_000, "pangenome"),

@@ -408,6 +408,7 @@ static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const 
     if (pl->fast.eligible && !pl->fast.cap_forced && g->n_segs) {
         uint32_t *tmp = nullptr;
         HIP_TRY(hipMalloc(&tmp, (size_t)g->n_segs * 8), { flatgfa_dev_plan_destroy(pl); return nullptr; });
+        for (int layout = 0; layout < 2; ++layout) {
         for (int attempt = 0; attempt < 10 && pl->fast.eligible; ++attempt) {
             uint32_t st = 0;
             if (fast_seg_depth(pl->fast, pl->g, tmp, tmp + g->n_segs, pl->status, nullptr) != FLATGFA_OK ||
@@ -425,6 +426,31 @@ static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const 
             uint32_t fullest = 0;
             if (hipMemcpy(&fullest, pl->status + 2, 4, hipMemcpyDeviceToHost) == hipSuccess && fullest && pl->fast.eligible) (void)fast_plan_grow(&pl->fast, true);
             (void)hipMemset(pl->status, 0, 12);
+        }
+        // An even layout -- every sub-bucket as deep as the fullest -- that had to grow to gigabytes (paths that run along
+        // the graph fill a few sub-buckets of a window and leave the others empty: 2000 contigs of 100 k steps on 4 M
+        // segments, 0.8 GB of steps, 4.8 GB of buckets): the plan is made again with its buckets laid out to the count.
+        if (layout == 0 && pl->fast.eligible && !getenv("FLATGFA_PACKED")) {
+            uint64_t even_bytes = 0;
+            const auto add = [&](const FastPlan &q) { if (!q.packed) even_bytes += ((uint64_t)q.n_win + 1) * q.n_slots * q.cap * 4; };
+            add(pl->fast);
+            for (uint32_t r = 0; r < pl->fast.n_more; ++r) add(pl->fast.more[r]);
+            if (even_bytes <= (2ull << 30)) break;
+            FastPlan again;
+            if (!fast_plan_create(pl->g, hb, he, &again, scan_workgroups, true)) { (void)hipFree(tmp); flatgfa_dev_plan_destroy(pl); return nullptr; }
+            bool all_packed = again.eligible && again.packed;
+            for (uint32_t r = 0; r < again.n_more; ++r) all_packed = all_packed && again.more[r].packed;
+            if (!all_packed) {
+                fast_plan_destroy(&again);
+                break;
+            }
+            again.mall_steps = pl->fast.mall_steps;
+            for (uint32_t r = 0; r < again.n_more; ++r) again.more[r].mall_steps = again.mall_steps;
+            fast_plan_destroy(&pl->fast);
+            pl->fast = again;
+        } else {
+            break;
+        }
         }
         // More than a record for two steps: pass 1 by partition (k_scan_dense) may beat pass 1 by runs.
         // The plan was sized for it (it makes the most records); now both are timed.

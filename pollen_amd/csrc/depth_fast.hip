@@ -213,6 +213,7 @@ int alloc_buckets(FastPlan *fp, uint64_t want_cap) {
 static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t *depth_out, uint32_t *uniq_out,
                      uint32_t *status, hipStream_t stream, const PathSums *ps, bool count_only);
 static thread_local uint32_t t_scan_workgroups = 0;  // fast_plan_create's `scan_workgroups`, for the ranges it makes
+static thread_local bool t_prefer_packed = false;    // ... and its `prefer_packed`
 
 // The A/B switches of past measurements (which policy a plan takes: NOTES.md) read the environment in measurement
 // builds only (-DFGFA_MEASURE, tools/variants.sh); the product library takes the policy that won.
@@ -653,6 +654,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
                           scan_lds_bytes(fp->nwp, true, true) + 64 <= kLdsLimit;
     // (the even layout may take 2 GB for a graph's buckets: this plan's share when segment ranges and path groups make several of it)
     bool want_packed = can_pack && (slots + fp->n_slots) * std::max<uint64_t>(cap, 4) * 4 > std::max<uint64_t>(128ull << 20, (2ull << 30) / std::max(1u, siblings));
+    want_packed = want_packed || (can_pack && t_prefer_packed);  // (a plan whose even layout had to grow to gigabytes is made again, packed: flatgfa_dev_plan_create)
     if (const char *f = getenv("FLATGFA_PACKED")) want_packed = can_pack && strtol(f, nullptr, 10) != 0;
     if (!want_packed) {
         const int rc = alloc_buckets(fp, std::max<uint64_t>(cap, 4));
@@ -942,10 +944,12 @@ static void adopt_plans(std::vector<FastPlan> *plans, FastPlan *fp) {
 }
 
 static bool fast_plan_create_impl(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp);
-bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp, uint32_t scan_workgroups) {
+bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp, uint32_t scan_workgroups, bool prefer_packed) {
     t_scan_workgroups = scan_workgroups;
+    t_prefer_packed = prefer_packed;
     const bool ok = fast_plan_create_impl(g, hb, he, fp);
     t_scan_workgroups = 0;
+    t_prefer_packed = false;
     return ok;
 }
 static bool fast_plan_create_impl(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp) {

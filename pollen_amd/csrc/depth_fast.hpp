@@ -95,8 +95,10 @@ struct FastPlan {
 // allocates the scratch: one range of at most 2048 windows, or several.  Returns false only on a HIP error.
 // `scan_workgroups`: how many persistent workgroups pass 1 runs (= sub-buckets per window); 0 = one per CU.  A plan that
 // is one lane of a pipeline (calls in flight) takes fewer, so that another call's kernels share the chip with its pass 1.
+// `prefer_packed`: record buckets laid out to the count wherever the plan allows it (by default only where the even layout
+// would take gigabytes from the start).
 bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *host_path_begin, const uint32_t *host_path_end,
-                      FastPlan *fp, uint32_t scan_workgroups = 0);
+                      FastPlan *fp, uint32_t scan_workgroups = 0, bool prefer_packed = false);
 void fast_plan_destroy(FastPlan *fp);
 // After a call whose records did not fit their sub-buckets (status bit 4): quadruple the capacity.
 // Returns false -- and marks the plan ineligible -- when that is not possible.
