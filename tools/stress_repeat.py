@@ -15,7 +15,9 @@ for name, (S, P, L, model) in {"cfgL": (1_000_000, 1000, 100_000, "pangenome"), 
                                "mixed-4M": (4_000_000, 3000, 20_000, "pangenome"), "uniform": (300_000, 200, 50_000, "uniform"),
                                "chromosome": (2_000_000, 300, 150_000, "chromosome"), "tiny": (500_000, 300_000, 90, "pangenome"),
                                "32k (eight bitsets per wave)": (1_000_000, 2000, 32_000, "pangenome"),
-                               "16M haplotypes (packed buckets)": (16_000_000, 4000, 100_000, "haplotype")}.items():
+                               "16M haplotypes (packed buckets)": (16_000_000, 4000, 100_000, "haplotype"),
+                               "contigs on 8 M segments (sparse tags: the owner-tracking walk)": (8_000_000, 40_000, 10_000, "chromosome"),
+                               "in-order short contigs": (1_000_000, 60_000, 1000, "haplotype")}.items():
     g = pa.synth(9, S, P, L, model, False)
     steps, pb, pe, seg_len = g.soa()
     plan = dev.DepthPlan(dev.DeviceGraph(steps, pb, pe, S, seg_len, device="cuda:0"))
@@ -30,6 +32,6 @@ for name, (S, P, L, model) in {"cfgL": (1_000_000, 1000, 100_000, "pangenome"), 
         if not torch.equal(out, ref):
             n_bad += 1
     plan.status()
-    print(f"{name}: {reps} repeats, {n_bad} differ from the first", flush=True)
+    print(f"{name}: {reps} repeats, {n_bad} differ from the first  [{plan.describe()[:160]}]", flush=True)
     bad += n_bad
 sys.exit(1 if bad else 0)
