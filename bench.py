@@ -77,6 +77,8 @@ WORKLOADS = {
     "chr-like-40M": (40_000_000, 90, 20_000_000, "chromosome"),  # ... on forty million segments: beyond one range of 4096-segment windows
     "chr-like-2k": (16_000_000, 2000, 500_000, "chromosome"),     # ... walked by two thousand paths of half a million steps
     "hap-chr20": (4_000_000, 2000, 100_000, "haplotype"),     # the size of one chromosome's graph (a few million segments, a couple of thousand contigs of ~100 k steps that stay in order): 200 M steps
+    "rep-chr20": (4_000_000, 2000, 100_000, "repeats"),       # ... whose walks go back over 16-271 segments every 6400 steps (tandem duplications): not monotone as a whole
+    "rep-16M": (16_000_000, 16_000, 100_000, "repeats"),
     "hap-16M": (16_000_000, 16_000, 100_000, "haplotype"),    # sixteen thousand haplotype walks of a hundred thousand steps that stay in their neighbourhood
     "hap-chr": (16_000_000, 90, 10_000_000, "haplotype"),      # ninety of ten million steps
     "cfgS": (10_000, 100, 10_000, "pangenome"),

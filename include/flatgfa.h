@@ -116,7 +116,8 @@ void flatgfa_free_text(char *text);
 /* Deterministic synthetic graph; model 0 = pangenome walk, 1 = uniform,
  * 2 = chromosome (paths walk along the graph, every other one downwards; one step in a hundred
  * jumps anywhere), 3 = haplotype (the same without those jumps: one step in 1600 skips up to 1087
- * segments). */
+ * segments), 4 = repeats (a haplotype walk that, one step in 6400, goes 16 .. 271 segments back and
+ * walks them again). */
 flatgfa_t flatgfa_synth(uint64_t seed, uint32_t n_segs, uint32_t n_paths, uint32_t steps_per_path, int model,
                         bool with_seq);
 

@@ -52,7 +52,7 @@ def seg_lens(seed: int, S: int) -> np.ndarray:
 
 def steps(seed: int, S: int, P: int, L: int, model: str = "pangenome") -> np.ndarray:
     """Returns the flat u32 handle array, shape (P*L,)."""
-    assert model in ("pangenome", "uniform", "chromosome", "haplotype")
+    assert model in ("pangenome", "uniform", "chromosome", "haplotype", "repeats")
     out = np.zeros((P, L), dtype=np.uint32)
     with np.errstate(over="ignore"):
         state = np.uint64(seed & 0xFFFFFFFFFFFFFFFF) * GOLDEN + np.arange(P, dtype=np.uint64)
@@ -66,17 +66,22 @@ def steps(seed: int, S: int, P: int, L: int, model: str = "pangenome") -> np.nda
             j = r >> np.uint64(32)
             if model == "uniform":
                 cur = j % np.uint64(S)
-            elif model in ("chromosome", "haplotype"):
+            elif model in ("chromosome", "haplotype", "repeats"):
                 odd = np.arange(P, dtype=np.uint64) & np.uint64(1)
                 out[:, t] ^= odd.astype(np.uint32)
                 u = (r >> np.uint64(8)) % np.uint64(100)
                 k = (r >> np.uint64(16)) & np.uint64(0xFF)
                 d = np.where(u < 70, np.uint64(1), np.where(u < 95, np.uint64(2) + (k & np.uint64(3)), np.uint64(8) + (k & np.uint64(63))))
-                if model == "haplotype":
+                if model in ("haplotype", "repeats"):
                     d = np.where(u >= 99, np.where((k & np.uint64(0xF0)) != 0, np.uint64(1), np.uint64(64) + (j & np.uint64(1023))), d)
                 d = d % np.uint64(S)
-                moved = np.where(odd == 1, cur + np.uint64(S) - d, cur + d) % np.uint64(S)
-                cur = moved if model == "haplotype" else np.where(u < 99, moved, j % np.uint64(S))
+                ahead = odd == 0
+                if model == "repeats":  # one step in 6400 goes 16 .. 271 segments back along the walk and walks them again (a tandem duplication)
+                    rep = (u == 98) & ((k & np.uint64(0xFC)) == 0)
+                    d = np.where(rep, (np.uint64(16) + (j & np.uint64(255))) % np.uint64(S), d)
+                    ahead = np.where(rep, ~ahead, ahead)
+                moved = np.where(ahead, cur + d, cur + np.uint64(S) - d) % np.uint64(S)
+                cur = moved if model in ("haplotype", "repeats") else np.where(u < 99, moved, j % np.uint64(S))
             else:
                 u = (r >> np.uint64(8)) % np.uint64(100)
                 k = (r >> np.uint64(16)) & np.uint64(0xFF)

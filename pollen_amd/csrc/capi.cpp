@@ -121,7 +121,7 @@ flatgfa_t flatgfa_load(const char *filename) {
 
 flatgfa_t flatgfa_synth(uint64_t seed, uint32_t n_segs, uint32_t n_paths, uint32_t steps_per_path, int model,
                         bool with_seq) {
-    if (n_segs == 0 || (model < 0 || model > 3) || (uint64_t)n_paths * steps_per_path > 0xFFFFFFFFull ||
+    if (n_segs == 0 || (model < 0 || model > 4) || (uint64_t)n_paths * steps_per_path > 0xFFFFFFFFull ||
         n_segs > 0x7FFFFFFFu) {
         set_error("flatgfa_synth: bad shape");
         return nullptr;

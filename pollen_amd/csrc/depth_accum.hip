@@ -1357,7 +1357,7 @@ bool accum_kernels_setup() {
 void launch_accum(const FastPlan &fp, AccArgs &aa, bool uniq, bool tagged, bool psum, hipStream_t stream) {
     const dim3 agrid(fp.n_win, fp.acc_parts);
     const bool pair = uniq && tagged && fp.acc_pair;
-    const bool nc = fp.n_noclaim != 0;
+    const bool nc = fp.n_noclaim != 0 || fp.n_flag_chunks != 0;
 #ifdef FGFA_MEASURE
     if (pair) {
         aa.parts = 2;

@@ -164,6 +164,65 @@ __global__ __launch_bounds__(256) void k_item_dirs(const uint32_t *__restrict__ 
 }
 
 
+// Plan time: which stretches of an item need no claim although its path is not monotone as a whole.  A path that enters
+// a window ONCE and walks it one way -- every step above (or every step below) the one before it while it stays -- meets none
+// of the window's segments twice, whatever it does elsewhere; a record in such a window counts for depth and unique
+// depth alike (depth.rs:30-34's test is true for each of its steps) and claims nothing.  Two bits per (path, window) in `vis`:
+// bit 0 = entered, bit 1 = not so (entered again, a step on the spot, or a change of direction inside).  Order does not
+// matter, so all steps are looked at in parallel.  One workgroup per item at a time.
+__global__ __launch_bounds__(256) void k_visit_bits(const uint32_t *__restrict__ steps, const uint4 *__restrict__ items, uint32_t n_items,
+                                                     const uint32_t *__restrict__ pbeg, uint32_t wb, uint32_t n_win, uint32_t *__restrict__ vis) {
+    for (uint32_t j = blockIdx.x; j < n_items; j += gridDim.x) {
+        const uint4 it = items[j];
+        const uint64_t first = pbeg[it.w];
+        for (uint64_t t = (uint64_t)it.x + threadIdx.x; t < it.y; t += 256) {
+            const uint32_t id = steps[t] >> 1, w = id >> wb;
+            if (w >= n_win) continue;  // (an id beyond the graph: the call reports it)
+            const uint64_t idx = (uint64_t)it.w * n_win + w;
+            uint32_t *cell = vis + (idx >> 4);
+            const uint32_t sh = 2u * (uint32_t)(idx & 15u);
+            const uint32_t id1 = t > first ? steps[t - 1] >> 1 : ~0u;
+            if (t == first || (id1 >> wb) != w) {
+                if (atomicOr(cell, 1u << sh) & (1u << sh)) atomicOr(cell, 2u << sh);
+            } else {
+                bool bad = id == id1;
+                if (t >= first + 2) {
+                    const uint32_t id2 = steps[t - 2] >> 1;
+                    if ((id2 >> wb) == w) bad = bad || ((id > id1) != (id1 > id2)) || id1 == id2;
+                }
+                if (bad) atomicOr(cell, 2u << sh);
+            }
+        }
+    }
+}
+// ... and which 16-step chunks of the items' blocks lie in such windows only: one bit per chunk of the step array (k_scan ANDs a
+// block's 64).  A thread per chunk; `n_flagged` counts them.
+__global__ __launch_bounds__(256) void k_chunk_flags(const uint32_t *__restrict__ steps, const uint4 *__restrict__ items, uint32_t n_items, uint64_t n_steps,
+                                                      uint32_t wb, uint32_t n_win, const uint32_t *__restrict__ vis, uint32_t *__restrict__ cflags,
+                                                      unsigned long long *__restrict__ n_flagged) {
+    for (uint32_t j = blockIdx.x; j < n_items; j += gridDim.x) {
+        const uint4 it = items[j];
+        const uint64_t t0 = std::min<uint64_t>(((uint64_t)it.x + 15) & ~15ull, it.y);  // (k_scan's make_item: the blocks start here ...)
+        const uint64_t n_chunks = ((uint64_t)it.y - t0) / 16;                           // (... and hold whole chunks only)
+        uint32_t mine = 0;
+        for (uint64_t c = threadIdx.x; c < n_chunks; c += 256) {
+            bool ok = true;
+            for (uint32_t k = 0; k < 16; ++k) {
+                const uint32_t w = (steps[t0 + 16 * c + k] >> 1) >> wb;
+                const uint64_t idx = (uint64_t)it.w * n_win + w;
+                ok = ok && w < n_win && ((vis[idx >> 4] >> (2u * (uint32_t)(idx & 15u))) & 3u) == 1u;
+            }
+            if (ok) {
+                const uint64_t bit = t0 / 16 + c;
+                atomicOr(&cflags[bit >> 5], 1u << (bit & 31u));
+                mine += 1;
+            }
+        }
+        if (mine) atomicAdd(n_flagged, (unsigned long long)mine);
+    }
+    (void)n_steps;
+}
+
 #define FAST_TRY(expr)                                                                      \
     do {                                                                                    \
         hipError_t _e = (expr);                                                             \
@@ -737,6 +796,43 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
                 for (const uint4 &it : dev_items) fp->n_noclaim += it.z >> 31;
             }
             for (const uint4 &it : items) item_steps += it.y - it.x;
+            // Items of paths that do not qualify as a whole: the stretches of them that lie in windows their path enters once
+            // and walks one way (k_visit_bits, k_chunk_flags) -- k_scan gives the records of such blocks the no-claim tag too.
+            // For one range over all segments, tagged; two bits per (path, window) and one per sixteen steps of scratch.
+            if (no_claim && fp->tagged && !ranged && fp->n_noclaim < fp->n_items && !getenv("FLATGFA_NO_CLAIM_BLOCKS_OFF")) {
+                const uint64_t vis_words = ((uint64_t)g.n_paths * n_win + 15) / 16 + 1, flag_words = g.n_steps / 512 + 4;
+                if (vis_words * 4 <= (256ull << 20)) {
+                    uint32_t *d_vis = nullptr, *d_pbeg = nullptr;
+                    unsigned long long *d_cnt = nullptr, flagged = 0;
+                    hipError_t e2 = hipMalloc(&d_vis, vis_words * 4);
+                    if (e2 == hipSuccess) e2 = hipMemset(d_vis, 0, vis_words * 4);
+                    if (e2 == hipSuccess) e2 = hipMalloc(&d_pbeg, (size_t)g.n_paths * 4);
+                    if (e2 == hipSuccess) e2 = hipMemcpy(d_pbeg, hb, (size_t)g.n_paths * 4, hipMemcpyHostToDevice);
+                    if (e2 == hipSuccess) e2 = hipMalloc(&d_cnt, 8);
+                    if (e2 == hipSuccess) e2 = hipMemset(d_cnt, 0, 8);
+                    if (e2 == hipSuccess) e2 = hipMalloc(&fp->cflags, flag_words * 4);
+                    if (e2 == hipSuccess) e2 = hipMemset(fp->cflags, 0, flag_words * 4);
+                    if (e2 == hipSuccess) {
+                        const dim3 grid(std::min<uint32_t>(fp->n_items, fp->n_cus * 8u));
+                        hipLaunchKernelGGL(k_visit_bits, grid, dim3(256), 0, nullptr, g.steps, reinterpret_cast<const uint4 *>(fp->items), fp->n_items, d_pbeg, wb, n_win, d_vis);
+                        hipLaunchKernelGGL(k_chunk_flags, grid, dim3(256), 0, nullptr, g.steps, reinterpret_cast<const uint4 *>(fp->items), fp->n_items, g.n_steps, wb, n_win,
+                                           d_vis, fp->cflags, d_cnt);
+                        e2 = hipMemcpy(&flagged, d_cnt, 8, hipMemcpyDeviceToHost);
+                    }
+                    if (d_vis) (void)hipFree(d_vis);
+                    if (d_pbeg) (void)hipFree(d_pbeg);
+                    if (d_cnt) (void)hipFree(d_cnt);
+                    // (worth it from a tenth of the chunks: pass 2's build with the no-claim test costs the claiming records 4 %, and cfg-L's
+                    // random walks have one chunk in a thousand that qualifies)
+                    if (e2 != hipSuccess || flagged * 160 < item_steps) {  // (nothing gained: the plain kernels, no table)
+                        if (fp->cflags) (void)hipFree(fp->cflags);
+                        fp->cflags = nullptr;
+                        flagged = 0;
+                    }
+                    FAST_TRY(e2);
+                    fp->n_flag_chunks = flagged;
+                }
+            }
             fp->est_records = runs64;
             // more than three records for four steps: not worth looking for runs (k_scan_dense)
             const bool can = !fp->dbg && dense_lds_bytes(fp->nwp) + 64 <= kLdsLimit;
@@ -1159,7 +1255,7 @@ void fast_plan_destroy(FastPlan *fp) {
     for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot, (void *)fp->perm,
                     (void *)fp->elist, (void *)fp->wave_off, (void *)fp->fat_off, (void *)fp->fat_woff, (void *)fp->items, (void *)fp->short_items,
                     (void *)fp->medium_items, (void *)fp->tiny_items, (void *)fp->rev_steps, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part,
-                    (void *)fp->pair_part, (void *)fp->pair_flag, (void *)fp->taken, (void *)fp->pk_off, (void *)fp->pk_base, (void *)fp->pk})
+                    (void *)fp->pair_part, (void *)fp->pair_flag, (void *)fp->taken, (void *)fp->pk_off, (void *)fp->pk_base, (void *)fp->pk, (void *)fp->cflags})
         if (p) (void)hipFree(p);
     *fp = FastPlan();
 }
@@ -1225,6 +1321,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     sa.tag_limit = std::max(2u, fp.tag_limit);
     sa.taken = fp.taken;
     sa.mall_steps = fp.mall_steps;
+    sa.cflags = tagged ? fp.cflags : nullptr;
     sa.pk_off = fp.pk_off;
     sa.pk_base = fp.pk_base;
     if (fp.packed && !tagged) { set_error("fast_seg_depth: a plan with packed buckets runs tagged calls only"); return FLATGFA_ERR_ARG; }

@@ -134,6 +134,7 @@ struct ScanArgs {
     // need -- counted once, with the items dealt in a fixed order -- and a workgroup's sub-buckets lie back to back:
     const uint32_t *pk_off;   // [n_slots][n_win + 1] where each of the workgroup's sub-buckets starts in its region (the last entry: the region's end, a sink)
     const uint64_t *pk_base;  // [n_slots] where the workgroup's region starts in `buckets`
+    const uint32_t *cflags;  // tagged: one bit per 16 steps -- the chunk's records need no claim (FastPlan::cflags); nullptr: the items' own flags only
     uint64_t mall_steps; // blocks that start below this step index are read without the nt hint, so that they stay in the Infinity Cache from one call to the next (FastPlan::mall_steps)
     uint32_t *taken;     // tagged: [n_slots] how many items each workgroup took (its private tags are 0 .. taken - 1): pass 2 clears all of a wave's
                          // bitsets at once where a sub-bucket has no more tags than the wave has bitsets, and none changes hands inside it
@@ -330,6 +331,25 @@ __device__ __forceinline__ void wait_block(const W &w) {
                    "=v"(a[8]), "=v"(a[9]), "=v"(a[10]), "=v"(a[11]), "=v"(a[12]), "=v"(a[13]), "=v"(a[14]), "=v"(a[15])  \
                  :                                                                                                      \
                  : "memory")
+// The same with a uniform bit F on top: every id comes out as (F << 31) | id, one v_alignbit_b32 where take_block has a v_lshrrev_b32
+// (k_scan: the plan says of every block whether its records need pass 2's claim, and the bit rides in the ids to the records' tags).
+#define FGFA_TAKE16F(F, R0, R1, R2, R3, R4, R5, R6, R7, R8, R9, R10, R11, R12, R13, R14, R15)                           \
+    asm volatile("v_alignbit_b32 %0, %16, " R0 ", 1\n\tv_alignbit_b32 %1, %16, " R1 ", 1\n\tv_alignbit_b32 %2, %16, " R2 ", 1"      \
+                 "\n\tv_alignbit_b32 %3, %16, " R3 ", 1\n\tv_alignbit_b32 %4, %16, " R4 ", 1\n\tv_alignbit_b32 %5, %16, " R5 ", 1"  \
+                 "\n\tv_alignbit_b32 %6, %16, " R6 ", 1\n\tv_alignbit_b32 %7, %16, " R7 ", 1\n\tv_alignbit_b32 %8, %16, " R8 ", 1"  \
+                 "\n\tv_alignbit_b32 %9, %16, " R9 ", 1\n\tv_alignbit_b32 %10, %16, " R10 ", 1\n\tv_alignbit_b32 %11, %16, " R11 ", 1" \
+                 "\n\tv_alignbit_b32 %12, %16, " R12 ", 1\n\tv_alignbit_b32 %13, %16, " R13 ", 1\n\tv_alignbit_b32 %14, %16, " R14 ", 1" \
+                 "\n\tv_alignbit_b32 %15, %16, " R15 ", 1"                                                              \
+                 : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]), "=v"(a[4]), "=v"(a[5]), "=v"(a[6]), "=v"(a[7]),       \
+                   "=v"(a[8]), "=v"(a[9]), "=v"(a[10]), "=v"(a[11]), "=v"(a[12]), "=v"(a[13]), "=v"(a[14]), "=v"(a[15])  \
+                 : "s"(F)                                                                                               \
+                 : "memory")
+template <int SET>
+__device__ __forceinline__ void take_block_flagged(uint32_t (&a)[16], uint32_t f) {
+    if (SET == 0) FGFA_TAKE16F(f, "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111");
+    else if (SET == 2) FGFA_TAKE16F(f, "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+    else FGFA_TAKE16F(f, "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+}
 template <int SET>
 __device__ __forceinline__ void take_block(uint32_t (&a)[16]) {
     if (SET == 0) FGFA_TAKE16("v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111");
@@ -375,10 +395,11 @@ __device__ __forceinline__ uint32_t take_slots(uint32_t *bcur, int lane, bool va
 // next item nobody has taken yet (two cells, by item parity), how many waves have left the item
 // (two cells), and how many items are complete.
 // k_scan's builds: plain, diagnostic (FLATGFA_DEBUG_SKIP), ranged (one of several walks of a graph beyond 16 M segments)
-constexpr int kModePlain = 0, kModeDbg = 1, kModeRanged = 2, kModeBig = 3, kModeRangedBig = 4, kModePacked = 5, kModePackedRanged = 6;  // (Big: builds of their own for bucket arrays of 2^30 records or more, see put(); Packed: sub-buckets of exactly the size their records need, items dealt in a fixed order)
+constexpr int kModePlain = 0, kModeDbg = 1, kModeRanged = 2, kModeBig = 3, kModeRangedBig = 4, kModePacked = 5, kModePackedRanged = 6, kModePlainFlags = 7, kModePackedFlags = 8;  // (...Flags: the plain and the packed build for plans with per-block no-claim flags, ScanArgs::cflags)  // (Big: builds of their own for bucket arrays of 2^30 records or more, see put(); Packed: sub-buckets of exactly the size their records need, items dealt in a fixed order)
 constexpr bool mode_ranged(int m) { return m == kModeRanged || m == kModeRangedBig || m == kModePackedRanged; }
 constexpr bool mode_big(int m) { return m == kModeBig || m == kModeRangedBig; }
-constexpr bool mode_packed(int m) { return m == kModePacked || m == kModePackedRanged; }
+constexpr bool mode_packed(int m) { return m == kModePacked || m == kModePackedRanged || m == kModePackedFlags; }
+constexpr bool mode_flags(int m) { return m == kModePlainFlags || m == kModePackedFlags; }
 // A wave's run queue.  A packed call keeps two LDS tables for up to 4096 windows (cursors and the sub-buckets'
 // offsets), which leaves its queues 88 entries less: a block of (nearly) all starts is then queued behind a
 // drain down to one entry, and one of more than 1005 starts -- ids without any run at all, which such a plan is

@@ -91,6 +91,9 @@ __device__ __forceinline__ uint32_t epoch_now(uint32_t *ctl) {
 // the last run).  The whole run must lie below n_segs: that is the bounds check of every step in
 // it.  A run that crosses into the next window (at most one: runs are shorter than a window) is
 // emitted as two records.
+// (the builds whose records' tags come from the blocks' ids, see k_scan's block_flag: builds of their own -- the flags' loads and the tag's select cost the others' k_scan 1-1.5 %)
+template <int MODE>
+constexpr bool kBlockFlags = mode_flags(MODE);
 template <int MODE, int K>
 __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *bcur, uint32_t *mine, uint32_t base, uint32_t n) {
     constexpr bool DBG = MODE == kModeDbg;
@@ -101,7 +104,7 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
     const uint32_t down = w.dir == 1u ? 0u : ~0u;
     uint2 e[K], s[K];
     bool valid[K], cross[K];
-    uint32_t win[K], rel[K], lenm1[K], pos[K];
+    uint32_t win[K], rel[K], lenm1[K], pos[K], ncm[K];
     bool bad = false, any_cross = false;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -115,6 +118,12 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
         lenm1[k] = (s[k].y - e[k].y - 1u) & 1023u;
         valid[k] = valid[k] && e[k].x != kInvalid;
         uint32_t id = e[k].x - (lenm1[k] & down);  // a downward run is emitted from its low end
+        if constexpr (kBlockFlags<MODE>) {
+            ncm[k] = (uint32_t)((int32_t)id >> 31) & (kTagNoClaim << kTagShift);  // (bit 31 of a block's ids: its records need no claim -- all tag bits set)
+            id &= 0x7FFFFFFFu;
+        } else {
+            ncm[k] = 0u;
+        }
         if (mode_ranged(MODE)) {  // (uniform) the run's part inside this walk's range, if any; beyond the graph: the bounds check below
             const uint32_t hi = id + lenm1[k];
             const bool outside = hi >= A.n_total;
@@ -139,13 +148,13 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const uint32_t l1 = cross[k] ? wmask - rel[k] : lenm1[k];
-        ovf |= put<DBG, mode_big(MODE), mode_packed(MODE)>(A, w, mine, valid[k], pos[k], win[k], rel[k] | (l1 << wb) | w.tagc);
+        ovf |= put<DBG, mode_big(MODE), mode_packed(MODE)>(A, w, mine, valid[k], pos[k], win[k], rel[k] | (l1 << wb) | w.tagc | ncm[k]);
     }
     if (__builtin_amdgcn_ballot_w64(any_cross)) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t pos2 = cross[k] ? atomicAdd(&bcur[win[k] + 1u], 1u) : 0u;
-            ovf |= put<DBG, mode_big(MODE), mode_packed(MODE)>(A, w, mine, cross[k], pos2, win[k] + 1u, ((lenm1[k] - (wmask - rel[k]) - 1u) << wb) | w.tagc);
+            ovf |= put<DBG, mode_big(MODE), mode_packed(MODE)>(A, w, mine, cross[k], pos2, win[k] + 1u, ((lenm1[k] - (wmask - rel[k]) - 1u) << wb) | w.tagc | ncm[k]);
         }
     }
     flag_if_any(A, ovf, kStOverflow);
@@ -438,8 +447,47 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     // before it (its cursor snapshot is taken then), or -- tagged -- the one kTagSlots before it.
     uint32_t need = 0;
     w.dir = __builtin_amdgcn_readfirstlane(it.dir);
-#define FGFA_ITEM_TAG() (TAGGED ? __builtin_amdgcn_readfirstlane(it.noclaim ? kTagNoClaim : it.shared ? kTagCount - 1u - it.shared : rr) << kTagShift : 1u << 24)
+#define FGFA_ITEM_TAG() (TAGGED ? __builtin_amdgcn_readfirstlane((it.noclaim && !kBlockFlags<MODE>) ? kTagNoClaim : it.shared ? kTagCount - 1u - it.shared : rr) << kTagShift : 1u << 24)
     w.tagc = FGFA_ITEM_TAG();
+    // Whether block j of the current item makes no-claim records: the item's path never meets a segment twice (items[].z bit 31),
+    // or every 16-step chunk of the block lies in windows its path enters once and walks one way (ScanArgs::cflags: a bit per
+    // chunk of the step array; a block's 64 are three scalar loads).  The bit rides on top of the block's ids (take_block_flagged)
+    // into the tag of every record they make (emit_raw).
+    typedef __attribute__((address_space(4))) const uint32_t cu32;
+    // (in two halves: the three words are asked for when a landing set is given its next block, and looked at once the block in hand
+    // has been walked -- a scalar load's quarter of a microsecond would otherwise be waited for on the spot, once per block)
+    const auto flag_fetch = [&](uint32_t j, uint32_t (&fw)[3]) {
+        fw[0] = fw[1] = fw[2] = 0u;
+        j = __builtin_amdgcn_readfirstlane(j);
+        if (TAGGED && kBlockFlags<MODE> && A.cflags && j < (uint32_t)__builtin_amdgcn_readfirstlane(it.nblk)) {
+            const uint32_t c0 = __builtin_amdgcn_readfirstlane((uint32_t)(it.t0 >> 4)) + 64u * j;
+            cu32 *cw = reinterpret_cast<cu32 *>(reinterpret_cast<uintptr_t>(A.cflags + (c0 >> 5)));
+            fw[0] = cw[0];
+            fw[1] = cw[1];
+            fw[2] = cw[2];
+        }
+    };
+    const auto flag_eval = [&](uint32_t j, const uint32_t (&fw)[3]) -> uint32_t {
+        uint32_t f = __builtin_amdgcn_readfirstlane(it.noclaim);
+        const uint32_t nblk_ = __builtin_amdgcn_readfirstlane(it.nblk);  // (the item's fields are the same in every lane; the compiler is told so)
+        j = __builtin_amdgcn_readfirstlane(j);
+        if (TAGGED && kBlockFlags<MODE> && A.cflags && j < nblk_) {
+            const uint32_t c0 = __builtin_amdgcn_readfirstlane((uint32_t)(it.t0 >> 4)) + 64u * j;
+            const uint32_t n = j + 1u == nblk_ ? __builtin_amdgcn_readfirstlane(it.nl_last) : 64u;
+            const unsigned long long lo = (unsigned long long)fw[0] | ((unsigned long long)fw[1] << 32);
+            const uint32_t sh = c0 & 31u;
+            const unsigned long long v = (lo >> sh) | (sh ? (unsigned long long)fw[2] << (64u - sh) : 0ull);
+            const unsigned long long need_ = n >= 64u ? ~0ull : (1ull << n) - 1ull;
+            f |= (v & need_) == need_ ? 1u : 0u;
+        }
+        return __builtin_amdgcn_readfirstlane(f);
+    };
+    const auto block_flag = [&](uint32_t j) -> uint32_t {
+        uint32_t fw[3];
+        flag_fetch(j, fw);
+        return flag_eval(j, fw);
+    };
+    uint32_t bfl[3] = {0u, 0u, 0u};  // (uniform) the flags of the blocks the landing sets hold
     uint32_t blk[3];  // the block each landing set holds (or will hold next)
     uint32_t resv;    // the block this wave takes after those
     // (a partial block is read whole: make_item has made sure that stays inside the step array)
@@ -462,6 +510,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         if (blk[0] < it.nblk) FGFA_LOAD_BLOCK(0, blk[0]);                   \
         if (blk[1] < it.nblk) FGFA_LOAD_BLOCK(1, blk[1]);                   \
         if (blk[2] < it.nblk) FGFA_LOAD_BLOCK(2, blk[2]);                   \
+        if (TAGGED && kBlockFlags<MODE>) bfl[0] = block_flag(blk[0]), bfl[1] = block_flag(blk[1]), bfl[2] = block_flag(blk[2]); \
     } while (0)
     // one block: wait for its data, take the next free block for its register set, process it
 #define FGFA_BLOCK(SET)                                                                       \
@@ -470,10 +519,13 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         wait_block<SET>(w);                                                                   \
         tmark<DBG>(A, w, 0);                                                                  \
         uint32_t a[16];                                                                       \
-        take_block<SET>(a);                                                                   \
+        if constexpr (TAGGED && kBlockFlags<MODE>) take_block_flagged<SET>(a, bfl[SET]);      \
+        else take_block<SET>(a);                                                              \
         const uint32_t mine_now = blk[SET];                                                   \
         blk[SET] = resv;  /* taken one block ago, so that the LDS round trip is off this path */ \
         if (blk[SET] < it.nblk) FGFA_LOAD_BLOCK(SET, blk[SET]);                               \
+        uint32_t fw_[3];                                                                      \
+        if (TAGGED && kBlockFlags<MODE>) flag_fetch(blk[SET], fw_);                           \
         uint32_t got = 0;                                                                     \
         if (lane == 0) got = atomicAdd(&ctl[kCtlNext + (rr & kRing)], 1u);                    \
         if (!FGFA_SKIP(kDbgNoTiles)) {                                                        \
@@ -482,6 +534,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             atomicOr(A.status, kStDebug);                                                     \
         }                                                                                     \
         resv = __builtin_amdgcn_readfirstlane(got);                                           \
+        if (TAGGED && kBlockFlags<MODE>) bfl[SET] = flag_eval(blk[SET], fw_);                 \
     }
     FGFA_PRELOAD();
 
@@ -881,6 +934,7 @@ bool scan_kernels_setup() {
         for (const void *k : {(const void *)k_scan<kModePlain, false>, (const void *)k_scan<kModePlain, true>, (const void *)k_scan<kModeRanged, false>,
                               (const void *)k_scan<kModeRanged, true>, (const void *)k_scan<kModeBig, true>, (const void *)k_scan<kModeRangedBig, true>,
                               (const void *)k_scan<kModePacked, true>, (const void *)k_scan<kModePackedRanged, true>,
+                              (const void *)k_scan<kModePlainFlags, true>, (const void *)k_scan<kModePackedFlags, true>,
 #ifdef FGFA_MEASURE
                               (const void *)k_scan<kModeDbg, false>,
 #endif
@@ -899,6 +953,8 @@ int launch_scan(const FastPlan &fp, const ScanArgs &sa, bool tagged, uint32_t gr
 #ifdef FGFA_MEASURE
     else if (fp.dbg) hipLaunchKernelGGL((k_scan<kModeDbg, false>), g, b, lds, stream, sa);
 #endif
+    else if (sa.cflags && tagged && !sa.ranged && fp.packed) hipLaunchKernelGGL((k_scan<kModePackedFlags, true>), g, b, lds, stream, sa);  // (a packed call's offsets are its region's: `big` is not its business)
+    else if (sa.cflags && tagged && !sa.ranged && !sa.big && !fp.packed) hipLaunchKernelGGL((k_scan<kModePlainFlags, true>), g, b, lds, stream, sa);
     else if (fp.packed && sa.ranged) hipLaunchKernelGGL((k_scan<kModePackedRanged, true>), g, b, lds, stream, sa);
     else if (fp.packed) hipLaunchKernelGGL((k_scan<kModePacked, true>), g, b, lds, stream, sa);
     else if (sa.big && !tagged) { set_error("fast_seg_depth: a bucket array this large needs a tagged call"); return FLATGFA_ERR_ARG; }

@@ -29,13 +29,18 @@ void walk(uint64_t seed, uint32_t S, uint32_t p, uint32_t L, int model, Handle *
         uint64_t j = r >> 32;
         if (model == 1) {
             cur = j % S;
-        } else if (model == 2 || model == 3) {  // chromosome: along the graph, odd paths downwards with flipped handles
+        } else if (model == 2 || model == 3 || model == 4) {  // chromosome: along the graph, odd paths downwards with flipped handles
             out[t].bits ^= p & 1u;
             uint64_t u = (r >> 8) % 100, k = (r >> 16) & 0xFF;
             uint64_t d = u < 70 ? 1 : u < 95 ? 2 + (k & 3) : 8 + (k & 63);
-            if (model == 3 && u >= 99) d = (k & 0xF0) ? 1 : 64 + (j & 1023);  // haplotype: no jumps anywhere; one step in 1600 skips up to 1087 segments (a structural variant, not another chromosome)
+            if (model >= 3 && u >= 99) d = (k & 0xF0) ? 1 : 64 + (j & 1023);  // haplotype: no jumps anywhere; one step in 1600 skips up to 1087 segments (a structural variant, not another chromosome)
             d %= S;
-            cur = (u < 99 || model == 3) ? ((p & 1u) ? cur + S - d : cur + d) % S : j % S;
+            bool ahead = (p & 1u) == 0;
+            if (model == 4 && u == 98 && (k & 0xFC) == 0) {  // repeats: a haplotype walk that, one step in 6400, goes 16 .. 271 segments BACK and walks them again (a tandem duplication)
+                d = (16 + (j & 255)) % S;
+                ahead = !ahead;
+            }
+            cur = (u < 99 || model >= 3) ? (ahead ? cur + d : cur + S - d) % S : j % S;
         } else {
             uint64_t u = (r >> 8) % 100, k = (r >> 16) & 0xFF;
             if (u < 90) cur += 1;

@@ -447,7 +447,7 @@ def load(filename: Union[str, os.PathLike]) -> FlatGFA:
 def synth(seed: int, n_segs: int, n_paths: int, steps_per_path: int, model: str = "pangenome",
           with_seq: bool = False) -> FlatGFA:
     """The deterministic synthetic graph of SURVEY.md 8(d)."""
-    m = {"pangenome": 0, "uniform": 1, "chromosome": 2, "haplotype": 3}[model]
+    m = {"pangenome": 0, "uniform": 1, "chromosome": 2, "haplotype": 3, "repeats": 4}[model]
     return FlatGFA(_lib.lib().flatgfa_synth(seed, n_segs, n_paths, steps_per_path, m, with_seq))
 
 

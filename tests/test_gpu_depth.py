@@ -258,6 +258,7 @@ SHAPES = [
     (29, 30_000, 200, 900, "chromosome"),      # the wave-per-path kernels see downward paths as runs of one
     (31, 300_000, 40, 60_000, "haplotype"),    # haplotype walks: strictly monotone but for those that wrap around the last segment (records that skip pass 2's claim)
     (32, 2_000_000, 9, 500_000, "haplotype"),  # ... long ones, cut into pieces that are put together again by the plan
+    (33, 400_000, 50, 50_000, "repeats"),      # haplotype walks that go back over a few segments now and then: no-claim records block by block
     (26, 17_000_000, 3, 4000, "uniform"),      # beyond 2048 windows of 8192 segments: two ranges, two walks of the steps
     (30, 40_000_000, 5, 60_000, "chromosome"), # three ranges; runs that straddle a range boundary are split between the walks
 ]
@@ -322,7 +323,7 @@ def test_more_synthetic_graphs_match_slow_odgi_goldens(name, cfg, device_path):
     assert g.depth_table() == read(os.path.join(GOLDEN, name + ".depth.tsv"))
 
 
-@pytest.mark.parametrize("model", ["pangenome", "uniform", "chromosome", "haplotype"])
+@pytest.mark.parametrize("model", ["pangenome", "uniform", "chromosome", "haplotype", "repeats"])
 def test_cfgL_full_size(model):
     # BASELINE.json configs[2]: 1M segments / 100M steps.  Checked against the oracle (a few
     # seconds of CPU) and through size-independent properties.
@@ -1150,6 +1151,44 @@ def test_strictly_monotone_short_paths_skip_the_claim(no_claim, monkeypatch):
     plan.seg_depth(d, None)
     plan.status()
     assert (d.cpu().numpy().view(np.uint32) == want_d).all()
+
+
+@pytest.mark.parametrize("shape", [(300_000, 40, 60_000), (2_000_000, 9, 500_000), (5_000_000, 600, 30_000)])
+def test_stretches_that_need_no_claim_in_paths_that_are_not_monotone(shape, monkeypatch):
+    """A path that goes back over a few segments now and then (the `repeats` model: a tandem duplication every 6400 steps) is not
+    monotone as a whole, but most windows it enters once and walks one way: the plan marks the 16-step chunks that lie in such
+    windows only (k_visit_bits, k_chunk_flags), and k_scan's blocks made of them carry the no-claim tag.  Whole paths, paths cut
+    into pieces, 4096- and 8192-segment windows; the counts are the oracle's with the marks and without (FLATGFA_NO_CLAIM=0)."""
+    import re
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    S, P, L = shape
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
+    g = pa.synth(21, S, P, L, "repeats", False)
+    steps, pb, pe, _ = g.soa()
+    wd, wu = fo.seg_depth_with_uniq(pools_of(g))
+    assert (wd != wu).any()  # (the walks do meet segments twice)
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    for nc in ("", "0"):
+        if nc:
+            monkeypatch.setenv("FLATGFA_NO_CLAIM", nc)
+        else:
+            monkeypatch.delenv("FLATGFA_NO_CLAIM", raising=False)
+        plan = DepthPlan(DeviceGraph(steps, pb, pe, S))
+        desc = plan.describe()
+        assert "pass2=tagged" in desc, desc
+        m = re.search(r"no_claim_chunks=(\d+)", desc)
+        if nc:
+            assert m is None, desc
+        else:
+            assert m and int(m.group(1)) > P * L // 16 // 4, desc  # (more than a quarter of all chunks)
+        for _ in range(2):
+            plan.seg_depth(d, u)
+            plan.status()
+            assert (d.cpu().numpy().view(np.uint32) == wd).all(), desc
+            assert (u.cpu().numpy().view(np.uint32) == wu).all(), desc
 
 
 def test_small_windows_where_workgroups_take_dozens_of_items(monkeypatch):

@@ -257,7 +257,7 @@ def test_c_abi_sentinels():
     assert walked == [[(0, True), (1, True), (3, False)], [(0, True), (1, True), (2, True), (3, False)]]
 
 
-@pytest.mark.parametrize("model", ["pangenome", "uniform", "chromosome", "haplotype"])
+@pytest.mark.parametrize("model", ["pangenome", "uniform", "chromosome", "haplotype", "repeats"])
 def test_synth_cxx_matches_numpy_spec(model):
     for (seed, S, P, L) in [(1, 97, 5, 300), (7, 1000, 13, 257), (123456789, 1, 3, 10), (2, 50_000, 4, 5000)]:
         assert_same_pools(pa.synth(seed, S, P, L, model, True), synth.pools(seed, S, P, L, model))

@@ -28,6 +28,7 @@ PINNED = set(range(80, 128))
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 OK_LOAD = re.compile(r"^global_load_dwordx4 v\[(\d+):(\d+)\], v\[(\d+):(\d+)\], off( offset:(16|32|48|1024|2048|3072))?( (nt|sc0|sc1))*$")
 OK_TAKE = re.compile(r"^v_lshrrev_b32(_e32)? v(\d+), 1, v(\d+)$")
+OK_TAKE_F = re.compile(r"^v_alignbit_b32 v(\d+), s\d+, v(\d+), 1$")  # (take_block_flagged: a uniform bit on top of the id)
 
 
 def regs_of(text):
@@ -151,6 +152,10 @@ def main():
             continue
         m = OK_TAKE.match(s)
         if m and int(m.group(3)) in pinned and int(m.group(2)) not in pinned:
+            n_take += 1
+            continue
+        m = OK_TAKE_F.match(s)
+        if m and int(m.group(2)) in pinned and int(m.group(1)) not in pinned:
             n_take += 1
             continue
         bad.append(f"{func}: {s}")
