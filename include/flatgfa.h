@@ -267,7 +267,8 @@ typedef struct flatgfa_dev_graph_t {
  * reference would panic on the slice index (pool.rs:341-347).  The plan is laid out for the path
  * spans and the step values it was created with (how many runs each path has decides which
  * kernel walks it; a path that walks the segment ids strictly one way is counted without the
- * per-path "seen" set, flatgfa_dev_plan_describe: no_claim_items / no_claim_paths): neither may change while it
+ * per-path "seen" set, and so are the stretches of a path in windows it enters once and walks one way,
+ * flatgfa_dev_plan_describe: no_claim_items / no_claim_paths / no_claim_chunks): neither may change while it
  * lives.  Every call still checks the step values against n_segs and its scratch against what the
  * steps need, and reports an error -- or completes the call through the simple kernels -- rather
  * than a wrong answer when they no longer fit; what it does not re-check per step is that a path
