@@ -1191,6 +1191,40 @@ def test_stretches_that_need_no_claim_in_paths_that_are_not_monotone(shape, monk
             assert (u.cpu().numpy().view(np.uint32) == wu).all(), desc
 
 
+def test_no_claim_marks_where_spans_overlap(monkeypatch):
+    """The per-block no-claim marks are bits of the step array, and spans may overlap (pool.rs:80-124 allows it): a chunk two paths
+    walk must qualify for both.  Path A walks a stretch once; path B walks the same steps and then, in a copy of them, half of
+    them again -- B meets those windows twice, A does not, and neither may go without claims there."""
+    import re
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
+    monkeypatch.delenv("FLATGFA_NO_CLAIM", raising=False)
+    S, L = 1_000_000, 160_000
+    g = pa.synth(5, S, 6, L, "repeats", False)
+    st, _, _, _ = g.soa()
+    walks = [st[i * L:(i + 1) * L] for i in range(6)]
+    steps = np.concatenate([walks[0], walks[0], walks[1], walks[2], walks[2], walks[3], walks[4], walks[5]]).astype(np.uint32)
+    pb = np.array([0, 0, 2 * L, 3 * L, 3 * L + L // 3, 5 * L, 6 * L, 7 * L, 5 * L + 77], dtype=np.uint32)
+    pe = np.array([L, L + L // 2, 3 * L, 4 * L, 5 * L, 6 * L, 7 * L, 8 * L, 8 * L - 5], dtype=np.uint32)
+    paths = np.zeros(len(pb), dtype=fo.PATH_DT)
+    paths["steps_start"], paths["steps_end"] = pb, pe
+    pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
+    pools.paths, pools.steps, pools.segs = paths, steps, np.zeros(S, dtype=fo.SEG_DT)
+    wd, wu = fo.seg_depth_with_uniq(pools)
+    plan = DepthPlan(DeviceGraph(steps, pb, pe, S))
+    desc = plan.describe()
+    assert re.search(r"no_claim_chunks=\d+", desc), desc
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    for _ in range(2):
+        plan.seg_depth(d, u)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == wd).all(), desc
+        assert (u.cpu().numpy().view(np.uint32) == wu).all(), desc
+
+
 def test_small_windows_where_workgroups_take_dozens_of_items(monkeypatch):
     """A graph beyond 4 M segments gets 8192-segment windows -- unless a pass-1 workgroup takes so many claiming items
     that pass 2 is better off with eight private bitsets per wave, which only 4096-segment windows leave LDS for
