@@ -9,13 +9,13 @@ R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/profiles; mkdir -p $OUT; cd $R
 #  its per-kernel samples, like these traces, are taken one call after the other)
 CMD="bench.py --steps 40 --warmup 3 --in-flight 1 --no-cold"  # (--no-cold: roofline.frac_cold's plan has a trace of its own, 2c)
 # 1. the bench line itself (all workloads; cfgL is the headline)
-for w in cfgL cfgL-uniform cfgL-chrom cfgL-short cfgL-fewlong cfgL-4paths cfgL-medium cfgL-32k chrom-10k chrom-1k tiny-paths hap-1k hap-10k hap-100 cfgL-100kseg cfgL-4Mseg cfgL-16Mseg cfgL-64Mseg cfgM cfgS; do
+for w in cfgL cfgL-uniform cfgL-chrom cfgL-short cfgL-fewlong cfgL-4paths cfgL-medium cfgL-32k chrom-10k chrom-1k tiny-paths hap-1k hap-10k hap-100 hap-chr20 rep-chr20 cfgL-100kseg cfgL-4Mseg cfgL-16Mseg cfgL-64Mseg cfgM cfgS; do
   timeout 600 python3 bench.py --steps 40 --warmup 3 --workload $w 2>$OUT/_bench_$w.err | tail -1 > $OUT/${TAG}_bench_$w.json
   # (a workload whose secondary measurements do not apply -- a million tiny paths -- still gets its line)
   [ -s $OUT/${TAG}_bench_$w.json ] || timeout 600 python3 bench.py --steps 40 --warmup 3 --workload $w --no-extras 2>>$OUT/_bench_$w.err | tail -1 > $OUT/${TAG}_bench_$w.json
 done
 # 1b. chromosome-scale graphs (0.9 - 1.8 G steps; the secondary measurements are cfg-L's business)
-for w in chr-like chr-like-2k hap-16M hap-chr cfgL-x16 x16-16Mseg x16-16Mseg-chrom x16-16Mseg-contigs x16-16Mseg-fewlong chr-like-40M; do
+for w in chr-like chr-like-2k hap-16M rep-16M hap-chr cfgL-x16 x16-16Mseg x16-16Mseg-chrom x16-16Mseg-contigs x16-16Mseg-fewlong chr-like-40M; do
   timeout 900 python3 bench.py --steps 10 --warmup 2 --workload $w --no-extras --no-cpu-baseline 2>$OUT/_bench_$w.err | tail -1 > $OUT/${TAG}_bench_$w.json
 done
 # 2. kernel trace + stats of the same command (csv)
