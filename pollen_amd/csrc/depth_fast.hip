@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void k_chunk_flags(const uint32_t *__restrict_
                                                       unsigned long long *__restrict__ n_flagged) {
     for (uint32_t j = blockIdx.x; j < n_items; j += gridDim.x) {
         const uint4 it = items[j];
+        if (!clear && (it.z >> 31)) continue;  // (an item whose whole path qualifies carries the tag anyway: its chunks neither need marks nor count as a gain)
         const uint64_t t0 = std::min<uint64_t>(((uint64_t)it.x + 15) & ~15ull, it.y);  // (k_scan's make_item: the blocks start here ...)
         const uint64_t n_chunks = ((uint64_t)it.y - t0) / 16;                           // (... and hold whole chunks only)
         uint32_t mine = 0;
@@ -222,6 +223,37 @@ __global__ __launch_bounds__(256) void k_chunk_flags(const uint32_t *__restrict_
             }
         }
         if (mine) atomicAdd(clear ? n_flagged + 1 : n_flagged, (unsigned long long)mine);
+    }
+}
+
+// ... and which of k_scan's BLOCKS are made of such chunks only: the bit of a block's first chunk in `bflags` (k_scan: one scalar
+// load and a bit test per block).  Blocks as make_item cuts them; a thread per block; set and clear launches as above.
+__global__ __launch_bounds__(256) void k_block_flags(const uint4 *__restrict__ items, uint32_t n_items, uint64_t n_steps, bool clear,
+                                                      const uint32_t *__restrict__ cflags, uint32_t *__restrict__ bflags, unsigned long long *__restrict__ n_flagged) {
+    for (uint32_t j = blockIdx.x; j < n_items; j += gridDim.x) {
+        const uint4 it = items[j];
+        if (!clear && (it.z >> 31)) continue;
+        const uint64_t t0 = std::min<uint64_t>(((uint64_t)it.x + 15) & ~15ull, it.y);
+        uint64_t chunks = ((uint64_t)it.y - t0) / 16;
+        if ((chunks % 64) && t0 + ((chunks + 63) / 64) * 1024 > n_steps) chunks -= chunks % 64;  // (make_item: a last block that would reach past the steps is left to the tail tiles)
+        const uint64_t nblk = (chunks + 63) / 64;
+        unsigned long long mine = 0;
+        for (uint64_t b = threadIdx.x; b < nblk; b += 256) {
+            const uint64_t c0 = t0 / 16 + 64 * b;
+            const uint32_t n = (uint32_t)std::min<uint64_t>(64, chunks - 64 * b), sh = (uint32_t)(c0 & 31u);
+            const uint32_t *cw = cflags + (c0 >> 5);
+            const unsigned long long lo = (unsigned long long)cw[0] | ((unsigned long long)cw[1] << 32);
+            const unsigned long long v = (lo >> sh) | (sh ? (unsigned long long)cw[2] << (64u - sh) : 0ull);
+            const unsigned long long need = n >= 64u ? ~0ull : (1ull << n) - 1ull;
+            const bool ok = (v & need) == need;
+            if (!clear && ok) {
+                atomicOr(&bflags[c0 >> 5], 1u << sh);
+                mine += n;
+            } else if (clear && !ok) {
+                (void)atomicAnd(&bflags[c0 >> 5], ~(1u << sh));
+            }
+        }
+        if (mine) atomicAdd(n_flagged, mine);
     }
 }
 
@@ -812,6 +844,9 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
                     if (e2 == hipSuccess) e2 = hipMemcpy(d_pbeg, hb, (size_t)g.n_paths * 4, hipMemcpyHostToDevice);
                     if (e2 == hipSuccess) e2 = hipMalloc(&d_cnt, 16);
                     if (e2 == hipSuccess) e2 = hipMemset(d_cnt, 0, 16);
+                    uint32_t *d_chunks = nullptr;
+                    if (e2 == hipSuccess) e2 = hipMalloc(&d_chunks, flag_words * 4);
+                    if (e2 == hipSuccess) e2 = hipMemset(d_chunks, 0, flag_words * 4);
                     if (e2 == hipSuccess) e2 = hipMalloc(&fp->cflags, flag_words * 4);
                     if (e2 == hipSuccess) e2 = hipMemset(fp->cflags, 0, flag_words * 4);
                     if (e2 == hipSuccess) {
@@ -822,16 +857,24 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
 #endif
                         for (int clear = 0; clear < (FGFA_SKIP_FLAG_CLEAR ? 1 : 2); ++clear)
                             hipLaunchKernelGGL(k_chunk_flags, grid, dim3(256), 0, nullptr, g.steps, reinterpret_cast<const uint4 *>(fp->items), fp->n_items, clear != 0, wb, n_win,
-                                               d_vis, fp->cflags, d_cnt);
+                                               d_vis, d_chunks, d_cnt);
+                        (void)hipMemsetAsync(d_cnt, 0, 16, nullptr);
+                        for (int clear = 0; clear < (FGFA_SKIP_FLAG_CLEAR ? 1 : 2); ++clear)
+                            hipLaunchKernelGGL(k_block_flags, grid, dim3(256), 0, nullptr, reinterpret_cast<const uint4 *>(fp->items), fp->n_items, g.n_steps, clear != 0,
+                                               d_chunks, fp->cflags, d_cnt);
                         e2 = hipMemcpy(cnt2, d_cnt, 16, hipMemcpyDeviceToHost);
-                        flagged = cnt2[0] > cnt2[1] ? cnt2[0] - cnt2[1] : 0;  // (marks set, less those another path's item took away; an upper bound where three overlap)
+                        flagged = cnt2[0];  // (chunks of claiming items' blocks that qualify as wholes; where spans overlap, before another path took a mark away)
                     }
                     if (d_vis) (void)hipFree(d_vis);
+                    if (d_chunks) (void)hipFree(d_chunks);
                     if (d_pbeg) (void)hipFree(d_pbeg);
                     if (d_cnt) (void)hipFree(d_cnt);
-                    // (worth it from a tenth of the chunks: pass 2's build with the no-claim test costs the claiming records 4 %, and cfg-L's
-                    // random walks have one chunk in a thousand that qualifies)
-                    if (e2 != hipSuccess || flagged * 160 < item_steps) {  // (nothing gained: the plain kernels, no table)
+                    // (worth it from half of the chunks: pass 2's build with the no-claim test costs the claiming records 4 %, k_scan's with the
+                    // marks 1-10 % (short items most), and the claims are two fifths of pass 2 -- contigs of ten blocks with a third of
+                    // their chunks marked lost 7 % of the call; cfg-L's random walks have one chunk in a thousand that qualifies)
+                    uint64_t min_pct = 50;
+                    if (const char *f = getenv("FLATGFA_NO_CLAIM_BLOCKS_MIN")) min_pct = strtoull(f, nullptr, 10);  // tests, measurements
+                    if (e2 != hipSuccess || flagged == 0 || flagged * 1600 < item_steps * min_pct) {  // (nothing gained: the plain kernels, no table)
                         if (fp->cflags) (void)hipFree(fp->cflags);
                         fp->cflags = nullptr;
                         flagged = 0;

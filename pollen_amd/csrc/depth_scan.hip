@@ -450,44 +450,23 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
 #define FGFA_ITEM_TAG() (TAGGED ? __builtin_amdgcn_readfirstlane((it.noclaim && !kBlockFlags<MODE>) ? kTagNoClaim : it.shared ? kTagCount - 1u - it.shared : rr) << kTagShift : 1u << 24)
     w.tagc = FGFA_ITEM_TAG();
     // Whether block j of the current item makes no-claim records: the item's path never meets a segment twice (items[].z bit 31),
-    // or every 16-step chunk of the block lies in windows its path enters once and walks one way (ScanArgs::cflags: a bit per
-    // chunk of the step array; a block's 64 are three scalar loads).  The bit rides on top of the block's ids (take_block_flagged)
+    // or every 16-step chunk of the block lies in windows its path enters once and walks one way (ScanArgs::cflags: the bit of the
+    // block's first chunk, set by the plan's k_block_flags).  The bit rides on top of the block's ids (take_block_flagged)
     // into the tag of every record they make (emit_raw).
     typedef __attribute__((address_space(4))) const uint32_t cu32;
-    // (in two halves: the three words are asked for when a landing set is given its next block, and looked at once the block in hand
-    // has been walked -- a scalar load's quarter of a microsecond would otherwise be waited for on the spot, once per block)
-    const auto flag_fetch = [&](uint32_t j, uint32_t (&fw)[3]) {
-        fw[0] = fw[1] = fw[2] = 0u;
+    // (in two halves: the word is asked for when a landing set is given its next block, and looked at when the block is taken --
+    // a scalar load's quarter of a microsecond would otherwise be waited for on the spot, once per block)
+    const auto flag_fetch = [&](uint32_t j) -> uint32_t {
+        uint32_t word = 0u;
         j = __builtin_amdgcn_readfirstlane(j);
         if (TAGGED && kBlockFlags<MODE> && A.cflags && j < (uint32_t)__builtin_amdgcn_readfirstlane(it.nblk)) {
             const uint32_t c0 = __builtin_amdgcn_readfirstlane((uint32_t)(it.t0 >> 4)) + 64u * j;
-            cu32 *cw = reinterpret_cast<cu32 *>(reinterpret_cast<uintptr_t>(A.cflags + (c0 >> 5)));
-            fw[0] = cw[0];
-            fw[1] = cw[1];
-            fw[2] = cw[2];
+            word = *reinterpret_cast<cu32 *>(reinterpret_cast<uintptr_t>(A.cflags + (c0 >> 5))) >> (c0 & 31u);
         }
+        return word;
     };
-    const auto flag_eval = [&](uint32_t j, const uint32_t (&fw)[3]) -> uint32_t {
-        uint32_t f = __builtin_amdgcn_readfirstlane(it.noclaim);
-        const uint32_t nblk_ = __builtin_amdgcn_readfirstlane(it.nblk);  // (the item's fields are the same in every lane; the compiler is told so)
-        j = __builtin_amdgcn_readfirstlane(j);
-        if (TAGGED && kBlockFlags<MODE> && A.cflags && j < nblk_) {
-            const uint32_t c0 = __builtin_amdgcn_readfirstlane((uint32_t)(it.t0 >> 4)) + 64u * j;
-            const uint32_t n = j + 1u == nblk_ ? __builtin_amdgcn_readfirstlane(it.nl_last) : 64u;
-            const unsigned long long lo = (unsigned long long)fw[0] | ((unsigned long long)fw[1] << 32);
-            const uint32_t sh = c0 & 31u;
-            const unsigned long long v = (lo >> sh) | (sh ? (unsigned long long)fw[2] << (64u - sh) : 0ull);
-            const unsigned long long need_ = n >= 64u ? ~0ull : (1ull << n) - 1ull;
-            f |= (v & need_) == need_ ? 1u : 0u;
-        }
-        return __builtin_amdgcn_readfirstlane(f);
-    };
-    const auto block_flag = [&](uint32_t j) -> uint32_t {
-        uint32_t fw[3];
-        flag_fetch(j, fw);
-        return flag_eval(j, fw);
-    };
-    uint32_t bfl[3] = {0u, 0u, 0u};  // (uniform) the flags of the blocks the landing sets hold
+    const auto flag_eval = [&](uint32_t word) -> uint32_t { return __builtin_amdgcn_readfirstlane((it.noclaim | word) & 1u); };
+    uint32_t fwb[3] = {0u, 0u, 0u};  // (uniform) bit 0: the mark of the block each landing set holds -- asked for with the block, looked at when it is taken
     uint32_t blk[3];  // the block each landing set holds (or will hold next)
     uint32_t resv;    // the block this wave takes after those
     // (a partial block is read whole: make_item has made sure that stays inside the step array)
@@ -510,7 +489,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         if (blk[0] < it.nblk) FGFA_LOAD_BLOCK(0, blk[0]);                   \
         if (blk[1] < it.nblk) FGFA_LOAD_BLOCK(1, blk[1]);                   \
         if (blk[2] < it.nblk) FGFA_LOAD_BLOCK(2, blk[2]);                   \
-        if (TAGGED && kBlockFlags<MODE>) bfl[0] = block_flag(blk[0]), bfl[1] = block_flag(blk[1]), bfl[2] = block_flag(blk[2]); \
+        if (TAGGED && kBlockFlags<MODE>) fwb[0] = flag_fetch(blk[0]), fwb[1] = flag_fetch(blk[1]), fwb[2] = flag_fetch(blk[2]); \
     } while (0)
     // one block: wait for its data, take the next free block for its register set, process it
 #define FGFA_BLOCK(SET)                                                                       \
@@ -519,13 +498,12 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
         wait_block<SET>(w);                                                                   \
         tmark<DBG>(A, w, 0);                                                                  \
         uint32_t a[16];                                                                       \
-        if constexpr (TAGGED && kBlockFlags<MODE>) take_block_flagged<SET>(a, bfl[SET]);      \
+        if constexpr (TAGGED && kBlockFlags<MODE>) take_block_flagged<SET>(a, flag_eval(fwb[SET])); \
         else take_block<SET>(a);                                                              \
         const uint32_t mine_now = blk[SET];                                                   \
         blk[SET] = resv;  /* taken one block ago, so that the LDS round trip is off this path */ \
         if (blk[SET] < it.nblk) FGFA_LOAD_BLOCK(SET, blk[SET]);                               \
-        uint32_t fw_[3];                                                                      \
-        if (TAGGED && kBlockFlags<MODE>) flag_fetch(blk[SET], fw_);                           \
+        if (TAGGED && kBlockFlags<MODE>) fwb[SET] = flag_fetch(blk[SET]);                     \
         uint32_t got = 0;                                                                     \
         if (lane == 0) got = atomicAdd(&ctl[kCtlNext + (rr & kRing)], 1u);                    \
         if (!FGFA_SKIP(kDbgNoTiles)) {                                                        \
@@ -534,7 +512,6 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             atomicOr(A.status, kStDebug);                                                     \
         }                                                                                     \
         resv = __builtin_amdgcn_readfirstlane(got);                                           \
-        if (TAGGED && kBlockFlags<MODE>) bfl[SET] = flag_eval(blk[SET], fw_);                 \
     }
     FGFA_PRELOAD();
 

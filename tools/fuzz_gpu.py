@@ -37,7 +37,10 @@ ENVS = [{}, {"FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0"}, {"FL
         {"FLATGFA_ACC_OWN": "1", "FLATGFA_ACC_SLOTS": "8", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
         {"FLATGFA_ACC_OWN": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed", "FLATGFA_PIECE_STEPS": "3000"},
         {"FLATGFA_ACC_OWN": "1", "FLATGFA_SCAN_WGS": "16", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
-        {"FLATGFA_ACC_OWN": "1", "FLATGFA_PACKED": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"}]
+        {"FLATGFA_ACC_OWN": "1", "FLATGFA_PACKED": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_NO_CLAIM_BLOCKS_MIN": "0", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_NO_CLAIM_BLOCKS_MIN": "0", "FLATGFA_PACKED": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_NO_CLAIM_BLOCKS_MIN": "0", "FLATGFA_PIECE_STEPS": "3000", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"}]
 
 
 def random_graph(rng):
