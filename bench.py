@@ -28,7 +28,7 @@ Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel: its own alg
 (k_scan reads every step once: 4N + 8P; k_accum writes the result vectors: 4Sk) over its average
 duration from HIP events recorded around each launch on the launch stream, eighteen consecutive calls
 that run one after the other on a plan of its own right behind the timed region (`frac`; `frac_cold`: the
-same with no step kept in the Infinity Cache); `roofline.whole_call` is the whole call's algorithmic bytes
+same with no step kept in the Infinity Cache; `whole_call.timed_region_cold`: the region itself that way); `roofline.whole_call` is the whole call's algorithmic bytes
 (4N + 8P + 4Sk) over the sum of its kernels, and -- `timed_region` -- over the region's ms_per_step.  `cpu_baseline` is the single-threaded C oracle (the reference's loop
 is single-threaded) timed on this host.
 """
@@ -457,6 +457,31 @@ def main():
                     "same_result": bool((cold.cpu().numpy() == op1.buf.cpu().numpy()).all()) if world == 1 else None}
             plan0.close()
             del plan0, cold
+            # ... and the timed region the same way: a pipeline whose lanes keep nothing of the steps in the Infinity Cache
+            if in_flight > 1 and isinstance(op, PipelinedDepth):
+                os.environ["FLATGFA_MALL_MB"] = "0"
+                try:
+                    op0 = PipelinedDepth(in_flight)
+                finally:
+                    del os.environ["FLATGFA_MALL_MB"]
+                op0.cur = len(op0.bufs) - 1
+                for _ in range(max(args.warmup, in_flight)):
+                    op0.run()
+                op0.finish()
+                torch.cuda.synchronize()
+                t0c = time.perf_counter()
+                for _ in range(args.steps):
+                    op0.run()
+                op0.finish()
+                torch.cuda.synchronize()
+                cold_region_ms = (time.perf_counter() - t0c) / args.steps * 1e3
+                same = all(bool((b.cpu().numpy() == op1.buf.cpu().numpy()).all()) for b in op0.bufs[:1])
+                roofline["whole_call"]["timed_region_cold"] = {
+                    "what": "the timed region again through a pipeline made with FLATGFA_MALL_MB=0: every step of every call from HBM",
+                    "calls_in_flight": in_flight, "ms_per_step": round(cold_region_ms, 5),
+                    "achieved": round(B_call / (cold_region_ms * 1e-3) / 1e9, 2), "frac": round(B_call / (cold_region_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "same_result": same}
+                del op0
         # An event pair also contains the launch itself; what it reads around a kernel of k_scan's
         # shape that does nothing is reported beside the kernel times, not subtracted from them
         # (rocprofv3's dispatch durations, profiles/, do not contain it).
