@@ -61,8 +61,9 @@ struct FastPlan {
                                    // with room for the short paths k_scan_short hands back
     uint32_t n_items = 0;
     uint32_t n_noclaim = 0;        // items whose path walks the segment ids strictly one way (their records skip pass 2's claim: depth_fast.hip kTagNoClaim)
-    uint32_t *cflags = nullptr;    // one bit per 16 steps of the step array: the chunk lies in windows its path enters once and walks one way -- a block
-                                   // of k_scan whose chunks all say so makes no-claim records too (k_visit_bits, k_chunk_flags); nullptr: none
+    uint32_t *cflags = nullptr;    // a bit per 16 steps of the step array, of which the one of a k_scan block's FIRST chunk counts: every chunk of the block
+                                   // lies in windows its path enters once and walks one way, and the block makes no-claim records too (k_visit_bits,
+                                   // k_chunk_flags, k_block_flags); nullptr: none
     uint64_t n_flag_chunks = 0;    // how many chunks say so
     uint32_t max_back = 0;
     bool accumulate = false;       // a group of paths behind the first (see fast_plan_create): pass 2 adds to the outputs

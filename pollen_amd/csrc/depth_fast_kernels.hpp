@@ -134,7 +134,7 @@ struct ScanArgs {
     // need -- counted once, with the items dealt in a fixed order -- and a workgroup's sub-buckets lie back to back:
     const uint32_t *pk_off;   // [n_slots][n_win + 1] where each of the workgroup's sub-buckets starts in its region (the last entry: the region's end, a sink)
     const uint64_t *pk_base;  // [n_slots] where the workgroup's region starts in `buckets`
-    const uint32_t *cflags;  // tagged: one bit per 16 steps -- the chunk's records need no claim (FastPlan::cflags); nullptr: the items' own flags only
+    const uint32_t *cflags;  // tagged: bit (first step / 16) of a block -- its records need no claim (FastPlan::cflags); nullptr: the items' own flags only
     uint64_t mall_steps; // blocks that start below this step index are read without the nt hint, so that they stay in the Infinity Cache from one call to the next (FastPlan::mall_steps)
     uint32_t *taken;     // tagged: [n_slots] how many items each workgroup took (its private tags are 0 .. taken - 1): pass 2 clears all of a wave's
                          // bitsets at once where a sub-bucket has no more tags than the wave has bitsets, and none changes hands inside it
