@@ -100,10 +100,18 @@ def kernel_bytes(name, N, P, S, k):
 
 
 def git_head():
+    """The commit this tree is at; on a GPU box (a snapshot without .git/) the one `make` stamped next to the library."""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
-                              timeout=5).stdout.strip() or None
+        out = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                             timeout=5).stdout.strip()
+        if out:
+            return out
     except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, "pollen_amd", "lib", "HEAD")) as f:
+            return f.read().strip() or None
+    except OSError:
         return None
 
 
@@ -169,7 +177,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     coll_device = device if backend == "nccl" else torch.device("cpu")  # where tensors of a collective live
-    scaling = args.scaling if world > 1 else "weak"  # N = 1: the two coincide; "weak" is what round 1 reported
+    scaling = args.scaling  # (N = 1: the two coincide, and the line says what the same command says at N > 1 -- "strong" by default, BASELINE.json configs[3])
 
     S, P, L, model = WORKLOADS[args.workload]
     N = P * L
@@ -197,6 +205,7 @@ def main():
             import ctypes
             self.pipe = dev.DepthPipeline(graph, k)
             self.bufs = [torch.zeros(2 * S, dtype=torch.int32, device=device) for _ in range(k)]
+            torch.cuda.synchronize(device)  # (the zero-fills run on torch's current stream, the first writers on the pipeline's own: nothing else orders them)
             self.cur = 0
             fn = dev._lib.lib().flatgfa_dev_pipeline_seg_depth
             none = ctypes.c_void_p(-1)  # (nothing to wait for: the buffers are this loop's own, a lane's calls are in order)
@@ -257,31 +266,51 @@ def main():
     sync_all()
 
     # ---- verification of what is being timed: the REDUCED vector against the oracle, on every rank ----
+    # Before the region (what the warm-up wrote) AND behind it: every result buffer the timed calls wrote, the buffers of
+    # the one-call-at-a-time loop and of the sampled pass, and those of the cold plan and the cold region are compared
+    # with the oracle's vector again once they have been written for the last time (`verified_after`); a line is only
+    # printed when all of them agree.
     verified = None
+    want = None
+    checked = []  # (what was compared with the oracle, and when: the line's `verified_after`)
     if not args.no_verify:
         from oracle import flatgfa_oracle as fo
         pools = fo.Pools(**{n: g.pool(n) for n in fo.POOL_ORDER})
         want_d, want_u = fo.seg_depth_with_uniq(pools)
         want = np.concatenate([want_d, want_u]).astype(np.int64)
+        del pools
         if world > 1 and not strong:
             # every rank has its own graph: the expected reduced vector is the sum of the ranks' oracle vectors
             t = torch.from_numpy(want).to(coll_device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             want = t.cpu().numpy()
-        got = op.buf.cpu().numpy().view(np.uint32).astype(np.int64)
-        ok = bool((got == want).all())
-        for b in op.bufs:  # (calls in flight: every plan's result, not only the last one's)
-            ok = ok and bool((b.cpu().numpy().view(np.uint32).astype(np.int64) == want).all())
+
+    def check_bufs(bufs, what):
+        """Every buffer of `bufs` ([depth | uniq], u32) against the oracle's vector, on every rank; exits when one differs."""
+        if want is None:
+            return None
+        ok, first_bad = True, None
+        for k, b in enumerate(bufs):
+            got = b.cpu().numpy().view(np.uint32).astype(np.int64)
+            if not bool((got == want).all()):
+                ok = False
+                if first_bad is None:
+                    bad = np.nonzero(got != want)[0]
+                    first_bad = (k, len(bad), bad[:4].tolist(), got[bad[:4]].tolist(), want[bad[:4]].tolist())
         if world > 1:
             t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=coll_device)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            ok = bool(int(t.item()))
-        verified = ok
-        if not verified:
-            bad = np.nonzero(got != want)[0]
-            raise SystemExit(f"rank {rank}: HIP result differs from the oracle in {len(bad)} of {len(want)} entries "
-                             f"(first at {bad[:4].tolist()}: got {got[bad[:4]].tolist()}, want {want[bad[:4]].tolist()}): "
-                             "refusing to report a number")
+            all_ok = bool(int(t.item()))
+        else:
+            all_ok = ok
+        if not all_ok:
+            detail = "" if first_bad is None else (f": buffer {first_bad[0]} differs in {first_bad[1]} of {len(want)} entries (first at {first_bad[2]}: "
+                                                   f"got {first_bad[3]}, want {first_bad[4]})")
+            raise SystemExit(f"rank {rank}: HIP result differs from the oracle {what}{detail}: refusing to report a number")
+        checked.append({"what": what, "buffers": len(bufs)})
+        return True
+
+    verified = check_bufs(op.bufs, "behind the warm-up, before the timed region")  # (calls in flight: every lane's result, not only the last one's)
 
     # ---- timed region: exactly K steps ----
     # Kernel durations come from HIP events recorded around each launch on the launch stream.  A step
@@ -311,6 +340,8 @@ def main():
     # duration next to another call's kernel on the same chip is not that kernel's own -- and every per-kernel
     # sample comes from the pass behind it, which runs one call after the other on the first plan alone.
     elapsed, kernels_region = timed_loop(lambda i: op.run(), args.steps, in_flight == 1)
+    status_all()
+    check_bufs(op.bufs, f"behind the timed region ({args.steps} steps, {in_flight} in flight)")  # (what the region's calls wrote, not the warm-up's)
     n_region_samples = len([i for i in range(args.steps) if i % EVENT_EVERY == EVENT_AT]) if in_flight == 1 else 0
     if in_flight > 1:
         SAMPLE_STEPS = 18
@@ -319,6 +350,8 @@ def main():
         for _ in range(2):
             op1.run()
         serial_elapsed, _ = timed_loop(lambda i: op1.run(), args.steps, False)
+        plan.status()
+        check_bufs(op1.bufs, "behind the one-call-at-a-time loop")
     # the sampled pass behind the region
     for _ in range(2):
         op1.run()
@@ -332,6 +365,7 @@ def main():
     n_timed_steps = n_region_samples + SAMPLE_STEPS
     status_all()
     plan.status()
+    check_bufs(op1.bufs, "behind the sampled pass (the calls whose kernels `roofline` prices)")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -455,6 +489,7 @@ def main():
                     "kernel_avg_ms": round(cold_ms, 5), "achieved": round(B_dom / (cold_ms * 1e-3) / 1e9, 2), "n": len(per0[dom]),
                     "kernels_avg_ms": {k: round(float(np.mean(v2)), 5) for k, v2 in per0.items()},
                     "same_result": bool((cold.cpu().numpy() == op1.buf.cpu().numpy()).all()) if world == 1 else None}
+            check_bufs([cold], "behind the cold plan's sampled calls (FLATGFA_MALL_MB=0)")
             plan0.close()
             del plan0, cold
             # ... and the timed region the same way: a pipeline whose lanes keep nothing of the steps in the Infinity Cache
@@ -475,7 +510,9 @@ def main():
                 op0.finish()
                 torch.cuda.synchronize()
                 cold_region_ms = (time.perf_counter() - t0c) / args.steps * 1e3
-                same = all(bool((b.cpu().numpy() == op1.buf.cpu().numpy()).all()) for b in op0.bufs[:1])
+                op0.pipe.status()
+                check_bufs(op0.bufs, f"behind the cold timed region ({args.steps} steps, {in_flight} in flight, FLATGFA_MALL_MB=0)")
+                same = all(bool((b.cpu().numpy() == op1.buf.cpu().numpy()).all()) for b in op0.bufs)
                 roofline["whole_call"]["timed_region_cold"] = {
                     "what": "the timed region again through a pipeline made with FLATGFA_MALL_MB=0: every step of every call from HBM",
                     "calls_in_flight": in_flight, "ms_per_step": round(cold_region_ms, 5),
@@ -569,6 +606,7 @@ def main():
             ppipe = dev.DepthPipeline(graph, in_flight)
             outs = [(torch.zeros(S, dtype=torch.int32, device=device), torch.zeros(P, dtype=torch.int64, device=device),
                      torch.zeros(P, dtype=torch.int64, device=device)) for _ in range(in_flight)]
+            torch.cuda.synchronize(device)  # (zero-fills on the current stream before first writers on the pipeline's own)
             for k in range(2 * in_flight):
                 ppipe.path_depth_all(*outs[k % in_flight], after_current_stream=False)
             ppipe.status()
@@ -881,6 +919,10 @@ def main():
                        "pipeline": op.pipe.describe() if isinstance(op, PipelinedDepth) else None,
                        "ranks_seen": ranks_seen, "uses_rccl": bool(world > 1 and backend == "nccl")},
             "bit_exact_vs_oracle": verified,
+            # one whole query with nothing else in flight (the loop of the same process that runs one call after the other);
+            # `ms_per_step` is the throughput of `calls_in_flight` overlapped queries
+            "one_call_ms": round(serial_elapsed / args.steps * 1e3, 5) if serial_elapsed else round(elapsed / args.steps * 1e3, 5),
+            "verified_after": checked if verified else None,
             "roofline": roofline, "cpu_baseline": cpu, "commit": git_head(),
         }
         if allreduce_ms is not None:

@@ -1308,7 +1308,8 @@ __global__ __launch_bounds__(kAccThreads) __attribute__((amdgpu_waves_per_eu(8, 
 
 bool accum_kernels_setup() {
     // pass 2 of a tagged call keeps its bitsets in dynamic shared memory (next to about 60 KB of static arrays, 93 KB with 8192-segment windows)
-    static const bool ok = [] {
+    static OncePerDevice once;
+    const bool ok = once([] {
         bool good = true;
         const auto set = [&](const void *k, uint32_t bytes) { good = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess && good; };
         set((const void *)k_accum<true, 11, false, false, false, true>, tagged_lds_bytes(11, kMaxShared));
@@ -1337,7 +1338,7 @@ bool accum_kernels_setup() {
         set((const void *)k_accum_pair<12, true>, tagged_lds_bytes(12, 0));
 #endif
         return good;
-    }();
+    });
     if (!ok) set_error("hipFuncSetAttribute(k_accum): dynamic shared memory");
     return ok;
 }

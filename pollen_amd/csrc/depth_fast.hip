@@ -921,7 +921,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             FAST_TRY(hipMemcpy(fp->other_ids, other.data(), other.size() * 4, hipMemcpyHostToDevice));
         }
     }
-    // (the attribute belongs to the kernel, not to the plan: set once per process by the translation unit that holds it)
+    // (the attribute belongs to the kernel, not to the plan: set once per device by the translation unit that holds it)
     if (!path_kernels_setup() || !scan_kernels_setup() || !accum_kernels_setup()) return false;
     FAST_TRY(hipMalloc(&fp->work_counter, 256));
     FAST_TRY(hipMemset(fp->work_counter, 0, 256));

@@ -10,11 +10,30 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 
 #include "depth_fast.hpp"
 #include "device_common.hpp"
 
 namespace fgfa_dev {
+
+// The runtime keeps a kernel's attributes (hipFuncSetAttribute: more than 64 KB of dynamic LDS) per DEVICE, and one process
+// may drive several (flatgfa_sharded_create: a plan per shard on its own device and host thread; Python: graphs on cuda:1 and
+// up).  `fn` runs once per device that is current when a plan is made there; devices beyond the mask's 64 run it every time.
+struct OncePerDevice {
+    std::mutex mu;
+    uint64_t done = 0;
+    template <class F>
+    bool operator()(F fn) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return true;
+        if (!fn()) return false;
+        if (dev >= 0 && dev < 64) done |= 1ull << dev;
+        return true;
+    }
+};
 
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
@@ -515,7 +534,7 @@ inline uint32_t tagged_lds_bytes(uint32_t wb, uint32_t n_shared, uint32_t slots 
 inline uint32_t dense_lds_bytes(uint32_t nwp) { return (6u * nwp + 64u + kDenseTile + 64u) * 4u; }  // (behind the stage: a sink, the totals of two tiles)
 
 // ---- the kernels' launchers: one per translation unit that holds kernels ----
-// (each sets its kernels' dynamic-LDS attribute once per process: the attribute belongs to the kernel, not to a plan)
+// (each sets its kernels' dynamic-LDS attribute once per DEVICE -- OncePerDevice above: the attribute belongs to the kernel, not to a plan)
 bool scan_kernels_setup();        // depth_scan.hip
 bool path_kernels_setup();        // depth_scan_paths.hip
 bool accum_kernels_setup();       // depth_accum.hip

@@ -906,7 +906,8 @@ __global__ __launch_bounds__(kThreads) void k_scan_dense(const ScanArgs A) {
 }  // namespace
 
 bool scan_kernels_setup() {
-    static const bool ok = [] {
+    static OncePerDevice once;
+    const bool ok = once([] {
         bool good = true;
         for (const void *k : {(const void *)k_scan<kModePlain, false>, (const void *)k_scan<kModePlain, true>, (const void *)k_scan<kModeRanged, false>,
                               (const void *)k_scan<kModeRanged, true>, (const void *)k_scan<kModeBig, true>, (const void *)k_scan<kModeRangedBig, true>,
@@ -918,7 +919,7 @@ bool scan_kernels_setup() {
                               (const void *)k_scan_dense})
             good = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) == hipSuccess && good;
         return good;
-    }();
+    });
     if (!ok) set_error("hipFuncSetAttribute(k_scan): dynamic shared memory");
     return ok;
 }

@@ -732,13 +732,14 @@ __global__ __launch_bounds__(kThreads) void k_scan_tiny(const ScanArgs A) {
 }  // namespace
 
 bool path_kernels_setup() {
-    static const bool ok = [] {
+    static OncePerDevice once;
+    const bool ok = once([] {
         bool good = true;
         for (const void *k : {(const void *)k_walk_short<true>, (const void *)k_walk_short<false>, (const void *)k_walk_medium<true>,
                               (const void *)k_walk_medium<false>, (const void *)k_walk_short<true, true>, (const void *)k_walk_medium<true, true>})
             good = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) == hipSuccess && good;
         return good;
-    }();
+    });
     if (!ok) set_error("hipFuncSetAttribute(k_scan_short): dynamic shared memory");
     return ok;
 }

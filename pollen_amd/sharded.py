@@ -94,6 +94,12 @@ class ShardedDepth:
             n_bufs = -(-max(n_bufs, len(self.local_fns)) // len(self.local_fns)) * len(self.local_fns)
         # one fused buffer per step in flight, so that a single collective carries both vectors
         self.bufs = [torch.zeros(k * self.n_segs, dtype=torch.int32, device=device) for _ in range(n_bufs)]
+        # The zero-fills run on torch's current stream; the buffers' first writers may run on side streams (`streams`) or
+        # on a stream the prepared calls were resolved for: those wait for the fills here, once (no host wait).
+        if self.streams is not None and torch.device(device).type == "cuda":
+            cur = torch.cuda.current_stream(torch.device(device))
+            for s in self.streams:
+                s.wait_stream(cur)
         self.works = [None] * len(self.bufs)
         self.cur = 0
         self.step = 0

@@ -1393,3 +1393,31 @@ def test_calls_in_flight_through_the_pipeline(calls_in_flight, monkeypatch):
         pipe.status()
     assert ei.value.code == -2  # FLATGFA_ERR_BOUNDS
     pipe.close()
+
+
+# ---- the randomised differential check (tools/fuzz_gpu.py) as part of the suite: a seeded slice of it ----
+@pytest.mark.parametrize("part", range(4))
+def test_fuzz_slice(part):
+    """Twenty-five seeded cases each of tools/fuzz_gpu.py: random graphs (segment counts from 1 to 9 M, mixes of tiny, short,
+    medium and long paths, monotone walks, spans with gaps and duplicates) through the forty-odd forced device
+    configurations of its ENVS list in turn -- node depth, unique depth, depth only, path sums of a subset and path depth
+    of all paths against the C oracle, bit for bit.  The four parts together walk cases 0..99 (every configuration twice)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(ROOT, "tools", "fuzz_gpu.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    saved = {k: os.environ.get(k) for k in fz.ENV_KEYS}
+    rng = np.random.default_rng(2026_06 + part)
+    failed = []
+    try:
+        for case in range(25 * part, 25 * part + 25):
+            ok, what = fz.run_case(rng, case, verbose=False)
+            if not ok:
+                failed.append(what)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert not failed, failed

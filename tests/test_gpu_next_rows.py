@@ -170,3 +170,67 @@ def test_overlap_few_pairs_touch(dense, monkeypatch):
     want = fo.path_touches(pools, np.arange(P, dtype=np.uint32))
     assert (got == want.reshape(P, P)).all()
     assert 0 < int(got.sum()) < P * P // 4
+
+
+# ---- f2 tied to rows the reference pins (tests/f2_pins.py): the product against slow_odgi's golden node depths and
+# ---- against its own path depth (a3), not against the oracle's restatement of window_depth.rs
+import f2_pins  # noqa: E402
+
+
+@pytest.mark.parametrize("name", f2_pins.PINNED_GRAPHS)
+def test_f2_one_base_windows_and_cut_intervals_against_golden_node_depths(name):
+    gfa = os.path.join(GOLDEN, name + ".gfa")
+    g = pa.parse(gfa)
+    pools = fo.parse_gfa(read(gfa))          # (layout only: which segment covers which base; the depths are the golden table's)
+    node_depth = f2_pins.golden_node_depth(name)
+    ln, mean = g.path_depth()
+    for pid in range(g.path_count):
+        layout = f2_pins.path_layout(pools, pid, node_depth)
+        total, want_mean = f2_pins.mean_depth(layout)
+        assert int(ln[pid]) == total
+        if total == 0:
+            continue
+        assert mean[pid] == want_mean
+        nm = g.get_path_name(pid)
+        if g.find_path(nm) != pid:
+            continue
+        # (b) windows of one base read the golden depth of the covering segment
+        want = f2_pins.per_base_depth(layout)
+        rows = g.window_depth_table(nm, 1).splitlines()
+        assert rows == [b"%s\t%d\t%d\t%d" % (nm, i, i + 1, want[i]) for i in range(total)], (name, pid)
+        # (c) intervals that cut segments: the golden depths summed in assign_depths' order, bitwise
+        for seed in range(3):
+            st, en = f2_pins.cut_points(total, 100 * pid + seed)
+            assert g.interval_depth(nm, st, en).tobytes() == f2_pins.expected_intervals(layout, st, en).tobytes(), (name, pid, seed)
+        # (a) one window over the whole path is path depth's mean (a few ulps where the length is no power of two)
+        w = g.interval_depth(nm, [0], [total])[0]
+        assert abs(w - mean[pid]) <= 8 * np.spacing(mean[pid])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_f2_whole_path_window_equals_path_depth_bitwise_for_power_of_two_lengths(seed):
+    g = pa.parse_bytes(f2_pins.pow2_gfa(seed, log2_len=7 + seed))
+    ln, mean = g.path_depth()
+    for pid in range(g.path_count):
+        assert int(ln[pid]) == 1 << (7 + seed)
+        nm = g.get_path_name(pid)
+        assert g.interval_depth(nm, [0], [int(ln[pid])]).tobytes() == mean[pid:pid + 1].tobytes()
+        assert g.window_depth_table(nm, int(ln[pid])) == b"%s\t0\t%d\t%s\n" % (nm, int(ln[pid]), pa.format_float(float(mean[pid]), 4).encode())
+
+
+def test_f2_pins_on_a_synthetic_graph_with_a_slow_odgi_golden():
+    g = pa.synth(13, 15_000, 12, 50_000, "chromosome", True)   # tests/golden/synth_chrom.depth.tsv is slow_odgi's table of this graph
+    pools = pools_of(g)
+    node_depth = f2_pins.golden_node_depth("synth_chrom")
+    for pid in (0, 5, 11):
+        layout = f2_pins.path_layout(pools, pid, node_depth)
+        total, want_mean = f2_pins.mean_depth(layout)
+        ln, mean = g.path_depth([pid])
+        assert int(ln[0]) == total and mean[0] == want_mean
+        nm = g.get_path_name(pid)
+        st, en = f2_pins.cut_points(total, pid, n_cuts=200)
+        assert g.interval_depth(nm, st, en).tobytes() == f2_pins.expected_intervals(layout, st, en).tobytes()
+        st1 = np.arange(3000, dtype=np.uint64)
+        got = g.interval_depth(nm, st1, st1 + 1)
+        want = f2_pins.per_base_depth(layout)[:3000]
+        assert [pa.format_float(float(x), 4) for x in got] == [str(d) for d in want]

@@ -88,3 +88,99 @@ def test_bed_parser_quirks():
     for bad in (b"\n", b"p\n", b"p\tx\t1\n", b"p\t1\n", b"p\t1\t\n"):
         with pytest.raises(fo.ParseError):
             fo.parse_bed(bad)
+
+
+# ---- f2 tied to rows the reference pins (tests/f2_pins.py says how): slow_odgi's golden node depths and path depth ----
+import f2_pins  # noqa: E402
+
+
+def _pinned_pools(name):
+    pools = fo.parse_gfa(read(os.path.join(GOLDEN, name + ".gfa")))
+    return pools, f2_pins.golden_node_depth(name)
+
+
+@pytest.mark.parametrize("name", f2_pins.PINNED_GRAPHS)
+def test_one_base_windows_read_the_golden_node_depth(name):
+    # (b) window_depth.rs:135-137 with windows of one base: the emitted column is the golden depth of the covering segment
+    pools, node_depth = _pinned_pools(name)
+    for pid in range(len(pools.paths)):
+        layout = f2_pins.path_layout(pools, pid, node_depth)
+        want = f2_pins.per_base_depth(layout)
+        if not want:
+            continue
+        nm = pools.path_name(pid)
+        if fo.find_path(pools, nm) != pid:   # (a duplicate name: the CLI route finds the first one only)
+            continue
+        rows = fo.window_depth_table(pools, nm, 1).splitlines()
+        assert len(rows) == len(want)
+        for i, row in enumerate(rows):
+            assert row == b"%s\t%d\t%d\t%d" % (nm, i, i + 1, want[i]), (name, pid, i)
+
+
+@pytest.mark.parametrize("name", f2_pins.PINNED_GRAPHS)
+def test_intervals_that_cut_segments_match_the_golden_depths_summed_in_reference_order(name):
+    # (c) assign_depths' f64 order restated in plain Python floats over the golden depths: bitwise
+    pools, node_depth = _pinned_pools(name)
+    for pid in range(len(pools.paths)):
+        layout = f2_pins.path_layout(pools, pid, node_depth)
+        total = sum(n for n, _ in layout)
+        if total == 0:
+            continue
+        for seed in range(3):
+            st, en = f2_pins.cut_points(total, 100 * pid + seed)
+            got = fo.interval_depth(pools, pid, st, en)
+            want = f2_pins.expected_intervals(layout, st, en)
+            assert got.tobytes() == want.tobytes(), (name, pid, seed)
+        # intervals need not cover the path: gaps, and an interval that ends where a segment does
+        if total >= 4:
+            st = np.array([1, total // 2], dtype=np.uint64)
+            en = np.array([total // 2 - 1 if total // 2 - 1 > 1 else 2, total - 1], dtype=np.uint64)
+            assert fo.interval_depth(pools, pid, st, en).tobytes() == f2_pins.expected_intervals(layout, st, en).tobytes()
+
+
+@pytest.mark.parametrize("name", f2_pins.PINNED_GRAPHS)
+def test_whole_path_window_agrees_with_path_depth(name):
+    # (a), any length: one window over the whole path and measure_path's mean are the same rational number
+    pools, node_depth = _pinned_pools(name)
+    ln, mean = fo.path_depth(pools)
+    for pid in range(len(pools.paths)):
+        layout = f2_pins.path_layout(pools, pid, node_depth)
+        total, want_mean = f2_pins.mean_depth(layout)
+        assert int(ln[pid]) == total
+        if total == 0:
+            continue
+        assert mean[pid] == want_mean                      # a3 against the golden depths (one division: exact agreement)
+        w = fo.interval_depth(pools, pid, [0], [total])[0]
+        assert abs(w - mean[pid]) <= 8 * np.spacing(mean[pid]), (name, pid, w, mean[pid])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_whole_path_window_equals_path_depth_bitwise_where_the_length_is_a_power_of_two(seed):
+    # (a), L = 2^k: every term depth * len / L and every partial sum is exact, so the two f64 values are identical
+    pools = fo.parse_gfa(f2_pins.pow2_gfa(seed, log2_len=7 + seed))
+    ln, mean = fo.path_depth(pools)
+    for pid in range(len(pools.paths)):
+        assert int(ln[pid]) == 1 << (7 + seed)
+        w = fo.interval_depth(pools, pid, [0], [int(ln[pid])])
+        assert w.tobytes() == mean[pid:pid + 1].tobytes(), (seed, pid)
+        nm = pools.path_name(pid)
+        assert fo.window_depth_table(pools, nm, int(ln[pid])) == b"%s\t0\t%d\t%s\n" % (nm, int(ln[pid]), fo.format_float(float(mean[pid]), 4).encode())
+
+
+def test_f2_pins_on_a_synthetic_graph_with_a_slow_odgi_golden():
+    # the same three ties on a graph of 15 k segments whose node depths slow_odgi wrote (synth_chrom.depth.tsv)
+    from oracle import synth
+    pools = synth.pools(seed=13, S=15_000, P=12, L=50_000, model="chromosome")
+    node_depth = f2_pins.golden_node_depth("synth_chrom")
+    for pid in (0, 5, 11):
+        layout = f2_pins.path_layout(pools, pid, node_depth)
+        total, want_mean = f2_pins.mean_depth(layout)
+        ln, mean = fo.path_depth(pools, [pid])
+        assert int(ln[0]) == total and mean[0] == want_mean
+        st, en = f2_pins.cut_points(total, pid, n_cuts=200)
+        assert fo.interval_depth(pools, pid, st, en).tobytes() == f2_pins.expected_intervals(layout, st, en).tobytes()
+        # one-base windows over the first 3000 bases
+        st1 = np.arange(3000, dtype=np.uint64)
+        got = fo.interval_depth(pools, pid, st1, st1 + 1)
+        want = np.array(f2_pins.per_base_depth(layout)[:3000], dtype=np.float64)
+        assert [fo.format_float(float(x), 4) for x in got] == [fo.format_float(float(x), 4) for x in want]

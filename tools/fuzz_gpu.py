@@ -109,67 +109,82 @@ def random_graph(rng):
     return S, P, steps, begins.astype(np.uint32), ends.astype(np.uint32)
 
 
+ENV_KEYS = sorted({k for e in ENVS for k in e} | {"FLATGFA_ACC_PAIR", "FLATGFA_ACC_SMALL"})  # every variable a case may set: cleared before the next one
+
+
+def run_case(rng, case, verbose=True):
+    """One random graph through the device configuration `case` selects; True when node depth, unique depth, depth-only,
+    path sums of a subset and path depth of all paths all equal the oracle's, bit for bit.  Sets FLATGFA_* variables of
+    the process (callers that care restore them: tests/test_gpu_depth.py::test_fuzz_slice)."""
+    from pollen_amd import device as dev
+    import torch
+    S, P, steps, pb, pe = random_graph(rng)
+    seg_len = rng.integers(1, 40, size=S).astype(np.uint32)
+    # oracle on raw arrays
+    paths = np.zeros(P, dtype=fo.PATH_DT)
+    paths["steps_start"], paths["steps_end"] = pb, pe
+    segs = np.zeros(S, dtype=fo.SEG_DT)
+    segs["seq_end"] = seg_len  # only the length matters to path depth
+    pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
+    pools.paths, pools.steps, pools.segs = paths, steps, segs
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    env = ENVS[case % len(ENVS)]
+    for k in ENV_KEYS:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    graph = dev.DeviceGraph(steps, pb, pe, S, seg_len, device="cuda:0")
+    plan = dev.DepthPlan(graph)
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    d2 = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    for _ in range(2):  # twice: the scratch must be clean again
+        plan.seg_depth(d, u)
+        plan.status()   # (a forced 8-record capacity: the call is only complete after this)
+        plan.seg_depth(d2, None)
+        plan.status()
+    # path depth of a strided subset of the paths: integer sums on the device, one f64 division here
+    ids = np.arange(P - 1, -1, -3, dtype=np.uint32)
+    t_ids = torch.from_numpy(ids.view(np.int32)).to("cuda:0")
+    ln = torch.zeros(len(ids), dtype=torch.int64, device="cuda:0")
+    ws = torch.zeros(len(ids), dtype=torch.int64, device="cuda:0")
+    plan.path_sums(t_ids, d2, ln, ws)
+    plan.status()
+    want_ln, want_mean = fo.path_depth(pools, ids)
+    got_ln = ln.cpu().numpy().view(np.uint64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        got_mean = ws.cpu().numpy().view(np.uint64).astype(np.float64) / got_ln.astype(np.float64)
+    # ... and of all paths in the call that also counts node depth (`fgfa depth`); the outputs start as garbage
+    d3 = torch.full((S,), -7, dtype=torch.int32, device="cuda:0")
+    ln_all = torch.full((P,), 12345, dtype=torch.int64, device="cuda:0")
+    ws_all = torch.full((P,), -1, dtype=torch.int64, device="cuda:0")
+    for _ in range(2):
+        plan.path_depth_all(d3, ln_all, ws_all)
+        plan.status()
+    want_ln_all, want_mean_all = fo.path_depth(pools, np.arange(P, dtype=np.uint32))
+    got_ln_all = ln_all.cpu().numpy().view(np.uint64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        got_mean_all = ws_all.cpu().numpy().view(np.uint64).astype(np.float64) / got_ln_all.astype(np.float64)
+    gd, gu, gd2, gd3 = (t.cpu().numpy().view(np.uint32) for t in (d, u, d2, d3))
+    ok = bool((gd == want_d).all() and (gu == want_u).all() and (gd2 == want_d).all() and (gd3 == want_d).all()
+              and (got_ln == want_ln).all() and got_mean.tobytes() == want_mean.tobytes()
+              and (got_ln_all == want_ln_all).all() and got_mean_all.tobytes() == want_mean_all.tobytes())
+    what = f"case {case}: S={S} P={P} N={len(steps)} env={env} [{plan.describe()[:60]}]"
+    if verbose:
+        print(f"{what} -> {'ok' if ok else 'MISMATCH'}", flush=True)
+        if not ok:
+            print("   depth bad:", int((gd != want_d).sum()), "uniq bad:", int((gu != want_u).sum()), "depth-only bad:", int((gd2 != want_d).sum()))
+    plan.close()
+    return ok, what
+
+
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
-    from pollen_amd import device as dev
-    import torch
     bad = 0
     for case in range(n_cases):
-        S, P, steps, pb, pe = random_graph(rng)
-        seg_len = rng.integers(1, 40, size=S).astype(np.uint32)
-        # oracle on raw arrays
-        paths = np.zeros(P, dtype=fo.PATH_DT)
-        paths["steps_start"], paths["steps_end"] = pb, pe
-        segs = np.zeros(S, dtype=fo.SEG_DT)
-        segs["seq_end"] = seg_len  # only the length matters to path depth
-        pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
-        pools.paths, pools.steps, pools.segs = paths, steps, segs
-        want_d, want_u = fo.seg_depth_with_uniq(pools)
-        env = ENVS[case % len(ENVS)]
-        for k in ("FLATGFA_SHORT_MAX", "FLATGFA_BUCKET_CAP", "FLATGFA_PIECE_STEPS", "FLATGFA_DEPTH_PATH", "FLATGFA_ACC_PARTS", "FLATGFA_RANGE_SEGS", "FLATGFA_DENSE", "FLATGFA_BIG_GROUPS", "FLATGFA_TAGGED", "FLATGFA_ACC_PAIR", "FLATGFA_SCAN_ALWAYS", "FLATGFA_WB", "FLATGFA_PATH_GROUPS", "FLATGFA_ACC_SMALL", "FLATGFA_NO_CLAIM", "FLATGFA_TAG_LIMIT", "FLATGFA_TAG_MEAN_ONLY", "FLATGFA_NO_PLAIN", "FLATGFA_NO_TINY", "FLATGFA_PACKED", "FLATGFA_ACC_SLOTS"):
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        graph = dev.DeviceGraph(steps, pb, pe, S, seg_len, device="cuda:0")
-        plan = dev.DepthPlan(graph)
-        d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
-        u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
-        d2 = torch.zeros(S, dtype=torch.int32, device="cuda:0")
-        for _ in range(2):  # twice: the scratch must be clean again
-            plan.seg_depth(d, u)
-            plan.status()   # (a forced 8-record capacity: the call is only complete after this)
-            plan.seg_depth(d2, None)
-            plan.status()
-        # path depth of a strided subset of the paths: integer sums on the device, one f64 division here
-        ids = np.arange(P - 1, -1, -3, dtype=np.uint32)
-        t_ids = torch.from_numpy(ids.view(np.int32)).to("cuda:0")
-        ln = torch.zeros(len(ids), dtype=torch.int64, device="cuda:0")
-        ws = torch.zeros(len(ids), dtype=torch.int64, device="cuda:0")
-        plan.path_sums(t_ids, d2, ln, ws)
-        plan.status()
-        want_ln, want_mean = fo.path_depth(pools, ids)
-        got_ln = ln.cpu().numpy().view(np.uint64)
-        got_mean = ws.cpu().numpy().view(np.uint64).astype(np.float64) / got_ln.astype(np.float64)
-        # ... and of all paths in the call that also counts node depth (`fgfa depth`); the outputs start as garbage
-        d3 = torch.full((S,), -7, dtype=torch.int32, device="cuda:0")
-        ln_all = torch.full((P,), 12345, dtype=torch.int64, device="cuda:0")
-        ws_all = torch.full((P,), -1, dtype=torch.int64, device="cuda:0")
-        for _ in range(2):
-            plan.path_depth_all(d3, ln_all, ws_all)
-            plan.status()
-        want_ln_all, want_mean_all = fo.path_depth(pools, np.arange(P, dtype=np.uint32))
-        got_ln_all = ln_all.cpu().numpy().view(np.uint64)
-        got_mean_all = ws_all.cpu().numpy().view(np.uint64).astype(np.float64) / got_ln_all.astype(np.float64)
-        gd, gu, gd2, gd3 = (t.cpu().numpy().view(np.uint32) for t in (d, u, d2, d3))
-        ok = (gd == want_d).all() and (gu == want_u).all() and (gd2 == want_d).all() and (gd3 == want_d).all() \
-            and (got_ln == want_ln).all() and got_mean.tobytes() == want_mean.tobytes() \
-            and (got_ln_all == want_ln_all).all() and got_mean_all.tobytes() == want_mean_all.tobytes()
-        print(f"case {case}: S={S} P={P} N={len(steps)} env={env} [{plan.describe()[:60]}] -> {'ok' if ok else 'MISMATCH'}", flush=True)
-        if not ok:
-            bad += 1
-            print("   depth bad:", int((gd != want_d).sum()), "uniq bad:", int((gu != want_u).sum()), "depth-only bad:", int((gd2 != want_d).sum()))
-        plan.close()
+        ok, _ = run_case(rng, case)
+        bad += 0 if ok else 1
     print("mismatching cases:", bad)
     return 1 if bad else 0
 

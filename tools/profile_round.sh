@@ -101,6 +101,9 @@ for c in ("FETCH_SIZE","WRITE_SIZE"):
             vals.setdefault(name,{})[c]=v
 import subprocess
 commit=subprocess.run(["git","-C","$R","rev-parse","--short","HEAD"],capture_output=True,text=True).stdout.strip() or None
+if not commit:  # (a GPU box has a snapshot without .git/: the commit `make` stamped next to the library)
+    try: commit=open("$R/pollen_amd/lib/HEAD").read().strip() or None
+    except OSError: pass
 out={"commit":commit,"source":"profiles/${TAG}_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; KB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 note)","workload":"cfgL","kernels":{}}
 for n,v in vals.items():
     f=v.get("FETCH_SIZE",0)*1024*2; w=v.get("WRITE_SIZE",0)*1024
