@@ -77,7 +77,8 @@ enum {
     FLATGFA_ERR_HIP = -4,       /* a HIP runtime call failed; see flatgfa_last_error() */
     FLATGFA_ERR_IO = -5,
     FLATGFA_ERR_TOO_LARGE = -6, /* more than 2^32-1 steps */
-    FLATGFA_ERR_PARSE = -7      /* GFA text the reference's parser panics on (flatgfa_translate_prealloc; the parse calls that return a handle return NULL) */
+    FLATGFA_ERR_PARSE = -7,     /* GFA text the reference's parser panics on (flatgfa_translate_prealloc; the parse calls that return a handle return NULL) */
+    FLATGFA_ERR_STALE_PLAN = -8 /* FLATGFA_CHECK_NO_CLAIM=1 only: the step values changed behind a device plan (flatgfa_dev_plan_steps_changed) */
 };
 
 /* Thread-local description of the last failure in this thread ("" if none). */
@@ -273,17 +274,42 @@ typedef struct flatgfa_dev_graph_t {
  * steps need, and reports an error -- or completes the call through the simple kernels -- rather
  * than a wrong answer when they no longer fit; what it does not re-check per step is that a path
  * the plan found strictly monotone still is (a compare per step: 12-18 % of the step scan on a
- * graph of such paths, profiles/NOTES.md R5.8): steps changed behind a plan that make such a path
- * revisit a segment are outside the contract.
+ * graph of such paths, profiles/NOTES.md R5.8), that a no-claim mark still holds, or that the
+ * reversed copy of a short downward path still mirrors it.  A caller that DOES change step values
+ * under a live plan says so with flatgfa_dev_plan_steps_changed (below), which makes the plan
+ * again from the steps as they are; FLATGFA_CHECK_NO_CLAIM=1 in the environment (read when a plan
+ * is made; a debugging aid, three more reads of the steps per call) re-derives those facts before
+ * every call and has flatgfa_dev_status return FLATGFA_ERR_STALE_PLAN where one no longer holds.
  * Creation runs the query a few times into scratch outputs: once to size the record buckets for
  * this graph (so that no later call runs out of room), and, up to 8 M steps, to time the bucketed
  * kernels against the atomic ones and keep the faster.  A graph beyond 16 M segments is walked in
- * ranges of at most 16 M (one pass over the steps per range and call).
+ * ranges of at most 16 M (one pass over the steps per range and call).  What is not needed for the
+ * first answer -- the per-block no-claim marks, three more reads of the steps -- is made on a
+ * stream of the plan's own behind its creation and used from the first call after it is there
+ * (flatgfa_dev_status and flatgfa_dev_plan_describe wait for it).
  * Calls on one plan must not overlap in time. */
 typedef struct flatgfa_dev_plan flatgfa_dev_plan_t;
 flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t *g, const uint32_t *host_path_begin,
                                             const uint32_t *host_path_end);
+/* The same, and the first answer with it: the reference's consumers ask ONE depth query per graph
+ * (flatgfa/src/cli/cmds.rs:234-285, flatgfa-sh/src/eval/instr.rs:27-72; bench/config.toml:29-32 times
+ * a process per query), and the query that sizes the plan's scratch is a whole query -- here it
+ * writes the caller's buffers.  depth_out u32[n_segs] (required) and uniq_out u32[n_segs] (or
+ * NULL: node depth alone) are device memory and hold seg_depth_with_uniq (ops/depth.rs:15-39) of
+ * the graph when the function returns (the device is synchronized).  *first_status (may be NULL):
+ * FLATGFA_OK, or FLATGFA_ERR_BOUNDS when a step named a segment id out of range (the counts are
+ * then those of the other steps, as after flatgfa_dev_seg_depth + flatgfa_dev_status). */
+flatgfa_dev_plan_t *flatgfa_dev_plan_create_first(const flatgfa_dev_graph_t *g, const uint32_t *host_path_begin,
+                                                  const uint32_t *host_path_end, uint32_t *depth_out, uint32_t *uniq_out,
+                                                  int *first_status);
 void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *plan);
+/* The step values (not the spans) of the plan's graph image were changed by the caller: waits for
+ * `stream` (the plan's), then makes the plan's launch plan and scratch again from the steps as they
+ * are -- which kernel walks which path, the reversed copies, which paths and blocks need no claim,
+ * the record buckets' sizes, the overlap query's bitmaps -- at the cost of creating it.  The
+ * reference's pools are immutable while a query runs (flatgfa/src/ops/depth.rs:30-34 reads them
+ * as they are); this is how a caller who owns the HBM buffers keeps that true of a plan. */
+int flatgfa_dev_plan_steps_changed(flatgfa_dev_plan_t *plan, void *stream);
 
 /* Node depth on device: seg_depth_with_uniq (ops/depth.rs:15-39) when uniq_out != NULL, seg_depth
  * (depth.rs:45-56) when NULL.  depth_out / uniq_out are u32[n_segs] in device memory.  Enqueues on
@@ -349,6 +375,8 @@ int flatgfa_dev_pipeline_path_depth_all(flatgfa_dev_pipeline_t *p, uint32_t *dep
                                         void *after_stream);
 int flatgfa_dev_pipeline_join(flatgfa_dev_pipeline_t *p, void *stream);
 int flatgfa_dev_pipeline_status(flatgfa_dev_pipeline_t *p);
+/* flatgfa_dev_plan_steps_changed for every lane (waits for all of them first). */
+int flatgfa_dev_pipeline_steps_changed(flatgfa_dev_pipeline_t *p);
 int flatgfa_dev_pipeline_describe(flatgfa_dev_pipeline_t *p, char *out, int cap);
 
 /* Which kernels this plan's calls run -- the choices made when it was created, some of them by

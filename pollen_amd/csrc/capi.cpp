@@ -40,6 +40,10 @@ struct CStore {
     uint32_t *d_depth = nullptr, *d_uniq = nullptr;
     uint64_t *d_sums = nullptr;  // [2 * paths] scratch of flatgfa_path_depth (inside d_small)
     double h2d_ms = 0, plan_ms = 0;  // what becoming resident took: the copies, and the plan's creation (flatgfa_residency_ms)
+    // The plan's creation is the first query (flatgfa_dev_plan_create_first): d_depth / d_uniq hold seg_depth_with_uniq of the
+    // graph until another query overwrites them, and the first node-depth call of the handle takes them as they are.
+    bool first_answer = false;
+    int first_rc = 0;
     std::vector<uint32_t> h_path_begin, h_path_end;
     flatgfa_dev_plan_t *plan = nullptr;
     hipStream_t stream = nullptr;
@@ -547,7 +551,8 @@ static int ensure_device(CStore *cs, int device) {
     flatgfa_dev_graph_t g{im.steps, (uint64_t)N, im.pb, im.pe, (uint32_t)P, (uint32_t)S, im.seg_len};
     tick("paths, segments, outputs");
     const auto t_plan = std::chrono::steady_clock::now();
-    im.plan = flatgfa_dev_plan_create(&g, h_pb, h_pe);
+    int first_rc = FLATGFA_OK;
+    im.plan = S ? flatgfa_dev_plan_create_first(&g, h_pb, h_pe, im.depth, im.uniq, &first_rc) : flatgfa_dev_plan_create(&g, h_pb, h_pe);
     const auto t_done = std::chrono::steady_clock::now();
     tick("plan (scratch + item lists)");
     if (!im.plan) return FLATGFA_ERR_HIP;  // the spans were checked above: what is left is the HIP runtime (see flatgfa_last_error)
@@ -567,6 +572,8 @@ static int ensure_device(CStore *cs, int device) {
     cs->h_path_begin.assign(h_pb, h_pb + P);
     cs->h_path_end.assign(h_pe, h_pe + P);
     cs->plan = im.plan;
+    cs->first_answer = S != 0;
+    cs->first_rc = first_rc;
     cs->on_device = true;
     return FLATGFA_OK;
 }
@@ -589,6 +596,11 @@ int flatgfa_residency_ms(flatgfa_t gfa, double *h2d_ms, double *plan_ms) {
 static int run_seg_depth(CStore *cs, bool want_uniq) {
     int rc = ensure_device(cs, -1);
     if (rc) return rc;
+    if (cs->first_answer) {  // (the query that sized the plan left both vectors here: the reference's consumers ask once per graph, cmds.rs:234-285)
+        cs->first_answer = false;
+        if (cs->first_rc) set_error("a step refers to a segment id (or a query to a path id) that is out of range");
+        return cs->first_rc;
+    }
     rc = flatgfa_dev_seg_depth(cs->plan, cs->d_depth, want_uniq ? cs->d_uniq : nullptr, cs->stream);
     if (rc) return rc;
     return flatgfa_dev_status(cs->plan, cs->stream);
@@ -607,9 +619,16 @@ int flatgfa_seg_depth(flatgfa_t gfa, uint64_t *depth_out, uint64_t *uniq_out) {
     std::lock_guard<std::mutex> op(gfa->op_mu);
     int rc = run_seg_depth(gfa, uniq_out != nullptr);
     if (rc) return rc;
-    rc = fetch_widen(gfa, gfa->d_depth, depth_out);
-    if (rc == FLATGFA_OK && uniq_out) rc = fetch_widen(gfa, gfa->d_uniq, uniq_out);
-    return rc;
+    if (!uniq_out) return fetch_widen(gfa, gfa->d_depth, depth_out);
+    // both vectors in one copy (they lie next to each other in the handle's allocation, 256-byte aligned), widened on two threads
+    const size_t S = gfa->view.segs.len, gap = (size_t)(gfa->d_uniq - gfa->d_depth);
+    if (!S) return FLATGFA_OK;
+    std::vector<uint32_t> tmp(gap + S);
+    CAPI_HIP(hipMemcpy(tmp.data(), gfa->d_depth, (gap + S) * 4, hipMemcpyDeviceToHost));
+    std::thread other([&] { for (size_t i = 0; i < S; ++i) uniq_out[i] = tmp[gap + i]; });
+    for (size_t i = 0; i < S; ++i) depth_out[i] = tmp[i];  // Vec<usize>
+    other.join();
+    return FLATGFA_OK;
 }
 
 int flatgfa_path_depth(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, uint64_t *length_out,
@@ -630,6 +649,7 @@ int flatgfa_path_depth(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, 
     if (n_ids == 0 || P == 0) return run_seg_depth(gfa, false);
     uint64_t *d_sums = gfa->d_sums;  // (the handle's own: a hipMalloc per call cost five times the kernels it bracketed)
     std::vector<uint64_t> sums(P * 2);
+    gfa->first_answer = false;  // (d_depth is written again)
     rc = flatgfa_dev_path_depth_all(gfa->plan, gfa->d_depth, d_sums, d_sums + P, gfa->stream);
     if (!rc) rc = flatgfa_dev_status(gfa->plan, gfa->stream);
     if (!rc && hipMemcpy(sums.data(), d_sums, P * 16, hipMemcpyDeviceToHost) != hipSuccess) rc = FLATGFA_ERR_HIP;
@@ -829,6 +849,7 @@ int flatgfa_seg_depth_subset(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n
         if (!gfa->sub_plan) return FLATGFA_ERR_HIP;
         gfa->sub_ids.assign(path_ids, path_ids + n_ids);
     }
+    gfa->first_answer = false;  // (the handle's result buffers now hold the subset's counts)
     rc = flatgfa_dev_seg_depth(gfa->sub_plan, gfa->d_depth, uniq_out ? gfa->d_uniq : nullptr, gfa->stream);
     if (!rc) rc = flatgfa_dev_status(gfa->sub_plan, gfa->stream);
     if (!rc) rc = fetch_widen(gfa, gfa->d_depth, depth_out);

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -272,6 +273,11 @@ struct flatgfa_dev_plan {
     uint32_t *all_ids = nullptr;       // 0..n_paths-1 (path_depth_all without the bucketed path)
     int64_t cache_claim = 0;           // bytes of the device's Infinity Cache this plan's resident steps lay claim to (g_cache_claimed)
     bool cache_claim_shared = false;   // ... a claim another plan over the same step array made first (g_cache_shares): counted once
+    std::vector<uint32_t> hb, he;      // the spans the plan was made with (flatgfa_dev_plan_steps_changed makes it again from them; the marks' job reads hb)
+    uint32_t scan_workgroups = 0;      // (plan_create_impl's argument, likewise)
+    hipStream_t side = nullptr;        // the stream the per-block no-claim marks are made on, off the way to the first answer
+    std::vector<MarksJob> marks;       // one job per range / path group of `fast` that wants marks (fast itself, then more[0 ..]); empty once all are installed
+    bool check_facts = false;          // FLATGFA_CHECK_NO_CLAIM=1: every call first looks again at what the plan took for granted about the step values
 };
 
 // The Infinity Cache (256 MiB on MI355X) is one per device: what the plans of a process keep resident in it is
@@ -304,56 +310,110 @@ extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int 
 
 static int atomic_seg_depth(flatgfa_dev_plan_t *pl, uint32_t *depth_out, uint32_t *uniq_out, hipStream_t stream);
 
-static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const uint32_t *hb, const uint32_t *he, uint32_t scan_workgroups);
+static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const uint32_t *hb, const uint32_t *he, uint32_t scan_workgroups,
+                                            uint32_t *first_depth = nullptr, uint32_t *first_uniq = nullptr, int *first_status = nullptr);
 extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t *g, const uint32_t *hb,
                                                         const uint32_t *he) {
     return plan_create_impl(g, hb, he, 0u);
 }
-// (scan_workgroups: pass 1's persistent workgroups, 0 = one per CU; a pipeline's lanes take fewer)
-static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const uint32_t *hb, const uint32_t *he, uint32_t scan_workgroups) {
-    if (!g) { set_error("plan_create: NULL graph"); return nullptr; }
-    std::vector<uint32_t> cb, ce;
-    if (g->n_paths && (!hb || !he)) {
-        cb.resize(g->n_paths);
-        ce.resize(g->n_paths);
-        HIP_TRY(hipMemcpy(cb.data(), g->path_begin, (size_t)g->n_paths * 4, hipMemcpyDeviceToHost), return nullptr);
-        HIP_TRY(hipMemcpy(ce.data(), g->path_end, (size_t)g->n_paths * 4, hipMemcpyDeviceToHost), return nullptr);
-        hb = cb.data();
-        he = ce.data();
-    }
-    std::vector<WorkItem> items;
-    for (uint32_t p = 0; p < g->n_paths; ++p) {
-        if (hb[p] > he[p] || (uint64_t)he[p] > g->n_steps) {
-            set_error("plan_create: path " + std::to_string(p) + " has a step span outside the steps pool");
-            return nullptr;
-        }
-        for (uint64_t b = hb[p]; b < he[p]; b += kScanPiece)
-            items.push_back(WorkItem{(uint32_t)b, (uint32_t)std::min<uint64_t>(b + kScanPiece, he[p]), p, 0u});
-    }
-    auto *pl = new flatgfa_dev_plan();
-    pl->g = *g;
-    HIP_TRY(hipGetDevice(&pl->device), { delete pl; return nullptr; });
+extern "C" flatgfa_dev_plan_t *flatgfa_dev_plan_create_first(const flatgfa_dev_graph_t *g, const uint32_t *hb, const uint32_t *he,
+                                                              uint32_t *depth_out, uint32_t *uniq_out, int *first_status) {
+    if (g && g->n_segs && !depth_out) { set_error("dev_plan_create_first: NULL depth_out"); return nullptr; }
+    return plan_create_impl(g, hb, he, 0u, depth_out, uniq_out, first_status);
+}
+
+// the properties of a device asked for once (hipGetDeviceProperties fills a kilobyte-sized struct through the driver: a tenth of a millisecond each time)
+static int device_cus(int device) {
+    static std::mutex mu;
+    static int cus[64] = {};
+    std::lock_guard<std::mutex> lk(mu);
+    if (device >= 0 && device < 64 && cus[device]) return cus[device];
     hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, pl->device), { delete pl; return nullptr; });
-    pl->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    pl->n_items = (uint32_t)items.size();
-    pl->n_windows = g->n_segs ? (uint32_t)(((uint64_t)g->n_segs + kWinBits - 1) / kWinBits) : 1;
-    HIP_TRY(hipMalloc(&pl->status, 256), { delete pl; return nullptr; });
-    HIP_TRY(hipMemset(pl->status, 0, 256), { flatgfa_dev_plan_destroy(pl); return nullptr; });
-    if (!items.empty()) {
-        HIP_TRY(hipMalloc(&pl->items, items.size() * sizeof(WorkItem)), { flatgfa_dev_plan_destroy(pl); return nullptr; });
-        HIP_TRY(hipMemcpy(pl->items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice),
-                { flatgfa_dev_plan_destroy(pl); return nullptr; });
+    int n = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+    else (void)hipGetLastError();
+    if (device >= 0 && device < 64) cus[device] = n;
+    return n;
+}
+namespace fgfa_dev {
+int device_cu_count(int device) { return device_cus(device); }
+void plan_tick(const char *what) {
+    static const bool on = getenv("FLATGFA_TIMING") != nullptr;
+    if (!on) return;
+    static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    if (what) {
+        const auto before = std::chrono::steady_clock::now();
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "plan: %-52s %8.3f ms (+ %.3f ms for the device to drain)\n", what, std::chrono::duration<double, std::milli>(before - last).count(),
+                std::chrono::duration<double, std::milli>(now - before).count());
     }
-    HIP_TRY(hipFuncSetAttribute((const void *)k_depth_uniq_path, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)(kWinWords * 4)),
-            { flatgfa_dev_plan_destroy(pl); return nullptr; });
+    last = std::chrono::steady_clock::now();
+}
+}
+
+static void release_cache_claim(flatgfa_dev_plan_t *pl) {
+    if (!pl->cache_claim) return;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    bool last = true;
+    if (pl->cache_claim_shared) {
+        for (size_t i = 0; i < g_cache_shares.size(); ++i) {
+            CacheShare &c = g_cache_shares[i];
+            if (c.device != pl->device || c.steps != pl->g.steps) continue;
+            last = --c.users == 0;
+            if (last) g_cache_shares.erase(g_cache_shares.begin() + (long)i);
+            break;
+        }
+    }
+    if (last && pl->device >= 0 && pl->device < 64) g_cache_claimed[pl->device] -= pl->cache_claim;
+    pl->cache_claim = 0;
+    pl->cache_claim_shared = false;
+}
+
+// The per-block no-claim marks are made on a stream of the plan's own, behind its creation:
+// (wait) for the jobs that are there, and install what they found.  Called between two calls of the plan.
+static void marks_poll(flatgfa_dev_plan_t *pl, bool wait) {
+    if (pl->marks.empty()) return;
+    bool pending = false;
+    for (size_t k = 0; k < pl->marks.size(); ++k) {
+        MarksJob &job = pl->marks[k];
+        if (!job.active) continue;
+        if (!wait && !fast_marks_ready(job)) { pending = true; continue; }
+        FastPlan *fp = k == 0 ? &pl->fast : (k - 1 < pl->fast.n_more ? &pl->fast.more[k - 1] : nullptr);
+        if (fp) fast_marks_finish(fp, &job);
+    }
+    if (!pending) pl->marks.clear();
+}
+static void marks_start(flatgfa_dev_plan_t *pl) {
+    if (!pl->fast.eligible) return;
+    bool any = pl->fast.marks_wanted;
+    for (uint32_t r = 0; r < pl->fast.n_more; ++r) any = any || pl->fast.more[r].marks_wanted;
+    if (!any) return;
+    if (!pl->side && hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); pl->side = nullptr; return; }
+    pl->marks.assign(1 + pl->fast.n_more, MarksJob());
+    for (size_t k = 0; k < pl->marks.size(); ++k) {
+        const FastPlan &fp = k == 0 ? pl->fast : pl->fast.more[k - 1];
+        if (fp.eligible && fp.marks_wanted) (void)fast_marks_start(fp, pl->g, pl->hb.data(), pl->side, &pl->marks[k]);  // (a job that cannot be had: no marks)
+    }
+}
+
+// What a plan is beyond its handle: the bucketed path's plan (which kernel walks which path, the scratch), sized and
+// timed on the graph.  Everything runs on the null stream.  With `first_depth` the query that sizes the record buckets
+// leaves its result in the caller's buffers (and every timing run behind it writes the same counts there): the plan's
+// creation IS the first query.  *first_st: the status bits that query raised (1 = an id out of range).
+static bool plan_build_fast(flatgfa_dev_plan_t *pl, uint32_t *first_depth, uint32_t *first_uniq, uint32_t *first_st) {
+    const flatgfa_dev_graph_t *g = &pl->g;
+    const uint32_t *hb = pl->hb.data(), *he = pl->he.data();
+    const uint32_t scan_workgroups = pl->scan_workgroups;
+    const auto tick = [](const char *what) { plan_tick(what); };
+    *first_st = 0;
     // FLATGFA_DEPTH_PATH=atomic forces the simple global-atomic kernels (used by the tests to
     // cover both device paths); anything else lets eligibility decide.
     const char *force = getenv("FLATGFA_DEPTH_PATH");
     if (!(force && std::string(force) == "atomic")) {
-        if (!fast_plan_create(pl->g, hb, he, &pl->fast, scan_workgroups)) { flatgfa_dev_plan_destroy(pl); return nullptr; }
+        if (!fast_plan_create(pl->g, hb, he, &pl->fast, scan_workgroups)) return false;
     }
+    tick("fast_plan_create (lists, items, scratch)");
     // Steps kept in the Infinity Cache.  k_scan streams the steps past the caches (nt: whole lines read once),
     // which is right for what does not fit them -- but a resident graph is queried again and again, and the
     // first so-many megabytes of its steps, read WITHOUT the hint, are still in the 256 MiB cache when the next
@@ -400,33 +460,50 @@ static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const 
         pl->fast.mall_steps = (uint64_t)budget / 4;
         for (uint32_t r = 0; r < pl->fast.n_more; ++r) pl->fast.more[r].mall_steps = pl->fast.mall_steps;
     }
-    // Size the sub-buckets for this graph now, with one query into scratch outputs, so that no
-    // later call runs out of room (the record counts per sub-bucket depend on the steps only):
+    // A caller that wants its first answer from the atomic kernels' plan gets it here.
+    const auto atomic_first = [&]() -> bool {
+        if (!first_depth || !g->n_segs) return true;
+        uint32_t st = 0;
+        if (atomic_seg_depth(pl, first_depth, first_uniq, nullptr) != FLATGFA_OK || hipMemcpy(&st, pl->status, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemset(pl->status, 0, 4) != hipSuccess)
+            return false;
+        *first_st |= st;
+        return true;
+    };
+    // Size the sub-buckets for this graph now, with one query into scratch outputs (or the caller's: the first
+    // answer), so that no later call runs out of room (the record counts per sub-bucket depend on the steps only):
     // a caller that consumes results on the stream -- an all-reduce right behind the kernels --
     // never sees an incomplete vector.  (FLATGFA_BUCKET_CAP keeps its forced capacity: the
     // tests want the overflow route.)
     if (pl->fast.eligible && !pl->fast.cap_forced && g->n_segs) {
         uint32_t *tmp = nullptr;
-        HIP_TRY(hipMalloc(&tmp, (size_t)g->n_segs * 8), { flatgfa_dev_plan_destroy(pl); return nullptr; });
+        const size_t need = (first_depth ? 0 : (size_t)g->n_segs) + (first_uniq ? 0 : (size_t)g->n_segs);
+        if (need) HIP_TRY(hipMalloc(&tmp, need * 4), return false);
+        uint32_t *const out_d = first_depth ? first_depth : tmp;
+        uint32_t *const out_u = first_uniq ? first_uniq : (first_depth ? tmp : tmp + g->n_segs);
+        bool complete = false;  // the outputs hold a whole query's counts
         for (int layout = 0; layout < 2; ++layout) {
         for (int attempt = 0; attempt < 10 && pl->fast.eligible; ++attempt) {
             uint32_t st = 0;
-            if (fast_seg_depth(pl->fast, pl->g, tmp, tmp + g->n_segs, pl->status, nullptr) != FLATGFA_OK ||
+            if (fast_seg_depth(pl->fast, pl->g, out_d, out_u, pl->status, nullptr) != FLATGFA_OK ||
                 hipMemcpy(&st, pl->status, 4, hipMemcpyDeviceToHost) != hipSuccess ||
                 hipMemset(pl->status, 0, 4) != hipSuccess) {
-                (void)hipFree(tmp);
-                flatgfa_dev_plan_destroy(pl);
-                return nullptr;
+                if (tmp) (void)hipFree(tmp);
+                return false;
             }
+            *first_st |= st & 1u;
+            complete = !(st & (4u | 16u));
             if (!(st & 4u)) break;  // (an out-of-range id is reported by the query that meets it)
             (void)fast_plan_grow(&pl->fast);
         }
+        tick("sizing query");
         {   // ... and with headroom: k_scan deals its items to the workgroups as they come, so another call may
             // fill a sub-bucket that was half full this time to the brim (see flatgfa_dev_status)
             uint32_t fullest = 0;
             if (hipMemcpy(&fullest, pl->status + 2, 4, hipMemcpyDeviceToHost) == hipSuccess && fullest && pl->fast.eligible) (void)fast_plan_grow(&pl->fast, true);
             (void)hipMemset(pl->status, 0, 12);
         }
+        tick("headroom");
         // An even layout -- every sub-bucket as deep as the fullest -- that had to grow to gigabytes (paths that run along
         // the graph fill a few sub-buckets of a window and leave the others empty: 2000 contigs of 100 k steps on 4 M
         // segments, 0.8 GB of steps, 4.8 GB of buckets): the plan is made again with its buckets laid out to the count.
@@ -437,7 +514,7 @@ static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const 
             for (uint32_t r = 0; r < pl->fast.n_more; ++r) add(pl->fast.more[r]);
             if (even_bytes <= (2ull << 30)) break;
             FastPlan again;
-            if (!fast_plan_create(pl->g, hb, he, &again, scan_workgroups, true)) { (void)hipFree(tmp); flatgfa_dev_plan_destroy(pl); return nullptr; }
+            if (!fast_plan_create(pl->g, hb, he, &again, scan_workgroups, true)) { if (tmp) (void)hipFree(tmp); return false; }
             bool all_packed = again.eligible && again.packed;
             for (uint32_t r = 0; r < again.n_more; ++r) all_packed = all_packed && again.more[r].packed;
             if (!all_packed) {
@@ -472,7 +549,7 @@ static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const 
                     for (int which = 0; which < 2 && ok; ++which) {
                         set_dense(which != 0);
                         ok = hipEventRecord(e0, nullptr) == hipSuccess;
-                        const int rc = fast_seg_depth(pl->fast, pl->g, tmp, tmp + g->n_segs, pl->status, nullptr);
+                        const int rc = fast_seg_depth(pl->fast, pl->g, out_d, out_u, pl->status, nullptr);
                         float ms = 0;
                         ok = ok && rc == FLATGFA_OK && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
                              hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
@@ -502,7 +579,7 @@ static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const 
                     pl->fast.big_groups = which != 0;
                     for (uint32_t r = 0; r < pl->fast.n_more; ++r) pl->fast.more[r].big_groups = which != 0;
                     ok = hipEventRecord(e0, nullptr) == hipSuccess;
-                    const int rc = fast_seg_depth(pl->fast, pl->g, tmp, tmp + g->n_segs, pl->status, nullptr);
+                    const int rc = fast_seg_depth(pl->fast, pl->g, out_d, out_u, pl->status, nullptr);
                     float ms = 0;
                     ok = ok && rc == FLATGFA_OK && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
                          hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
@@ -543,7 +620,7 @@ static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const 
                     for (int which = 0; which < 2 && ok; ++which) {
                         set_own(which != 0);
                         ok = hipEventRecord(e0, nullptr) == hipSuccess;
-                        const int rc = fast_seg_depth(pl->fast, pl->g, tmp, tmp + g->n_segs, pl->status, nullptr);
+                        const int rc = fast_seg_depth(pl->fast, pl->g, out_d, out_u, pl->status, nullptr);
                         float ms = 0;
                         ok = ok && rc == FLATGFA_OK && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
                              hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
@@ -575,8 +652,8 @@ static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const 
             for (int which = 0; which < 2 && ok; ++which) {
                 for (int rep = 0; rep < 4 && ok; ++rep) {
                     ok = hipEventRecord(e0, nullptr) == hipSuccess;
-                    const int rc = which ? atomic_seg_depth(pl, tmp, tmp + g->n_segs, nullptr)
-                                         : fast_seg_depth(pl->fast, pl->g, tmp, tmp + g->n_segs, pl->status, nullptr);
+                    const int rc = which ? atomic_seg_depth(pl, out_d, out_u, nullptr)
+                                         : fast_seg_depth(pl->fast, pl->g, out_d, out_u, pl->status, nullptr);
                     float ms = 0;
                     ok = ok && rc == FLATGFA_OK && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
                          hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
@@ -589,33 +666,126 @@ static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const 
             if (ok && best[1] < best[0]) fast_plan_destroy(&pl->fast);
             if (getenv("FLATGFA_TIMING")) fprintf(stderr, "plan: bucketed %.1f us, atomic %.1f us\n", best[0] * 1e3, best[1] * 1e3);
         }
-        (void)hipFree(tmp);
+        tick("timed choices");
+        if (tmp) (void)hipFree(tmp);
+        // (a plan that could not be given room -- it then runs the atomic kernels -- left an incomplete vector behind)
+        if (!complete && !atomic_first()) return false;
+    } else if (!atomic_first()) {
+        return false;
     }
     // Everything above went through the null stream, which a caller's non-blocking stream does not
     // wait for -- and a memset of device memory need not have happened when hipMemset returns: a
     // plan without a trial call (no paths, say) could have its status words read, on the caller's
     // stream, before they were cleared (seen once: a freed block's contents taken for status bits).
     (void)hipStreamSynchronize(nullptr);
+    tick("null stream drained");
+    // ... and behind it, on a stream of the plan's own, what can wait until the first answer is out: the per-block no-claim marks
+    marks_start(pl);
+    return true;
+}
+
+// (scan_workgroups: pass 1's persistent workgroups, 0 = one per CU; a pipeline's lanes take fewer)
+static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const uint32_t *hb, const uint32_t *he, uint32_t scan_workgroups,
+                                            uint32_t *first_depth, uint32_t *first_uniq, int *first_status) {
+    if (first_status) *first_status = FLATGFA_OK;
+    if (!g) { set_error("plan_create: NULL graph"); return nullptr; }
+    std::vector<uint32_t> cb, ce;
+    if (g->n_paths && (!hb || !he)) {
+        cb.resize(g->n_paths);
+        ce.resize(g->n_paths);
+        HIP_TRY(hipMemcpy(cb.data(), g->path_begin, (size_t)g->n_paths * 4, hipMemcpyDeviceToHost), return nullptr);
+        HIP_TRY(hipMemcpy(ce.data(), g->path_end, (size_t)g->n_paths * 4, hipMemcpyDeviceToHost), return nullptr);
+        hb = cb.data();
+        he = ce.data();
+    }
+    std::vector<WorkItem> items;
+    for (uint32_t p = 0; p < g->n_paths; ++p) {
+        if (hb[p] > he[p] || (uint64_t)he[p] > g->n_steps) {
+            set_error("plan_create: path " + std::to_string(p) + " has a step span outside the steps pool");
+            return nullptr;
+        }
+        for (uint64_t b = hb[p]; b < he[p]; b += kScanPiece)
+            items.push_back(WorkItem{(uint32_t)b, (uint32_t)std::min<uint64_t>(b + kScanPiece, he[p]), p, 0u});
+    }
+    plan_tick(nullptr);
+    auto *pl = new flatgfa_dev_plan();
+    pl->g = *g;
+    pl->hb.assign(hb, hb + g->n_paths);
+    pl->he.assign(he, he + g->n_paths);
+    pl->scan_workgroups = scan_workgroups;
+    if (const char *c = getenv("FLATGFA_CHECK_NO_CLAIM")) pl->check_facts = c[0] != '0' && c[0] != 0;
+    HIP_TRY(hipGetDevice(&pl->device), { delete pl; return nullptr; });
+    pl->n_cus = device_cus(pl->device);
+    pl->n_items = (uint32_t)items.size();
+    pl->n_windows = g->n_segs ? (uint32_t)(((uint64_t)g->n_segs + kWinBits - 1) / kWinBits) : 1;
+    HIP_TRY(hipMalloc(&pl->status, 256), { delete pl; return nullptr; });
+    HIP_TRY(hipMemset(pl->status, 0, 256), { flatgfa_dev_plan_destroy(pl); return nullptr; });
+    if (!items.empty()) {
+        HIP_TRY(hipMalloc(&pl->items, items.size() * sizeof(WorkItem)), { flatgfa_dev_plan_destroy(pl); return nullptr; });
+        HIP_TRY(hipMemcpy(pl->items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice),
+                { flatgfa_dev_plan_destroy(pl); return nullptr; });
+    }
+    {   // (per device, like the other kernels' attributes)
+        static OncePerDevice once;
+        if (!once([] { return hipFuncSetAttribute((const void *)k_depth_uniq_path, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kWinWords * 4)) == hipSuccess; })) {
+            set_error("hipFuncSetAttribute(k_depth_uniq_path): dynamic shared memory");
+            flatgfa_dev_plan_destroy(pl);
+            return nullptr;
+        }
+    }
+    plan_tick("handle: status words, atomic path's items, attributes");
+    uint32_t first_st = 0;
+    if (!plan_build_fast(pl, first_depth, first_uniq, &first_st)) { flatgfa_dev_plan_destroy(pl); return nullptr; }
+    plan_tick("behind the first answer: the marks' job enqueued");
+    if (first_status && (first_st & 1u)) {
+        set_error("a step refers to a segment id (or a query to a path id) that is out of range");
+        *first_status = FLATGFA_ERR_BOUNDS;
+    }
     return pl;
+}
+
+// What plan_build_fast made, given back: the marks' jobs (waited for, nothing installed), the claim on the Infinity Cache, the plan.
+static void plan_release_fast(flatgfa_dev_plan_t *pl) {
+    if (pl->side) (void)hipStreamSynchronize(pl->side);
+    for (MarksJob &job : pl->marks) {
+        FastPlan nothing;  // (finish releases the job's scratch; what it would install goes with this)
+        nothing.cflags = reinterpret_cast<uint32_t *>(1);  // (non-null: nothing is installed)
+        fast_marks_finish(&nothing, &job);
+    }
+    pl->marks.clear();
+    release_cache_claim(pl);
+    fast_plan_destroy(&pl->fast);
+}
+
+extern "C" int flatgfa_dev_plan_steps_changed(flatgfa_dev_plan_t *pl, void *stream_) {
+    if (!pl) { set_error("dev_plan_steps_changed: NULL plan"); return FLATGFA_ERR_ARG; }
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_), return FLATGFA_ERR_HIP);
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev), return FLATGFA_ERR_HIP);
+    if (dev != pl->device) HIP_TRY(hipSetDevice(pl->device), return FLATGFA_ERR_HIP);
+    plan_release_fast(pl);
+    // everything else that was derived from the step values: the overlap query's bitmaps, the (seg_len, depth) table
+    for (void **p : {(void **)&pl->overlap_bits, (void **)&pl->overlap_qbits}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    pl->overlap_qbytes = 0;
+    pl->overlap_qall = false;
+    HIP_TRY(hipMemset(pl->status, 0, 256), return FLATGFA_ERR_HIP);
+    pl->calls_since_status = 0;
+    pl->last_fast = false;
+    pl->last_depth = pl->last_uniq = nullptr;
+    pl->last_len = pl->last_weighted = nullptr;
+    uint32_t st = 0;
+    const bool ok = plan_build_fast(pl, nullptr, nullptr, &st);
+    if (dev != pl->device) (void)hipSetDevice(dev);
+    return ok ? FLATGFA_OK : FLATGFA_ERR_HIP;
 }
 
 extern "C" void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *pl) {
     if (!pl) return;
-    if (pl->cache_claim) {
-        std::lock_guard<std::mutex> lk(g_cache_mu);
-        bool last = true;
-        if (pl->cache_claim_shared) {
-            for (size_t i = 0; i < g_cache_shares.size(); ++i) {
-                CacheShare &c = g_cache_shares[i];
-                if (c.device != pl->device || c.steps != pl->g.steps) continue;
-                last = --c.users == 0;
-                if (last) g_cache_shares.erase(g_cache_shares.begin() + (long)i);
-                break;
-            }
-        }
-        if (last && pl->device >= 0 && pl->device < 64) g_cache_claimed[pl->device] -= pl->cache_claim;
-    }
-    fast_plan_destroy(&pl->fast);
+    plan_release_fast(pl);
+    if (pl->side) (void)hipStreamDestroy(pl->side);
     if (pl->overlap_bits) (void)hipFree(pl->overlap_bits);
     if (pl->overlap_qbits) (void)hipFree(pl->overlap_qbits);
     if (pl->len_depth) (void)hipFree(pl->len_depth);
@@ -656,12 +826,17 @@ extern "C" int flatgfa_dev_seg_depth(flatgfa_dev_plan_t *pl, uint32_t *depth_out
     hipStream_t stream = (hipStream_t)stream_;
     const flatgfa_dev_graph_t &g = pl->g;
     if (g.n_segs == 0) return FLATGFA_OK;
+    marks_poll(pl, false);  // (the per-block no-claim marks, once they are there: installed between two calls)
     pl->last_fast = pl->fast.eligible;
     pl->last_depth = depth_out;
     pl->last_uniq = uniq_out;
     pl->last_len = pl->last_weighted = nullptr;
     pl->calls_since_status += 1;
     if (pl->fast.eligible) {
+        if (pl->check_facts) {
+            const int rc = fast_check_plan_facts(pl->fast, g, pl->hb.data(), pl->he.data(), pl->status, stream);
+            if (rc) return rc;
+        }
         return fast_seg_depth(pl->fast, g, depth_out, uniq_out, pl->status, stream);
     }
     return atomic_seg_depth(pl, depth_out, uniq_out, stream);
@@ -752,12 +927,17 @@ extern "C" int flatgfa_dev_path_depth_all(flatgfa_dev_plan_t *pl, uint32_t *dept
         HIP_TRY(hipMemsetAsync(weighted_out, 0, (size_t)g.n_paths * 8, (hipStream_t)stream_), return FLATGFA_ERR_HIP);
         return FLATGFA_OK;
     }
+    marks_poll(pl, false);
     pl->last_fast = pl->fast.eligible;
     pl->last_depth = depth_out;
     pl->last_uniq = nullptr;
     pl->last_len = length_out;
     pl->last_weighted = weighted_out;
     pl->calls_since_status += 1;
+    if (pl->check_facts && pl->fast.eligible) {
+        const int rc = fast_check_plan_facts(pl->fast, g, pl->hb.data(), pl->he.data(), pl->status, (hipStream_t)stream_);
+        if (rc) return rc;
+    }
     return path_depth_all_enqueue(pl, depth_out, length_out, weighted_out, (hipStream_t)stream_, true);
 }
 
@@ -780,7 +960,10 @@ extern "C" int flatgfa_dev_status(flatgfa_dev_plan_t *pl, void *stream_) {
         HIP_TRY(hipStreamSynchronize(stream), return FLATGFA_ERR_HIP);
         const uint32_t st = st3[0];
         const uint32_t n_calls = pl->calls_since_status;
-        if (attempt == 0) pl->calls_since_status = 0;
+        if (attempt == 0) {
+            pl->calls_since_status = 0;
+            marks_poll(pl, true);  // (no call is in flight: the marks' job is waited for here, and what it found installed)
+        }
         if (st3[2]) {
             // A call filled a sub-bucket more than half: k_scan deals its items to the workgroups as they
             // come, so a later call may fill it differently -- on a graph whose paths run along it,
@@ -794,6 +977,11 @@ extern "C" int flatgfa_dev_status(flatgfa_dev_plan_t *pl, void *stream_) {
         if (st & 1u) {
             set_error("a step refers to a segment id (or a query to a path id) that is out of range");
             return FLATGFA_ERR_BOUNDS;
+        }
+        if (st & 32u) {  // (kStStale: FLATGFA_CHECK_NO_CLAIM=1)
+            set_error("the step values changed behind the plan (a path it found strictly monotone no longer is, a no-claim mark or a reversed copy no longer holds): "
+                      "call flatgfa_dev_plan_steps_changed, or make the plan again");
+            return FLATGFA_ERR_STALE_PLAN;
         }
         if (st & 8u) {  // (depth_fast.hip: kStInternal)
             char what[512] = "";
@@ -831,6 +1019,7 @@ extern "C" int flatgfa_dev_status(flatgfa_dev_plan_t *pl, void *stream_) {
 // Which kernels a plan's calls run: the choices made (some of them by timing) when it was created.
 extern "C" int flatgfa_dev_plan_describe(flatgfa_dev_plan_t *pl, char *out, int cap) {
     if (!pl || !out || cap <= 0) return 0;
+    marks_poll(pl, true);  // (what the description says about no-claim marks is what later calls run with)
     const FastPlan &f = pl->fast;
     std::string s;
     if (!f.eligible) {
@@ -975,9 +1164,7 @@ extern "C" flatgfa_dev_pipeline_t *flatgfa_dev_pipeline_create(const flatgfa_dev
         // 0.133 -> 0.168).  Graphs beyond 2^28 steps, whose pass 1 is bound by instruction issue as much as by memory, take
         // eleven sixteenths whatever is in flight (ninety paths of ten million steps 2.17 -> 1.89 ms; sixteen thousand
         // haplotype walks even; half the chip loses there: profiles/NOTES.md R5.10).
-        int n_cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) n_cus = prop.multiProcessorCount;
+        const int n_cus = device_cus(p->device);
         const uint32_t wgs = calls_in_flight < 2 ? 0u : (uint32_t)(calls_in_flight >= 3 && g->n_steps <= (1ull << 28) ? n_cus / 2 : n_cus * 11 / 16);
         flatgfa_dev_plan_t *pl = plan_create_impl(g, hb, he, wgs);
         if (!pl) { flatgfa_dev_pipeline_destroy(p); return nullptr; }
@@ -1024,6 +1211,16 @@ extern "C" int flatgfa_dev_pipeline_status(flatgfa_dev_pipeline_t *p) {
     int rc = FLATGFA_OK;
     for (size_t k = 0; k < p->plans.size(); ++k) {
         const int r = flatgfa_dev_status(p->plans[k], p->streams[k]);  // (synchronizes the lane; completes its last call if that ran out of room)
+        if (r != FLATGFA_OK && rc == FLATGFA_OK) rc = r;
+    }
+    return rc;
+}
+
+extern "C" int flatgfa_dev_pipeline_steps_changed(flatgfa_dev_pipeline_t *p) {
+    if (!p) { set_error("dev_pipeline_steps_changed: NULL pipeline"); return FLATGFA_ERR_ARG; }
+    int rc = FLATGFA_OK;
+    for (size_t k = 0; k < p->plans.size(); ++k) {
+        const int r = flatgfa_dev_plan_steps_changed(p->plans[k], p->streams[k]);
         if (r != FLATGFA_OK && rc == FLATGFA_OK) rc = r;
     }
     return rc;

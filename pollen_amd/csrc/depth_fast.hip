@@ -334,11 +334,9 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     if (const char *f = getenv("FLATGFA_WB")) wb = (uint32_t)strtoul(f, nullptr, 10);
     const uint32_t n_win = (uint32_t)(((uint64_t)n_range + (1u << wb) - 1) >> wb);
     if (n_win > max_win) return true;
-    hipDeviceProp_t prop;
     int dev = 0;
     FAST_TRY(hipGetDevice(&dev));
-    FAST_TRY(hipGetDeviceProperties(&prop, dev));
-    fp->n_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+    fp->n_cus = (uint32_t)device_cu_count(dev);
     fp->n_slots = fp->n_cus;
     // Pass 1's persistent workgroups: one per CU -- or fewer for a plan that is one lane of a pipeline (calls in flight:
     // flatgfa_dev_pipeline_create), where the CUs it leaves are another call's.  FLATGFA_SCAN_WGS=n: tests, measurements.
@@ -387,6 +385,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         // (FLATGFA_NO_CLAIM=0: every path claims, monotone or not -- tests and measurements)
         if (const char *nc = getenv("FLATGFA_NO_CLAIM"); nc && nc[0] == '0') std::fill(mono.begin(), mono.end(), 0u);
     }
+    plan_tick("range: k_count_runs + its copies");
     const bool short_any = getenv("FLATGFA_SHORT_ANY") != nullptr;  // tests: let k_scan_short find out and hand back
     const bool no_rev = measure_switch("FLATGFA_NO_REVERSED_COPIES");
     // A wave-per-path kernel only knows runs that go up.  A path that walks the ids downwards (a
@@ -448,6 +447,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         for (size_t i = 0; i < whole.size(); ++i) sorted[i] = whole[order[i]];
         whole.swap(sorted);
     }
+    plan_tick("range: paths classified, k_first_ids, sorted");
     if (!rev_list.empty()) {
         fp->n_rev_steps = (uint32_t)(rev_len + 1024);  // (a block is read whole)
         FAST_TRY(hipMalloc(&fp->rev_steps, (size_t)fp->n_rev_steps * 4));
@@ -538,6 +538,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     }
     fp->n_shared = cut(piece ? piece : 32768, &items);
     std::stable_sort(items.begin(), items.end(), longer);
+    plan_tick("range: the deal played through, items cut");
     // A wave-per-path list: the paths read from the graph's steps, then those read from their reversed copies; of
     // either kind the ones that need no claim lie next to the boundary, so that one stretch of the list names them
     // all: [claim][no claim | no claim, reversed][claim, reversed], each part longest first.
@@ -725,6 +726,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         FAST_TRY(hipMalloc(&fp->wave_off, wave_off.size() * 4));
         FAST_TRY(hipMemcpy(fp->wave_off, wave_off.data(), wave_off.size() * 4, hipMemcpyHostToDevice));
     }
+    plan_tick("range: pass 2 lists made and uploaded");
     // Worst case is one record per step (plus one per block and window crossing) for k_scan and
     // one depth plus one uniq record per step for k_scan_short, spread evenly over the
     // sub-buckets; real graphs need a fraction of that (runs), skewed ones more, so the
@@ -766,6 +768,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipMemset(fp->dir, 0, (size_t)fp->dstride * n_win * sizeof(uint2)));
     FAST_TRY(hipMalloc(&fp->islot, (size_t)fp->dstride * 4));
     FAST_TRY(hipMemset(fp->islot, 0, (size_t)fp->dstride * 4));
+    plan_tick("range: buckets, cursors, directory allocated and cleared");
     FAST_TRY(hipMalloc(&fp->items, (items.size() + fp->max_back + 1) * sizeof(uint4)));
     if (!items.empty()) {
         FAST_TRY(hipMemcpy(fp->items, items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
@@ -830,60 +833,23 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
                 for (const uint4 &it : dev_items) fp->n_noclaim += it.z >> 31;
             }
             for (const uint4 &it : items) item_steps += it.y - it.x;
+            fp->item_steps = item_steps;
             // Items of paths that do not qualify as a whole: the stretches of them that lie in windows their path enters once
             // and walks one way (k_visit_bits, k_chunk_flags) -- k_scan gives the records of such blocks the no-claim tag too.
             // For one range over all segments, tagged; two bits per (path, window) and one per sixteen steps of scratch.
-            if (no_claim && fp->tagged && !ranged && fp->n_noclaim < fp->n_items && !getenv("FLATGFA_NO_CLAIM_BLOCKS_OFF")) {
-                const uint64_t vis_words = ((uint64_t)g.n_paths * n_win + 15) / 16 + 1, flag_words = g.n_steps / 512 + 4;
-                if (vis_words * 4 <= (256ull << 20)) {
-                    uint32_t *d_vis = nullptr, *d_pbeg = nullptr;
-                    unsigned long long *d_cnt = nullptr, flagged = 0, cnt2[2] = {0, 0};
-                    hipError_t e2 = hipMalloc(&d_vis, vis_words * 4);
-                    if (e2 == hipSuccess) e2 = hipMemset(d_vis, 0, vis_words * 4);
-                    if (e2 == hipSuccess) e2 = hipMalloc(&d_pbeg, (size_t)g.n_paths * 4);
-                    if (e2 == hipSuccess) e2 = hipMemcpy(d_pbeg, hb, (size_t)g.n_paths * 4, hipMemcpyHostToDevice);
-                    if (e2 == hipSuccess) e2 = hipMalloc(&d_cnt, 16);
-                    if (e2 == hipSuccess) e2 = hipMemset(d_cnt, 0, 16);
-                    uint32_t *d_chunks = nullptr;
-                    if (e2 == hipSuccess) e2 = hipMalloc(&d_chunks, flag_words * 4);
-                    if (e2 == hipSuccess) e2 = hipMemset(d_chunks, 0, flag_words * 4);
-                    if (e2 == hipSuccess) e2 = hipMalloc(&fp->cflags, flag_words * 4);
-                    if (e2 == hipSuccess) e2 = hipMemset(fp->cflags, 0, flag_words * 4);
-                    if (e2 == hipSuccess) {
-                        const dim3 grid(std::min<uint32_t>(fp->n_items, fp->n_cus * 8u));
-                        hipLaunchKernelGGL(k_visit_bits, grid, dim3(256), 0, nullptr, g.steps, reinterpret_cast<const uint4 *>(fp->items), fp->n_items, d_pbeg, wb, n_win, d_vis);
-#ifndef FGFA_SKIP_FLAG_CLEAR
-#define FGFA_SKIP_FLAG_CLEAR 0  /* a test's build: the marks of overlapping spans not taken away again (tests/test_gpu_depth.py::test_no_claim_marks_where_spans_overlap must then fail) */
-#endif
-                        for (int clear = 0; clear < (FGFA_SKIP_FLAG_CLEAR ? 1 : 2); ++clear)
-                            hipLaunchKernelGGL(k_chunk_flags, grid, dim3(256), 0, nullptr, g.steps, reinterpret_cast<const uint4 *>(fp->items), fp->n_items, clear != 0, wb, n_win,
-                                               d_vis, d_chunks, d_cnt);
-                        (void)hipMemsetAsync(d_cnt, 0, 16, nullptr);
-                        for (int clear = 0; clear < (FGFA_SKIP_FLAG_CLEAR ? 1 : 2); ++clear)
-                            hipLaunchKernelGGL(k_block_flags, grid, dim3(256), 0, nullptr, reinterpret_cast<const uint4 *>(fp->items), fp->n_items, g.n_steps, clear != 0,
-                                               d_chunks, fp->cflags, d_cnt);
-                        e2 = hipMemcpy(cnt2, d_cnt, 16, hipMemcpyDeviceToHost);
-                        flagged = cnt2[0];  // (chunks of claiming items' blocks that qualify as wholes; where spans overlap, before another path took a mark away)
-                    }
-                    if (d_vis) (void)hipFree(d_vis);
-                    if (d_chunks) (void)hipFree(d_chunks);
-                    if (d_pbeg) (void)hipFree(d_pbeg);
-                    if (d_cnt) (void)hipFree(d_cnt);
-                    // (worth it from half of the chunks: pass 2's build with the no-claim test costs the claiming records 4 %, k_scan's with the
-                    // marks 1-10 % (short items most), and the claims are two fifths of pass 2 -- contigs of ten blocks with a third of
-                    // their chunks marked lost 7 % of the call; cfg-L's random walks have one chunk in a thousand that qualifies)
-                    uint64_t min_pct = 50;
-                    if (const char *f = getenv("FLATGFA_NO_CLAIM_BLOCKS_MIN")) min_pct = strtoull(f, nullptr, 10);  // tests, measurements
-                    if (e2 != hipSuccess || flagged == 0 || flagged * 1600 < item_steps * min_pct) {  // (nothing gained: the plain kernels, no table)
-                        if (fp->cflags) (void)hipFree(fp->cflags);
-                        fp->cflags = nullptr;
-                        flagged = 0;
-                    }
-                    FAST_TRY(e2);
-                    fp->n_flag_chunks = flagged;
-                }
+            // Three more reads of the steps, and not on the way to the first answer: the plan's owner runs them on a side
+            // stream (fast_marks_start) and installs them between two later calls -- except where the buckets are laid out
+            // to the count (a build of k_scan with marks cuts its runs at block ends: the counting call must see them).
+            fp->marks_wanted = no_claim && fp->tagged && !ranged && fp->n_noclaim < fp->n_items && !getenv("FLATGFA_NO_CLAIM_BLOCKS_OFF") &&
+                               (((uint64_t)g.n_paths * n_win + 15) / 16 + 1) * 4 <= (256ull << 20);
+            if (fp->marks_wanted && want_packed) {
+                MarksJob job;
+                if (!fast_marks_start(*fp, g, hb, nullptr, &job)) return false;
+                fast_marks_finish(fp, &job);
+                fp->marks_wanted = false;
             }
             fp->est_records = runs64;
+            plan_tick("range: items uploaded, k_item_dirs");
             // more than three records for four steps: not worth looking for runs (k_scan_dense)
             const bool can = !fp->dbg && dense_lds_bytes(fp->nwp) + 64 <= kLdsLimit;
             // More than a record for two steps: k_scan_dense may be the better pass 1 -- when the
@@ -925,6 +891,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     if (!path_kernels_setup() || !scan_kernels_setup() || !accum_kernels_setup()) return false;
     FAST_TRY(hipMalloc(&fp->work_counter, 256));
     FAST_TRY(hipMemset(fp->work_counter, 0, 256));
+    plan_tick("range: lists uploaded, kernel attributes");
     // Two pass-2 workgroups per window (k_accum_pair): tagged plans without split paths whose windows
     // do not fill the chip twice over anyway.  FLATGFA_ACC_PAIR=1 (measurements, tests).
     // In round 3 it paid where a window had 64 k records or more (the chromosome model 4 % faster, ten
@@ -1248,6 +1215,167 @@ static bool fast_plan_create_impl(const flatgfa_dev_graph_t &g, const uint32_t *
         }
     }
     return true;
+}
+
+#ifndef FGFA_SKIP_FLAG_CLEAR
+#define FGFA_SKIP_FLAG_CLEAR 0  /* a test's build: the marks of overlapping spans not taken away again (tests/test_gpu_depth.py::test_no_claim_marks_where_spans_overlap must then fail) */
+#endif
+
+static void marks_release(MarksJob *job) {
+    for (void *p : {(void *)job->vis, (void *)job->pbeg, (void *)job->chunks, (void *)job->flags, (void *)job->cnt})
+        if (p) (void)hipFree(p);
+    if (job->done) (void)hipEventDestroy(job->done);
+    *job = MarksJob();
+}
+
+bool fast_marks_start(const FastPlan &fp, const flatgfa_dev_graph_t &g, const uint32_t *hb, hipStream_t side, MarksJob *job) {
+    *job = MarksJob();
+    if (!fp.marks_wanted || !fp.items || !fp.n_items) return true;
+    const uint64_t vis_words = ((uint64_t)g.n_paths * fp.n_win + 15) / 16 + 1, flag_words = g.n_steps / 512 + 4;
+    hipError_t e = hipMalloc(&job->vis, vis_words * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(job->vis, 0, vis_words * 4, side);
+    if (e == hipSuccess) e = hipMalloc(&job->pbeg, (size_t)g.n_paths * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(job->pbeg, hb, (size_t)g.n_paths * 4, hipMemcpyHostToDevice, side);
+    if (e == hipSuccess) e = hipMalloc(&job->cnt, 32);
+    if (e == hipSuccess) e = hipMemsetAsync(job->cnt, 0, 32, side);
+    if (e == hipSuccess) e = hipMalloc(&job->chunks, flag_words * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(job->chunks, 0, flag_words * 4, side);
+    if (e == hipSuccess) e = hipMalloc(&job->flags, flag_words * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(job->flags, 0, flag_words * 4, side);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&job->done, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error(std::string("no-claim marks: ") + hipGetErrorString(e));
+        marks_release(job);
+        return false;
+    }
+    const dim3 grid(std::min<uint32_t>(fp.n_items, fp.n_cus * 8u));
+    const uint4 *items = reinterpret_cast<const uint4 *>(fp.items);
+    hipLaunchKernelGGL(k_visit_bits, grid, dim3(256), 0, side, g.steps, items, fp.n_items, job->pbeg, fp.wb, fp.n_win, job->vis);
+    for (int clear = 0; clear < (FGFA_SKIP_FLAG_CLEAR ? 1 : 2); ++clear)
+        hipLaunchKernelGGL(k_chunk_flags, grid, dim3(256), 0, side, g.steps, items, fp.n_items, clear != 0, fp.wb, fp.n_win, job->vis, job->chunks, job->cnt);
+    // (cnt[2]: the chunks of claiming items' blocks that qualify as wholes; where spans overlap, before another path took a mark away)
+    for (int clear = 0; clear < (FGFA_SKIP_FLAG_CLEAR ? 1 : 2); ++clear)
+        hipLaunchKernelGGL(k_block_flags, grid, dim3(256), 0, side, items, fp.n_items, g.n_steps, clear != 0, job->chunks, job->flags, job->cnt + 2);
+    e = hipEventRecord(job->done, side);
+    if (e != hipSuccess || hipGetLastError() != hipSuccess) {
+        set_error("no-claim marks: launch failed");
+        (void)hipStreamSynchronize(side);
+        marks_release(job);
+        return false;
+    }
+    job->active = true;
+    return true;
+}
+
+bool fast_marks_ready(const MarksJob &job) { return !job.active || hipEventQuery(job.done) == hipSuccess; }
+
+void fast_marks_finish(FastPlan *fp, MarksJob *job) {
+    if (!job->active) return;
+    unsigned long long cnt[4] = {0, 0, 0, 0};
+    hipError_t e = hipEventSynchronize(job->done);
+    if (e == hipSuccess) e = hipMemcpy(cnt, job->cnt, 32, hipMemcpyDeviceToHost);
+    const unsigned long long flagged = cnt[2];
+    // (worth it from half of the chunks: pass 2's build with the no-claim test costs the claiming records 4 %, k_scan's with the
+    // marks 1-10 % (short items most), and the claims are two fifths of pass 2 -- contigs of ten blocks with a third of
+    // their chunks marked lost 7 % of the call; cfg-L's random walks have one chunk in a thousand that qualifies)
+    uint64_t min_pct = 50;
+    if (const char *f = getenv("FLATGFA_NO_CLAIM_BLOCKS_MIN")) min_pct = strtoull(f, nullptr, 10);  // tests, measurements
+    if (e == hipSuccess && flagged != 0 && flagged * 1600 >= fp->item_steps * min_pct && !fp->cflags) {
+        fp->cflags = job->flags;
+        job->flags = nullptr;
+        fp->n_flag_chunks = flagged;
+    }
+    if (e != hipSuccess) (void)hipGetLastError();
+    marks_release(job);
+}
+
+// ---- FLATGFA_CHECK_NO_CLAIM=1: what a plan takes for granted about the step values, looked at again before a call ----
+// Every listed stretch of steps (x .. y of `steps`; `first` = where its path starts: pbeg[w], or x itself) must walk the
+// segment ids strictly one way, the steps before it (down to `first`) included: a local test on three consecutive steps.
+__global__ __launch_bounds__(256) void k_check_mono(const uint32_t *__restrict__ steps, const uint4 *__restrict__ list, uint32_t n, const uint32_t *__restrict__ pbeg,
+                                                     uint32_t need_flag, uint32_t *__restrict__ status) {
+    for (uint32_t j = blockIdx.x; j < n; j += gridDim.x) {
+        const uint4 it = list[j];
+        if (need_flag && !(it.z & need_flag)) continue;
+        const uint64_t first = pbeg ? pbeg[it.w] : it.x;
+        bool bad = false;
+        for (uint64_t t = (uint64_t)it.x + threadIdx.x; t < it.y; t += 256) {
+            if (t < first + 1) continue;
+            const uint32_t a = steps[t] >> 1, b = steps[t - 1] >> 1;
+            bad = bad || a == b;
+            if (t >= first + 2) {
+                const uint32_t c = steps[t - 2] >> 1;
+                bad = bad || b == c || ((a > b) != (b > c));
+            }
+        }
+        if (bad) atomicOr(status, kStStale);
+    }
+}
+// a reversed copy (x .. y of `rev`) against its path's steps as they are now
+__global__ __launch_bounds__(256) void k_check_rev(const uint32_t *__restrict__ steps, const uint32_t *__restrict__ rev, const uint4 *__restrict__ list, uint32_t n,
+                                                    const uint32_t *__restrict__ pend, uint32_t *__restrict__ status) {
+    for (uint32_t j = blockIdx.x; j < n; j += gridDim.x) {
+        const uint4 it = list[j];
+        const uint64_t e = pend[it.w];
+        bool bad = false;
+        for (uint32_t i = threadIdx.x; i < it.y - it.x; i += 256) bad = bad || rev[it.x + i] != steps[e - 1u - i];
+        if (bad) atomicOr(status, kStStale);
+    }
+}
+// a mark the plan holds that the step values no longer earn
+__global__ __launch_bounds__(256) void k_check_flags(const uint32_t *__restrict__ held, const uint32_t *__restrict__ fresh, uint64_t n_words, uint32_t *__restrict__ status) {
+    bool bad = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * 256) bad = bad || (held[i] & ~fresh[i]) != 0u;
+    if (bad) atomicOr(status, kStStale);
+}
+
+static int check_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *d_pbeg, const uint32_t *d_pend, uint32_t *status, hipStream_t stream) {
+    if (!fp.eligible) return FLATGFA_OK;
+    const uint32_t grid = fp.n_cus * 8u;
+    if (fp.n_items && fp.n_noclaim)
+        hipLaunchKernelGGL(k_check_mono, dim3(std::min(fp.n_items, grid)), dim3(256), 0, stream, g.steps, reinterpret_cast<const uint4 *>(fp.items), fp.n_items, d_pbeg, kItemNoClaim, status);
+    struct L { const void *list; uint32_t n, n_rev, mono_lo, mono_n; };
+    for (const L &l : {L{fp.short_items, fp.n_short, fp.n_short_rev, fp.short_mono_lo, fp.short_mono_n}, L{fp.medium_items, fp.n_medium, fp.n_medium_rev, fp.medium_mono_lo, fp.medium_mono_n},
+                       L{fp.tiny_items, fp.n_tiny, 0u, fp.tiny_mono_lo, fp.tiny_mono_n}}) {
+        if (!l.n) continue;
+        const uint4 *list = reinterpret_cast<const uint4 *>(l.list);
+        const uint32_t n_fwd = l.n - l.n_rev;
+        // the paths taken as strictly one way: those read from the graph's steps, then those read from their reversed copies
+        const uint32_t fwd_mono = l.mono_lo < n_fwd ? std::min(l.mono_n, n_fwd - l.mono_lo) : 0u, rev_mono = l.mono_n - fwd_mono;
+        if (fwd_mono) hipLaunchKernelGGL(k_check_mono, dim3(std::min(fwd_mono, grid)), dim3(256), 0, stream, g.steps, list + l.mono_lo, fwd_mono, (const uint32_t *)nullptr, 0u, status);
+        if (rev_mono) hipLaunchKernelGGL(k_check_mono, dim3(std::min(rev_mono, grid)), dim3(256), 0, stream, (const uint32_t *)fp.rev_steps, list + l.mono_lo + fwd_mono, rev_mono, (const uint32_t *)nullptr, 0u, status);
+        if (l.n_rev) hipLaunchKernelGGL(k_check_rev, dim3(std::min(l.n_rev, grid)), dim3(256), 0, stream, g.steps, (const uint32_t *)fp.rev_steps, list + n_fwd, l.n_rev, d_pend, status);
+    }
+    if (fp.cflags) {  // the marks, made again from the steps as they are
+        FastPlan again = fp;
+        again.marks_wanted = true;
+        MarksJob job;
+        if (!fast_marks_start(again, g, hb, stream, &job)) return FLATGFA_ERR_HIP;
+        if (job.active) {
+            const uint64_t flag_words = g.n_steps / 512 + 4;
+            hipLaunchKernelGGL(k_check_flags, dim3(256), dim3(256), 0, stream, (const uint32_t *)fp.cflags, (const uint32_t *)job.flags, flag_words, status);
+            (void)hipStreamSynchronize(stream);
+            marks_release(&job);
+        }
+    }
+    return hipGetLastError() == hipSuccess ? FLATGFA_OK : FLATGFA_ERR_HIP;
+}
+
+int fast_check_plan_facts(const FastPlan &fp, const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, uint32_t *status, hipStream_t stream) {
+    if (!fp.eligible || !g.n_paths) return FLATGFA_OK;
+    uint32_t *d_spans = nullptr;
+    if (hipMalloc(&d_spans, (size_t)g.n_paths * 8) != hipSuccess) { (void)hipGetLastError(); set_error("check: hipMalloc"); return FLATGFA_ERR_HIP; }
+    int rc = FLATGFA_OK;
+    if (hipMemcpyAsync(d_spans, hb, (size_t)g.n_paths * 4, hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(d_spans + g.n_paths, he, (size_t)g.n_paths * 4, hipMemcpyHostToDevice, stream) != hipSuccess) rc = FLATGFA_ERR_HIP;
+    // (path groups: a group's plan was made with spans of its own -- empty ones for the other groups' paths --, but its items and
+    // lists only name paths of its own, whose spans are the graph's)
+    if (rc == FLATGFA_OK) rc = check_range(fp, g, hb, d_spans, d_spans + g.n_paths, status, stream);
+    for (uint32_t r = 0; r < fp.n_more && rc == FLATGFA_OK; ++r) rc = check_range(fp.more[r], g, hb, d_spans, d_spans + g.n_paths, status, stream);
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(d_spans);
+    return rc;
 }
 
 // Scratch for path sums riding on seg_depth: one {sum len, sum depth * len} per (window, item).

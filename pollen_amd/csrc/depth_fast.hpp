@@ -3,10 +3,34 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cstdint>
+#include <mutex>
 
 #include "../../include/flatgfa.h"
 
 namespace fgfa_dev {
+
+// The runtime keeps a kernel's attributes (hipFuncSetAttribute: more than 64 KB of dynamic LDS) per DEVICE, and one process
+// may drive several (flatgfa_sharded_create: a plan per shard on its own device and host thread; Python: graphs on cuda:1 and
+// up).  `fn` runs once per device that is current when a plan is made there; devices beyond the mask's 64 run it every time.
+struct OncePerDevice {
+    std::mutex mu;
+    uint64_t done = 0;
+    template <class F>
+    bool operator()(F fn) {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return true;
+        if (!fn()) return false;
+        if (dev >= 0 && dev < 64) done |= 1ull << dev;
+        return true;
+    }
+};
+
+// multiProcessorCount of a device, asked for once per device (depth_device.hip)
+int device_cu_count(int device);
+// FLATGFA_TIMING=1: prints what the calling thread spent since its last tick (the device drained first), to stderr; `what` == nullptr restarts the clock
+void plan_tick(const char *what);
 
 struct FastPlan {
     bool eligible = false;
@@ -65,6 +89,9 @@ struct FastPlan {
                                    // lies in windows its path enters once and walks one way, and the block makes no-claim records too (k_visit_bits,
                                    // k_chunk_flags, k_block_flags); nullptr: none
     uint64_t n_flag_chunks = 0;    // how many chunks say so
+    bool marks_wanted = false;     // create_range: this plan may gain from such marks (tagged, one range, items that claim) -- they are made off the
+                                   // critical path (fast_marks_start on a side stream, fast_marks_finish installs them between two calls)
+    uint64_t item_steps = 0;       // steps of k_scan's items (what the marks' share is measured against)
     uint32_t max_back = 0;
     bool accumulate = false;       // a group of paths behind the first (see fast_plan_create): pass 2 adds to the outputs
     bool too_many_items = false;   // create_range's verdict: only the number of items (or of split paths) per k_scan workgroup stands between this range and a tagged plan
@@ -94,6 +121,31 @@ struct FastPlan {
     uint32_t *other_ids = nullptr;     // u32[n_other] the paths k_scan_short walks (their sums need k_path_sums)
     uint32_t n_other = 0;
 };
+
+// The per-block no-claim marks of a plan (k_visit_bits, k_chunk_flags, k_block_flags: three more reads of the steps) are
+// not on the way to the first answer: a job enqueues them on a stream of its own; once they are there they are looked
+// at on the host (do enough blocks qualify?) and installed between two calls.
+struct MarksJob {
+    bool active = false;
+    uint32_t *vis = nullptr, *pbeg = nullptr, *chunks = nullptr, *flags = nullptr;
+    unsigned long long *cnt = nullptr;
+    hipEvent_t done = nullptr;
+};
+// Enqueues the job's kernels on `side` (which must not be a stream a call of the plan runs on).  `host_path_begin`: the
+// spans the plan was made with (P entries, alive until the job is finished).  False on a HIP error (the plan then
+// simply has no marks).  A plan that does not want marks (fp.marks_wanted) gets no job: job->active stays false.
+bool fast_marks_start(const FastPlan &fp, const flatgfa_dev_graph_t &g, const uint32_t *host_path_begin, hipStream_t side, MarksJob *job);
+// Has the job finished?  (never blocks)
+bool fast_marks_ready(const MarksJob &job);
+// Waits for the job, releases its scratch and installs the marks in `fp` if enough blocks qualify (no call of the plan
+// may be enqueued concurrently from another thread; calls already running are not affected: their arguments were
+// copied when they were launched).
+void fast_marks_finish(FastPlan *fp, MarksJob *job);
+// Debug (FLATGFA_CHECK_NO_CLAIM=1): re-derives, on `stream` and before a call's kernels, the facts about the step values
+// that the plan relies on without re-checking them per call -- items and short paths found strictly monotone, the
+// per-block marks, the reversed copies -- and raises status bit kStStale where one no longer holds.
+int fast_check_plan_facts(const FastPlan &fp, const flatgfa_dev_graph_t &g, const uint32_t *host_path_begin, const uint32_t *host_path_end, uint32_t *status,
+                          hipStream_t stream);
 
 // Decides eligibility (16-byte aligned steps, directories that stay small next to the steps) and
 // allocates the scratch: one range of at most 2048 windows, or several.  Returns false only on a HIP error.

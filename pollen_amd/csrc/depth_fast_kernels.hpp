@@ -10,30 +10,12 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
-#include <mutex>
 
 #include "depth_fast.hpp"
 #include "device_common.hpp"
 
 namespace fgfa_dev {
 
-// The runtime keeps a kernel's attributes (hipFuncSetAttribute: more than 64 KB of dynamic LDS) per DEVICE, and one process
-// may drive several (flatgfa_sharded_create: a plan per shard on its own device and host thread; Python: graphs on cuda:1 and
-// up).  `fn` runs once per device that is current when a plan is made there; devices beyond the mask's 64 run it every time.
-struct OncePerDevice {
-    std::mutex mu;
-    uint64_t done = 0;
-    template <class F>
-    bool operator()(F fn) {
-        int dev = -1;
-        if (hipGetDevice(&dev) != hipSuccess) return false;
-        std::lock_guard<std::mutex> lk(mu);
-        if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return true;
-        if (!fn()) return false;
-        if (dev >= 0 && dev < 64) done |= 1ull << dev;
-        return true;
-    }
-};
 
 constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
@@ -43,7 +25,7 @@ constexpr int kAccThreads = 1024;
 constexpr uint32_t kAccWaves = kAccThreads / 64;
 constexpr uint32_t kLdsLimit = 160 * 1024;
 // status word bits (flatgfa_dev_status)
-constexpr uint32_t kStBounds = 1u, kStDebug = 2u, kStOverflow = 4u, kStInternal = 8u, kStBackOverflow = 16u;  // (16: more short paths handed back than the list holds: larger buckets would not help, the atomic kernels complete the call)  // (8: an invariant between the two passes did not hold -- a bug, reported as an error rather than as counts)
+constexpr uint32_t kStBounds = 1u, kStDebug = 2u, kStOverflow = 4u, kStInternal = 8u, kStBackOverflow = 16u, kStStale = 32u;  // (32: FLATGFA_CHECK_NO_CLAIM=1 found the step values changed behind the plan)  // (16: more short paths handed back than the list holds: larger buckets would not help, the atomic kernels complete the call)  // (8: an invariant between the two passes did not hold -- a bug, reported as an error rather than as counts)
 
 // ---- the wave-per-path kernels (k_scan_short): windows of 4096 segments, at most 256 of them ----
 constexpr uint32_t kRunBits = 11;  // a run of a depth-only call is cut at multiples of 2^11 ids (it then never crosses a window's end)

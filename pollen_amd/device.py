@@ -59,18 +59,46 @@ class DeviceGraph:
 
 
 class DepthPlan:
-    """A prepared depth query (flatgfa_dev_plan_t): launch plan + scratch HBM for one DeviceGraph."""
+    """A prepared depth query (flatgfa_dev_plan_t): launch plan + scratch HBM for one DeviceGraph.
 
-    def __init__(self, graph: DeviceGraph):
+    The plan is laid out for the step values it was made with: a caller that changes ``graph.steps`` (a mutable
+    tensor) under a live plan calls :meth:`steps_changed` before the next query -- a path the plan found strictly
+    monotone is counted without the per-path "seen" set, and nothing re-checks that per call (``FLATGFA_CHECK_NO_CLAIM=1``
+    in the environment does, as a debugging aid: ``status()`` then raises with code -8).
+
+    ``first=(depth_out, uniq_out)`` (int32 CUDA tensors of n_segs elements; uniq_out may be None): the query that sizes
+    the plan's scratch writes the caller's buffers -- creating the plan is the first query (flatgfa_dev_plan_create_first);
+    the tensors are complete when the constructor returns, and ``first_status`` is 0 or -2 (an id out of range)."""
+
+    def __init__(self, graph: DeviceGraph, first=None):
         torch = _torch()
         self.graph = graph
+        self.first_status = 0
         with torch.cuda.device(graph.device):
             g = graph.c_struct()
-            self._p = ctypes.c_void_p(_lib.lib().flatgfa_dev_plan_create(
-                ctypes.byref(g), graph.h_path_begin.ctypes.data if graph.n_paths else None,
-                graph.h_path_end.ctypes.data if graph.n_paths else None))
+            hb = graph.h_path_begin.ctypes.data if graph.n_paths else None
+            he = graph.h_path_end.ctypes.data if graph.n_paths else None
+            if first is None:
+                self._p = ctypes.c_void_p(_lib.lib().flatgfa_dev_plan_create(ctypes.byref(g), hb, he))
+            else:
+                d, u = first
+                S = graph.n_segs
+                for t in (d, u):
+                    if t is not None:
+                        assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous() and t.numel() == S
+                torch.cuda.current_stream(graph.device).synchronize()  # (the plan's creation runs on the null stream: whatever filled the buffers is done first)
+                st = ctypes.c_int(0)
+                self._p = ctypes.c_void_p(_lib.lib().flatgfa_dev_plan_create_first(
+                    ctypes.byref(g), hb, he, d.data_ptr() if S else None, u.data_ptr() if (u is not None and S) else None, ctypes.byref(st)))
+                self.first_status = int(st.value)
         if not self._p.value:
             raise FlatGFAError("dev_plan_create", -2)
+
+    def steps_changed(self) -> None:
+        """The values of ``graph.steps`` were changed (not the spans): make the plan again from the steps as they are
+        (flatgfa_dev_plan_steps_changed; waits for torch's current stream first)."""
+        with _torch().cuda.device(self.graph.device):
+            _check(_lib.lib().flatgfa_dev_plan_steps_changed(self._p, self._stream()), "dev_plan_steps_changed")
 
     def close(self) -> None:
         if getattr(self, "_p", None) is not None and self._p.value:
@@ -228,6 +256,11 @@ class DepthPipeline:
             after = ctypes.c_void_p(torch.cuda.current_stream(self.graph.device).cuda_stream) if after_current_stream else ctypes.c_void_p(-1)
             _check(_lib.lib().flatgfa_dev_pipeline_path_depth_all(self._p, depth_out.data_ptr() if S else None, length_out.data_ptr() if P else None,
                                                                   weighted_out.data_ptr() if P else None, after), "dev_pipeline_path_depth_all")
+
+    def steps_changed(self) -> None:
+        """The values of ``graph.steps`` were changed: every lane's plan is made again (flatgfa_dev_pipeline_steps_changed)."""
+        with _torch().cuda.device(self.graph.device):
+            _check(_lib.lib().flatgfa_dev_pipeline_steps_changed(self._p), "dev_pipeline_steps_changed")
 
     def join(self) -> None:
         """torch's current stream waits for every call enqueued so far (no host wait)."""

@@ -1421,3 +1421,193 @@ def test_fuzz_slice(part):
             else:
                 os.environ[k] = v
     assert not failed, failed
+
+
+# ---- step values changed behind a live plan (include/flatgfa.h: flatgfa_dev_plan_steps_changed, FLATGFA_CHECK_NO_CLAIM) ----
+def _pools_of_arrays(steps, pb, pe, S):
+    paths = np.zeros(len(pb), dtype=fo.PATH_DT)
+    paths["steps_start"], paths["steps_end"] = pb, pe
+    pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
+    pools.paths, pools.steps, pools.segs = paths, np.ascontiguousarray(steps, dtype=np.uint32), np.zeros(S, dtype=fo.SEG_DT)
+    return pools
+
+
+def _graph_with_facts(S, seed):
+    """Long monotone walks (no-claim items), short monotone ones up and down (wave-per-path lists, reversed copies), a few
+    walks that revisit, and walks with a tandem repeat now and then (per-block marks)."""
+    kinds = [("up", 60_000), ("down", 45_000), ("loop", 30_000), ("up", 1500), ("down", 1200), ("down", 900), ("up", 90), ("flat", 5000),
+             ("up", 70_000), ("down", 1800)] * 3
+    return _monotone_graph(S, kinds, seed=seed)
+
+
+def _break_a_fact(steps, pb, pe, which):
+    """One step changed so that a path the plan took for strictly monotone meets a segment twice."""
+    s = steps.copy()
+    lens = pe.astype(np.int64) - pb.astype(np.int64)
+    if which == "long":       # the first path (60 000 steps, upwards): a step in its middle repeats the one five before it
+        k = int(pb[0]) + int(lens[0]) // 2
+    elif which == "short_up":  # a short one read forwards
+        p = int(np.nonzero((lens > 1000) & (lens < 2000))[0][0])
+        k = int(pb[p]) + int(lens[p]) // 3
+    else:                      # a short one read from its reversed copy
+        p = int(np.nonzero((lens > 1000) & (lens < 2000))[0][1])
+        k = int(pb[p]) + int(lens[p]) // 3
+    s[k] = s[k - 5]
+    return s
+
+
+@pytest.mark.parametrize("which", ["long", "short_up", "short_down"])
+def test_steps_changed_remakes_the_plan(which, monkeypatch):
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.delenv("FLATGFA_CHECK_NO_CLAIM", raising=False)
+    S = 300_000
+    steps, pb, pe, pools = _graph_with_facts(S, seed=3)
+    graph = DeviceGraph(steps, pb, pe, S)
+    plan = DepthPlan(graph)
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    plan.seg_depth(d, u)
+    plan.status()
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    assert (d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all()
+    import re
+    desc = plan.describe()
+    assert re.search(r"no_claim_items=[1-9]", desc) and re.search(r"no_claim_paths=[1-9]", desc), desc   # (both kinds of facts are in play)
+    changed = _break_a_fact(steps, pb, pe, which)
+    assert (changed != steps).sum() == 1
+    graph.steps.copy_(torch.from_numpy(changed.view(np.int32)))   # behind the plan's back ...
+    plan.steps_changed()                                          # ... and said so
+    want_d2, want_u2 = fo.seg_depth_with_uniq(_pools_of_arrays(changed, pb, pe, S))
+    assert (want_u2 != want_u).any()                              # (the change does move unique depth)
+    for _ in range(2):
+        plan.seg_depth(d, u)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == want_d2).all()
+        assert (u.cpu().numpy().view(np.uint32) == want_u2).all()
+    # path depth rides on the same plan
+    ln = torch.zeros(len(pb), dtype=torch.int64, device="cuda:0")
+    ws = torch.zeros(len(pb), dtype=torch.int64, device="cuda:0")
+    graph2 = DeviceGraph(changed, pb, pe, S, np.ones(S, dtype=np.uint32))
+    plan2 = DepthPlan(graph2)
+    plan2.path_depth_all(d, ln, ws)
+    plan2.status()
+    assert (d.cpu().numpy().view(np.uint32) == want_d2).all()
+
+
+@pytest.mark.parametrize("which", ["long", "short_up", "short_down"])
+def test_check_mode_finds_steps_changed_behind_the_plan(which, monkeypatch):
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.setenv("FLATGFA_CHECK_NO_CLAIM", "1")
+    S = 300_000
+    steps, pb, pe, pools = _graph_with_facts(S, seed=5)
+    graph = DeviceGraph(steps, pb, pe, S)
+    plan = DepthPlan(graph)
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    want_d, want_u = fo.seg_depth_with_uniq(pools)
+    for _ in range(2):                      # the checks pass on the steps the plan was made with
+        plan.seg_depth(d, u)
+        plan.status()
+        assert (u.cpu().numpy().view(np.uint32) == want_u).all()
+    changed = _break_a_fact(steps, pb, pe, which)
+    graph.steps.copy_(torch.from_numpy(changed.view(np.int32)))
+    plan.seg_depth(d, u)
+    with pytest.raises(pa.FlatGFAError) as err:
+        plan.status()
+    assert err.value.code == -8, err.value    # FLATGFA_ERR_STALE_PLAN
+    plan.steps_changed()
+    want_d2, want_u2 = fo.seg_depth_with_uniq(_pools_of_arrays(changed, pb, pe, S))
+    plan.seg_depth(d, u)
+    plan.status()
+    assert (d.cpu().numpy().view(np.uint32) == want_d2).all() and (u.cpu().numpy().view(np.uint32) == want_u2).all()
+
+
+def test_check_mode_finds_a_stale_block_mark(monkeypatch):
+    """The `repeats` model's walks go back over a few segments now and then: most blocks carry the no-claim mark.  A step changed
+    inside a marked block so that its path enters a window twice takes the mark's ground away."""
+    import re
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
+    monkeypatch.setenv("FLATGFA_CHECK_NO_CLAIM", "1")
+    g = pa.synth(3, 600_000, 24, 100_000, "repeats", False)
+    steps, pb, pe, _ = g.soa()
+    S = 600_000
+    graph = DeviceGraph(steps, pb, pe, S)
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    plan = DepthPlan(graph, first=(d, u))
+    want_d, want_u = fo.seg_depth_with_uniq(pools_of(g))
+    assert plan.first_status == 0
+    assert (d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all()   # call 1: no marks yet
+    desc = plan.describe()
+    m = re.search(r"no_claim_chunks=(\d+)", desc)
+    assert m and int(m.group(1)) > 0, desc
+    plan.seg_depth(d, u)                                                                                              # call 2: with the marks
+    plan.status()
+    assert (d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all()
+    # a step in the middle of path 3 takes the id of the step 40 000 before it: a second entry into that window
+    changed = steps.copy()
+    k = int(pb[3]) + 70_000
+    changed[k] = changed[k - 40_000]
+    graph.steps.copy_(torch.from_numpy(changed.view(np.int32)))
+    plan.seg_depth(d, u)
+    with pytest.raises(pa.FlatGFAError) as err:
+        plan.status()
+    assert err.value.code == -8
+    plan.steps_changed()
+    want_d2, want_u2 = fo.seg_depth_with_uniq(_pools_of_arrays(changed, pb, pe, S))
+    plan.seg_depth(d, u)
+    plan.status()
+    assert (d.cpu().numpy().view(np.uint32) == want_d2).all() and (u.cpu().numpy().view(np.uint32) == want_u2).all()
+
+
+# ---- the first answer: creating the plan is the first query (flatgfa_dev_plan_create_first) ----
+@pytest.mark.parametrize("shape", [(1, 100_000, 100, 10_000, "pangenome"), (2, 1_000_000, 300, 40_000, "pangenome"), (3, 600_000, 24, 100_000, "repeats"),
+                                   (4, 400_000, 2000, 900, "haplotype"), (5, 10_000, 100, 10_000, "pangenome"), (6, 5_000_000, 40, 200_000, "chromosome"),
+                                   (7, 50_000, 30, 30_000, "uniform")], ids=lambda s: f"S{s[1]}_P{s[2]}_L{s[3]}_{s[4]}")
+def test_first_answer_is_the_plans_sizing_query(shape, device_path):
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    seed, S, P, L, model = shape
+    g = pa.synth(seed, S, P, L, model, False)
+    steps, pb, pe, _ = g.soa()
+    want_d, want_u = fo.seg_depth_with_uniq(pools_of(g))
+    graph = DeviceGraph(steps, pb, pe, S)
+    d = torch.full((S,), -3, dtype=torch.int32, device="cuda:0")     # (the outputs start as garbage)
+    u = torch.full((S,), -5, dtype=torch.int32, device="cuda:0")
+    plan = DepthPlan(graph, first=(d, u))
+    assert plan.first_status == 0
+    assert (d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all()
+    d2 = torch.full((S,), -7, dtype=torch.int32, device="cuda:0")
+    plan2 = DepthPlan(graph, first=(d2, None))                          # node depth alone
+    assert (d2.cpu().numpy().view(np.uint32) == want_d).all()
+    for p in (plan, plan2):                                             # ... and the plans are plans like any other
+        d.fill_(-1)
+        u.fill_(-1)
+        p.seg_depth(d, u)
+        p.status()
+        assert (d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all()
+
+
+def test_first_answer_reports_an_id_out_of_range():
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    S = 50_000
+    g = pa.synth(9, S, 20, 20_000, "pangenome", False)
+    steps, pb, pe, _ = g.soa()
+    steps = steps.copy()
+    steps[12345] = (S + 7) << 1
+    graph = DeviceGraph(steps, pb, pe, S)
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    plan = DepthPlan(graph, first=(d, u))
+    assert plan.first_status == -2                                      # FLATGFA_ERR_BOUNDS
+    plan.seg_depth(d, u)
+    with pytest.raises(pa.FlatGFAError):
+        plan.status()
