@@ -263,6 +263,12 @@ def main():
     for _ in range(max(args.warmup, len(op.bufs))):  # (every result buffer written at least once: all of them are verified below)
         op.run()
     status_all()
+    # What a plan makes behind its creation on a side stream (the per-block no-claim marks: three more reads of the steps, started by
+    # its first call) is part of warming up, not of the steady state the region measures: describe() waits for it.
+    for p_ in plans:
+        p_.describe()
+    if isinstance(op, PipelinedDepth):
+        op.pipe.describe()
     sync_all()
 
     # ---- verification of what is being timed: the REDUCED vector against the oracle, on every rank ----
@@ -471,6 +477,8 @@ def main():
             for _ in range(3):
                 plan0.seg_depth(cold[:S], cold[S:])
             plan0.status()
+            plan0.describe()  # (waits for what the plan makes behind its creation: not part of the calls sampled below)
+            torch.cuda.synchronize(device)
             dev.profile_enable(True)
             dev.profile_read()
             for _ in range(SAMPLE_STEPS):
@@ -503,6 +511,7 @@ def main():
                 for _ in range(max(args.warmup, in_flight)):
                     op0.run()
                 op0.finish()
+                op0.pipe.describe()  # (every lane's background work done before the region)
                 torch.cuda.synchronize()
                 t0c = time.perf_counter()
                 for _ in range(args.steps):
@@ -554,8 +563,7 @@ def main():
                 fa_u.fill_(-1)
                 torch.cuda.synchronize(device)
                 c0 = time.perf_counter()
-                fplan = dev.DepthPlan(graph, first=(fa_d, fa_u))
-                torch.cuda.synchronize(device)
+                fplan = dev.DepthPlan(graph, first=(fa_d, fa_u))   # (the buffers are complete when this returns: no synchronize here)
                 fa_runs.append((time.perf_counter() - c0) * 1e3)
                 got = torch.cat([fa_d, fa_u]).cpu().numpy().view(np.uint32).astype(np.int64)
                 if fplan.first_status != 0 or not bool((got == want).all()):
@@ -661,6 +669,10 @@ def main():
             cplan = dev.DepthPlan(dev.DeviceGraph(cs, cb, ce, S, cl, device=str(device)))
             cd = torch.zeros(S, dtype=torch.int32, device=device)
             cu = torch.zeros(S, dtype=torch.int32, device=device)
+            cplan.seg_depth(cd, cu)
+            cplan.status()
+            cplan.describe()
+            torch.cuda.synchronize(device)
             chrom_ms = timed(lambda: cplan.seg_depth(cd, cu))
             cplan.status()
             want = fo.seg_depth_with_uniq(fo.Pools(**{n: gc.pool(n) for n in fo.POOL_ORDER})) if not args.no_verify else None
@@ -686,6 +698,8 @@ def main():
                 keep.append((gk, grk, plk))
             for o in ops:
                 o.run()
+            for _, _, plk in keep:
+                plk.describe()
             torch.cuda.synchronize(device)
             rot_elapsed, _ = timed_loop(lambda i: ops[i % len(ops)].run(), args.steps, False)
             same_elapsed, _ = timed_loop(lambda i: op1.run(), args.steps, False)

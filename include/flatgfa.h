@@ -285,8 +285,9 @@ typedef struct flatgfa_dev_graph_t {
  * kernels against the atomic ones and keep the faster.  A graph beyond 16 M segments is walked in
  * ranges of at most 16 M (one pass over the steps per range and call).  What is not needed for the
  * first answer -- the per-block no-claim marks, three more reads of the steps -- is made on a
- * stream of the plan's own behind its creation and used from the first call after it is there
- * (flatgfa_dev_status and flatgfa_dev_plan_describe wait for it).
+ * side stream by the first call behind the plan's creation and used from the first call after it
+ * is there (flatgfa_dev_plan_describe waits for it; a caller that only wants the first answer never
+ * pays for it).
  * Calls on one plan must not overlap in time. */
 typedef struct flatgfa_dev_plan flatgfa_dev_plan_t;
 flatgfa_dev_plan_t *flatgfa_dev_plan_create(const flatgfa_dev_graph_t *g, const uint32_t *host_path_begin,

@@ -623,11 +623,25 @@ int flatgfa_seg_depth(flatgfa_t gfa, uint64_t *depth_out, uint64_t *uniq_out) {
     // both vectors in one copy (they lie next to each other in the handle's allocation, 256-byte aligned), widened on two threads
     const size_t S = gfa->view.segs.len, gap = (size_t)(gfa->d_uniq - gfa->d_depth);
     if (!S) return FLATGFA_OK;
+    const auto widen = [&](const uint32_t *src) {
+        std::thread other([&] { for (size_t i = 0; i < S; ++i) uniq_out[i] = src[gap + i]; });
+        for (size_t i = 0; i < S; ++i) depth_out[i] = src[i];  // Vec<usize>
+        other.join();
+    };
+    if ((gap + S) * 4 <= kChunk) {  // through one of the process's pinned staging buffers: the copy runs at the link's rate (a pageable target: a third of it)
+        StagePool &pool = *stage_pool();
+        std::lock_guard<std::mutex> lk(pool.mu);
+        if (pool.ensure(gfa->device, 1) == hipSuccess) {
+            CAPI_HIP(hipMemcpyAsync(pool.stage[0], gfa->d_depth, (gap + S) * 4, hipMemcpyDeviceToHost, gfa->stream));
+            CAPI_HIP(hipStreamSynchronize(gfa->stream));
+            widen(reinterpret_cast<const uint32_t *>(pool.stage[0]));
+            return FLATGFA_OK;
+        }
+        (void)hipGetLastError();
+    }
     std::vector<uint32_t> tmp(gap + S);
     CAPI_HIP(hipMemcpy(tmp.data(), gfa->d_depth, (gap + S) * 4, hipMemcpyDeviceToHost));
-    std::thread other([&] { for (size_t i = 0; i < S; ++i) uniq_out[i] = tmp[gap + i]; });
-    for (size_t i = 0; i < S; ++i) depth_out[i] = tmp[i];  // Vec<usize>
-    other.join();
+    widen(tmp.data());
     return FLATGFA_OK;
 }
 

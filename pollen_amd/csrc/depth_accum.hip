@@ -1375,7 +1375,7 @@ void launch_accum(const FastPlan &fp, AccArgs &aa, bool uniq, bool tagged, bool 
         if (fp.dense && fp.wb == 12) FGFA_TAGGED_LAUNCH(agrid, tl, 12, true, (int)kTagSlots);
         else if (fp.dense && fp.wb == 13) FGFA_TAGGED_LAUNCH(agrid, tl, 13, true, (int)kTagSlots);
 #ifdef FGFA_MEASURE
-        else if (fp.wb == 11 && getenv("FLATGFA_ACC_SMALL")) hipLaunchKernelGGL((k_accum_small<11>), agrid, dim3(kAccThreads), tl, stream, aa);
+        else if (fp.wb == 11 && test_hook("FLATGFA_ACC_SMALL")) hipLaunchKernelGGL((k_accum_small<11>), agrid, dim3(kAccThreads), tl, stream, aa);
 #endif
         else if (fp.wb == 11) FGFA_TAGGED_LAUNCH(agrid, tl, 11, false, (int)kTagSlots);
         else if (fp.acc_own && fp.wb == 12 && fp.acc_slots == 8 && fp.n_shared <= 64) FGFA_OWN_LAUNCH(agrid, tagged_lds_bytes(12, fp.n_shared, 8), 12, 8);

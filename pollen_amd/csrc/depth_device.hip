@@ -277,6 +277,7 @@ struct flatgfa_dev_plan {
     uint32_t scan_workgroups = 0;      // (plan_create_impl's argument, likewise)
     hipStream_t side = nullptr;        // the stream the per-block no-claim marks are made on, off the way to the first answer
     std::vector<MarksJob> marks;       // one job per range / path group of `fast` that wants marks (fast itself, then more[0 ..]); empty once all are installed
+    bool marks_to_start = false;       // ... whose jobs are enqueued by the first call (or status, or describe) behind the plan's creation: a caller that only wants the first answer never pays for them
     bool check_facts = false;          // FLATGFA_CHECK_NO_CLAIM=1: every call first looks again at what the plan took for granted about the step values
 };
 
@@ -372,7 +373,12 @@ static void release_cache_claim(flatgfa_dev_plan_t *pl) {
 
 // The per-block no-claim marks are made on a stream of the plan's own, behind its creation:
 // (wait) for the jobs that are there, and install what they found.  Called between two calls of the plan.
+static void marks_start(flatgfa_dev_plan_t *pl);
 static void marks_poll(flatgfa_dev_plan_t *pl, bool wait) {
+    if (pl->marks_to_start) {
+        pl->marks_to_start = false;
+        marks_start(pl);
+    }
     if (pl->marks.empty()) return;
     bool pending = false;
     for (size_t k = 0; k < pl->marks.size(); ++k) {
@@ -389,7 +395,19 @@ static void marks_start(flatgfa_dev_plan_t *pl) {
     bool any = pl->fast.marks_wanted;
     for (uint32_t r = 0; r < pl->fast.n_more; ++r) any = any || pl->fast.more[r].marks_wanted;
     if (!any) return;
-    if (!pl->side && hipStreamCreateWithFlags(&pl->side, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); pl->side = nullptr; return; }
+    if (!pl->side) {  // (one such stream per device for the whole process: creating a stream costs as much as the first answer)
+        static std::mutex mu;
+        static hipStream_t pool[64] = {};
+        std::lock_guard<std::mutex> lk(mu);
+        hipStream_t &slot = pool[pl->device >= 0 && pl->device < 64 ? pl->device : 0];
+        if (!slot) {
+            // the lowest priority the device has: the marks' kernels read the steps three more times, and a query that runs beside them should not wait for that
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+            if (hipStreamCreateWithPriority(&slot, hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); slot = nullptr; return; }
+        }
+        pl->side = slot;
+    }
     pl->marks.assign(1 + pl->fast.n_more, MarksJob());
     for (size_t k = 0; k < pl->marks.size(); ++k) {
         const FastPlan &fp = k == 0 ? pl->fast : pl->fast.more[k - 1];
@@ -570,7 +588,7 @@ static bool plan_build_fast(flatgfa_dev_plan_t *pl, uint32_t *first_depth, uint3
         // inside the item of the step before: a win where a path has hundreds of records per window
         // (paths along the graph: -10 %; ids without runs: -35 %), a few instructions lost where it
         // has a dozen (+4 %).  Timed on this graph, both ways.
-        if (pl->fast.eligible && !pl->fast.tagged && !getenv("FLATGFA_BIG_GROUPS")) {  // (a tagged plan walks sub-buckets, not items)
+        if (pl->fast.eligible && !pl->fast.tagged && !test_hook("FLATGFA_BIG_GROUPS")) {  // (a tagged plan walks sub-buckets, not items)
             hipEvent_t e0 = nullptr, e1 = nullptr;
             float best[2] = {1e30f, 1e30f};
             bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
@@ -593,7 +611,7 @@ static bool plan_build_fast(flatgfa_dev_plan_t *pl, uint32_t *first_depth, uint3
             pl->fast.big_groups = big;
             for (uint32_t r = 0; r < pl->fast.n_more; ++r) pl->fast.more[r].big_groups = big;
             if (getenv("FLATGFA_TIMING")) fprintf(stderr, "plan: pass 2 item by item %.1f us, with the one-item shortcut %.1f us\n", best[0] * 1e3, best[1] * 1e3);
-        } else if (const char *f = getenv("FLATGFA_BIG_GROUPS")) {
+        } else if (const char *f = test_hook("FLATGFA_BIG_GROUPS")) {
             pl->fast.big_groups = strtol(f, nullptr, 10) != 0;
             for (uint32_t r = 0; r < pl->fast.n_more; ++r) pl->fast.more[r].big_groups = pl->fast.big_groups;
         }
@@ -612,7 +630,7 @@ static bool plan_build_fast(flatgfa_dev_plan_t *pl, uint32_t *first_depth, uint3
                 pl->fast.acc_own = on;
                 for (uint32_t r = 0; r < pl->fast.n_more; ++r) pl->fast.more[r].acc_own = on;
             };
-            if (any && !getenv("FLATGFA_ACC_OWN")) {
+            if (any && !test_hook("FLATGFA_ACC_OWN")) {
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 float best[2] = {1e30f, 1e30f};
                 bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
@@ -644,7 +662,7 @@ static bool plan_build_fast(flatgfa_dev_plan_t *pl, uint32_t *first_depth, uint3
                               "FLATGFA_DEBUG_SKIP",
 #endif
                               "FLATGFA_WB", "FLATGFA_DENSE", "FLATGFA_TAGGED", "FLATGFA_PATH_GROUPS"})
-            shaped = shaped || getenv(k) != nullptr;
+            shaped = shaped || test_hook(k) != nullptr;
         if (pl->fast.eligible && !shaped && g->n_steps <= (8u << 20)) {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             float best[2] = {1e30f, 1e30f};
@@ -679,8 +697,9 @@ static bool plan_build_fast(flatgfa_dev_plan_t *pl, uint32_t *first_depth, uint3
     // stream, before they were cleared (seen once: a freed block's contents taken for status bits).
     (void)hipStreamSynchronize(nullptr);
     tick("null stream drained");
-    // ... and behind it, on a stream of the plan's own, what can wait until the first answer is out: the per-block no-claim marks
-    marks_start(pl);
+    // ... and what can wait until the first answer is out -- the per-block no-claim marks -- is enqueued, on a stream of the
+    // plan's own, by whatever the caller does with the plan next (marks_poll)
+    pl->marks_to_start = true;
     return true;
 }
 
@@ -736,7 +755,6 @@ static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const 
     plan_tick("handle: status words, atomic path's items, attributes");
     uint32_t first_st = 0;
     if (!plan_build_fast(pl, first_depth, first_uniq, &first_st)) { flatgfa_dev_plan_destroy(pl); return nullptr; }
-    plan_tick("behind the first answer: the marks' job enqueued");
     if (first_status && (first_st & 1u)) {
         set_error("a step refers to a segment id (or a query to a path id) that is out of range");
         *first_status = FLATGFA_ERR_BOUNDS;
@@ -746,6 +764,7 @@ static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const 
 
 // What plan_build_fast made, given back: the marks' jobs (waited for, nothing installed), the claim on the Infinity Cache, the plan.
 static void plan_release_fast(flatgfa_dev_plan_t *pl) {
+    pl->marks_to_start = false;
     if (pl->side) (void)hipStreamSynchronize(pl->side);
     for (MarksJob &job : pl->marks) {
         FastPlan nothing;  // (finish releases the job's scratch; what it would install goes with this)
@@ -784,8 +803,7 @@ extern "C" int flatgfa_dev_plan_steps_changed(flatgfa_dev_plan_t *pl, void *stre
 
 extern "C" void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *pl) {
     if (!pl) return;
-    plan_release_fast(pl);
-    if (pl->side) (void)hipStreamDestroy(pl->side);
+    plan_release_fast(pl);  // (pl->side is the device's, not the plan's: it stays)
     if (pl->overlap_bits) (void)hipFree(pl->overlap_bits);
     if (pl->overlap_qbits) (void)hipFree(pl->overlap_qbits);
     if (pl->len_depth) (void)hipFree(pl->len_depth);
@@ -962,7 +980,7 @@ extern "C" int flatgfa_dev_status(flatgfa_dev_plan_t *pl, void *stream_) {
         const uint32_t n_calls = pl->calls_since_status;
         if (attempt == 0) {
             pl->calls_since_status = 0;
-            marks_poll(pl, true);  // (no call is in flight: the marks' job is waited for here, and what it found installed)
+            marks_poll(pl, false);  // (no call is in flight: if the marks' job is done, what it found is installed -- it is never waited for here)
         }
         if (st3[2]) {
             // A call filled a sub-bucket more than half: k_scan deals its items to the workgroups as they
@@ -1230,7 +1248,7 @@ extern "C" int flatgfa_dev_pipeline_describe(flatgfa_dev_pipeline_t *p, char *ou
     if (!p || p->plans.empty() || !out || cap <= 0) return 0;
     std::string s = "calls_in_flight=" + std::to_string(p->plans.size()) + " ";
     char buf[768] = "";
-    (void)flatgfa_dev_plan_describe(p->plans[0], buf, (int)sizeof buf);
+    for (size_t k = p->plans.size(); k-- > 0;) (void)flatgfa_dev_plan_describe(p->plans[k], buf, (int)sizeof buf);  // (every lane's marks are waited for; the first lane's description is given)
     s += buf;
     const int n = (int)std::min<size_t>(s.size(), (size_t)cap - 1);
     memcpy(out, s.data(), (size_t)n);

@@ -331,7 +331,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // difference array and per-path bitsets in LDS).
     uint32_t wb = g.n_segs <= 1024u * 4096u ? 12u : 13u;
     if (force_wb) wb = force_wb;  // (fast_plan_create: 4096-segment windows on a larger graph, for the sake of its split paths)
-    if (const char *f = getenv("FLATGFA_WB")) wb = (uint32_t)strtoul(f, nullptr, 10);
+    if (const char *f = test_hook("FLATGFA_WB")) wb = (uint32_t)strtoul(f, nullptr, 10);
     const uint32_t n_win = (uint32_t)(((uint64_t)n_range + (1u << wb) - 1) >> wb);
     if (n_win > max_win) return true;
     int dev = 0;
@@ -341,7 +341,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // Pass 1's persistent workgroups: one per CU -- or fewer for a plan that is one lane of a pipeline (calls in flight:
     // flatgfa_dev_pipeline_create), where the CUs it leaves are another call's.  FLATGFA_SCAN_WGS=n: tests, measurements.
     if (t_scan_workgroups) fp->n_slots = std::max(8u, std::min<uint32_t>(fp->n_cus, t_scan_workgroups));
-    if (const char *f = getenv("FLATGFA_SCAN_WGS")) fp->n_slots = std::max(8u, std::min<uint32_t>(fp->n_cus, (uint32_t)strtoul(f, nullptr, 10)));
+    if (const char *f = test_hook("FLATGFA_SCAN_WGS")) fp->n_slots = std::max(8u, std::min<uint32_t>(fp->n_cus, (uint32_t)strtoul(f, nullptr, 10)));
     if (fp->n_slots > kMaxSlots) return true;
     fp->n_win = n_win;
     fp->wb = wb;
@@ -349,14 +349,14 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     fp->lds_bytes_scan = scan_lds_bytes(fp->nwp, n_win > kMaxWin);
     if (fp->lds_bytes_scan + 64 > kLdsLimit) return true;
 #ifdef FGFA_MEASURE  // ablations that make the results wrong by construction exist in measurement builds only (tools/variants.sh)
-    if (const char *d = getenv("FLATGFA_DEBUG_SKIP")) fp->dbg = (uint32_t)strtoul(d, nullptr, 10);
+    if (const char *d = test_hook("FLATGFA_DEBUG_SKIP")) fp->dbg = (uint32_t)strtoul(d, nullptr, 10);
 #endif
     if (fp->dbg && ranged) return true;  // the diagnostic build of k_scan has no registers left for ranges
     // Paths of at most `short_max` steps are walked by single waves (k_scan_short), unless their
     // last block would reach beyond the step array.  Those kernels address at most 256 windows
     // of 4096 segments.
     uint64_t short_max = (fp->dbg || ranged || wb != kShortWinBits || n_win > kShortMaxWin || g.n_segs > kShortMaxSegs) ? 0 : kShortMax;  // (the wave-per-path kernels know nothing of ranges)
-    if (const char *forced = getenv("FLATGFA_SHORT_MAX")) short_max = std::min<uint64_t>(short_max, strtoull(forced, nullptr, 10));
+    if (const char *forced = test_hook("FLATGFA_SHORT_MAX")) short_max = std::min<uint64_t>(short_max, strtoull(forced, nullptr, 10));
     // Which kernel walks a path depends on how many runs it has: short paths must fit the run queue,
     // paths with at most kMediumRuns runs are walked wave by wave too, by pairs of waves that share a
     // bigger hash set (k_scan_short's medium variant).  The counts come from a one-off kernel.
@@ -383,10 +383,10 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         (void)hipFree(d_runs);
         FAST_TRY(e);
         // (FLATGFA_NO_CLAIM=0: every path claims, monotone or not -- tests and measurements)
-        if (const char *nc = getenv("FLATGFA_NO_CLAIM"); nc && nc[0] == '0') std::fill(mono.begin(), mono.end(), 0u);
+        if (const char *nc = test_hook("FLATGFA_NO_CLAIM"); nc && nc[0] == '0') std::fill(mono.begin(), mono.end(), 0u);
     }
     plan_tick("range: k_count_runs + its copies");
-    const bool short_any = getenv("FLATGFA_SHORT_ANY") != nullptr;  // tests: let k_scan_short find out and hand back
+    const bool short_any = test_hook("FLATGFA_SHORT_ANY") != nullptr;  // tests: let k_scan_short find out and hand back
     const bool no_rev = measure_switch("FLATGFA_NO_REVERSED_COPIES");
     // A wave-per-path kernel only knows runs that go up.  A path that walks the ids downwards (a
     // contig on the reverse strand) has far fewer runs when it is read backwards, and the order of a
@@ -395,7 +395,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // (the *_mono lists: paths that walk the ids strictly one way -- the wave-per-path kernels skip their claims)
     std::vector<uint4> items, short_items, medium_items, short_rev, medium_rev, whole, rev_list, tiny_items;
     std::vector<uint4> short_mono, medium_mono, short_rev_mono, medium_rev_mono, tiny_mono;
-    const bool no_tiny = getenv("FLATGFA_NO_TINY") != nullptr;  // (measurements, tests: tiny paths go to k_scan_short as before)
+    const bool no_tiny = test_hook("FLATGFA_NO_TINY") != nullptr;  // (measurements, tests: tiny paths go to k_scan_short as before)
     uint64_t rev_len = 0;
     for (uint32_t p = 0; p < g.n_paths; ++p) {
         const uint64_t b = hb[p], e = he[p], n = e - b;
@@ -485,7 +485,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     };
     const auto longer = [](const uint4 &a, const uint4 &b) { return a.y - a.x > b.y - b.x; };
     uint64_t piece = 0;
-    if (const char *forced = getenv("FLATGFA_PIECE_STEPS")) {
+    if (const char *forced = test_hook("FLATGFA_PIECE_STEPS")) {
         piece = (std::max<uint64_t>(256, strtoull(forced, nullptr, 10)) + 255) & ~255ull;
     } else {
         constexpr uint64_t kTurnaround = 8192;  // steps a workgroup could have walked while it changes items
@@ -583,7 +583,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // CUs, several that share the window's paths and sub-buckets and add their counts up (1000
     // paths over 100 k segments: 25 workgroups took 0.48 ms where 250 take 0.06).
     fp->acc_parts = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>({16, fp->n_cus / n_win, (g.n_steps / n_win + (32u << 10) - 1) >> 15}));  // a workgroup per 32 k steps: a wave's walk is a chain of dependent round trips, a microsecond per 64 records
-    if (const char *f = getenv("FLATGFA_ACC_PARTS")) fp->acc_parts = std::max(1u, std::min(64u, (uint32_t)strtoul(f, nullptr, 10)));
+    if (const char *f = test_hook("FLATGFA_ACC_PARTS")) fp->acc_parts = std::max(1u, std::min(64u, (uint32_t)strtoul(f, nullptr, 10)));
     const uint32_t acc_waves = fp->acc_parts * kAccWaves;
     // Tagged calls (records say whose they are; see kTagShift): every workgroup's items -- the handed-back
     // ones included -- must have tags of their own next to the split paths', and pass 2 needs LDS for a
@@ -592,7 +592,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     {
         const uint32_t grid = (fp->n_short || fp->n_medium || fp->n_tiny) ? fp->n_slots : std::min<uint32_t>(fp->n_items, fp->n_slots);
         const uint64_t per_wg = grid ? ((uint64_t)fp->n_items + fp->max_back + grid - 1) / grid : 0;
-        const char *t = getenv("FLATGFA_TAGGED");
+        const char *t = test_hook("FLATGFA_TAGGED");
         const uint32_t shared_cap = wb <= 12 ? kMaxShared : 0u;
         const bool base_ok = !fp->dbg && !(t && t[0] == '0') && (fp->n_shared == 0 || fp->acc_parts == 1);
         const bool taggable = base_ok && fp->n_shared <= shared_cap;
@@ -602,10 +602,10 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         // are fixed, every further one goes to whoever is done first), with some room to spare --
         // a workgroup that does run out of tags stops taking items (k_scan) and the others go on.
         uint32_t limit = fp->n_shared + 1u < kTagCount ? kTagCount - 1u - fp->n_shared : 0u;  // (the highest tag says "no claim")
-        if (const char *f = getenv("FLATGFA_TAG_LIMIT")) limit = std::min<uint32_t>(limit, std::max(2u, (uint32_t)strtoul(f, nullptr, 10)));
+        if (const char *f = test_hook("FLATGFA_TAG_LIMIT")) limit = std::min<uint32_t>(limit, std::max(2u, (uint32_t)strtoul(f, nullptr, 10)));
         fp->tag_limit = limit;
         uint64_t most = per_wg;
-        if (taggable && grid && per_wg <= limit && fp->n_items + fp->max_back > 2ull * grid && !getenv("FLATGFA_TAG_MEAN_ONLY")) {
+        if (taggable && grid && per_wg <= limit && fp->n_items + fp->max_back > 2ull * grid && !test_hook("FLATGFA_TAG_MEAN_ONLY")) {
             constexpr uint64_t kTurn = 2048;  // steps' worth an item costs beyond its steps
             std::priority_queue<std::pair<uint64_t, uint32_t>, std::vector<std::pair<uint64_t, uint32_t>>, std::greater<std::pair<uint64_t, uint32_t>>> hands;
             std::vector<uint32_t> taken(grid, 0u);
@@ -737,7 +737,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     uint64_t cap = (std::min<uint64_t>(g.n_steps, walked) + slots - 1) / slots;
     if (ranged) cap = (uint64_t)((double)cap * n_range / g.n_segs) + 1;  // a range sees its share of the runs
     cap = cap + cap / 4 + 256;
-    if (const char *forced = getenv("FLATGFA_BUCKET_CAP")) {  // tests: force the overflow route
+    if (const char *forced = test_hook("FLATGFA_BUCKET_CAP")) {  // tests: force the overflow route
         cap = strtoull(forced, nullptr, 10);
         fp->cap_forced = true;
     }
@@ -777,7 +777,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             FAST_TRY(hipMalloc(&d_runs64, 8));
             FAST_TRY(hipMemset(d_runs64, 0, 8));
             // (FLATGFA_NO_CLAIM=0: every item claims, monotone or not -- tests and measurements)
-            const char *nc_env = getenv("FLATGFA_NO_CLAIM");
+            const char *nc_env = test_hook("FLATGFA_NO_CLAIM");
             const bool no_claim = !(nc_env && nc_env[0] == '0');
             uint4 *d_mono = nullptr;
             if (fp->n_shared && no_claim) FAST_TRY(hipMalloc(&d_mono, (size_t)fp->n_items * sizeof(uint4)));
@@ -840,7 +840,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             // Three more reads of the steps, and not on the way to the first answer: the plan's owner runs them on a side
             // stream (fast_marks_start) and installs them between two later calls -- except where the buckets are laid out
             // to the count (a build of k_scan with marks cuts its runs at block ends: the counting call must see them).
-            fp->marks_wanted = no_claim && fp->tagged && !ranged && fp->n_noclaim < fp->n_items && !getenv("FLATGFA_NO_CLAIM_BLOCKS_OFF") &&
+            fp->marks_wanted = no_claim && fp->tagged && !ranged && fp->n_noclaim < fp->n_items && !test_hook("FLATGFA_NO_CLAIM_BLOCKS_OFF") &&
                                (((uint64_t)g.n_paths * n_win + 15) / 16 + 1) * 4 <= (256ull << 20);
             if (fp->marks_wanted && want_packed) {
                 MarksJob job;
@@ -859,7 +859,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             fp->dense_maybe = can && runs64 * 2 > item_steps;
             fp->dense = fp->dense_maybe;
         }
-        if (const char *f = getenv("FLATGFA_DENSE")) {  // tests, measurements
+        if (const char *f = test_hook("FLATGFA_DENSE")) {  // tests, measurements
             fp->dense = !fp->dbg && strtol(f, nullptr, 10) != 0 && dense_lds_bytes(fp->nwp) + 64 <= kLdsLimit;
             fp->dense_maybe = false;
         }
@@ -903,7 +903,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     const bool pair_ok = fp->tagged && fp->n_shared == 0 && wb == 12 && fp->acc_parts == 1 && n_win <= 2 * fp->n_cus;
     fp->acc_pair = false;
 #ifdef FGFA_MEASURE
-    if (const char *f = getenv("FLATGFA_ACC_PAIR")) fp->acc_pair = pair_ok && strtol(f, nullptr, 10) != 0;
+    if (const char *f = test_hook("FLATGFA_ACC_PAIR")) fp->acc_pair = pair_ok && strtol(f, nullptr, 10) != 0;
 #else
     (void)pair_ok;
 #endif
@@ -916,9 +916,9 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         const uint32_t grid = std::min<uint32_t>(std::max<uint32_t>(fp->n_items, 1u), fp->n_slots);
         const bool can8 = fp->tagged && wb == 12 && fp->n_shared <= 64 && fp->acc_parts == 1;
         fp->acc_slots = can8 && (uint64_t)fp->n_items + fp->max_back > 4ull * grid ? 8u : kTagSlots;
-        if (const char *f = getenv("FLATGFA_ACC_SLOTS")) fp->acc_slots = can8 && strtol(f, nullptr, 10) == 8 ? 8u : kTagSlots;
+        if (const char *f = test_hook("FLATGFA_ACC_SLOTS")) fp->acc_slots = can8 && strtol(f, nullptr, 10) == 8 ? 8u : kTagSlots;
         if (fp->acc_slots == 8) fp->acc_pair = false;
-        if (const char *f = getenv("FLATGFA_ACC_OWN")) fp->acc_own = strtol(f, nullptr, 10) != 0;  // tests, measurements
+        if (const char *f = test_hook("FLATGFA_ACC_OWN")) fp->acc_own = strtol(f, nullptr, 10) != 0;  // tests, measurements
     }
     if (fp->acc_pair) {
         FAST_TRY(hipMalloc(&fp->pair_part, (size_t)n_win * 2 * 2 * (1u << wb) * 4));
@@ -1018,7 +1018,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
 static bool append_ranges(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, uint32_t max_win, uint32_t force_wb,
                           std::vector<FastPlan> *plans, bool *all, bool *many, bool *want12 = nullptr, uint32_t n_groups = 1) {
     uint64_t max_range = (uint64_t)max_win << (force_wb ? force_wb : 13u);
-    if (const char *f = getenv("FLATGFA_RANGE_SEGS")) max_range = std::max<uint64_t>(8192, strtoull(f, nullptr, 10) & ~8191ull);  // tests
+    if (const char *f = test_hook("FLATGFA_RANGE_SEGS")) max_range = std::max<uint64_t>(8192, strtoull(f, nullptr, 10) & ~8191ull);  // tests
     const uint32_t n_ranges = (uint32_t)((g.n_segs + max_range - 1) / max_range);
     if (n_ranges > 64) {
         *all = false;
@@ -1080,13 +1080,13 @@ static bool fast_plan_create_impl(const flatgfa_dev_graph_t &g, const uint32_t *
     // the wave-per-path kernels -- the PATHS are walked in groups, each with plans of its own over
     // the same ranges: the first group's pass 2 stores its counts, the others' add theirs.  Every
     // step is still read once per range.  (FLATGFA_PATH_GROUPS=0: never; n: at least n groups, tests.)
-    if (const char *off = getenv("FLATGFA_MAX_WINDOWS")) {
+    if (const char *off = test_hook("FLATGFA_MAX_WINDOWS")) {
         const uint32_t wb = g.n_segs <= 1024u * 4096u ? 12u : 13u;
         if ((((uint64_t)g.n_segs + (1u << wb) - 1) >> wb) > strtoul(off, nullptr, 10)) return true;
     }
     uint32_t want_groups = 1;
     bool groups_ok = true;
-    if (const char *e = getenv("FLATGFA_PATH_GROUPS")) {
+    if (const char *e = test_hook("FLATGFA_PATH_GROUPS")) {
         want_groups = (uint32_t)strtoul(e, nullptr, 10);
         groups_ok = want_groups != 0;
         want_groups = std::max(1u, std::min(64u, want_groups));
@@ -1115,7 +1115,7 @@ static bool fast_plan_create_impl(const flatgfa_dev_graph_t &g, const uint32_t *
             }
             bool all_tagged = all;
             for (const FastPlan &q : plans) all_tagged = all_tagged && q.tagged;
-            if (want12 && !all_tagged && !force_wb && !tried_wb12 && !getenv("FLATGFA_WB") && !getenv("FLATGFA_RANGE_SEGS")) {
+            if (want12 && !all_tagged && !force_wb && !tried_wb12 && !test_hook("FLATGFA_WB") && !test_hook("FLATGFA_RANGE_SEGS")) {
                 tried_wb12 = true;
                 tries.push_back({kMaxWinTagged, 12u});  // next; if that does not yield a tagged plan either, this try comes again
                 tries.push_back({max_win, 0u});
@@ -1133,8 +1133,8 @@ static bool fast_plan_create_impl(const flatgfa_dev_graph_t &g, const uint32_t *
                 // eight (16 000 paths of 100 k steps on 16 M segments: pass 2 2.14 -> 1.81 ms, pass 1 pays 0.1 for twice
                 // the windows; with eight items per workgroup, or items that claim nothing, it is a loss: NOTES R5.12).
                 const auto wants_small_windows = [&](const FastPlan &q) {
-                    return q.eligible && q.tagged && q.wb == 13 && !q.n_more && g.n_segs <= (uint64_t)kMaxWinTagged << 12 && !getenv("FLATGFA_WB") &&
-                           !getenv("FLATGFA_RANGE_SEGS") && q.n_items >= 16ull * q.n_slots && 2ull * q.n_noclaim < q.n_items && q.n_shared <= 64 &&
+                    return q.eligible && q.tagged && q.wb == 13 && !q.n_more && g.n_segs <= (uint64_t)kMaxWinTagged << 12 && !test_hook("FLATGFA_WB") &&
+                           !test_hook("FLATGFA_RANGE_SEGS") && q.n_items >= 16ull * q.n_slots && 2ull * q.n_noclaim < q.n_items && q.n_shared <= 64 &&
                            q.est_records / q.n_win >= 32768;
                 };
                 if (!force_wb && plans.size() == 1 && wants_small_windows(plans[0])) {
@@ -1209,7 +1209,7 @@ static bool fast_plan_create_impl(const flatgfa_dev_graph_t &g, const uint32_t *
         }
         destroy_plans(&plans);
         if (ti + 1 == tries.size() && max_win == kMaxWinTagged && !force_wb) {
-            const uint64_t max_range = getenv("FLATGFA_RANGE_SEGS") ? 0 : (uint64_t)max_win << 13;
+            const uint64_t max_range = test_hook("FLATGFA_RANGE_SEGS") ? 0 : (uint64_t)max_win << 13;
             const uint64_t n_ranges = max_range ? (g.n_segs + max_range - 1) / max_range : 1;
             if (((uint64_t)g.n_segs + 8191) / 8192 > kMaxWin * n_ranges) tries.push_back({kMaxWin, 0u});  // (else the smaller cut-off would make the same ranges)
         }
@@ -1280,7 +1280,7 @@ void fast_marks_finish(FastPlan *fp, MarksJob *job) {
     // marks 1-10 % (short items most), and the claims are two fifths of pass 2 -- contigs of ten blocks with a third of
     // their chunks marked lost 7 % of the call; cfg-L's random walks have one chunk in a thousand that qualifies)
     uint64_t min_pct = 50;
-    if (const char *f = getenv("FLATGFA_NO_CLAIM_BLOCKS_MIN")) min_pct = strtoull(f, nullptr, 10);  // tests, measurements
+    if (const char *f = test_hook("FLATGFA_NO_CLAIM_BLOCKS_MIN")) min_pct = strtoull(f, nullptr, 10);  // tests, measurements
     if (e == hipSuccess && flagged != 0 && flagged * 1600 >= fp->item_steps * min_pct && !fp->cflags) {
         fp->cflags = job->flags;
         job->flags = nullptr;
@@ -1452,7 +1452,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     // -- unless it has no items of its own and nothing can come back (the run counts of the lists are
     // exact): then the launch is left out, every record is one of the wave-per-path kernels', and a
     // path that does not fit after all (steps changed behind the plan) raises kStBackOverflow.
-    const bool scan_skip = has_pre && fp.n_items == 0 && fp.exact_short && !fp.dbg && !getenv("FLATGFA_SCAN_ALWAYS");
+    const bool scan_skip = has_pre && fp.n_items == 0 && fp.exact_short && !fp.dbg && !test_hook("FLATGFA_SCAN_ALWAYS");
     const uint32_t grid = scan_skip ? 0u : has_pre ? fp.n_slots : std::min<uint32_t>(fp.n_items, fp.n_slots);
     ScanArgs sa;
     sa.zero_a = sa.zero_b = nullptr;
@@ -1504,18 +1504,18 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     sa.pk_base = fp.pk_base;
     if (fp.packed && !tagged) { set_error("fast_seg_depth: a plan with packed buckets runs tagged calls only"); return FLATGFA_ERR_ARG; }
     sa.tprof = nullptr;
-    if (getenv("FLATGFA_SCAN_TIME") && hipMalloc(&sa.tprof, kTprofRow * 8 * (size_t)fp.n_slots) == hipSuccess) (void)hipMemset(sa.tprof, 0, kTprofRow * 8 * (size_t)fp.n_slots);
+    if (test_hook("FLATGFA_SCAN_TIME") && hipMalloc(&sa.tprof, kTprofRow * 8 * (size_t)fp.n_slots) == hipSuccess) (void)hipMemset(sa.tprof, 0, kTprofRow * 8 * (size_t)fp.n_slots);
     AccArgs aa{fp.n_range, fp.n_win, fp.n_slots, fp.cap, fp.counts, fp.counts0, scan_skip ? 2u : has_pre ? 1u : 0u, fp.buckets,
                reinterpret_cast<const uint2 *>(fp.dir), fp.islot, fp.dstride, fp.elist, fp.wave_off, fp.n_items,
                fp.work_counter, scan_skip ? 0u : fp.max_back, depth_out, uniq_out, status, fp.dbg,
                reinterpret_cast<const uint4 *>(fp.items), g.seg_len, ps ? reinterpret_cast<ulonglong2 *>(fp.psum_part) : nullptr,
-               fp.fat_off, fp.fat_woff, fp.acc_parts, tagged ? fp.n_shared : 0u, nullptr, fp.pair_part, fp.pair_flag, fp.accumulate ? 1u : 0u, getenv("FLATGFA_NO_PLAIN") ? nullptr : fp.taken, fp.taken ? fp.taken + fp.n_slots : nullptr,
+               fp.fat_off, fp.fat_woff, fp.acc_parts, tagged ? fp.n_shared : 0u, nullptr, fp.pair_part, fp.pair_flag, fp.accumulate ? 1u : 0u, test_hook("FLATGFA_NO_PLAIN") ? nullptr : fp.taken, fp.taken ? fp.taken + fp.n_slots : nullptr,
                fp.packed ? reinterpret_cast<const uint2 *>(fp.pk) : nullptr};  // (FLATGFA_NO_PLAIN: measurements)
 #ifdef FGFA_MEASURE
-    if (const char *sk = getenv("FLATGFA_ACC_SKIP")) aa.dbg = (uint32_t)strtoul(sk, nullptr, 10);  // (diagnostic: pass 2 without its revisit counts 128 / depth 256 / claims 64 / words behind the first 1024)
+    if (const char *sk = test_hook("FLATGFA_ACC_SKIP")) aa.dbg = (uint32_t)strtoul(sk, nullptr, 10);  // (diagnostic: pass 2 without its revisit counts 128 / depth 256 / claims 64 / words behind the first 1024)
 #endif
     const size_t tprof_words = (size_t)fp.n_win * fp.acc_parts * kAccWaves * 16;
-    if (getenv("FLATGFA_ACC_TIME") && uniq_out && hipMalloc(&aa.tprof, tprof_words * 4) != hipSuccess) aa.tprof = nullptr;
+    if (test_hook("FLATGFA_ACC_TIME") && uniq_out && hipMalloc(&aa.tprof, tprof_words * 4) != hipSuccess) aa.tprof = nullptr;
     // The wave-per-path kernels: the paths read from the graph's steps, then those read from their
     // reversed copies (a handed-back one is walked by k_scan from the graph's own steps).
     if (fp.n_short && hipMemsetAsync(fp.work_counter, 0, 4, stream) != hipSuccess) return FLATGFA_ERR_HIP;
@@ -1613,7 +1613,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
                 tagged ? " [tagged]" : "", pct(st, 0.5), pct(st, 1.0), pct(fw, 0.05), pct(fw, 0.5), pct(fw, 0.95), pct(lw, 0.05), pct(lw, 0.5), pct(lw, 0.95), pct(lw, 1.0), pct(en, 0.5), pct(en, 1.0));
         // FLATGFA_SCAN_TIME=<file>: one line per workgroup and call -- call, workgroup, XCC, HW_ID, items, start, first / last wave out of work, end (us)
         static int call_no = 0;
-        const char *where = getenv("FLATGFA_SCAN_TIME");
+        const char *where = test_hook("FLATGFA_SCAN_TIME");
         if (where && strchr(where, '/')) {
             if (FILE *f = fopen(where, "a")) {
                 for (uint32_t i = 0; i < grid; ++i)

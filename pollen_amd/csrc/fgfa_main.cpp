@@ -22,6 +22,8 @@
 
 #include "../../include/flatgfa.h"
 
+static inline const char *test_hook(const char *name) { return getenv(name); }  // (a test hook, not a user-facing switch: device_common.hpp)
+
 static int die(const char *what) {
     fprintf(stderr, "fgfa: %s: %s\n", what, flatgfa_last_error());
     return 1;
@@ -285,7 +287,7 @@ int main(int argc, char **argv) {
     // (no tear-down: the process is over, and unloading the HIP runtime takes longer than the query did)
     fflush(stdout);
     fflush(stderr);
-    if (!getenv("FLATGFA_SLOW_EXIT")) _exit(rc);
+    if (!test_hook("FLATGFA_SLOW_EXIT")) _exit(rc);
     flatgfa_free(g);
     return rc;
 }

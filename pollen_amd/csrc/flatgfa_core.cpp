@@ -220,8 +220,8 @@ bool parse_step_chunk(const StepChunk &c, const NameMap &names, Handle *steps) {
 template <class S>
 void parse_steps_parallel(const std::vector<Cursor> &deferred, const NameMap &names, S *st, StepsPre *pre) {
     size_t kChunk = 1 << 20, min_bytes = 4u << 20;
-    if (const char *f = getenv("FLATGFA_PARSE_CHUNK")) kChunk = std::max<size_t>(1, strtoull(f, nullptr, 10));      // tests
-    if (const char *f = getenv("FLATGFA_PARSE_MIN_BYTES")) min_bytes = strtoull(f, nullptr, 10);                    // tests
+    if (const char *f = test_hook("FLATGFA_PARSE_CHUNK")) kChunk = std::max<size_t>(1, strtoull(f, nullptr, 10));      // tests
+    if (const char *f = test_hook("FLATGFA_PARSE_MIN_BYTES")) min_bytes = strtoull(f, nullptr, 10);                    // tests
     // the step field of every path line, cut after commas into chunks of about a megabyte
     std::vector<StepChunk> chunks;
     std::vector<size_t> first_chunk;  // per path

@@ -6,6 +6,12 @@
 // text parser, the zero-copy `.flatgfa` container, and the odgi-style emitters.
 // Device code lives in depth_device.hip; this header is plain C++17.
 #pragma once
+#include <cstdlib>
+// (a test hook, not a user-facing switch: see device_common.hpp)
+#ifndef FGFA_TEST_HOOK_DEFINED
+#define FGFA_TEST_HOOK_DEFINED
+inline const char *test_hook(const char *name) { return std::getenv(name); }
+#endif
 #include <cstddef>
 #include <cstdint>
 #include <cstring>

@@ -235,7 +235,7 @@ extern "C" int flatgfa_dev_path_overlaps_impl(const flatgfa_dev_graph_t *g, int 
     // for the queries of this call only, a batch (of at most 1 GB) at a time.
     const uint64_t per_query = 2ull * words * 4u;
     uint64_t dense_max = 1ull << 30;
-    if (const char *f = getenv("FLATGFA_OVERLAP_DENSE_MAX")) dense_max = strtoull(f, nullptr, 10);  // tests: 0 = query bitsets only
+    if (const char *f = test_hook("FLATGFA_OVERLAP_DENSE_MAX")) dense_max = strtoull(f, nullptr, 10);  // tests: 0 = query bitsets only
     const bool all_paths = (uint64_t)g->n_paths * per_query <= dense_max;
     const uint32_t batch = all_paths ? g->n_paths : (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(n_q, (1ull << 30) / per_query));
     // (what the cache holds is recorded, not inferred from its size: bitsets of every path in path

@@ -17,12 +17,12 @@ graph = dev.DeviceGraph(steps, pb, pe, S, seg_len, device="cuda:0")
 d = torch.empty(S, dtype=torch.int32, device="cuda:0"); u = torch.empty(S, dtype=torch.int32, device="cuda:0")
 for r in range(runs):
     d.fill_(-1); u.fill_(-1); torch.cuda.synchronize()
-    t0 = time.perf_counter(); plan = dev.DepthPlan(graph, first=(d, u)); torch.cuda.synchronize(); t1 = time.perf_counter()
+    t0 = time.perf_counter(); plan = dev.DepthPlan(graph, first=(d, u)); t1 = time.perf_counter()   # (complete on return: no synchronize)
     ok = bool((d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all())
     t2 = time.perf_counter(); desc = plan.describe(); t3 = time.perf_counter()   # (waits for the marks' job)
     plan.seg_depth(d, u); plan.status()
     ok2 = bool((d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all())
     print(f"{wl} run {r}: first answer {1e3 * (t1 - t0):.3f} ms (exact: {ok}); marks waited for {1e3 * (t3 - t2):.3f} ms more; second call exact: {ok2}; {desc}", flush=True)
     plan.close()
-t0 = time.perf_counter(); plan = dev.DepthPlan(graph); torch.cuda.synchronize(); t1 = time.perf_counter()
+t0 = time.perf_counter(); plan = dev.DepthPlan(graph); t1 = time.perf_counter()
 print(f"{wl}: flatgfa_dev_plan_create alone {1e3 * (t1 - t0):.3f} ms")
