@@ -1050,6 +1050,7 @@ extern "C" int flatgfa_dev_plan_describe(flatgfa_dev_plan_t *pl, char *out, int 
             " pass2=" + (f.tagged ? (f.n_shared ? "tagged(shared bitsets)" : f.acc_pair ? "tagged(two workgroups per window)" : "tagged") : (f.big_groups ? "directory(one-item shortcut)" : "directory")) +
             " windows=" + std::to_string(f.n_win) + "x" + std::to_string(1u << f.wb) + " ranges=" + std::to_string((f.n_more + 1) / f.n_groups) +
             (f.n_groups > 1 ? " path_groups=" + std::to_string(f.n_groups) : std::string()) +
+            (f.narrow_emit && f.tagged && !f.packed && !f.dense && !f.cflags && !f.n_more ? " emit=two_chunks" : "") +
             " scan_workgroups=" + std::to_string(f.n_slots) + " workgroups_per_window=" + std::to_string(f.acc_parts) + " items=" + std::to_string(f.n_items) + (f.acc_own ? " bitset_owners=tracked" : "") + " no_claim_items=" + std::to_string(f.n_noclaim) + (f.n_flag_chunks ? " no_claim_chunks=" + std::to_string(f.n_flag_chunks) : std::string()) + " no_claim_paths=" + std::to_string(f.short_mono_n + f.medium_mono_n + f.tiny_mono_n) + " split_paths=" + std::to_string(f.n_shared) +
             " short_paths=" + std::to_string(f.n_short) + " medium_paths=" + std::to_string(f.n_medium) + " tiny_paths=" + std::to_string(f.n_tiny) +
             " steps=" + std::to_string(f.class_steps[0]) + "/" + std::to_string(f.class_steps[1]) + "/" + std::to_string(f.class_steps[2]) + "/" + std::to_string(f.class_steps[3]) +  // (by k_scan / short / medium / tiny)

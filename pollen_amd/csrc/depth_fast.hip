@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256) void k_item_dirs(const uint32_t *__restrict__ 
             items[j].z = z;
             if (mono) mono[j] = make_uint4(state, steps[b] >> 1, steps[e - 1] >> 1, 0u);
             atomicAdd(n_runs, (unsigned long long)(e - b) - max(up, down));  // the records k_scan will make of the item (but for window crossings)
+            atomicAdd(n_runs + 1, (unsigned long long)min(asc, desc));         // its steps against the grain (what spoils a window for the per-block no-claim marks)
         }
         __syncthreads();
     }
@@ -773,9 +774,9 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     if (!items.empty()) {
         FAST_TRY(hipMemcpy(fp->items, items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
         if (!measure_switch("FLATGFA_NO_ITEM_DIRS")) {  // (measurement builds: every item taken as running upwards)
-            unsigned long long *d_runs64 = nullptr, runs64 = 0, item_steps = 0;
-            FAST_TRY(hipMalloc(&d_runs64, 8));
-            FAST_TRY(hipMemset(d_runs64, 0, 8));
+            unsigned long long *d_runs64 = nullptr, runs64 = 0, item_steps = 0, counted[2] = {0, 0};
+            FAST_TRY(hipMalloc(&d_runs64, 16));
+            FAST_TRY(hipMemset(d_runs64, 0, 16));
             // (FLATGFA_NO_CLAIM=0: every item claims, monotone or not -- tests and measurements)
             const char *nc_env = test_hook("FLATGFA_NO_CLAIM");
             const bool no_claim = !(nc_env && nc_env[0] == '0');
@@ -783,7 +784,8 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             if (fp->n_shared && no_claim) FAST_TRY(hipMalloc(&d_mono, (size_t)fp->n_items * sizeof(uint4)));
             hipLaunchKernelGGL(k_item_dirs, dim3(std::min<uint32_t>(fp->n_items, fp->n_cus * 8u)), dim3(256), 0, nullptr, g.steps,
                                reinterpret_cast<uint4 *>(fp->items), fp->n_items, d_runs64, d_mono);
-            hipError_t e = hipMemcpy(&runs64, d_runs64, 8, hipMemcpyDeviceToHost);
+            hipError_t e = hipMemcpy(counted, d_runs64, 16, hipMemcpyDeviceToHost);
+            runs64 = counted[0];
             (void)hipFree(d_runs64);
             // The pieces of a split path: the path never meets a segment twice when every piece runs strictly one way,
             // all of them the same way, and each piece starts beyond (below) where the piece before it ended.
@@ -842,6 +844,11 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             // to the count (a build of k_scan with marks cuts its runs at block ends: the counting call must see them).
             fp->marks_wanted = no_claim && fp->tagged && !ranged && fp->n_noclaim < fp->n_items && !test_hook("FLATGFA_NO_CLAIM_BLOCKS_OFF") &&
                                (((uint64_t)g.n_paths * n_win + 15) / 16 + 1) * 4 <= (256ull << 20);
+            // ... and not worth looking for where the walks turn round all the time: a step against its item's grain spoils the
+            // window it lies in, and with sixteen of them to a block of 1024 steps next to no block is left clean (the benchmark's
+            // random walks: forty-five a block, one chunk in a thousand qualifies; a walk with a tandem repeat every 6400 steps: one
+            // in six blocks has any).  FLATGFA_NO_CLAIM_BLOCKS_MIN (tests) asks for the marks regardless.
+            if (fp->marks_wanted && counted[1] * 64 >= item_steps && !test_hook("FLATGFA_NO_CLAIM_BLOCKS_MIN")) fp->marks_wanted = false;
             if (fp->marks_wanted && want_packed) {
                 MarksJob job;
                 if (!fast_marks_start(*fp, g, hb, nullptr, &job)) return false;
@@ -849,6 +856,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
                 fp->marks_wanted = false;
             }
             fp->est_records = runs64;
+            fp->narrow_emit = runs64 * 8 < item_steps;  // (long runs: see mode_wide)
             plan_tick("range: items uploaded, k_item_dirs");
             // more than three records for four steps: not worth looking for runs (k_scan_dense)
             const bool can = !fp->dbg && dense_lds_bytes(fp->nwp) + 64 <= kLdsLimit;

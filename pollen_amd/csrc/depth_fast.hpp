@@ -48,6 +48,7 @@ struct FastPlan {
     bool big_groups = false;   // pass 2 looks for steps that lie inside one item (worth it when a path has hundreds of records per window; the plan's creator times both)
     bool dense_maybe = false;  // between one and nine records for ten steps: the plan's creator times k_scan_dense against k_scan
     bool dense = false;        // nearly every step starts a run: pass 1 partitions the steps themselves (k_scan_dense)
+    bool narrow_emit = false;  // fewer than a record for eight steps: the plain tagged build of k_scan that emits two chunks side by side, not four (kModePlainNarrow)
     uint32_t acc_parts = 1;  // workgroups per window in pass 2 (small graphs: fewer windows than CUs)
     uint64_t est_records = 0;  // records k_scan will make of its items (counted when the plan is made)
     bool acc_pair = false;     // tagged calls with unique depth run two workgroups per window, both resident on a CU (k_accum_pair)

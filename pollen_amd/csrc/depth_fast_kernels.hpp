@@ -396,11 +396,12 @@ __device__ __forceinline__ uint32_t take_slots(uint32_t *bcur, int lane, bool va
 // next item nobody has taken yet (two cells, by item parity), how many waves have left the item
 // (two cells), and how many items are complete.
 // k_scan's builds: plain, diagnostic (FLATGFA_DEBUG_SKIP), ranged (one of several walks of a graph beyond 16 M segments)
-constexpr int kModePlain = 0, kModeDbg = 1, kModeRanged = 2, kModeBig = 3, kModeRangedBig = 4, kModePacked = 5, kModePackedRanged = 6, kModePlainFlags = 7, kModePackedFlags = 8;  // (...Flags: the plain and the packed build for plans with per-block no-claim flags, ScanArgs::cflags)  // (Big: builds of their own for bucket arrays of 2^30 records or more, see put(); Packed: sub-buckets of exactly the size their records need, items dealt in a fixed order)
+constexpr int kModePlain = 0, kModeDbg = 1, kModeRanged = 2, kModeBig = 3, kModeRangedBig = 4, kModePacked = 5, kModePackedRanged = 6, kModePlainFlags = 7, kModePackedFlags = 8, kModePlainNarrow = 9;  // (...Flags: the plain and the packed build for plans with per-block no-claim flags, ScanArgs::cflags)  // (Big: builds of their own for bucket arrays of 2^30 records or more, see put(); Packed: sub-buckets of exactly the size their records need, items dealt in a fixed order)
 constexpr bool mode_ranged(int m) { return m == kModeRanged || m == kModeRangedBig || m == kModePackedRanged; }
 constexpr bool mode_big(int m) { return m == kModeBig || m == kModeRangedBig; }
 constexpr bool mode_packed(int m) { return m == kModePacked || m == kModePackedRanged || m == kModePackedFlags; }
 constexpr bool mode_flags(int m) { return m == kModePlainFlags || m == kModePackedFlags; }
+constexpr bool mode_plain(int m) { return m == kModePlain || m == kModePlainNarrow; }
 // A wave's run queue.  A packed call keeps two LDS tables for up to 4096 windows (cursors and the sub-buckets'
 // offsets), which leaves its queues 88 entries less: a block of (nearly) all starts is then queued behind a
 // drain down to one entry, and one of more than 1005 starts -- ids without any run at all, which such a plan is
@@ -412,6 +413,11 @@ constexpr uint32_t kQueueOf = mode_packed(MODE) ? kQPacked : kQ2;
 #define FGFA_WIDE 4
 #endif
 constexpr int kWide = FGFA_WIDE;  // chunks of 64 queue entries k_scan emits side by side
+// ... but two where runs are long (kModePlainNarrow: the plain build for plans that count fewer than a record for eight steps -- the
+// benchmark's walks make one for ten): a block then rarely leaves four chunks' worth behind, and what it leaves goes out sooner
+// (same box, cfg-L: k_scan 90.3 / 90.0 / 89.5 -> 88.1 / 88.7 / 88.7 us warm, 102.5 -> 101.7 and 93.8 -> 91.3 with every step from
+// HBM; paths along the graph, three records for ten steps: 118.8 -> 120.7 the other way, so they keep four: NOTES R6.5)
+constexpr int mode_wide(int m) { return m == kModePlainNarrow ? 2 : kWide; }
 // (kCtlRing cells each for the block counters, the arrival counters and the items, indexed by the
 // item's ordinal mod kCtlRing in a tagged call -- a wave with records to append may be kTagSlots items
 // ahead of the slowest there, one without any kIdleAhead -- and mod 2 otherwise)

@@ -358,10 +358,10 @@ __device__ __forceinline__ void block16r(const ScanArgs &A, RWave &w, uint32_t *
     // by side.  (Draining only here was measured: no gain on such paths, and short items -- 32 k
     // steps -- lost 15 %: their waves more often find the item before them not wrapped up yet.)
     // (the diagnostic build keeps cycle counters in registers and has room for one chunk at a time only)
-    if (kWide > 1 && !FGFA_SKIP(kDbgNoEmit) && w.fill >= 64u * (DBG ? 1 : kWide) + 1u) {
+    if (mode_wide(MODE) > 1 && !FGFA_SKIP(kDbgNoEmit) && w.fill >= 64u * (DBG ? 1 : mode_wide(MODE)) + 1u) {
         if (!w.epoch_ok && epoch_now(ctl) >= need) w.epoch_ok = true;
         tmark<DBG>(A, w, 1);
-        if (w.epoch_ok) drain_raw<MODE, (DBG ? 1 : kWide)>(A, w, bcur, mine, false);
+        if (w.epoch_ok) drain_raw<MODE, (DBG ? 1 : mode_wide(MODE))>(A, w, bcur, mine, false);
         tmark<DBG>(A, w, 3);
     }
 }
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keeps the span math on the scalar unit
     uint32_t *mine = PACKED ? A.buckets + A.pk_base[blockIdx.x] : A.buckets + (size_t)blockIdx.x * A.cap;  // this workgroup's sub-bucket of window 0 (packed: its region)
-    if (TAGGED && (MODE == kModePlain || FGFA_TPROF_ALL) && A.tprof && threadIdx.x == 0) {
+    if (TAGGED && (mode_plain(MODE) || FGFA_TPROF_ALL) && A.tprof && threadIdx.x == 0) {
         A.tprof[kTprofRow * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
         // where it runs: HW_ID (wave, SIMD, CU, shader array and engine) and XCC_ID
         A.tprof[kTprofRow * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
                 w.epoch_ok = true;
             }
             tmark<DBG>(A, w, 1);
-            drain_raw<MODE, (DBG ? 1 : kWide)>(A, w, bcur, mine, true);
+            drain_raw<MODE, (DBG ? 1 : mode_wide(MODE))>(A, w, bcur, mine, true);
         }
         tmark<DBG>(A, w, 3);
         // This wave is done with the item: it requests its first two blocks of the next one right away.
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
 #undef FGFA_LOAD_BLOCK
 #undef FGFA_ITEM_TAG
     // publish how many records this workgroup left in each window's sub-bucket
-    if (TAGGED && (MODE == kModePlain || FGFA_TPROF_ALL) && A.tprof && lane == 0) A.tprof[kTprofRow * blockIdx.x + 4 + wave] = __builtin_amdgcn_s_memrealtime();
+    if (TAGGED && (mode_plain(MODE) || FGFA_TPROF_ALL) && A.tprof && lane == 0) A.tprof[kTprofRow * blockIdx.x + 4 + wave] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
     for (uint32_t wdw = threadIdx.x; wdw < A.n_win; wdw += kThreads)
         A.counts[(size_t)wdw * A.n_slots + blockIdx.x] = bcur[wdw];
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(kThreads) void k_scan(const ScanArgs A) {
             A.work_counter[2] = 0u;
         }
     }
-    if (TAGGED && (MODE == kModePlain || FGFA_TPROF_ALL) && A.tprof && threadIdx.x == 0) {
+    if (TAGGED && (mode_plain(MODE) || FGFA_TPROF_ALL) && A.tprof && threadIdx.x == 0) {
         A.tprof[kTprofRow * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         A.tprof[kTprofRow * blockIdx.x + 3] = rr;  // the items it took
     }
@@ -912,7 +912,7 @@ bool scan_kernels_setup() {
         for (const void *k : {(const void *)k_scan<kModePlain, false>, (const void *)k_scan<kModePlain, true>, (const void *)k_scan<kModeRanged, false>,
                               (const void *)k_scan<kModeRanged, true>, (const void *)k_scan<kModeBig, true>, (const void *)k_scan<kModeRangedBig, true>,
                               (const void *)k_scan<kModePacked, true>, (const void *)k_scan<kModePackedRanged, true>,
-                              (const void *)k_scan<kModePlainFlags, true>, (const void *)k_scan<kModePackedFlags, true>,
+                              (const void *)k_scan<kModePlainFlags, true>, (const void *)k_scan<kModePackedFlags, true>, (const void *)k_scan<kModePlainNarrow, true>,
 #ifdef FGFA_MEASURE
                               (const void *)k_scan<kModeDbg, false>,
 #endif
@@ -940,6 +940,7 @@ int launch_scan(const FastPlan &fp, const ScanArgs &sa, bool tagged, uint32_t gr
     else if (sa.big) hipLaunchKernelGGL((k_scan<kModeBig, true>), g, b, lds, stream, sa);
     else if (sa.ranged && tagged) hipLaunchKernelGGL((k_scan<kModeRanged, true>), g, b, lds, stream, sa);
     else if (sa.ranged) hipLaunchKernelGGL((k_scan<kModeRanged, false>), g, b, lds, stream, sa);
+    else if (tagged && fp.narrow_emit) hipLaunchKernelGGL((k_scan<kModePlainNarrow, true>), g, b, lds, stream, sa);
     else if (tagged) hipLaunchKernelGGL((k_scan<kModePlain, true>), g, b, lds, stream, sa);
     else hipLaunchKernelGGL((k_scan<kModePlain, false>), g, b, lds, stream, sa);
     return FLATGFA_OK;

@@ -30,6 +30,8 @@ u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
 for _ in range(3):
     plan.seg_depth(d, u)
 plan.status()
+plan.describe()  # (waits for what the plan makes behind its creation on a side stream)
+torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(calls):
     plan.seg_depth(d, u)
