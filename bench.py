@@ -115,6 +115,9 @@ def git_head():
         return None
 
 
+T_PROCESS0 = time.perf_counter()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -496,6 +499,7 @@ def main():
                             f"{m_res.group(1)} MB of them resident there from call to call), {len(per0[dom])} consecutive calls, HIP events",
                     "kernel_avg_ms": round(cold_ms, 5), "achieved": round(B_dom / (cold_ms * 1e-3) / 1e9, 2), "n": len(per0[dom]),
                     "kernels_avg_ms": {k: round(float(np.mean(v2)), 5) for k, v2 in per0.items()},
+                    "seconds_into_process": round(time.perf_counter() - T_PROCESS0, 1),
                     "same_result": bool((cold.cpu().numpy() == op1.buf.cpu().numpy()).all()) if world == 1 else None}
             check_bufs([cold], "behind the cold plan's sampled calls (FLATGFA_MALL_MB=0)")
             plan0.close()
@@ -892,6 +896,37 @@ def main():
         finally:
             if os.path.exists(fpath):
                 os.unlink(fpath)
+
+    # The boxes of this pool run the cold step scan in one of two states (102 and 92-94 us at cfg-L), and a box changes from the
+    # slow one to the fast one some tens of seconds into sustained work (the same library, alternating processes on one box:
+    # tools/ab_wide.sh, profiles/NOTES.md R6.5) -- `frac_cold` above is sampled a few seconds into this process.  The same
+    # sampling once more, at the end of the secondary measurements, says which state the box is in by then.
+    if rank == 0 and world == 1 and roofline and roofline.get("cold") and extras is not None:
+        os.environ["FLATGFA_MALL_MB"] = "0"
+        try:
+            plan0 = dev.DepthPlan(graph)
+        finally:
+            del os.environ["FLATGFA_MALL_MB"]
+        cold = torch.zeros(2 * S, dtype=torch.int32, device=device)
+        for _ in range(3):
+            plan0.seg_depth(cold[:S], cold[S:])
+        plan0.status()
+        plan0.describe()
+        torch.cuda.synchronize(device)
+        dev.profile_enable(True)
+        dev.profile_read()
+        for _ in range(SAMPLE_STEPS):
+            plan0.seg_depth(cold[:S], cold[S:])
+        plan0.status()
+        dev.profile_enable(False)
+        late = [ms for n_, ms in dev.profile_read() if n_ == roofline["kernel"]]
+        check_bufs([cold], "behind the cold plan's late sample")
+        if late:
+            late_ms = float(np.mean(late))
+            roofline["cold"]["late"] = {"kernel_avg_ms": round(late_ms, 5), "n": len(late), "seconds_into_process": round(time.perf_counter() - T_PROCESS0, 1),
+                                        "frac": round(roofline["algorithmic_bytes"] / (late_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        plan0.close()
+        del plan0, cold
 
     # ---- CPU baseline: the oracle, one core, same arrays (rank 0, N=1 only) ----
     cpu = None

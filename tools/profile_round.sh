@@ -2,7 +2,7 @@
 # Produces the committed profile summaries for one round (run via gpurun from the repo root):
 #   tools/profile_round.sh r01
 # Writes gpurun_out/profiles/<tag>_*; copy them into profiles/ afterwards.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/profiles; mkdir -p $OUT; cd $R
 # (the kernels' own durations: one call in flight -- bench.py's timed region keeps two, whose kernels share the chip;
