@@ -395,6 +395,15 @@ static void marks_start(flatgfa_dev_plan_t *pl) {
     bool any = pl->fast.marks_wanted;
     for (uint32_t r = 0; r < pl->fast.n_more; ++r) any = any || pl->fast.more[r].marks_wanted;
     if (!any) return;
+    // (the job's scratch and stream belong to the plan's device, whatever device the calling thread has current)
+    int cur = pl->device;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return; }
+    struct Restore {
+        int dev;
+        bool on;
+        ~Restore() { if (on) (void)hipSetDevice(dev); }
+    } restore{cur, cur != pl->device};
+    if (restore.on && hipSetDevice(pl->device) != hipSuccess) { (void)hipGetLastError(); restore.on = false; return; }
     if (!pl->side) {  // (one such stream per device for the whole process: creating a stream costs as much as the first answer)
         static std::mutex mu;
         static hipStream_t pool[64] = {};

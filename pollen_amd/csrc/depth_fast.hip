@@ -1276,7 +1276,12 @@ bool fast_marks_start(const FastPlan &fp, const flatgfa_dev_graph_t &g, const ui
     return true;
 }
 
-bool fast_marks_ready(const MarksJob &job) { return !job.active || hipEventQuery(job.done) == hipSuccess; }
+bool fast_marks_ready(const MarksJob &job) {
+    if (!job.active) return true;
+    const hipError_t e = hipEventQuery(job.done);
+    if (e != hipSuccess) (void)hipGetLastError();  // ("not ready" must not be what a later check of the launches finds)
+    return e == hipSuccess;
+}
 
 void fast_marks_finish(FastPlan *fp, MarksJob *job) {
     if (!job->active) return;
