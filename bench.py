@@ -679,12 +679,12 @@ def main():
             torch.cuda.synchronize(device)
             chrom_ms = timed(lambda: cplan.seg_depth(cd, cu))
             cplan.status()
-            want = fo.seg_depth_with_uniq(fo.Pools(**{n: gc.pool(n) for n in fo.POOL_ORDER})) if not args.no_verify else None
+            want_c = fo.seg_depth_with_uniq(fo.Pools(**{n: gc.pool(n) for n in fo.POOL_ORDER})) if not args.no_verify else None
             extras["chromosome_model"] = {
                 "what": f"seg_depth_with_uniq on synth(seed=1, S={S}, P={P}, L={L}, model=chromosome)", "ms_per_call": round(chrom_ms, 5),
                 "steps_per_s": round(N / (chrom_ms * 1e-3), 1),
-                "bit_exact_vs_oracle": None if want is None else bool(
-                    (cd.cpu().numpy().view(np.uint32) == want[0]).all() and (cu.cpu().numpy().view(np.uint32) == want[1]).all())}
+                "bit_exact_vs_oracle": None if want_c is None else bool(
+                    (cd.cpu().numpy().view(np.uint32) == want_c[0]).all() and (cu.cpu().numpy().view(np.uint32) == want_c[1]).all())}
             cplan.close()
             del gc, cs, cplan, cd, cu
         # The timed loop walks the same 400 MB image every step; MI355X has 256 MiB of Infinity

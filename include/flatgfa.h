@@ -237,7 +237,10 @@ int flatgfa_sharded_ranks_seen(flatgfa_sharded_t *sh);
  * device is touched).  cuts_out[r], r = 0 .. n_shards, counts path steps along the path order: shard r walks
  * [cuts_out[r], cuts_out[r + 1]).  Cut r lies at the path boundary nearest to the even cut (total * r / n_shards) when
  * that is within an eighth of a shard's share of it -- or always, with FLATGFA_SHARD_WHOLE_PATHS -- and inside the path
- * otherwise. */
+ * otherwise.  This is flatgfa_sharded_create's rule for a graph whose paths' step spans lie in path order in the steps pool
+ * (every path's steps behind those of the path before it: what the parser emits, flatgfa/src/parse.rs:149-159); where they do
+ * not -- the types allow arbitrary spans -- flatgfa_sharded_create cuts at path boundaries only, as with
+ * FLATGFA_SHARD_WHOLE_PATHS. */
 int flatgfa_shard_cuts(const uint64_t *path_steps, uint32_t n_paths, int n_shards, unsigned flags, uint64_t *cuts_out);
 
 /* ------------------------------------------------------------------------ */

@@ -206,7 +206,9 @@ class DepthPlan:
 class DepthPipeline:
     """Calls in flight (flatgfa_dev_pipeline_t): K plans of one resident graph on K internal streams, taken in turn, so
     that pass 2 of one call shares the chip with pass 1 of the next.  `seg_depth` enqueues and returns; the buffers of a
-    call may be read after `join()` (torch's current stream then waits for every call so far) or `status()`."""
+    call may be read after `join()` (torch's current stream then waits for every call so far) or `status()`.
+    As with a DepthPlan, the lanes' plans are laid out for the step values they were made with: after writing to
+    ``graph.steps`` call :meth:`steps_changed`."""
 
     def __init__(self, graph: DeviceGraph, calls_in_flight: int = 2):
         torch = _torch()
