@@ -1145,6 +1145,33 @@ static bool fast_plan_create_impl(const flatgfa_dev_graph_t &g, const uint32_t *
                            !test_hook("FLATGFA_RANGE_SEGS") && q.n_items >= 16ull * q.n_slots && 2ull * q.n_noclaim < q.n_items && q.n_shared <= 64 &&
                            q.est_records / q.n_win >= 32768;
                 };
+                // ... and the other way round: 8192-segment windows on a graph of two to four million segments.  Pass 2 pays a fixed
+                // part per window (its arrays cleared, 256 sub-buckets opened, the scan and the store: 15 us of a workgroup's time
+                // whatever the records), and 4096-segment windows are two to four per CU there; with half as many, twice as wide,
+                // cfg-L's walks on 4 M segments take 0.186 -> 0.162 ms (`k_accum` 85 -> 67 us, `k_scan` 97 -> 92: NOTES R6.9).  Only where
+                // pass 2 needs nothing the wide windows have no LDS for -- eight bitsets per wave (more than four items per
+                // pass-1 workgroup: 2000 contigs on 4 M segments lose 17 % of pass 2 that way), split paths' shared bitsets, the
+                // wave-per-path kernels' records (they know 4096-segment windows only).
+                const auto wants_wide_windows = [&](const FastPlan &q) {
+                    return q.eligible && q.tagged && q.wb == 12 && !q.n_more && !q.packed && !test_hook("FLATGFA_WB") && !test_hook("FLATGFA_RANGE_SEGS") &&
+                           q.n_win >= 2u * q.n_cus && q.acc_slots == kTagSlots && q.acc_parts == 1 && q.n_shared == 0 && !q.n_short && !q.n_medium && !q.n_tiny &&
+                           (uint64_t)q.n_items <= 4ull * q.n_slots && !q.dense && !q.dense_maybe;
+                };
+                if (!force_wb && plans.size() == 1 && wants_wide_windows(plans[0])) {
+                    std::vector<FastPlan> alt;
+                    bool a_all = true, a_many = false;
+                    if (!append_ranges(g, hb, he, kMaxWinTagged, 13u, &alt, &a_all, &a_many)) {
+                        destroy_plans(&alt);
+                        destroy_plans(&plans);
+                        return false;
+                    }
+                    if (a_all && !a_many && alt.size() == 1 && alt[0].eligible && alt[0].tagged && alt[0].n_shared == 0 && !alt[0].packed) {
+                        destroy_plans(&plans);
+                        plans.swap(alt);
+                    } else {
+                        destroy_plans(&alt);
+                    }
+                }
                 if (!force_wb && plans.size() == 1 && wants_small_windows(plans[0])) {
                     std::vector<FastPlan> alt;
                     bool a_all = true, a_many = false;

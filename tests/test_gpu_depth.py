@@ -1611,3 +1611,27 @@ def test_first_answer_reports_an_id_out_of_range():
     plan.seg_depth(d, u)
     with pytest.raises(pa.FlatGFAError):
         plan.status()
+
+
+def test_wide_windows_on_graphs_of_a_few_million_segments(monkeypatch):
+    """Two to four million segments are two to four 4096-segment windows per CU, and pass 2 pays a fixed part per window: a plan whose
+    pass 2 needs nothing the wide windows have no LDS for (four bitsets per wave suffice, no split paths, no wave-per-path records) takes
+    8192-segment windows there; one whose workgroups take more than four items each keeps 4096 (and its eight bitsets per wave)."""
+    import re
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    for k in ("FLATGFA_WB", "FLATGFA_RANGE_SEGS", "FLATGFA_DEPTH_PATH", "FLATGFA_PACKED"):
+        monkeypatch.delenv(k, raising=False)
+    for S, P, L, model, want_w in ((3_000_000, 600, 50_000, "pangenome", 8192), (2_500_000, 2400, 20_000, "haplotype", 4096), (1_500_000, 500, 40_000, "pangenome", 4096)):
+        g = pa.synth(5, S, P, L, model, False)
+        steps, pb, pe, _ = g.soa()
+        want_d, want_u = fo.seg_depth_with_uniq(pools_of(g))
+        plan = DepthPlan(DeviceGraph(steps, pb, pe, S))
+        desc = plan.describe()
+        assert int(re.search(r"windows=\d+x(\d+)", desc).group(1)) == want_w, desc
+        d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+        for _ in range(2):
+            plan.seg_depth(d, u)
+            plan.status()
+            assert (d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all(), desc
