@@ -526,18 +526,27 @@ static int ensure_device(CStore *cs, int device) {
     const size_t Pa = (P + 63) & ~(size_t)63, Sa = (S + 63) & ~(size_t)63;  // 256-byte aligned sub-arrays
     std::vector<uint32_t> host(2 * Pa + Sa);
     uint32_t *h_pb = host.data(), *h_pe = host.data() + Pa, *h_len = host.data() + 2 * Pa;
-    for (size_t i = 0; i < P; ++i) {
-        h_pb[i] = v.paths[i].steps.start;
-        h_pe[i] = v.paths[i].steps.end;
-    }
-    for (size_t i = 0; i < S; ++i) h_len[i] = v.segs[i].seq.len();
-    tick("span arrays on the host");
+    // (on a thread of its own, beside the upload of the steps: a million segments' lengths out of a freshly mapped file are a
+    // millisecond of page faults that the link need not wait for)
+    std::thread soa([&] {
+        for (size_t i = 0; i < P; ++i) {
+            h_pb[i] = v.paths[i].steps.start;
+            h_pe[i] = v.paths[i].steps.end;
+        }
+        for (size_t i = 0; i < S; ++i) h_len[i] = v.segs[i].seq.len();
+    });
+    struct Joiner {
+        std::thread &t;
+        ~Joiner() { if (t.joinable()) t.join(); }
+    } joiner{soa};
     if (N) {
         CAPI_HIP(hipMalloc(&im.steps, N * 4));
         tick("steps: hipMalloc");
         CAPI_HIP(upload(im.steps, v.steps.data, N * 4, im.stream));
     }
     tick("steps: upload");
+    soa.join();
+    tick("span arrays on the host (beside the upload)");
     if (P || S) {
         CAPI_HIP(hipMalloc(&im.small, (2 * Pa + 3 * Sa + 4 * Pa) * 4));  // (the last 4 * Pa words: two u64 sums per path)
         CAPI_HIP(hipMemcpy(im.small, host.data(), host.size() * 4, hipMemcpyHostToDevice));
@@ -614,35 +623,44 @@ static int fetch_widen(CStore *cs, const uint32_t *dev, uint64_t *out) {
     return FLATGFA_OK;
 }
 
+// Both result vectors as the device left them (u32; they lie next to each other in the handle's allocation, 256-byte aligned), fetched
+// in ONE copy -- through one of the process's pinned staging buffers where they fit one: the link's rate, a pageable target gets a third
+// of it -- and handed to `use(depth32, uniq32)`.
+extern "C++" {
+template <class F>
+static int with_both_u32(CStore *gfa, F use) {
+    const size_t S = gfa->view.segs.len, gap = (size_t)(gfa->d_uniq - gfa->d_depth);
+    if ((gap + S) * 4 <= kChunk) {
+        StagePool &pool = *stage_pool();
+        std::lock_guard<std::mutex> lk(pool.mu);
+        if (pool.ensure(gfa->device, 1) == hipSuccess) {
+            CAPI_HIP(hipMemcpyAsync(pool.stage[0], gfa->d_depth, (gap + S) * 4, hipMemcpyDeviceToHost, gfa->stream));
+            CAPI_HIP(hipStreamSynchronize(gfa->stream));
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(pool.stage[0]);
+            return use(src, src + gap);
+        }
+        (void)hipGetLastError();
+    }
+    std::unique_ptr<uint32_t[]> tmp(new uint32_t[gap + S]);
+    CAPI_HIP(hipMemcpy(tmp.get(), gfa->d_depth, (gap + S) * 4, hipMemcpyDeviceToHost));
+    return use(tmp.get(), tmp.get() + gap);
+}
+}  // extern "C++"
+
 int flatgfa_seg_depth(flatgfa_t gfa, uint64_t *depth_out, uint64_t *uniq_out) {
     if (!gfa || (!depth_out && gfa->view.segs.len)) { set_error("flatgfa_seg_depth: NULL argument"); return FLATGFA_ERR_ARG; }
     std::lock_guard<std::mutex> op(gfa->op_mu);
     int rc = run_seg_depth(gfa, uniq_out != nullptr);
     if (rc) return rc;
     if (!uniq_out) return fetch_widen(gfa, gfa->d_depth, depth_out);
-    // both vectors in one copy (they lie next to each other in the handle's allocation, 256-byte aligned), widened on two threads
-    const size_t S = gfa->view.segs.len, gap = (size_t)(gfa->d_uniq - gfa->d_depth);
+    const size_t S = gfa->view.segs.len;
     if (!S) return FLATGFA_OK;
-    const auto widen = [&](const uint32_t *src) {
-        std::thread other([&] { for (size_t i = 0; i < S; ++i) uniq_out[i] = src[gap + i]; });
-        for (size_t i = 0; i < S; ++i) depth_out[i] = src[i];  // Vec<usize>
+    return with_both_u32(gfa, [&](const uint32_t *d32, const uint32_t *u32) {  // widened on two threads: Vec<usize>
+        std::thread other([&] { for (size_t i = 0; i < S; ++i) uniq_out[i] = u32[i]; });
+        for (size_t i = 0; i < S; ++i) depth_out[i] = d32[i];
         other.join();
-    };
-    if ((gap + S) * 4 <= kChunk) {  // through one of the process's pinned staging buffers: the copy runs at the link's rate (a pageable target: a third of it)
-        StagePool &pool = *stage_pool();
-        std::lock_guard<std::mutex> lk(pool.mu);
-        if (pool.ensure(gfa->device, 1) == hipSuccess) {
-            CAPI_HIP(hipMemcpyAsync(pool.stage[0], gfa->d_depth, (gap + S) * 4, hipMemcpyDeviceToHost, gfa->stream));
-            CAPI_HIP(hipStreamSynchronize(gfa->stream));
-            widen(reinterpret_cast<const uint32_t *>(pool.stage[0]));
-            return FLATGFA_OK;
-        }
-        (void)hipGetLastError();
-    }
-    std::vector<uint32_t> tmp(gap + S);
-    CAPI_HIP(hipMemcpy(tmp.data(), gfa->d_depth, (gap + S) * 4, hipMemcpyDeviceToHost));
-    widen(tmp.data());
-    return FLATGFA_OK;
+        return (int)FLATGFA_OK;
+    });
 }
 
 int flatgfa_path_depth(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, uint64_t *length_out,
@@ -680,12 +698,23 @@ int flatgfa_path_depth(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, 
 int flatgfa_depth_table(flatgfa_t gfa, char **text, size_t *len) {
     if (!gfa || !text) { set_error("flatgfa_depth_table: NULL argument"); return FLATGFA_ERR_ARG; }
     const size_t S = gfa->view.segs.len;
-    std::vector<uint64_t> d(S), u(S);
-    int rc = flatgfa_seg_depth(gfa, d.data(), u.data());
+    if (!S) {
+        std::string out;
+        fgfa::emit_seg_depth(gfa->view, nullptr, nullptr, &out);
+        return give_text(out, text, len);
+    }
+    // the table straight from the device's 32-bit counts into the buffer the caller gets: no widened vectors, no intermediate string
+    std::lock_guard<std::mutex> op(gfa->op_mu);
+    int rc = run_seg_depth(gfa, true);
     if (rc) return rc;
-    std::string out;
-    fgfa::emit_seg_depth(gfa->view, d.data(), u.data(), &out);
-    return give_text(out, text, len);
+    return with_both_u32(gfa, [&](const uint32_t *d32, const uint32_t *u32) {
+        size_t n = 0;
+        char *p = fgfa::emit_seg_depth_u32_malloc(gfa->view, d32, u32, &n);
+        if (!p) { set_error("out of memory"); return (int)FLATGFA_ERR_IO; }
+        *text = p;
+        if (len) *len = n;
+        return (int)FLATGFA_OK;
+    });
 }
 
 int flatgfa_path_depth_table(flatgfa_t gfa, const uint32_t *path_ids, uint32_t n_ids, char **text, size_t *len) {

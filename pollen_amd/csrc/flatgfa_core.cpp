@@ -829,7 +829,8 @@ static inline char *write_u64(char *p, uint64_t x) {
 // One line per segment, in pool order: `{seg.name as u32}\t{depth}\t{uniq}\n` (depth.rs:70-79).
 // A million lines are 13 MB of decimal digits: big tables are formatted by several threads, each
 // its own stretch of segments into its own buffer, and stitched together in order.
-static char *emit_seg_lines(const View &v, const uint64_t *depth, const uint64_t *uniq, size_t lo, size_t hi, char *p) {
+template <typename T>
+static char *emit_seg_lines(const View &v, const T *depth, const T *uniq, size_t lo, size_t hi, char *p) {
     for (size_t i = lo; i < hi; ++i) {
         p = write_u64(p, (uint32_t)v.segs[i].name);  // `seg.name as u32`, depth.rs:71
         *p++ = '\t';
@@ -878,6 +879,46 @@ void emit_seg_depth(const View &v, const uint64_t *depth, const uint64_t *uniq, 
     for (unsigned t = 0; t < nthr; ++t)
         workers.emplace_back([&, t]() { memcpy(&(*out)[at[t]], parts[t].buf.get(), parts[t].len); });
     for (auto &w : workers) w.join();
+}
+
+// The same table from the device's own 32-bit counts, into ONE malloc'd buffer the caller owns (flatgfa_depth_table: no
+// widening pass, no intermediate string, no second copy of 13 MB).  NUL-terminated; *len excludes the NUL.  nullptr: out of memory.
+char *emit_seg_depth_u32_malloc(const View &v, const uint32_t *depth, const uint32_t *uniq, size_t *len) {
+    static const char kHead[] = "#node.id\tdepth\tdepth.uniq\n";
+    constexpr size_t kHeadLen = sizeof kHead - 1, kLineMax = 33;  // three numbers of at most ten digits, two tabs and a newline
+    const size_t S = v.segs.len;
+    unsigned nthr = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (S < (1u << 16)) nthr = 1;
+    struct Part {
+        std::unique_ptr<char[]> buf;
+        size_t len = 0;
+    };
+    std::vector<Part> parts(nthr);
+    std::vector<std::thread> workers;
+    const auto fill = [&](unsigned t) {
+        const size_t lo = S * t / nthr, hi = S * (t + 1) / nthr;
+        parts[t].buf.reset(new char[(hi - lo) * kLineMax + 1]);
+        parts[t].len = (size_t)(emit_seg_lines(v, depth, uniq, lo, hi, parts[t].buf.get()) - parts[t].buf.get());
+    };
+    for (unsigned t = 1; t < nthr; ++t) workers.emplace_back(fill, t);
+    fill(0);
+    for (auto &w : workers) w.join();
+    size_t total = kHeadLen;
+    std::vector<size_t> at(nthr);
+    for (unsigned t = 0; t < nthr; ++t) {
+        at[t] = total;
+        total += parts[t].len;
+    }
+    char *out = (char *)malloc(total + 1);
+    if (!out) return nullptr;
+    memcpy(out, kHead, kHeadLen);
+    workers.clear();
+    for (unsigned t = 1; t < nthr; ++t) workers.emplace_back([&, t]() { memcpy(out + at[t], parts[t].buf.get(), parts[t].len); });
+    memcpy(out + at[0], parts[0].buf.get(), parts[0].len);
+    for (auto &w : workers) w.join();
+    out[total] = 0;
+    *len = total;
+    return out;
 }
 
 void emit_path_depth(const View &v, const uint32_t *path_ids, size_t n, const uint64_t *lengths,

@@ -234,6 +234,8 @@ bool validate_step_ids(const View &v);
 std::string format_float(double x, int digits);
 // ops/depth.rs:67-82
 void emit_seg_depth(const View &v, const uint64_t *depth, const uint64_t *uniq, std::string *out);
+// ... from 32-bit counts into one malloc'd, NUL-terminated buffer (nullptr: out of memory)
+char *emit_seg_depth_u32_malloc(const View &v, const uint32_t *depth, const uint32_t *uniq, size_t *len);
 // ops/depth.rs:143-160
 void emit_path_depth(const View &v, const uint32_t *path_ids, size_t n, const uint64_t *lengths,
                      const double *means, std::string *out);
