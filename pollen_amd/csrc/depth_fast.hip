@@ -61,33 +61,43 @@ namespace {
 // each path has, and whether it walks the segment ids strictly upwards or strictly downwards from its first
 // step to its last (mono[p] = 1: it never meets a segment twice, so a wave-per-path kernel need not look).
 // One workgroup per path at a time.
+// `ext` (or null): per path what k_item_dirs and k_first_ids would say of it as a whole item -- {ascents, descents, steps that follow
+// their predecessor upwards (id + 1), downwards (id - 1), the first id, the last id} -- so that a plan none of whose paths is cut
+// needs neither of those kernels (one read of the steps instead of two on the way to the first answer).
 __global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__ steps, const uint32_t *__restrict__ pb,
                                                      const uint32_t *__restrict__ pe, uint32_t n_paths,
-                                                     uint32_t *__restrict__ runs, uint32_t *__restrict__ runs_down, uint32_t *__restrict__ mono) {
-    __shared__ uint32_t total, total_down, asc, desc;
+                                                     uint32_t *__restrict__ runs, uint32_t *__restrict__ runs_down, uint32_t *__restrict__ mono,
+                                                     uint32_t *__restrict__ ext) {
+    __shared__ uint32_t total, total_down, asc, desc, ups, downs;
     for (uint32_t p = blockIdx.x; p < n_paths; p += gridDim.x) {
-        if (threadIdx.x == 0) total = total_down = asc = desc = 0;
+        if (threadIdx.x == 0) total = total_down = asc = desc = ups = downs = 0;
         __syncthreads();
         const uint64_t b = pb[p], e = pe[p];
-        uint32_t mine = 0, down = 0, a = 0, c = 0;  // (down: the runs the path has when it is read backwards)
+        uint32_t mine = 0, down = 0, a = 0, c = 0, u = 0, d = 0;  // (down: the runs the path has when it is read backwards)
         for (uint64_t i = b + threadIdx.x; i < e; i += 256) {
             const uint32_t id = steps[i] >> 1, before = i == b ? 0u : steps[i - 1] >> 1;
             mine += (i == b || id != before + 1u || (id & 31u) == 0u) ? 1u : 0u;
             down += (i == b || id + 1u != before || (before & 31u) == 0u) ? 1u : 0u;
             a += (i != b && id > before) ? 1u : 0u;
             c += (i != b && id < before) ? 1u : 0u;
+            u += (i != b && id == before + 1u) ? 1u : 0u;
+            d += (i != b && id + 1u == before) ? 1u : 0u;
         }
         for (int off = 32; off > 0; off >>= 1) {
             mine += __shfl_down(mine, off, 64);
             down += __shfl_down(down, off, 64);
             a += __shfl_down(a, off, 64);
             c += __shfl_down(c, off, 64);
+            u += __shfl_down(u, off, 64);
+            d += __shfl_down(d, off, 64);
         }
         if ((threadIdx.x & 63) == 0) {
             atomicAdd(&total, mine);
             atomicAdd(&total_down, down);
             atomicAdd(&asc, a);
             atomicAdd(&desc, c);
+            atomicAdd(&ups, u);
+            atomicAdd(&downs, d);
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -95,6 +105,15 @@ __global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__
             runs_down[p] = total_down;
             const uint32_t pairs = e > b ? (uint32_t)(e - b - 1) : 0u;
             mono[p] = (e > b && (asc == pairs || desc == pairs)) ? 1u : 0u;
+            if (ext) {
+                uint32_t *x = ext + 6 * (size_t)p;
+                x[0] = asc;
+                x[1] = desc;
+                x[2] = ups;
+                x[3] = downs;
+                x[4] = e > b ? steps[b] >> 1 : 0u;
+                x[5] = e > b ? steps[e - 1] >> 1 : 0u;
+            }
         }
         __syncthreads();
     }
@@ -361,28 +380,33 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // Which kernel walks a path depends on how many runs it has: short paths must fit the run queue,
     // paths with at most kMediumRuns runs are walked wave by wave too, by pairs of waves that share a
     // bigger hash set (k_scan_short's medium variant).  The counts come from a one-off kernel.
-    std::vector<uint32_t> runs, runs_down, mono;
+    std::vector<uint32_t> runs, runs_down, mono, ext;  // (ext: six facts per path, see k_count_runs; for up to 2^18 paths)
     if (short_max) {
         // (counted over the spans this plan walks -- a plan may be given others than the graph's own)
         uint32_t *d_runs = nullptr;
         const size_t np = g.n_paths;
-        FAST_TRY(hipMalloc(&d_runs, np * 20));
-        hipError_t e = hipMemcpy(d_runs + 3 * np, hb, np * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_runs + 4 * np, he, np * 4, hipMemcpyHostToDevice);
+        const bool want_ext = np <= (1u << 18) && !measure_switch("FLATGFA_NO_ITEM_DIRS");
+        // (device layout: [runs | runs_down | mono | ext x 6 | begin | end], np words each: one copy in, one copy out)
+        const size_t n_out = want_ext ? 9 : 3;
+        FAST_TRY(hipMalloc(&d_runs, np * (n_out + 2) * 4));
+        std::vector<uint32_t> spans(2 * np);
+        std::copy(hb, hb + np, spans.begin());
+        std::copy(he, he + np, spans.begin() + (ptrdiff_t)np);
+        hipError_t e = hipMemcpy(d_runs + n_out * np, spans.data(), np * 8, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             (void)hipFree(d_runs);
             FAST_TRY(e);
         }
         hipLaunchKernelGGL(k_count_runs, dim3(std::min<uint32_t>(g.n_paths, fp->n_cus * 8u)), dim3(256), 0, nullptr, g.steps,
-                           d_runs + 3 * np, d_runs + 4 * np, g.n_paths, d_runs, d_runs + np, d_runs + 2 * np);
-        runs.resize(g.n_paths);
-        runs_down.resize(g.n_paths);
-        mono.resize(g.n_paths);
-        e = hipMemcpy(runs.data(), d_runs, (size_t)g.n_paths * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(runs_down.data(), d_runs + g.n_paths, (size_t)g.n_paths * 4, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(mono.data(), d_runs + 2 * (size_t)g.n_paths, (size_t)g.n_paths * 4, hipMemcpyDeviceToHost);
+                           d_runs + n_out * np, d_runs + (n_out + 1) * np, g.n_paths, d_runs, d_runs + np, d_runs + 2 * np, want_ext ? d_runs + 3 * np : nullptr);
+        std::vector<uint32_t> out(n_out * np);
+        e = hipMemcpy(out.data(), d_runs, n_out * np * 4, hipMemcpyDeviceToHost);
         (void)hipFree(d_runs);
         FAST_TRY(e);
+        runs.assign(out.begin(), out.begin() + (ptrdiff_t)np);
+        runs_down.assign(out.begin() + (ptrdiff_t)np, out.begin() + (ptrdiff_t)(2 * np));
+        mono.assign(out.begin() + (ptrdiff_t)(2 * np), out.begin() + (ptrdiff_t)(3 * np));
+        if (want_ext) ext.assign(out.begin() + (ptrdiff_t)(3 * np), out.end());
         // (FLATGFA_NO_CLAIM=0: every path claims, monotone or not -- tests and measurements)
         if (const char *nc = test_hook("FLATGFA_NO_CLAIM"); nc && nc[0] == '0') std::fill(mono.begin(), mono.end(), 0u);
     }
@@ -430,6 +454,9 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // chance gave one workgroup (the capacity every sub-bucket gets is the fullest one's, §2).
     if (whole.size() > 1 && !measure_switch("FLATGFA_KEEP_PATH_ORDER")) {
         std::vector<uint32_t> at(whole.size()), first(whole.size(), 0u);
+        if (!ext.empty()) {  // (the counting kernel looked already)
+            for (size_t i = 0; i < whole.size(); ++i) first[i] = ext[6 * (size_t)whole[i].w + 4];
+        } else {
         for (size_t i = 0; i < whole.size(); ++i) at[i] = whole[i].x;
         uint32_t *d_at = nullptr;
         FAST_TRY(hipMalloc(&d_at, whole.size() * 8));
@@ -441,6 +468,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         }
         (void)hipFree(d_at);
         FAST_TRY(e);
+        }
         std::vector<uint32_t> order(whole.size());
         std::iota(order.begin(), order.end(), 0u);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return first[a] < first[b]; });
@@ -713,19 +741,27 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             }
         }
         fat_off[fp->acc_parts] = fp->n_fat;
-        FAST_TRY(hipMalloc(&fp->fat_off, fat_off.size() * 4));
-        FAST_TRY(hipMemcpy(fp->fat_off, fat_off.data(), fat_off.size() * 4, hipMemcpyHostToDevice));
-        FAST_TRY(hipMalloc(&fp->fat_woff, (fat_woff.size() + 1) * 4));
-        if (!fat_woff.empty()) FAST_TRY(hipMemcpy(fp->fat_woff, fat_woff.data(), fat_woff.size() * 4, hipMemcpyHostToDevice));
         // k_scan leaves an item's cursors and sub-bucket at the item's place in this order
         std::vector<uint32_t> perm(fp->n_items + 1, 0);
         for (size_t at = 0; at < elist.size(); ++at) perm[elist[at] & 0x7FFFFFFFu] = (uint32_t)at | (elist[at] & 0x80000000u);
-        FAST_TRY(hipMalloc(&fp->perm, perm.size() * 4));
-        FAST_TRY(hipMemcpy(fp->perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
-        FAST_TRY(hipMalloc(&fp->elist, (elist.size() + 1) * 4));
-        if (!elist.empty()) FAST_TRY(hipMemcpy(fp->elist, elist.data(), elist.size() * 4, hipMemcpyHostToDevice));
-        FAST_TRY(hipMalloc(&fp->wave_off, wave_off.size() * 4));
-        FAST_TRY(hipMemcpy(fp->wave_off, wave_off.data(), wave_off.size() * 4, hipMemcpyHostToDevice));
+        // (the five lists in one allocation and one copy, every one on a 256-byte boundary: an allocation and a copy each cost a
+        // tenth of what the first answer costs)
+        const auto padded = [](size_t words) { return (words + 63) & ~(size_t)63; };
+        const size_t o_fat_off = 0, o_fat_woff = o_fat_off + padded(fat_off.size()), o_perm = o_fat_woff + padded(fat_woff.size() + 1),
+                     o_elist = o_perm + padded(perm.size()), o_wave_off = o_elist + padded(elist.size() + 1), total_words = o_wave_off + padded(wave_off.size());
+        std::vector<uint32_t> slab(total_words, 0u);
+        std::copy(fat_off.begin(), fat_off.end(), slab.begin() + (ptrdiff_t)o_fat_off);
+        std::copy(fat_woff.begin(), fat_woff.end(), slab.begin() + (ptrdiff_t)o_fat_woff);
+        std::copy(perm.begin(), perm.end(), slab.begin() + (ptrdiff_t)o_perm);
+        std::copy(elist.begin(), elist.end(), slab.begin() + (ptrdiff_t)o_elist);
+        std::copy(wave_off.begin(), wave_off.end(), slab.begin() + (ptrdiff_t)o_wave_off);
+        FAST_TRY(hipMalloc(&fp->lists_slab, total_words * 4));
+        FAST_TRY(hipMemcpy(fp->lists_slab, slab.data(), total_words * 4, hipMemcpyHostToDevice));
+        fp->fat_off = fp->lists_slab + o_fat_off;
+        fp->fat_woff = fp->lists_slab + o_fat_woff;
+        fp->perm = fp->lists_slab + o_perm;
+        fp->elist = fp->lists_slab + o_elist;
+        fp->wave_off = fp->lists_slab + o_wave_off;
     }
     plan_tick("range: pass 2 lists made and uploaded");
     // Worst case is one record per step (plus one per block and window crossing) for k_scan and
@@ -771,15 +807,43 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     FAST_TRY(hipMemset(fp->islot, 0, (size_t)fp->dstride * 4));
     plan_tick("range: buckets, cursors, directory allocated and cleared");
     FAST_TRY(hipMalloc(&fp->items, (items.size() + fp->max_back + 1) * sizeof(uint4)));
+    // No path cut into pieces, and the counting kernel's facts at hand: an item is a whole path, and what k_item_dirs would find
+    // out about it -- which way it mostly runs, whether it runs strictly one way, how many records it makes, how many of its
+    // steps go against its grain -- is known (that kernel's read of the steps is then left out).
+    const bool derived = !ext.empty() && fp->n_shared == 0 && !items.empty() && !measure_switch("FLATGFA_NO_ITEM_DIRS");
+    unsigned long long derived_counts[2] = {0, 0};
+    uint32_t derived_noclaim = 0;
+    if (derived) {
+        const char *nc0 = test_hook("FLATGFA_NO_CLAIM");
+        const bool no_claim0 = !(nc0 && nc0[0] == '0');
+        for (uint4 &it : items) {
+            const uint32_t *x = &ext[6 * (size_t)it.w];
+            const uint32_t n = it.y - it.x, pairs = n - 1u;  // (an item has at least one step)
+            const uint32_t state = (x[0] == pairs ? 1u : 0u) | (x[1] == pairs ? 2u : 0u);
+            it.z = (it.z & ~1u) | (x[3] > x[2] ? 1u : 0u);
+            if (state && no_claim0) {
+                it.z |= kItemNoClaim;
+                derived_noclaim += 1;
+            }
+            derived_counts[0] += (unsigned long long)n - std::max(x[2], x[3]);
+            derived_counts[1] += std::min(x[0], x[1]);
+        }
+    }
     if (!items.empty()) {
         FAST_TRY(hipMemcpy(fp->items, items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
         if (!measure_switch("FLATGFA_NO_ITEM_DIRS")) {  // (measurement builds: every item taken as running upwards)
             unsigned long long *d_runs64 = nullptr, runs64 = 0, item_steps = 0, counted[2] = {0, 0};
-            FAST_TRY(hipMalloc(&d_runs64, 16));
-            FAST_TRY(hipMemset(d_runs64, 0, 16));
             // (FLATGFA_NO_CLAIM=0: every item claims, monotone or not -- tests and measurements)
             const char *nc_env = test_hook("FLATGFA_NO_CLAIM");
             const bool no_claim = !(nc_env && nc_env[0] == '0');
+            if (derived) {
+                counted[0] = derived_counts[0];
+                counted[1] = derived_counts[1];
+                runs64 = counted[0];
+                fp->n_noclaim = derived_noclaim;
+            } else {
+            FAST_TRY(hipMalloc(&d_runs64, 16));
+            FAST_TRY(hipMemset(d_runs64, 0, 16));
             uint4 *d_mono = nullptr;
             if (fp->n_shared && no_claim) FAST_TRY(hipMalloc(&d_mono, (size_t)fp->n_items * sizeof(uint4)));
             hipLaunchKernelGGL(k_item_dirs, dim3(std::min<uint32_t>(fp->n_items, fp->n_cus * 8u)), dim3(256), 0, nullptr, g.steps,
@@ -834,6 +898,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
                 }
                 for (const uint4 &it : dev_items) fp->n_noclaim += it.z >> 31;
             }
+            }  // (!derived)
             for (const uint4 &it : items) item_steps += it.y - it.x;
             fp->item_steps = item_steps;
             // Items of paths that do not qualify as a whole: the stretches of them that lie in windows their path enters once
@@ -1470,8 +1535,9 @@ bool fast_plan_grow(FastPlan *fp, bool ahead_of_need) {
 void fast_plan_destroy(FastPlan *fp) {
     for (uint32_t r = 0; r < fp->n_more; ++r) fast_plan_destroy(&fp->more[r]);
     delete[] fp->more;
-    for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot, (void *)fp->perm,
-                    (void *)fp->elist, (void *)fp->wave_off, (void *)fp->fat_off, (void *)fp->fat_woff, (void *)fp->items, (void *)fp->short_items,
+    // (perm, elist, wave_off, fat_off and fat_woff lie in lists_slab)
+    for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot, (void *)fp->lists_slab,
+                    (void *)fp->items, (void *)fp->short_items,
                     (void *)fp->medium_items, (void *)fp->tiny_items, (void *)fp->rev_steps, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part,
                     (void *)fp->pair_part, (void *)fp->pair_flag, (void *)fp->taken, (void *)fp->pk_off, (void *)fp->pk_base, (void *)fp->pk, (void *)fp->cflags})
         if (p) (void)hipFree(p);

@@ -77,6 +77,7 @@ struct FastPlan {
     uint32_t *islot = nullptr;     // u32[dstride] per position of pass 2's walk order: the sub-bucket that holds the item's records | first of its path << 31
     uint32_t *perm = nullptr;      // u32[n_items] where item j stands in pass 2's walk order | first of its path << 31
     uint32_t dstride = 0;          // n_items + max_back + 1
+    uint32_t *lists_slab = nullptr;  // one allocation behind perm, elist, wave_off, fat_off and fat_woff
     uint32_t *elist = nullptr;     // k_scan's items in pass 2's order (grouped by path, split among its waves)
     uint32_t *wave_off = nullptr;  // u32[16 * acc_parts + 1] the stretch of elist each wave of pass 2 walks
     uint32_t *fat_off = nullptr;   // u32[acc_parts + 1] the long paths each of a window's workgroups walks with all its waves
