@@ -230,7 +230,8 @@ int flatgfa_sharded_enqueue(flatgfa_sharded_t *sh, int with_uniq);
 int flatgfa_sharded_sync(flatgfa_sharded_t *sh);
 int flatgfa_sharded_fetch(flatgfa_sharded_t *sh, int shard, uint64_t *depth_out, uint64_t *uniq_out);
 /* How many ranks the handle's exchange really spans: every shard contributes a one to an all-reduce over the
- * handle's communicator (RCCL), or -- shards that exchange by adds -- is counted as it answers.  Equals
+ * handle's communicator (RCCL), or -- shards that exchange by adds -- to the same copies and adds its vectors go
+ * through, and every shard reads back its own copy of the sum (FLATGFA_ERR_HIP if they disagree).  Equals
  * n_shards on a handle that works; negative = an error code. */
 int flatgfa_sharded_ranks_seen(flatgfa_sharded_t *sh);
 /* Where flatgfa_sharded_create would cut a graph whose paths, in path order, have path_steps[p] steps (host only: no

@@ -273,8 +273,9 @@ int shard_count_ranks(flatgfa_sharded &h, Shard &s) {
         const Rccl *r = rccl(nullptr);
         const ncclResult_t e = r->AllReduce(s.d_ones, s.d_ones + 1, 1, ncclUint32, ncclSum, s.comm, s.stream);
         if (e != ncclSuccess) { s.err = std::string("ncclAllReduce: ") + r->GetErrorString(e); return FLATGFA_ERR_HIP; }
-    } else {
-        SH_HIP(hipMemcpyAsync(s.d_ones + 1, s.d_ones, 4, hipMemcpyDeviceToDevice, s.stream));
+    } else {  // (flatgfa_sharded_ranks_seen sums them the way the vectors are summed, then reads every shard's copy)
+        SH_HIP(hipStreamSynchronize(s.stream));
+        return FLATGFA_OK;
     }
     SH_HIP(hipMemcpyAsync(&s.ranks_seen, s.d_ones + 1, 4, hipMemcpyDeviceToHost, s.stream));
     SH_HIP(hipStreamSynchronize(s.stream));
@@ -328,11 +329,11 @@ int run_all(flatgfa_sharded &h, int cmd) {
     return rc;
 }
 
-// Shards that share a device (or a handle without RCCL): the sum on shard 0's device, handed back to all.
-int exchange_by_adds(flatgfa_sharded &h) {
-    if (h.S == 0) return FLATGFA_OK;
+// Shards that share a device (or a handle without RCCL): the sum of every shard's `cnt` words at send(shard) on shard 0's
+// device, `then` behind it on that stream, the result handed back to every recv(shard).
+template <class Send, class Recv, class Then>
+int sum_by_adds(flatgfa_sharded &h, size_t cnt, Send send, Recv recv, Then then) {
     DeviceGuard guard;
-    const size_t cnt = vec_count(h, h.with_uniq);
     Shard &root = *h.sh[0];
     Shard &s = root;  // (for SH_HIP's error text)
     for (auto &x : h.sh) {
@@ -340,28 +341,37 @@ int exchange_by_adds(flatgfa_sharded &h) {
         SH_HIP(hipStreamSynchronize(x->stream));
     }
     SH_HIP(hipSetDevice(root.device));
-    SH_HIP(hipMemcpyAsync(root.d_recv, root.d_send, cnt * 4, hipMemcpyDeviceToDevice, root.stream));
+    SH_HIP(hipMemcpyAsync(recv(root), send(root), cnt * 4, hipMemcpyDeviceToDevice, root.stream));
     struct Bounce {  // (shards on other devices are copied here first)
         uint32_t *p = nullptr;
         ~Bounce() { if (p) (void)hipFree(p); }
     } bounce;
     for (int i = 1; i < h.n; ++i) {
-        const uint32_t *src = h.sh[i]->d_send;
+        const uint32_t *src = send(*h.sh[i]);
         if (h.sh[i]->device != root.device) {
             if (!bounce.p) SH_HIP(hipMalloc(&bounce.p, cnt * 4));
             SH_HIP(hipMemcpyPeerAsync(bounce.p, root.device, src, h.sh[i]->device, cnt * 4, root.stream));
             src = bounce.p;
         }
-        hipLaunchKernelGGL(k_add_into, dim3(2048), dim3(256), 0, root.stream, root.d_recv, src, cnt);
+        hipLaunchKernelGGL(k_add_into, dim3((unsigned)std::min<size_t>((cnt + 255) / 256, 2048)), dim3(256), 0, root.stream, recv(root), src, cnt);
     }
-    if (h.with_uniq && h.K)
-        hipLaunchKernelGGL(k_fix_uniq, dim3(std::min<uint32_t>((h.S + 255u) / 256u, 2048u)), dim3(256), 0, root.stream, root.d_recv + h.S,
-                           root.d_recv + 2 * (size_t)h.S, h.S, h.K, h.bits, h.per_word);
+    then(root);
     SH_HIP(hipGetLastError());
     for (int i = 1; i < h.n; ++i)
-        SH_HIP(hipMemcpyPeerAsync(h.sh[i]->d_recv, h.sh[i]->device, root.d_recv, root.device, cnt * 4, root.stream));
+        SH_HIP(hipMemcpyPeerAsync(recv(*h.sh[i]), h.sh[i]->device, recv(root), root.device, cnt * 4, root.stream));
     SH_HIP(hipStreamSynchronize(root.stream));
     return FLATGFA_OK;
+}
+
+int exchange_by_adds(flatgfa_sharded &h) {
+    if (h.S == 0) return FLATGFA_OK;
+    return sum_by_adds(
+        h, vec_count(h, h.with_uniq), [](Shard &x) { return x.d_send; }, [](Shard &x) { return x.d_recv; },
+        [&](Shard &root) {
+            if (h.with_uniq && h.K)
+                hipLaunchKernelGGL(k_fix_uniq, dim3(std::min<uint32_t>((h.S + 255u) / 256u, 2048u)), dim3(256), 0, root.stream,
+                                   root.d_recv + h.S, root.d_recv + 2 * (size_t)h.S, h.S, h.K, h.bits, h.per_word);
+        });
 }
 
 int enqueue_locked(flatgfa_sharded &h, bool with_uniq) {
@@ -602,10 +612,19 @@ int flatgfa_sharded_ranks_seen(flatgfa_sharded_t *h) {
     std::lock_guard<std::mutex> lk(h->op_mu);
     const int rc = run_all(*h, kCmdCountRanks);
     if (rc) return rc;
-    if (!h->use_rccl) {  // (shards that share a device exchange by adds: every shard is its own rank)
-        int n = 0;
-        for (auto &s : h->sh) n += (int)s->ranks_seen;
-        return n;
+    if (!h->use_rccl) {  // the ones go the way the vectors go (exchange_by_adds), and every shard reads its own copy of the sum
+        if (h->n > 1) {
+            const int rc2 = sum_by_adds(*h, 1, [](Shard &x) { return x.d_ones; }, [](Shard &x) { return x.d_ones + 1; }, [](Shard &) {});
+            if (rc2) { set_error(h->sh[0]->err); return rc2; }
+        }
+        DeviceGuard guard;
+        for (auto &s : h->sh) {
+            if (hipSetDevice(s->device) != hipSuccess ||
+                hipMemcpy(&s->ranks_seen, s->d_ones + (h->n > 1 ? 1 : 0), 4, hipMemcpyDeviceToHost) != hipSuccess) {
+                set_error("flatgfa_sharded_ranks_seen: reading a shard's count failed");
+                return FLATGFA_ERR_HIP;
+            }
+        }
     }
     for (auto &s : h->sh)
         if (s->ranks_seen != h->sh[0]->ranks_seen) { set_error("flatgfa_sharded_ranks_seen: the shards disagree"); return FLATGFA_ERR_HIP; }
