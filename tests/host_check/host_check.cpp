@@ -277,6 +277,21 @@ int main(int argc, char **argv) {
             }
         }
     }
+    {   // the table straight from 32-bit counts (flatgfa_depth_table), enough segments for all of its threads: the same bytes
+        Store big;
+        synth_store(9, 70000, 4, 100, 0, false, &big);
+        std::vector<uint32_t> d32(big.segs.size()), u32(big.segs.size());
+        std::vector<uint64_t> d(big.segs.size()), u(big.segs.size());
+        for (size_t i = 0; i < d.size(); ++i) d[i] = d32[i] = (uint32_t)(i * 2654435761ull % 4000000000ull), u[i] = u32[i] = (uint32_t)(i % 977);
+        std::string tab;
+        emit_seg_depth(big.view(), d.data(), u.data(), &tab);
+        size_t len = 0;
+        char *m = emit_seg_depth_u32_malloc(big.view(), d32.data(), u32.data(), &len);
+        const bool same = m && len == tab.size() && !memcmp(m, tab.data(), len) && m[len] == 0;
+        free(m);
+        if (!same) { fprintf(stderr, "emit_seg_depth_u32_malloc differs from emit_seg_depth\n"); return 1; }
+        h = fnv(h, tab.data(), tab.size());
+    }
     printf("threads %016llx\n", (unsigned long long)h);
     all = fnv(all, &h, 8);
     printf("all %016llx\n", (unsigned long long)all);
