@@ -550,8 +550,10 @@ static bool plan_build_fast(flatgfa_dev_plan_t *pl, uint32_t *first_depth, uint3
             }
             again.mall_steps = pl->fast.mall_steps;
             for (uint32_t r = 0; r < again.n_more; ++r) again.more[r].mall_steps = again.mall_steps;
+            tick("the plan made again with packed buckets");
             fast_plan_destroy(&pl->fast);
             pl->fast = again;
+            tick("the even plan's scratch freed");
         } else {
             break;
         }

@@ -60,57 +60,113 @@ namespace {
 // Plan time: how many runs (as k_scan_short cuts them: +1 continuations, cut at multiples of 32)
 // each path has, and whether it walks the segment ids strictly upwards or strictly downwards from its first
 // step to its last (mono[p] = 1: it never meets a segment twice, so a wave-per-path kernel need not look).
-// One workgroup per path at a time.
 // `ext` (or null): per path what k_item_dirs and k_first_ids would say of it as a whole item -- {ascents, descents, steps that follow
 // their predecessor upwards (id + 1), downwards (id - 1), the first id, the last id} -- so that a plan none of whose paths is cut
 // needs neither of those kernels (one read of the steps instead of two on the way to the first answer).
+// A workgroup takes one PIECE of a path at a time (gridDim.y pieces per path: a graph of four chromosome-long paths fills the
+// chip like one of a thousand): 16 bytes a lane and four loads in flight, the counts as population counts of wave-wide
+// predicates.  With one piece per path the workgroup writes the path's words; with more, every piece ADDS its counts to words
+// the host has cleared (integer adds: any order), piece 0 writes the two ids, and `mono` is the host's to derive from `ext`.
 __global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__ steps, const uint32_t *__restrict__ pb,
-                                                     const uint32_t *__restrict__ pe, uint32_t n_paths,
+                                                     const uint32_t *__restrict__ pe, uint32_t n_paths, uint64_t n_steps,
                                                      uint32_t *__restrict__ runs, uint32_t *__restrict__ runs_down, uint32_t *__restrict__ mono,
                                                      uint32_t *__restrict__ ext) {
-    __shared__ uint32_t total, total_down, asc, desc, ups, downs;
+    __shared__ uint32_t tot[6];  // runs, runs read backwards, ascents, descents, +1 steps, -1 steps
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t pieces = gridDim.y, piece = blockIdx.y;
     for (uint32_t p = blockIdx.x; p < n_paths; p += gridDim.x) {
-        if (threadIdx.x == 0) total = total_down = asc = desc = ups = downs = 0;
+        if (threadIdx.x < 6) tot[threadIdx.x] = 0;
         __syncthreads();
         const uint64_t b = pb[p], e = pe[p];
-        uint32_t mine = 0, down = 0, a = 0, c = 0, u = 0, d = 0;  // (down: the runs the path has when it is read backwards)
-        for (uint64_t i = b + threadIdx.x; i < e; i += 256) {
-            const uint32_t id = steps[i] >> 1, before = i == b ? 0u : steps[i - 1] >> 1;
-            mine += (i == b || id != before + 1u || (id & 31u) == 0u) ? 1u : 0u;
-            down += (i == b || id + 1u != before || (before & 31u) == 0u) ? 1u : 0u;
-            a += (i != b && id > before) ? 1u : 0u;
-            c += (i != b && id < before) ? 1u : 0u;
-            u += (i != b && id == before + 1u) ? 1u : 0u;
-            d += (i != b && id + 1u == before) ? 1u : 0u;
+        // this piece: steps [lo, hi) of [b, e), cut at multiples of four steps (16 bytes) of the pool
+        uint64_t lo = b, hi = e;
+        if (pieces > 1) {
+            const uint64_t len = e - b;
+            lo = piece ? (b + len * piece / pieces) & ~3ull : b;
+            hi = piece + 1 < pieces ? (b + len * (piece + 1) / pieces) & ~3ull : e;
+            lo = lo < b ? b : lo;
+            hi = hi < lo ? lo : hi;
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            mine += __shfl_down(mine, off, 64);
-            down += __shfl_down(down, off, 64);
-            a += __shfl_down(a, off, 64);
-            c += __shfl_down(c, off, 64);
-            u += __shfl_down(u, off, 64);
-            d += __shfl_down(d, off, 64);
+        uint32_t n_run = 0, n_down = 0, n_asc = 0, n_desc = 0, n_up = 0, n_dn = 0;  // (the same in every lane of a wave)
+        // one group of 256 steps: lane l holds steps g0 + 4 l .. + 3 in `v`, `prev` = the step before its first
+        const auto count = [&](uint64_t g0, const uint4 &v, bool interior) {
+            const uint32_t s[4] = {v.x, v.y, v.z, v.w};
+            uint32_t prev = (uint32_t)__shfl_up((int)v.w, 1, 64);
+            if (lane == 0) prev = g0 > b ? steps[g0 - 1] : 0u;
+            const uint64_t i0 = g0 + 4u * lane;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t i = i0 + (uint64_t)j;
+                const uint32_t id = s[j] >> 1, before = (j ? s[j - 1] : prev) >> 1;
+                const bool valid = interior || (i >= lo && i < hi), first = !interior && i == b;
+                const bool follows_up = id == before + 1u, follows_down = id + 1u == before;
+                n_run += (uint32_t)__popcll(__ballot(valid && (first || !follows_up || (id & 31u) == 0u)));
+                n_down += (uint32_t)__popcll(__ballot(valid && (first || !follows_down || (before & 31u) == 0u)));
+                n_asc += (uint32_t)__popcll(__ballot(valid && !first && id > before));
+                n_desc += (uint32_t)__popcll(__ballot(valid && !first && id < before));
+                n_up += (uint32_t)__popcll(__ballot(valid && !first && follows_up));
+                n_dn += (uint32_t)__popcll(__ballot(valid && !first && follows_down));
+            }
+        };
+        const auto load = [&](uint64_t g0) -> uint4 {
+            const uint64_t i0 = g0 + 4u * lane;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (i0 < hi) {
+                if (i0 + 4u <= n_steps) {
+                    v = *reinterpret_cast<const uint4 *>(steps + i0);
+                } else {  // (the pool's last, partial quad)
+                    v.x = steps[i0];
+                    if (i0 + 1u < n_steps) v.y = steps[i0 + 1u];
+                    if (i0 + 2u < n_steps) v.z = steps[i0 + 2u];
+                }
+            }
+            return v;
+        };
+        // a wave takes every fourth group of 256 steps, four of its groups at a time (wave-uniform loop)
+        for (uint64_t g = (lo & ~3ull) + 256ull * wave; g < hi; g += 4096u) {
+            uint4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = g + 1024u * k < hi ? load(g + 1024u * k) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t g0 = g + 1024u * k;
+                if (g0 < hi) {
+                    if (g0 > lo && g0 > b && g0 + 256u <= hi) count(g0, v[k], true);
+                    else count(g0, v[k], false);
+                }
+            }
         }
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&total, mine);
-            atomicAdd(&total_down, down);
-            atomicAdd(&asc, a);
-            atomicAdd(&desc, c);
-            atomicAdd(&ups, u);
-            atomicAdd(&downs, d);
+        if (lane == 0) {
+            atomicAdd(&tot[0], n_run);
+            atomicAdd(&tot[1], n_down);
+            atomicAdd(&tot[2], n_asc);
+            atomicAdd(&tot[3], n_desc);
+            atomicAdd(&tot[4], n_up);
+            atomicAdd(&tot[5], n_dn);
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            runs[p] = total;
-            runs_down[p] = total_down;
-            const uint32_t pairs = e > b ? (uint32_t)(e - b - 1) : 0u;
-            mono[p] = (e > b && (asc == pairs || desc == pairs)) ? 1u : 0u;
-            if (ext) {
-                uint32_t *x = ext + 6 * (size_t)p;
-                x[0] = asc;
-                x[1] = desc;
-                x[2] = ups;
-                x[3] = downs;
+            uint32_t *x = ext ? ext + 6 * (size_t)p : nullptr;
+            if (pieces == 1) {
+                runs[p] = tot[0];
+                runs_down[p] = tot[1];
+                const uint32_t pairs = e > b ? (uint32_t)(e - b - 1) : 0u;
+                mono[p] = (e > b && (tot[2] == pairs || tot[3] == pairs)) ? 1u : 0u;
+                if (x) {
+                    x[0] = tot[2];
+                    x[1] = tot[3];
+                    x[2] = tot[4];
+                    x[3] = tot[5];
+                }
+            } else {  // (x != nullptr: the host asks for pieces only together with `ext`)
+                atomicAdd(&runs[p], tot[0]);
+                atomicAdd(&runs_down[p], tot[1]);
+                atomicAdd(&x[0], tot[2]);
+                atomicAdd(&x[1], tot[3]);
+                atomicAdd(&x[2], tot[4]);
+                atomicAdd(&x[3], tot[5]);
+            }
+            if (x && piece == 0) {
                 x[4] = e > b ? steps[b] >> 1 : 0u;
                 x[5] = e > b ? steps[e - 1] >> 1 : 0u;
             }
@@ -397,8 +453,20 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             (void)hipFree(d_runs);
             FAST_TRY(e);
         }
-        hipLaunchKernelGGL(k_count_runs, dim3(std::min<uint32_t>(g.n_paths, fp->n_cus * 8u)), dim3(256), 0, nullptr, g.steps,
-                           d_runs + n_out * np, d_runs + (n_out + 1) * np, g.n_paths, d_runs, d_runs + np, d_runs + 2 * np, want_ext ? d_runs + 3 * np : nullptr);
+        // (few long paths: several pieces each, so that the kernel fills the chip -- the pieces add to cleared words)
+        uint32_t pieces = 1;
+        if (want_ext && np < fp->n_cus * 8u && g.n_steps / np >= (1u << 16)) pieces = std::min<uint32_t>((fp->n_cus * 8u + (uint32_t)np - 1u) / (uint32_t)np, 4096u);
+        if (const char *forced = test_hook("FLATGFA_COUNT_PIECES")) pieces = want_ext ? std::max(1, atoi(forced)) : 1u;
+        if (pieces > 1) {
+            e = hipMemsetAsync(d_runs, 0, n_out * np * 4, nullptr);
+            if (e != hipSuccess) {
+                (void)hipFree(d_runs);
+                FAST_TRY(e);
+            }
+        }
+        hipLaunchKernelGGL(k_count_runs, dim3(std::min<uint32_t>(g.n_paths, fp->n_cus * 8u), pieces), dim3(256), 0, nullptr, g.steps,
+                           d_runs + n_out * np, d_runs + (n_out + 1) * np, g.n_paths, g.n_steps, d_runs, d_runs + np, d_runs + 2 * np,
+                           want_ext ? d_runs + 3 * np : nullptr);
         std::vector<uint32_t> out(n_out * np);
         e = hipMemcpy(out.data(), d_runs, n_out * np * 4, hipMemcpyDeviceToHost);
         (void)hipFree(d_runs);
@@ -407,6 +475,12 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         runs_down.assign(out.begin() + (ptrdiff_t)np, out.begin() + (ptrdiff_t)(2 * np));
         mono.assign(out.begin() + (ptrdiff_t)(2 * np), out.begin() + (ptrdiff_t)(3 * np));
         if (want_ext) ext.assign(out.begin() + (ptrdiff_t)(3 * np), out.end());
+        if (pieces > 1) {  // (no one piece knows: a path is monotone when all of its pairs ascend or all of them descend)
+            for (size_t p = 0; p < np; ++p) {
+                const uint32_t pairs = he[p] > hb[p] ? he[p] - hb[p] - 1u : 0u;
+                mono[p] = (he[p] > hb[p] && (ext[6 * p] == pairs || ext[6 * p + 1] == pairs)) ? 1u : 0u;
+            }
+        }
         // (FLATGFA_NO_CLAIM=0: every path claims, monotone or not -- tests and measurements)
         if (const char *nc = test_hook("FLATGFA_NO_CLAIM"); nc && nc[0] == '0') std::fill(mono.begin(), mono.end(), 0u);
     }
@@ -785,9 +859,21 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     const bool can_pack = fp->tagged && !fp->n_short && !fp->n_medium && !fp->n_tiny && !fp->dbg && !fp->cap_forced && n_win <= kMaxWinTagged && fp->acc_parts == 1 &&
                           scan_lds_bytes(fp->nwp, true, true) + 64 <= kLdsLimit;
     // (the even layout may take 2 GB for a graph's buckets: this plan's share when segment ranges and path groups make several of it)
-    bool want_packed = can_pack && (slots + fp->n_slots) * std::max<uint64_t>(cap, 4) * 4 > std::max<uint64_t>(128ull << 20, (2ull << 30) / std::max(1u, siblings));
+    const uint64_t even_limit = std::max<uint64_t>(128ull << 20, (2ull << 30) / std::max(1u, siblings));
+    const uint64_t even_first = (slots + fp->n_slots) * std::max<uint64_t>(cap, 4) * 4;
+    bool want_packed = can_pack && even_first > even_limit;
+    // From half of that the counting call is asked first (a third of a query): it says how deep the deepest sub-bucket is, and
+    // an even layout with headroom -- three times that for every sub-bucket -- that would pass the limit is not made at all.  (Paths
+    // that run along the graph: 2000 contigs of 100 k steps on 4 M segments start at 1.25 GB, overflow in the sizing query and
+    // grow to 4.8 GB, and the plan was then made a second time, packed: 11 ms to its first answer, now 3.)
+    bool ask_first = can_pack && !want_packed && !t_prefer_packed && even_first > even_limit / 2;
     want_packed = want_packed || (can_pack && t_prefer_packed);  // (a plan whose even layout had to grow to gigabytes is made again, packed: flatgfa_dev_plan_create)
-    if (const char *f = getenv("FLATGFA_PACKED")) want_packed = can_pack && strtol(f, nullptr, 10) != 0;
+    if (const char *f = getenv("FLATGFA_PACKED")) {
+        want_packed = can_pack && strtol(f, nullptr, 10) != 0;
+        ask_first = false;
+    }
+    if (const char *f = test_hook("FLATGFA_PACKED_ASK")) ask_first = can_pack && !want_packed && strtol(f, nullptr, 10) != 0;  // (tests: small graphs ask too)
+    want_packed = want_packed || ask_first;
     if (!want_packed) {
         const int rc = alloc_buckets(fp, std::max<uint64_t>(cap, 4));
         if (rc < 0) return false;
@@ -905,8 +991,9 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             // and walks one way (k_visit_bits, k_chunk_flags) -- k_scan gives the records of such blocks the no-claim tag too.
             // For one range over all segments, tagged; two bits per (path, window) and one per sixteen steps of scratch.
             // Three more reads of the steps, and not on the way to the first answer: the plan's owner runs them on a side
-            // stream (fast_marks_start) and installs them between two later calls -- except where the buckets are laid out
-            // to the count (a build of k_scan with marks cuts its runs at block ends: the counting call must see them).
+            // stream (fast_marks_start) and installs them between two later calls.  (Buckets laid out to the count too: a mark
+            // rides on top of the ids of a whole block, and a block's first step starts a run in every build of k_scan -- the
+            // marked build makes the records the counting call saw.)
             fp->marks_wanted = no_claim && fp->tagged && !ranged && fp->n_noclaim < fp->n_items && !test_hook("FLATGFA_NO_CLAIM_BLOCKS_OFF") &&
                                (((uint64_t)g.n_paths * n_win + 15) / 16 + 1) * 4 <= (256ull << 20);
             // ... and not worth looking for where the walks turn round all the time: a step against its item's grain spoils the
@@ -914,12 +1001,6 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             // random walks: forty-five a block, one chunk in a thousand qualifies; a walk with a tandem repeat every 6400 steps: one
             // in six blocks has any).  FLATGFA_NO_CLAIM_BLOCKS_MIN (tests) asks for the marks regardless.
             if (fp->marks_wanted && counted[1] * 64 >= item_steps && !test_hook("FLATGFA_NO_CLAIM_BLOCKS_MIN")) fp->marks_wanted = false;
-            if (fp->marks_wanted && want_packed) {
-                MarksJob job;
-                if (!fast_marks_start(*fp, g, hb, nullptr, &job)) return false;
-                fast_marks_finish(fp, &job);
-                fp->marks_wanted = false;
-            }
             fp->est_records = runs64;
             fp->narrow_emit = runs64 * 8 < item_steps;  // (long runs: see mode_wide)
             plan_tick("range: items uploaded, k_item_dirs");
@@ -1037,6 +1118,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             fp->lds_bytes_scan = lds_even;
             return true;
         }
+        plan_tick("range: packed buckets: the counting call");
         const bool countable = !(st & kStBackOverflow);  // (blocks without any runs do not fit a packed call's queues: the even layout)
         std::vector<uint32_t> off(row * fp->n_slots);
         std::vector<uint64_t> base(fp->n_slots);
@@ -1059,6 +1141,13 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             total += o;
         }
         fits = fits && countable && total < (1ull << 32);
+        // (three times the deepest: a call deals the items as they come, so its fullest sub-bucket is not the counted one, and
+        // what ends up more than half full is doubled for headroom -- flatgfa_dev_plan_create; twice the deepest was kept even,
+        // doubled there, and made again packed after all)
+        if (fits && ask_first && (slots + fp->n_slots) * std::max<uint64_t>(3 * deepest, 4) * 4 <= even_limit) {
+            fits = false;  // the even layout can be had: kept (its k_scan deals the items as they come and keeps one table less in LDS)
+            cap = std::max<uint64_t>(cap, 3 * deepest);
+        }
         (void)hipFree(fp->buckets);
         fp->buckets = nullptr;
         if (!fits) {  // (not the case this layout is for: the even one, if it can be had)
@@ -1081,6 +1170,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             fp->cap = (uint32_t)std::max<uint64_t>(deepest, 4);  // (what describe() reports: the deepest sub-bucket)
             fp->bucket_records = total;
         }
+        plan_tick("range: packed buckets: laid out, allocated, tables uploaded");
     }
     fp->eligible = true;
     return true;

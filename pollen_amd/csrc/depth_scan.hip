@@ -157,7 +157,20 @@ __device__ __forceinline__ void emit_raw(const ScanArgs &A, RWave &w, uint32_t *
             ovf |= put<DBG, mode_big(MODE), mode_packed(MODE)>(A, w, mine, cross[k], pos2, win[k] + 1u, ((lenm1[k] - (wmask - rel[k]) - 1u) << wb) | w.tagc | ncm[k]);
         }
     }
-    flag_if_any(A, ovf, kStOverflow);
+    if constexpr (mode_packed(MODE)) {
+        // A packed call that runs out of room does so all the time -- the counting call, in which no sub-bucket has any: every
+        // chunk of every wave would OR into the one status word (a million atomics on one address: 4.9 ms of a 0.3 ms kernel on
+        // 200 M steps).  The workgroup says it once: a spare control word (behind kCtlEpoch, cleared with the others) remembers.
+        if (__builtin_amdgcn_ballot_w64(ovf)) {
+            uint32_t *said = bcur + 2u * A.nwp + kCtlEpoch + 2u;
+            if (w.lane == 0 && __hip_atomic_load(said, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {
+                __hip_atomic_store(said, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                atomicOr(A.status, kStOverflow);
+            }
+        }
+    } else {
+        flag_if_any(A, ovf, kStOverflow);
+    }
 }
 
 // Emit the oldest entries, 64 at a time, while at least 65 are queued, then move what is left to

@@ -1635,3 +1635,114 @@ def test_wide_windows_on_graphs_of_a_few_million_segments(monkeypatch):
             plan.seg_depth(d, u)
             plan.status()
             assert (d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all(), desc
+
+
+def test_counting_kernel_in_pieces_finds_the_same_facts(monkeypatch):
+    """The plan-time counting kernel (runs per path, which paths are monotone, how an unsplit item runs) takes a path in one piece or in
+    several that add their counts up (a graph of few long paths: `cfgL-4paths`); what the plan then is -- which kernel walks how many paths,
+    how many items carry the no-claim tag: the description -- must not depend on it, nor may a count."""
+    import re
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    for k in ("FLATGFA_SHORT_MAX", "FLATGFA_DEPTH_PATH", "FLATGFA_COUNT_PIECES", "FLATGFA_PACKED", "FLATGFA_NO_CLAIM"):
+        monkeypatch.delenv(k, raising=False)
+    shapes = [(40_000, 7, 90_001, "pangenome"), (40_000, 12, 33_333, "haplotype"), (40_000, 12, 33_333, "repeats"), (9_000, 300, 777, "chromosome"),
+              (9_000, 3000, 97, "haplotype"), (300_000, 3, 400_003, "haplotype")]
+    for S, P, L, model in shapes:
+        g = pa.synth(11, S, P, L, model, False)
+        steps, pb, pe, _ = g.soa()
+        want_d, want_u = fo.seg_depth_with_uniq(pools_of(g))
+        graph = DeviceGraph(steps, pb, pe, S)
+        seen = {}
+        for pieces in (None, "1", "2", "5", "64"):
+            if pieces is None:
+                monkeypatch.delenv("FLATGFA_COUNT_PIECES", raising=False)
+            else:
+                monkeypatch.setenv("FLATGFA_COUNT_PIECES", pieces)
+            monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+            d = torch.full((S,), -3, dtype=torch.int32, device="cuda:0")
+            u = torch.full((S,), -3, dtype=torch.int32, device="cuda:0")
+            plan = DepthPlan(graph, first=(d, u))
+            # (what the sizing and timing runs decide -- which pass 1 was faster, how deep the fullest sub-bucket got with the items dealt
+            # as they came -- is not the counting kernel's business)
+            seen[pieces] = re.sub(r" (pass1|bucket_cap|scratch_mb)=\S+", "", plan.describe())
+            assert (d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all(), (pieces, seen[pieces])
+            plan.seg_depth(d, u)
+            plan.status()
+            assert (d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all(), (pieces, seen[pieces])
+            plan.close()
+        assert len(set(seen.values())) == 1, seen
+
+
+@pytest.mark.parametrize("shape", [(300_000, 40, 60_000), (2_000_000, 9, 500_000), (3_000_000, 600, 30_000)])
+def test_packed_buckets_take_their_marks_behind_the_first_answer(shape, monkeypatch):
+    """A plan with packed buckets has its per-block no-claim marks made behind its first answer like any other (a mark rides on the
+    ids of a whole block, and a block's first step starts a run in every build of k_scan: the marked build makes exactly the records
+    the counting call laid the buckets out for).  The first answer comes from the unmarked build, the calls after `describe()` (which
+    waits for the marks) from the marked one: all exact, and none of them ran out of room -- the plan is still bucketed and packed."""
+    import re
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    S, P, L = shape
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
+    monkeypatch.setenv("FLATGFA_PACKED", "1")
+    monkeypatch.delenv("FLATGFA_NO_CLAIM", raising=False)
+    g = pa.synth(23, S, P, L, "repeats", False)
+    steps, pb, pe, _ = g.soa()
+    wd, wu = fo.seg_depth_with_uniq(pools_of(g))
+    d = torch.full((S,), -1, dtype=torch.int32, device="cuda:0")
+    u = torch.full((S,), -1, dtype=torch.int32, device="cuda:0")
+    plan = DepthPlan(DeviceGraph(steps, pb, pe, S), first=(d, u))
+    assert (d.cpu().numpy().view(np.uint32) == wd).all() and (u.cpu().numpy().view(np.uint32) == wu).all()
+    plan.seg_depth(d, u)   # (starts the marks' job)
+    plan.status()
+    assert (d.cpu().numpy().view(np.uint32) == wd).all() and (u.cpu().numpy().view(np.uint32) == wu).all()
+    desc = plan.describe()
+    assert "buckets=packed" in desc and "path=bucketed" in desc and re.search(r"no_claim_chunks=\d+", desc), desc
+    for k in range(3):
+        d.fill_(-5)
+        u.fill_(-5)
+        plan.seg_depth(d, u if k != 1 else None)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == wd).all(), desc
+        if k != 1:
+            assert (u.cpu().numpy().view(np.uint32) == wu).all(), desc
+    after = plan.describe()
+    assert "buckets=packed" in after and "path=bucketed" in after, after
+    plan.close()
+
+
+def test_a_plan_asks_the_counting_call_before_it_makes_an_even_layout_of_a_gigabyte(monkeypatch):
+    """An even layout gives every sub-bucket the room of the fullest.  Where the first estimate is past half the limit the plan runs
+    the counting call first and packs its buckets when the even layout with headroom would pass the limit -- contigs that run along
+    the graph fill a few sub-buckets of a window and leave the others empty -- and keeps the even layout when it would not (random
+    walks fill them all alike).  FLATGFA_PACKED_ASK=1 makes small graphs ask."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    for k in ("FLATGFA_PACKED", "FLATGFA_WB", "FLATGFA_RANGE_SEGS", "FLATGFA_NO_CLAIM"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    monkeypatch.setenv("FLATGFA_SHORT_MAX", "0")
+    monkeypatch.setenv("FLATGFA_PACKED_ASK", "1")
+    seen = {}
+    for name, (S, P, L, model) in {"walks": (1_000_000, 300, 20_000, "pangenome"), "contigs": (4_000_000, 1000, 50_000, "haplotype")}.items():
+        g = pa.synth(31, S, P, L, model, False)
+        steps, pb, pe, _ = g.soa()
+        wd, wu = fo.seg_depth_with_uniq(pools_of(g))
+        d = torch.full((S,), -1, dtype=torch.int32, device="cuda:0")
+        u = torch.full((S,), -1, dtype=torch.int32, device="cuda:0")
+        plan = DepthPlan(DeviceGraph(steps, pb, pe, S), first=(d, u))
+        assert (d.cpu().numpy().view(np.uint32) == wd).all() and (u.cpu().numpy().view(np.uint32) == wu).all()
+        seen[name] = plan.describe()
+        assert "path=bucketed" in seen[name], seen
+        for _ in range(2):
+            plan.seg_depth(d, u)
+            plan.status()
+            assert (d.cpu().numpy().view(np.uint32) == wd).all() and (u.cpu().numpy().view(np.uint32) == wu).all(), seen
+        assert "path=bucketed" in plan.describe()
+        plan.close()
+    assert "buckets=even" in seen["walks"], seen
+    # (the contigs' even layout with headroom stays far below 2 GB at this size: asked, counted, and kept even as well -- the rule's other
+    # branch is what `hap-chr20` takes, tools/plan_facts.py; here both must simply be right)
+    assert "buckets=" in seen["contigs"], seen

@@ -40,7 +40,11 @@ ENVS = [{}, {"FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_SHORT_MAX": "0"}, {"FL
         {"FLATGFA_ACC_OWN": "1", "FLATGFA_PACKED": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
         {"FLATGFA_NO_CLAIM_BLOCKS_MIN": "0", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
         {"FLATGFA_NO_CLAIM_BLOCKS_MIN": "0", "FLATGFA_PACKED": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
-        {"FLATGFA_NO_CLAIM_BLOCKS_MIN": "0", "FLATGFA_PIECE_STEPS": "3000", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"}]
+        {"FLATGFA_NO_CLAIM_BLOCKS_MIN": "0", "FLATGFA_PIECE_STEPS": "3000", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_COUNT_PIECES": "3", "FLATGFA_DEPTH_PATH": "bucketed"}, {"FLATGFA_COUNT_PIECES": "17"},  # the plan-time counting kernel takes a path in pieces
+        {"FLATGFA_COUNT_PIECES": "2", "FLATGFA_SHORT_MAX": "300", "FLATGFA_DEPTH_PATH": "bucketed"},
+        {"FLATGFA_PACKED_ASK": "1", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed"},  # the counting call first, then the layout it speaks for
+        {"FLATGFA_PACKED": "1", "FLATGFA_NO_CLAIM_BLOCKS_MIN": "0", "FLATGFA_SHORT_MAX": "0", "FLATGFA_DEPTH_PATH": "bucketed", "FLATGFA_PIECE_STEPS": "2048"}]
 
 
 def random_graph(rng):
