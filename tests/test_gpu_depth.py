@@ -1746,3 +1746,83 @@ def test_a_plan_asks_the_counting_call_before_it_makes_an_even_layout_of_a_gigab
     # (the contigs' even layout with headroom stays far below 2 GB at this size: asked, counted, and kept even as well -- the rule's other
     # branch is what `hap-chr20` takes, tools/plan_facts.py; here both must simply be right)
     assert "buckets=" in seen["contigs"], seen
+
+
+@pytest.mark.parametrize("L", [1500, 70_001])
+def test_one_step_back_wherever_it_lies_keeps_a_path_from_going_without_claims(L, monkeypatch):
+    """What the plan-time counting kernel says of a path decides whether its records claim their segments: a path it takes for strictly
+    monotone goes without, and a single revisit it overlooked would count a segment's unique depth twice.  Paths that walk their own
+    stretch of ids upwards (or downwards) with ONE step back -- at the first steps, the last, around every boundary the kernel has
+    (a lane's four steps, a wave's 256, a workgroup's 1024 and 4096, the cuts between the pieces of a path) -- between paths that
+    are strictly monotone; spans that start at odd offsets, a pool that ends in a partial quad.  One piece per path and several."""
+    from pollen_amd.device import DepthPlan, DeviceGraph
+    import torch
+    monkeypatch.setenv("FLATGFA_DEPTH_PATH", "bucketed")
+    for k in ("FLATGFA_SHORT_MAX", "FLATGFA_PACKED", "FLATGFA_NO_CLAIM", "FLATGFA_COUNT_PIECES"):
+        monkeypatch.delenv(k, raising=False)
+    spots = [2, 3, 4, 5, 6, 7, 8, 9, 252, 253, 254, 255, 256, 257, 258, 259, 1020, 1021, 1022, 1023, 1024, 1025, 1026, 1027, L - 3, L - 2, L - 1]
+    if L > 5000:
+        spots += [4092, 4093, 4094, 4095, 4096, 4097, 4098, 4099, 8189, 8190, 8191, 8192, 8193]
+        for pieces in (2, 3, 5, 8, 64):   # (8: what the plan takes by itself for this many paths of this length)
+            for k in (range(1, pieces) if pieces < 64 else (1, 32, 63)):
+                c = L * k // pieces
+                spots += [c - 5, c - 4, c - 3, c - 2, c - 1, c, c + 1, c + 2, c + 3, c + 4]
+    spots = sorted({q for q in spots if 2 <= q < L})
+    chunks, pb, pe = [], [], []
+    at = 0
+    P = 0
+    rng = np.random.default_rng(L)
+    def add(ids, q=0, mod=None):
+        nonlocal at, P
+        # (steps no path walks: the next span starts at an odd offset -- with `mod`, at the one that puts the path's step q there in its quad)
+        n_junk = 1 + P % 4 if mod is None else 1 + (mod - (at + 1 + q)) % 4
+        junk = rng.integers(0, 50, size=n_junk).astype(np.uint32)
+        chunks.append(junk << 1)
+        at += len(junk)
+        chunks.append((ids.astype(np.uint32) << 1) | (P & 1))
+        pb.append(at)
+        at += len(ids)
+        pe.append(at)
+        P += 1
+    S = 300_000                     # (up to 2^20 segments the plan runs the counting kernel over every path)
+    back = 0
+    for q in spots:
+        # upwards with the step back first in its quad (where a lane's, a wave's, a piece's stretch begins) and elsewhere in it; downwards
+        for down, mod in ((False, 0), (False, 1 + q % 3), (True, None)):
+            ids = np.arange(L, dtype=np.int64)
+            ids[q:] -= 2            # step q goes back to the id of step q - 2, and the walk goes on from there
+            ids += (P * 7919) % (S - L - 8)
+            add(ids[::-1] if down else ids, q, mod)
+            back += 1
+        if q % 7 == 0:              # strictly monotone neighbours (these do go without claims)
+            add(np.arange(L, dtype=np.int64) + (P * 7919) % (S - L - 8))
+            add((np.arange(L, dtype=np.int64) + (P * 7919) % (S - L - 8))[::-1])
+    steps = np.concatenate(chunks).astype(np.uint32)
+    if len(steps) % 4 == 0:         # (the pool ends in a partial quad, right behind the last path)
+        steps = steps[:-1]
+        pe[-1] -= 1
+    pb = np.array(pb, dtype=np.uint32)
+    pe = np.array(pe, dtype=np.uint32)
+    paths = np.zeros(P, dtype=fo.PATH_DT)
+    paths["steps_start"], paths["steps_end"] = pb, pe
+    pools = fo.Pools(**{n: np.zeros(0, dtype=np.uint8) for n in fo.POOL_ORDER})
+    pools.paths, pools.steps, pools.segs = paths, steps, np.zeros(S, dtype=fo.SEG_DT)
+    wd, wu = fo.seg_depth_with_uniq(pools)
+    assert back <= int((wd.astype(np.int64) - wu.astype(np.int64)).sum()) <= 2 * back   # (a path with a step back meets one or two segments twice)
+    graph = DeviceGraph(steps, pb, pe, S)
+    for pieces in (None, "1", "2", "3", "5", "64"):
+        if pieces is None:
+            monkeypatch.delenv("FLATGFA_COUNT_PIECES", raising=False)
+        else:
+            monkeypatch.setenv("FLATGFA_COUNT_PIECES", pieces)
+        d = torch.full((S,), -3, dtype=torch.int32, device="cuda:0")
+        u = torch.full((S,), -3, dtype=torch.int32, device="cuda:0")
+        plan = DepthPlan(graph, first=(d, u))
+        desc = plan.describe()
+        bad = np.flatnonzero(u.cpu().numpy().view(np.uint32) != wu)
+        assert (d.cpu().numpy().view(np.uint32) == wd).all() and len(bad) == 0, (pieces, bad[:8], desc)
+        assert "no_claim_items=0" not in desc or "no_claim_paths=0" not in desc, desc   # (the monotone neighbours were found)
+        plan.seg_depth(d, u)
+        plan.status()
+        assert (d.cpu().numpy().view(np.uint32) == wd).all() and (u.cpu().numpy().view(np.uint32) == wu).all(), (pieces, desc)
+        plan.close()
