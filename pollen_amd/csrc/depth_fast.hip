@@ -456,7 +456,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         // (few long paths: several pieces each, so that the kernel fills the chip -- the pieces add to cleared words)
         uint32_t pieces = 1;
         if (want_ext && np < fp->n_cus * 8u && g.n_steps / np >= (1u << 16)) pieces = std::min<uint32_t>((fp->n_cus * 8u + (uint32_t)np - 1u) / (uint32_t)np, 4096u);
-        if (const char *forced = test_hook("FLATGFA_COUNT_PIECES")) pieces = want_ext ? std::max(1, atoi(forced)) : 1u;
+        if (const char *forced = test_hook("FLATGFA_COUNT_PIECES")) pieces = want_ext ? (uint32_t)std::min(std::max(1, atoi(forced)), 4096) : 1u;
         if (pieces > 1) {
             e = hipMemsetAsync(d_runs, 0, n_out * np * 4, nullptr);
             if (e != hipSuccess) {
