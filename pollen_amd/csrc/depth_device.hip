@@ -339,12 +339,13 @@ static int device_cus(int device) {
 namespace fgfa_dev {
 int device_cu_count(int device) { return device_cus(device); }
 void plan_tick(const char *what) {
-    static const bool on = getenv("FLATGFA_TIMING") != nullptr;
-    if (!on) return;
+    static const char *const mode = getenv("FLATGFA_TIMING");  // (=host: the host's clock alone, the device not drained behind a stage)
+    if (!mode) return;
+    static const bool drain = std::string(mode) != "host";
     static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
     if (what) {
         const auto before = std::chrono::steady_clock::now();
-        (void)hipDeviceSynchronize();
+        if (drain) (void)hipDeviceSynchronize();
         const auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "plan: %-52s %8.3f ms (+ %.3f ms for the device to drain)\n", what, std::chrono::duration<double, std::milli>(before - last).count(),
                 std::chrono::duration<double, std::milli>(now - before).count());
