@@ -21,6 +21,7 @@
 
 #include "../../include/flatgfa.h"
 #include "depth_fast.hpp"
+#include "temp_arena.hpp"
 #include "device_common.hpp"
 #include "prof.hpp"
 
@@ -354,6 +355,71 @@ void plan_tick(const char *what) {
 }
 }
 
+namespace fgfa_dev {
+hipError_t plan_memcpy(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    constexpr size_t kChunk = (size_t)4 << 20;
+    if (bytes < ((size_t)4 << 20) || (kind != hipMemcpyHostToDevice && kind != hipMemcpyDeviceToHost)) return hipMemcpy(dst, src, bytes, kind);
+    // two pinned halves per process (portable: any device), two events per device; a plan's creation is not a place where threads
+    // race for them, so one lock around the whole copy
+    static std::mutex mu;
+    static char *pinned = nullptr;
+    static hipEvent_t ev[64][2] = {};
+    std::lock_guard<std::mutex> lk(mu);
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    if (device < 0 || device >= 64) return hipMemcpy(dst, src, bytes, kind);
+    if (!pinned && hipHostMalloc((void **)&pinned, 2 * kChunk, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        pinned = nullptr;
+        return hipMemcpy(dst, src, bytes, kind);
+    }
+    for (int k = 0; k < 2; ++k)
+        if (!ev[device][k] && (e = hipEventCreateWithFlags(&ev[device][k], hipEventDisableTiming)) != hipSuccess) return e;
+    const bool up = kind == hipMemcpyHostToDevice;
+    // (a chunk travels for a tenth of a millisecond: polled, not slept on)
+    const auto wait = [](hipEvent_t x) -> hipError_t {
+        hipError_t q;
+        while ((q = hipEventQuery(x)) == hipErrorNotReady) {}
+        (void)hipGetLastError();  // ("not ready" must not be what a later check of the launches finds)
+        return q;
+    };
+    size_t off = 0, prev_off = 0, prev_n = 0;
+    int k = 0;
+    bool busy[2] = {false, false};
+    while (off < bytes || prev_n) {
+        const size_t n = std::min(kChunk, bytes - off);
+        char *half = pinned + (size_t)k * kChunk;
+        if (n) {
+            if (busy[k]) {  // (its last transfer must be over before the half is written again)
+                if ((e = wait(ev[device][k])) != hipSuccess) return e;
+                busy[k] = false;
+            }
+            if (up) {
+                memcpy(half, (const char *)src + off, n);
+                if ((e = hipMemcpyAsync((char *)dst + off, half, n, hipMemcpyHostToDevice, nullptr)) != hipSuccess) return e;
+            } else {
+                if ((e = hipMemcpyAsync(half, (const char *)src + off, n, hipMemcpyDeviceToHost, nullptr)) != hipSuccess) return e;
+            }
+            if ((e = hipEventRecord(ev[device][k], nullptr)) != hipSuccess) return e;
+            busy[k] = true;
+        }
+        if (!up && prev_n) {  // the chunk before this one has arrived in the other half: hand it on while this one travels
+            if ((e = wait(ev[device][k ^ 1])) != hipSuccess) return e;
+            busy[k ^ 1] = false;
+            memcpy((char *)dst + prev_off, pinned + (size_t)(k ^ 1) * kChunk, prev_n);
+        }
+        prev_off = off;
+        prev_n = up ? 0 : n;
+        off += n;
+        k ^= 1;
+    }
+    for (int h = 0; h < 2; ++h)
+        if (busy[h] && (e = wait(ev[device][h])) != hipSuccess) return e;
+    return hipSuccess;
+}
+}  // namespace fgfa_dev
+
 static void release_cache_claim(flatgfa_dev_plan_t *pl) {
     if (!pl->cache_claim) return;
     std::lock_guard<std::mutex> lk(g_cache_mu);
@@ -541,6 +607,11 @@ static bool plan_build_fast(flatgfa_dev_plan_t *pl, uint32_t *first_depth, uint3
             add(pl->fast);
             for (uint32_t r = 0; r < pl->fast.n_more; ++r) add(pl->fast.more[r]);
             if (even_bytes <= (2ull << 30)) break;
+            // (a plan that cannot have packed buckets -- paths that single waves walk, pass 1 by partition -- is not made again to find
+            // that out: a million tiny paths paid 12 ms of their 25 for it)
+            bool could = pl->fast.can_pack;
+            for (uint32_t r = 0; r < pl->fast.n_more; ++r) could = could && pl->fast.more[r].can_pack;
+            if (!could) break;
             FastPlan again;
             if (!fast_plan_create(pl->g, hb, he, &again, scan_workgroups, true)) { if (tmp) (void)hipFree(tmp); return false; }
             bool all_packed = again.eligible && again.packed;
@@ -720,16 +791,17 @@ static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const 
                                             uint32_t *first_depth, uint32_t *first_uniq, int *first_status) {
     if (first_status) *first_status = FLATGFA_OK;
     if (!g) { set_error("plan_create: NULL graph"); return nullptr; }
-    std::vector<uint32_t> cb, ce;
+    fgfa_dev::TempScope temporaries;  // (the large vectors of a plan's creation come from blocks the thread keeps: temp_arena.hpp)
+    fgfa_dev::Vec<uint32_t> cb, ce;
     if (g->n_paths && (!hb || !he)) {
         cb.resize(g->n_paths);
         ce.resize(g->n_paths);
-        HIP_TRY(hipMemcpy(cb.data(), g->path_begin, (size_t)g->n_paths * 4, hipMemcpyDeviceToHost), return nullptr);
-        HIP_TRY(hipMemcpy(ce.data(), g->path_end, (size_t)g->n_paths * 4, hipMemcpyDeviceToHost), return nullptr);
+        HIP_TRY(fgfa_dev::plan_memcpy(cb.data(), g->path_begin, (size_t)g->n_paths * 4, hipMemcpyDeviceToHost), return nullptr);
+        HIP_TRY(fgfa_dev::plan_memcpy(ce.data(), g->path_end, (size_t)g->n_paths * 4, hipMemcpyDeviceToHost), return nullptr);
         hb = cb.data();
         he = ce.data();
     }
-    std::vector<WorkItem> items;
+    fgfa_dev::Vec<WorkItem> items;
     for (uint32_t p = 0; p < g->n_paths; ++p) {
         if (hb[p] > he[p] || (uint64_t)he[p] > g->n_steps) {
             set_error("plan_create: path " + std::to_string(p) + " has a step span outside the steps pool");
@@ -753,7 +825,7 @@ static flatgfa_dev_plan_t *plan_create_impl(const flatgfa_dev_graph_t *g, const 
     HIP_TRY(hipMemset(pl->status, 0, 256), { flatgfa_dev_plan_destroy(pl); return nullptr; });
     if (!items.empty()) {
         HIP_TRY(hipMalloc(&pl->items, items.size() * sizeof(WorkItem)), { flatgfa_dev_plan_destroy(pl); return nullptr; });
-        HIP_TRY(hipMemcpy(pl->items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice),
+        HIP_TRY(fgfa_dev::plan_memcpy(pl->items, items.data(), items.size() * sizeof(WorkItem), hipMemcpyHostToDevice),
                 { flatgfa_dev_plan_destroy(pl); return nullptr; });
     }
     {   // (per device, like the other kernels' attributes)
@@ -938,7 +1010,7 @@ static int path_depth_all_enqueue(flatgfa_dev_plan_t *pl, uint32_t *depth_out, u
         std::vector<uint32_t> ids(g.n_paths);
         for (uint32_t i = 0; i < g.n_paths; ++i) ids[i] = i;
         HIP_TRY(hipMalloc(&pl->all_ids, (size_t)g.n_paths * 4), return FLATGFA_ERR_HIP);
-        HIP_TRY(hipMemcpy(pl->all_ids, ids.data(), (size_t)g.n_paths * 4, hipMemcpyHostToDevice), return FLATGFA_ERR_HIP);
+        HIP_TRY(fgfa_dev::plan_memcpy(pl->all_ids, ids.data(), (size_t)g.n_paths * 4, hipMemcpyHostToDevice), return FLATGFA_ERR_HIP);
     }
     return path_sums_launch(pl, pl->all_ids, g.n_paths, depth_out, length_out, weighted_out, 1u, stream);
 }

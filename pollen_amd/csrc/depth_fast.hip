@@ -52,6 +52,7 @@
 #include <vector>
 
 #include "depth_fast_kernels.hpp"
+#include "temp_arena.hpp"
 #include "prof.hpp"
 
 namespace fgfa_dev {
@@ -64,9 +65,66 @@ namespace {
 // their predecessor upwards (id + 1), downwards (id - 1), the first id, the last id} -- so that a plan none of whose paths is cut
 // needs neither of those kernels (one read of the steps instead of two on the way to the first answer).
 // A workgroup takes one PIECE of a path at a time (gridDim.y pieces per path: a graph of four chromosome-long paths fills the
-// chip like one of a thousand): 16 bytes a lane and four loads in flight, the counts as population counts of wave-wide
-// predicates.  With one piece per path the workgroup writes the path's words; with more, every piece ADDS its counts to words
+// chip like one of a thousand) -- or, where its next four paths are short, each of its waves one of them: 16 bytes a lane and
+// four loads in flight, the counts as population counts of wave-wide predicates.  With one piece per path the workgroup writes the path's words; with more, every piece ADDS its counts to words
 // the host has cleared (integer adds: any order), piece 0 writes the two ids, and `mono` is the host's to derive from `ext`.
+// (the six counts of one wave over steps [lo, hi) of the path [b, e): the same in every lane)
+struct RunCounts {
+    uint32_t run = 0, down = 0, asc = 0, desc = 0, up = 0, dn = 0;
+};
+// A wave walks the groups of 256 steps first, first + outer, ... of [lo, hi), four of them (inner apart) at a time: lane l holds steps
+// g0 + 4 l .. + 3 of a group, 16 bytes, four loads in flight.  All of the wave's lanes come here together (the loop is wave-uniform).
+__device__ __forceinline__ void count_steps(const uint32_t *__restrict__ steps, uint64_t n_steps, uint64_t b, uint64_t lo, uint64_t hi, uint32_t lane,
+                                            uint64_t first, uint32_t inner, uint32_t outer, RunCounts &c) {
+    // one group: `prev` = the step before the lane's first
+    const auto count = [&](uint64_t g0, const uint4 &v, bool interior) {
+        const uint32_t s[4] = {v.x, v.y, v.z, v.w};
+        uint32_t prev = (uint32_t)__shfl_up((int)v.w, 1, 64);
+        if (lane == 0) prev = g0 > b ? steps[g0 - 1] : 0u;
+        const uint64_t i0 = g0 + 4u * lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t i = i0 + (uint64_t)j;
+            const uint32_t id = s[j] >> 1, before = (j ? s[j - 1] : prev) >> 1;
+            const bool valid = interior || (i >= lo && i < hi), first_step = !interior && i == b;
+            const bool follows_up = id == before + 1u, follows_down = id + 1u == before;
+            c.run += (uint32_t)__popcll(__ballot(valid && (first_step || !follows_up || (id & 31u) == 0u)));
+            c.down += (uint32_t)__popcll(__ballot(valid && (first_step || !follows_down || (before & 31u) == 0u)));
+            c.asc += (uint32_t)__popcll(__ballot(valid && !first_step && id > before));
+            c.desc += (uint32_t)__popcll(__ballot(valid && !first_step && id < before));
+            c.up += (uint32_t)__popcll(__ballot(valid && !first_step && follows_up));
+            c.dn += (uint32_t)__popcll(__ballot(valid && !first_step && follows_down));
+        }
+    };
+    const auto load = [&](uint64_t g0) -> uint4 {
+        const uint64_t i0 = g0 + 4u * lane;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (i0 < hi) {
+            if (i0 + 4u <= n_steps) {
+                v = *reinterpret_cast<const uint4 *>(steps + i0);
+            } else {  // (the pool's last, partial quad)
+                v.x = steps[i0];
+                if (i0 + 1u < n_steps) v.y = steps[i0 + 1u];
+                if (i0 + 2u < n_steps) v.z = steps[i0 + 2u];
+            }
+        }
+        return v;
+    };
+    for (uint64_t g = first; g < hi; g += outer) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = g + (uint64_t)inner * k < hi ? load(g + (uint64_t)inner * k) : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t g0 = g + (uint64_t)inner * k;
+            if (g0 < hi) {
+                if (g0 > lo && g0 > b && g0 + 256u <= hi) count(g0, v[k], true);
+                else count(g0, v[k], false);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__ steps, const uint32_t *__restrict__ pb,
                                                      const uint32_t *__restrict__ pe, uint32_t n_paths, uint64_t n_steps,
                                                      uint32_t *__restrict__ runs, uint32_t *__restrict__ runs_down, uint32_t *__restrict__ mono,
@@ -74,7 +132,40 @@ __global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__
     __shared__ uint32_t tot[6];  // runs, runs read backwards, ascents, descents, +1 steps, -1 steps
     const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t pieces = gridDim.y, piece = blockIdx.y;
-    for (uint32_t p = blockIdx.x; p < n_paths; p += gridDim.x) {
+    constexpr uint32_t kWavePath = 2048;  // steps: the workgroup's next four paths that short, and each of its waves takes one by itself
+    uint32_t p = blockIdx.x;
+    while (p < n_paths) {
+        // (the same answer in every thread of the workgroup: the two ways must not mix, one of them has barriers)
+        bool each_its_own = pieces == 1;
+        for (uint32_t k = 0; k < 4 && each_its_own; ++k) {
+            const uint32_t q = p + k * gridDim.x;
+            if (q < n_paths) each_its_own = pe[q] - pb[q] <= kWavePath;
+        }
+        if (each_its_own) {  // a million paths of a hundred steps: no barrier, no LDS, four paths at a time (4.1 -> 0.4 ms)
+            const uint32_t q = p + wave * gridDim.x;
+            if (q < n_paths) {
+                const uint64_t b = pb[q], e = pe[q];
+                RunCounts c;
+                count_steps(steps, n_steps, b, b, e, lane, b & ~3ull, 256u, 1024u, c);
+                if (lane == 0) {
+                    runs[q] = c.run;
+                    runs_down[q] = c.down;
+                    const uint32_t pairs = e > b ? (uint32_t)(e - b - 1) : 0u;
+                    mono[q] = (e > b && (c.asc == pairs || c.desc == pairs)) ? 1u : 0u;
+                    if (ext) {
+                        uint32_t *x = ext + 6 * (size_t)q;
+                        x[0] = c.asc;
+                        x[1] = c.desc;
+                        x[2] = c.up;
+                        x[3] = c.dn;
+                        x[4] = e > b ? steps[b] >> 1 : 0u;
+                        x[5] = e > b ? steps[e - 1] >> 1 : 0u;
+                    }
+                }
+            }
+            p += 4 * gridDim.x;
+            continue;
+        }
         if (threadIdx.x < 6) tot[threadIdx.x] = 0;
         __syncthreads();
         const uint64_t b = pb[p], e = pe[p];
@@ -87,62 +178,16 @@ __global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__
             lo = lo < b ? b : lo;
             hi = hi < lo ? lo : hi;
         }
-        uint32_t n_run = 0, n_down = 0, n_asc = 0, n_desc = 0, n_up = 0, n_dn = 0;  // (the same in every lane of a wave)
-        // one group of 256 steps: lane l holds steps g0 + 4 l .. + 3 in `v`, `prev` = the step before its first
-        const auto count = [&](uint64_t g0, const uint4 &v, bool interior) {
-            const uint32_t s[4] = {v.x, v.y, v.z, v.w};
-            uint32_t prev = (uint32_t)__shfl_up((int)v.w, 1, 64);
-            if (lane == 0) prev = g0 > b ? steps[g0 - 1] : 0u;
-            const uint64_t i0 = g0 + 4u * lane;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint64_t i = i0 + (uint64_t)j;
-                const uint32_t id = s[j] >> 1, before = (j ? s[j - 1] : prev) >> 1;
-                const bool valid = interior || (i >= lo && i < hi), first = !interior && i == b;
-                const bool follows_up = id == before + 1u, follows_down = id + 1u == before;
-                n_run += (uint32_t)__popcll(__ballot(valid && (first || !follows_up || (id & 31u) == 0u)));
-                n_down += (uint32_t)__popcll(__ballot(valid && (first || !follows_down || (before & 31u) == 0u)));
-                n_asc += (uint32_t)__popcll(__ballot(valid && !first && id > before));
-                n_desc += (uint32_t)__popcll(__ballot(valid && !first && id < before));
-                n_up += (uint32_t)__popcll(__ballot(valid && !first && follows_up));
-                n_dn += (uint32_t)__popcll(__ballot(valid && !first && follows_down));
-            }
-        };
-        const auto load = [&](uint64_t g0) -> uint4 {
-            const uint64_t i0 = g0 + 4u * lane;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (i0 < hi) {
-                if (i0 + 4u <= n_steps) {
-                    v = *reinterpret_cast<const uint4 *>(steps + i0);
-                } else {  // (the pool's last, partial quad)
-                    v.x = steps[i0];
-                    if (i0 + 1u < n_steps) v.y = steps[i0 + 1u];
-                    if (i0 + 2u < n_steps) v.z = steps[i0 + 2u];
-                }
-            }
-            return v;
-        };
-        // a wave takes every fourth group of 256 steps, four of its groups at a time (wave-uniform loop)
-        for (uint64_t g = (lo & ~3ull) + 256ull * wave; g < hi; g += 4096u) {
-            uint4 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = g + 1024u * k < hi ? load(g + 1024u * k) : make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint64_t g0 = g + 1024u * k;
-                if (g0 < hi) {
-                    if (g0 > lo && g0 > b && g0 + 256u <= hi) count(g0, v[k], true);
-                    else count(g0, v[k], false);
-                }
-            }
-        }
+        // a wave takes every fourth group of 256 steps, four of its groups at a time
+        RunCounts c;
+        count_steps(steps, n_steps, b, lo, hi, lane, (lo & ~3ull) + 256ull * wave, 1024u, 4096u, c);
         if (lane == 0) {
-            atomicAdd(&tot[0], n_run);
-            atomicAdd(&tot[1], n_down);
-            atomicAdd(&tot[2], n_asc);
-            atomicAdd(&tot[3], n_desc);
-            atomicAdd(&tot[4], n_up);
-            atomicAdd(&tot[5], n_dn);
+            atomicAdd(&tot[0], c.run);
+            atomicAdd(&tot[1], c.down);
+            atomicAdd(&tot[2], c.asc);
+            atomicAdd(&tot[3], c.desc);
+            atomicAdd(&tot[4], c.up);
+            atomicAdd(&tot[5], c.dn);
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -172,6 +217,7 @@ __global__ __launch_bounds__(256) void k_count_runs(const uint32_t *__restrict__
             }
         }
         __syncthreads();
+        p += gridDim.x;
     }
 }
 
@@ -436,7 +482,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // Which kernel walks a path depends on how many runs it has: short paths must fit the run queue,
     // paths with at most kMediumRuns runs are walked wave by wave too, by pairs of waves that share a
     // bigger hash set (k_scan_short's medium variant).  The counts come from a one-off kernel.
-    std::vector<uint32_t> runs, runs_down, mono, ext;  // (ext: six facts per path, see k_count_runs; for up to 2^18 paths)
+    Vec<uint32_t> runs, runs_down, mono, ext;  // (ext: six facts per path, see k_count_runs; for up to 2^18 paths)
     if (short_max) {
         // (counted over the spans this plan walks -- a plan may be given others than the graph's own)
         uint32_t *d_runs = nullptr;
@@ -445,10 +491,10 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         // (device layout: [runs | runs_down | mono | ext x 6 | begin | end], np words each: one copy in, one copy out)
         const size_t n_out = want_ext ? 9 : 3;
         FAST_TRY(hipMalloc(&d_runs, np * (n_out + 2) * 4));
-        std::vector<uint32_t> spans(2 * np);
+        Vec<uint32_t> spans(2 * np);
         std::copy(hb, hb + np, spans.begin());
         std::copy(he, he + np, spans.begin() + (ptrdiff_t)np);
-        hipError_t e = hipMemcpy(d_runs + n_out * np, spans.data(), np * 8, hipMemcpyHostToDevice);
+        hipError_t e = plan_memcpy(d_runs + n_out * np, spans.data(), np * 8, hipMemcpyHostToDevice);
         if (e != hipSuccess) {
             (void)hipFree(d_runs);
             FAST_TRY(e);
@@ -467,8 +513,8 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         hipLaunchKernelGGL(k_count_runs, dim3(std::min<uint32_t>(g.n_paths, fp->n_cus * 8u), pieces), dim3(256), 0, nullptr, g.steps,
                            d_runs + n_out * np, d_runs + (n_out + 1) * np, g.n_paths, g.n_steps, d_runs, d_runs + np, d_runs + 2 * np,
                            want_ext ? d_runs + 3 * np : nullptr);
-        std::vector<uint32_t> out(n_out * np);
-        e = hipMemcpy(out.data(), d_runs, n_out * np * 4, hipMemcpyDeviceToHost);
+        Vec<uint32_t> out(n_out * np);
+        e = plan_memcpy(out.data(), d_runs, n_out * np * 4, hipMemcpyDeviceToHost);
         (void)hipFree(d_runs);
         FAST_TRY(e);
         runs.assign(out.begin(), out.begin() + (ptrdiff_t)np);
@@ -492,8 +538,8 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // path's steps does not matter to the counts: such a path is walked from a reversed copy of its
     // steps, made here once (rev_steps; every copy starts at a multiple of 16).
     // (the *_mono lists: paths that walk the ids strictly one way -- the wave-per-path kernels skip their claims)
-    std::vector<uint4> items, short_items, medium_items, short_rev, medium_rev, whole, rev_list, tiny_items;
-    std::vector<uint4> short_mono, medium_mono, short_rev_mono, medium_rev_mono, tiny_mono;
+    Vec<uint4> items, short_items, medium_items, short_rev, medium_rev, whole, rev_list, tiny_items;
+    Vec<uint4> short_mono, medium_mono, short_rev_mono, medium_rev_mono, tiny_mono;
     const bool no_tiny = test_hook("FLATGFA_NO_TINY") != nullptr;  // (measurements, tests: tiny paths go to k_scan_short as before)
     uint64_t rev_len = 0;
     for (uint32_t p = 0; p < g.n_paths; ++p) {
@@ -527,26 +573,26 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // sub-bucket then holds one path's records of its window, not those of the five or six that
     // chance gave one workgroup (the capacity every sub-bucket gets is the fullest one's, §2).
     if (whole.size() > 1 && !measure_switch("FLATGFA_KEEP_PATH_ORDER")) {
-        std::vector<uint32_t> at(whole.size()), first(whole.size(), 0u);
+        Vec<uint32_t> at(whole.size()), first(whole.size(), 0u);
         if (!ext.empty()) {  // (the counting kernel looked already)
             for (size_t i = 0; i < whole.size(); ++i) first[i] = ext[6 * (size_t)whole[i].w + 4];
         } else {
         for (size_t i = 0; i < whole.size(); ++i) at[i] = whole[i].x;
         uint32_t *d_at = nullptr;
         FAST_TRY(hipMalloc(&d_at, whole.size() * 8));
-        hipError_t e = hipMemcpy(d_at, at.data(), whole.size() * 4, hipMemcpyHostToDevice);
+        hipError_t e = plan_memcpy(d_at, at.data(), whole.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_first_ids, dim3((uint32_t)((whole.size() + 255) / 256)), dim3(256), 0, nullptr, g.steps, d_at, (uint32_t)whole.size(),
                                d_at + whole.size());
-            e = hipMemcpy(first.data(), d_at + whole.size(), whole.size() * 4, hipMemcpyDeviceToHost);
+            e = plan_memcpy(first.data(), d_at + whole.size(), whole.size() * 4, hipMemcpyDeviceToHost);
         }
         (void)hipFree(d_at);
         FAST_TRY(e);
         }
-        std::vector<uint32_t> order(whole.size());
+        Vec<uint32_t> order(whole.size());
         std::iota(order.begin(), order.end(), 0u);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return first[a] < first[b]; });
-        std::vector<uint4> sorted(whole.size());
+        Vec<uint4> sorted(whole.size());
         for (size_t i = 0; i < whole.size(); ++i) sorted[i] = whole[order[i]];
         whole.swap(sorted);
     }
@@ -557,7 +603,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         FAST_TRY(hipMemset(fp->rev_steps, 0, (size_t)fp->n_rev_steps * 4));
         uint4 *d_list = nullptr;
         FAST_TRY(hipMalloc(&d_list, rev_list.size() * sizeof(uint4)));
-        hipError_t e = hipMemcpy(d_list, rev_list.data(), rev_list.size() * sizeof(uint4), hipMemcpyHostToDevice);
+        hipError_t e = plan_memcpy(d_list, rev_list.data(), rev_list.size() * sizeof(uint4), hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_reverse_copy, dim3(std::min<uint32_t>((uint32_t)rev_list.size(), fp->n_cus * 8u)), dim3(256), 0, nullptr,
                                g.steps, d_list, (uint32_t)rev_list.size(), fp->rev_steps);
@@ -575,7 +621,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // (the largest such size: for 1000 paths of 100 k steps, no cutting at all).
     // (z: bit 0 = the item walks the ids downwards, set by k_item_dirs; from bit 1 up, 1 + the
     // ordinal of the split path the item is a piece of, or 0 for a whole path)
-    const auto cut = [&](uint64_t piece, std::vector<uint4> *out) -> uint32_t {
+    const auto cut = [&](uint64_t piece, Vec<uint4> *out) -> uint32_t {
         uint32_t n_split = 0;
         for (const uint4 &w : whole) {
             const uint64_t b = w.x, n = (uint64_t)w.y - w.x;
@@ -598,10 +644,10 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         for (const uint32_t twice_m : {4u, 5u, 6u, 8u, 10u, 12u, 16u, 20u, 24u}) {  // pieces of N / (m CUs), m = 2 .. 12
             uint64_t cand = std::max<uint64_t>(32768, (2 * long_steps + (uint64_t)twice_m * fp->n_slots - 1) / ((uint64_t)twice_m * fp->n_slots));
             cand = (cand + 255) & ~255ull;
-            std::vector<uint4> trial;
+            Vec<uint4> trial;
             cut(cand, &trial);
             std::stable_sort(trial.begin(), trial.end(), longer);
-            std::vector<uint64_t> hand(fp->n_slots, 0);
+            Vec<uint64_t> hand(fp->n_slots, 0);
             for (size_t i = 0; i < trial.size(); ++i) {
                 const size_t round = i / fp->n_slots, pos = i % fp->n_slots;
                 hand[(round & 1) ? fp->n_slots - 1 - pos : pos] += (uint64_t)(trial[i].y - trial[i].x) + kTurnaround;
@@ -620,13 +666,13 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         // items longest first as they get to them, and if whole paths dealt that way (to the least
         // loaded workgroup each) leave the longest hand within a tenth of the best cut's, they stay whole.
         if (piece && !measure_switch("FLATGFA_KEEP_CUTS")) {
-            std::vector<uint4> trial;
+            Vec<uint4> trial;
             const uint32_t n_split = cut(piece, &trial);
             if (n_split > (wb <= 12 ? kMaxShared : 0u)) {
-                std::vector<uint64_t> lens;
+                Vec<uint64_t> lens;
                 for (const uint4 &w : whole) lens.push_back((uint64_t)w.y - w.x);
                 std::sort(lens.begin(), lens.end(), std::greater<uint64_t>());
-                std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> hands;
+                std::priority_queue<uint64_t, Vec<uint64_t>, std::greater<uint64_t>> hands;
                 for (uint32_t i = 0; i < fp->n_slots; ++i) hands.push(0);
                 uint64_t longest = 0;
                 for (const uint64_t n : lens) {
@@ -645,13 +691,13 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // A wave-per-path list: the paths read from the graph's steps, then those read from their reversed copies; of
     // either kind the ones that need no claim lie next to the boundary, so that one stretch of the list names them
     // all: [claim][no claim | no claim, reversed][claim, reversed], each part longest first.
-    const auto lay_out = [&](std::vector<uint4> *fwd, std::vector<uint4> *fwd_mono, std::vector<uint4> *rev_mono, std::vector<uint4> *rev,
+    const auto lay_out = [&](Vec<uint4> *fwd, Vec<uint4> *fwd_mono, Vec<uint4> *rev_mono, Vec<uint4> *rev,
                              uint32_t *n_rev, uint32_t *mono_lo, uint32_t *mono_n) {
-        for (std::vector<uint4> *v : {fwd, fwd_mono, rev_mono, rev}) std::stable_sort(v->begin(), v->end(), longer);
+        for (Vec<uint4> *v : {fwd, fwd_mono, rev_mono, rev}) std::stable_sort(v->begin(), v->end(), longer);
         *mono_lo = (uint32_t)fwd->size();
         *mono_n = (uint32_t)(fwd_mono->size() + rev_mono->size());
         *n_rev = (uint32_t)(rev_mono->size() + rev->size());
-        for (std::vector<uint4> *v : {fwd_mono, rev_mono, rev}) fwd->insert(fwd->end(), v->begin(), v->end());
+        for (Vec<uint4> *v : {fwd_mono, rev_mono, rev}) fwd->insert(fwd->end(), v->begin(), v->end());
     };
     lay_out(&short_items, &short_mono, &short_rev_mono, &short_rev, &fp->n_short_rev, &fp->short_mono_lo, &fp->short_mono_n);
     lay_out(&medium_items, &medium_mono, &medium_rev_mono, &medium_rev, &fp->n_medium_rev, &fp->medium_mono_lo, &fp->medium_mono_n);
@@ -663,7 +709,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     fp->n_medium = (uint32_t)medium_items.size();
     fp->n_tiny = (uint32_t)tiny_items.size();
     {
-        const auto steps_of = [](const std::vector<uint4> &v) {
+        const auto steps_of = [](const Vec<uint4> &v) {
             uint64_t n = 0;
             for (const uint4 &d : v) n += d.y - d.x;
             return n;
@@ -710,8 +756,8 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         uint64_t most = per_wg;
         if (taggable && grid && per_wg <= limit && fp->n_items + fp->max_back > 2ull * grid && !test_hook("FLATGFA_TAG_MEAN_ONLY")) {
             constexpr uint64_t kTurn = 2048;  // steps' worth an item costs beyond its steps
-            std::priority_queue<std::pair<uint64_t, uint32_t>, std::vector<std::pair<uint64_t, uint32_t>>, std::greater<std::pair<uint64_t, uint32_t>>> hands;
-            std::vector<uint32_t> taken(grid, 0u);
+            std::priority_queue<std::pair<uint64_t, uint32_t>, Vec<std::pair<uint64_t, uint32_t>>, std::greater<std::pair<uint64_t, uint32_t>>> hands;
+            Vec<uint32_t> taken(grid, 0u);
             for (uint32_t i = 0; i < grid; ++i) {
                 uint64_t h = 0;
                 for (uint32_t k = 0; k < 2; ++k)
@@ -745,9 +791,9 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     // each of its waves a contiguous stretch of the list: paths are dealt to the waves longest
     // first, each to the wave with the least steps so far.
     {
-        std::vector<std::vector<uint32_t>> by_path;  // item indices per path that has items
-        std::vector<uint64_t> path_steps;
-        std::vector<int64_t> slot_of(g.n_paths, -1);
+        Vec<Vec<uint32_t>> by_path;  // item indices per path that has items
+        Vec<uint64_t> path_steps;
+        Vec<int64_t> slot_of(g.n_paths, -1);
         for (uint32_t j = 0; j < fp->n_items; ++j) {
             const uint32_t p = items[j].w;
             if (slot_of[p] < 0) {
@@ -758,7 +804,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             by_path[(size_t)slot_of[p]].push_back(j);
             path_steps[(size_t)slot_of[p]] += items[j].y - items[j].x;
         }
-        std::vector<uint32_t> order(by_path.size());
+        Vec<uint32_t> order(by_path.size());
         std::iota(order.begin(), order.end(), 0u);
         std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return path_steps[a] > path_steps[b]; });
         // A path with more than half a wave's even share of the steps would hold its wave up (four
@@ -768,8 +814,8 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         uint64_t total_steps = 0;
         for (uint64_t v : path_steps) total_steps += v;
         const uint64_t fat_min = total_steps / (2ull * acc_waves) + 1;
-        std::vector<std::vector<uint32_t>> per_wave(acc_waves), fat_of_part(fp->acc_parts);
-        std::vector<uint64_t> load(acc_waves, 0), part_load(fp->acc_parts, 0);
+        Vec<Vec<uint32_t>> per_wave(acc_waves), fat_of_part(fp->acc_parts);
+        Vec<uint64_t> load(acc_waves, 0), part_load(fp->acc_parts, 0);
         for (uint32_t gi : order) {
             if (path_steps[gi] < fat_min || by_path[gi].size() < kAccWaves / 2 || measure_switch("FLATGFA_NO_FAT_PATHS")) continue;  // (fewer pieces than half the waves: better one wave busy all the time than three)
             const uint32_t q = (uint32_t)(std::min_element(part_load.begin(), part_load.end()) - part_load.begin());
@@ -791,17 +837,17 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
                 first = false;
             }
         }
-        std::vector<uint32_t> elist, wave_off(acc_waves + 1, 0);
+        Vec<uint32_t> elist, wave_off(acc_waves + 1, 0);
         for (uint32_t wv = 0; wv < acc_waves; ++wv) {
             wave_off[wv] = (uint32_t)elist.size();
             elist.insert(elist.end(), per_wave[wv].begin(), per_wave[wv].end());
         }
         wave_off[acc_waves] = (uint32_t)elist.size();
-        std::vector<uint32_t> fat_off(fp->acc_parts + 1, 0), fat_woff;
+        Vec<uint32_t> fat_off(fp->acc_parts + 1, 0), fat_woff;
         for (uint32_t q = 0; q < fp->acc_parts; ++q) {
             fat_off[q] = fp->n_fat;
             for (uint32_t gi : fat_of_part[q]) {
-                const std::vector<uint32_t> &its = by_path[gi];
+                const Vec<uint32_t> &its = by_path[gi];
                 for (uint32_t wv = 0; wv < kAccWaves; ++wv) {
                     fat_woff.push_back((uint32_t)elist.size());
                     bool first = true;
@@ -816,21 +862,21 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         }
         fat_off[fp->acc_parts] = fp->n_fat;
         // k_scan leaves an item's cursors and sub-bucket at the item's place in this order
-        std::vector<uint32_t> perm(fp->n_items + 1, 0);
+        Vec<uint32_t> perm(fp->n_items + 1, 0);
         for (size_t at = 0; at < elist.size(); ++at) perm[elist[at] & 0x7FFFFFFFu] = (uint32_t)at | (elist[at] & 0x80000000u);
         // (the five lists in one allocation and one copy, every one on a 256-byte boundary: an allocation and a copy each cost a
         // tenth of what the first answer costs)
         const auto padded = [](size_t words) { return (words + 63) & ~(size_t)63; };
         const size_t o_fat_off = 0, o_fat_woff = o_fat_off + padded(fat_off.size()), o_perm = o_fat_woff + padded(fat_woff.size() + 1),
                      o_elist = o_perm + padded(perm.size()), o_wave_off = o_elist + padded(elist.size() + 1), total_words = o_wave_off + padded(wave_off.size());
-        std::vector<uint32_t> slab(total_words, 0u);
+        Vec<uint32_t> slab(total_words, 0u);
         std::copy(fat_off.begin(), fat_off.end(), slab.begin() + (ptrdiff_t)o_fat_off);
         std::copy(fat_woff.begin(), fat_woff.end(), slab.begin() + (ptrdiff_t)o_fat_woff);
         std::copy(perm.begin(), perm.end(), slab.begin() + (ptrdiff_t)o_perm);
         std::copy(elist.begin(), elist.end(), slab.begin() + (ptrdiff_t)o_elist);
         std::copy(wave_off.begin(), wave_off.end(), slab.begin() + (ptrdiff_t)o_wave_off);
         FAST_TRY(hipMalloc(&fp->lists_slab, total_words * 4));
-        FAST_TRY(hipMemcpy(fp->lists_slab, slab.data(), total_words * 4, hipMemcpyHostToDevice));
+        FAST_TRY(plan_memcpy(fp->lists_slab, slab.data(), total_words * 4, hipMemcpyHostToDevice));
         fp->fat_off = fp->lists_slab + o_fat_off;
         fp->fat_woff = fp->lists_slab + o_fat_woff;
         fp->perm = fp->lists_slab + o_perm;
@@ -859,6 +905,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     const bool can_pack = fp->tagged && !fp->n_short && !fp->n_medium && !fp->n_tiny && !fp->dbg && !fp->cap_forced && n_win <= kMaxWinTagged && fp->acc_parts == 1 &&
                           scan_lds_bytes(fp->nwp, true, true) + 64 <= kLdsLimit;
     // (the even layout may take 2 GB for a graph's buckets: this plan's share when segment ranges and path groups make several of it)
+    fp->can_pack = can_pack;  // (less what is found out below: pass 1 by partition keeps the even layout)
     const uint64_t even_limit = std::max<uint64_t>(128ull << 20, (2ull << 30) / std::max(1u, siblings));
     const uint64_t even_first = (slots + fp->n_slots) * std::max<uint64_t>(cap, 4) * 4;
     bool want_packed = can_pack && even_first > even_limit;
@@ -916,7 +963,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         }
     }
     if (!items.empty()) {
-        FAST_TRY(hipMemcpy(fp->items, items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        FAST_TRY(plan_memcpy(fp->items, items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
         if (!measure_switch("FLATGFA_NO_ITEM_DIRS")) {  // (measurement builds: every item taken as running upwards)
             unsigned long long *d_runs64 = nullptr, runs64 = 0, item_steps = 0, counted[2] = {0, 0};
             // (FLATGFA_NO_CLAIM=0: every item claims, monotone or not -- tests and measurements)
@@ -934,30 +981,30 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             if (fp->n_shared && no_claim) FAST_TRY(hipMalloc(&d_mono, (size_t)fp->n_items * sizeof(uint4)));
             hipLaunchKernelGGL(k_item_dirs, dim3(std::min<uint32_t>(fp->n_items, fp->n_cus * 8u)), dim3(256), 0, nullptr, g.steps,
                                reinterpret_cast<uint4 *>(fp->items), fp->n_items, d_runs64, d_mono);
-            hipError_t e = hipMemcpy(counted, d_runs64, 16, hipMemcpyDeviceToHost);
+            hipError_t e = plan_memcpy(counted, d_runs64, 16, hipMemcpyDeviceToHost);
             runs64 = counted[0];
             (void)hipFree(d_runs64);
             // The pieces of a split path: the path never meets a segment twice when every piece runs strictly one way,
             // all of them the same way, and each piece starts beyond (below) where the piece before it ended.
-            std::vector<uint4> dev_items;
+            Vec<uint4> dev_items;
             if (e == hipSuccess && (d_mono || !no_claim)) {
                 dev_items.resize(items.size());
-                e = hipMemcpy(dev_items.data(), fp->items, items.size() * sizeof(uint4), hipMemcpyDeviceToHost);
+                e = plan_memcpy(dev_items.data(), fp->items, items.size() * sizeof(uint4), hipMemcpyDeviceToHost);
             }
             if (e == hipSuccess && !no_claim) {
                 for (uint4 &it : dev_items) it.z &= ~kItemNoClaim;
-                e = hipMemcpy(fp->items, dev_items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice);
+                e = plan_memcpy(fp->items, dev_items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice);
             } else if (e == hipSuccess && d_mono) {
-                std::vector<uint4> mono(items.size());
-                e = hipMemcpy(mono.data(), d_mono, items.size() * sizeof(uint4), hipMemcpyDeviceToHost);
+                Vec<uint4> mono(items.size());
+                e = plan_memcpy(mono.data(), d_mono, items.size() * sizeof(uint4), hipMemcpyDeviceToHost);
                 if (e == hipSuccess) {
-                    std::vector<std::vector<uint32_t>> pieces(fp->n_shared);
+                    Vec<Vec<uint32_t>> pieces(fp->n_shared);
                     for (uint32_t j = 0; j < fp->n_items; ++j) {
                         const uint32_t sh = (dev_items[j].z & ~kItemNoClaim) >> 1;
                         if (sh) pieces[sh - 1].push_back(j);
                     }
                     bool any = false;
-                    for (std::vector<uint32_t> &pc : pieces) {
+                    for (Vec<uint32_t> &pc : pieces) {
                         std::sort(pc.begin(), pc.end(), [&](uint32_t a, uint32_t b) { return dev_items[a].x < dev_items[b].x; });
                         uint32_t way = 3u;  // the ways all pieces so far can be read: 1 upwards, 2 downwards
                         for (size_t k = 0; k < pc.size() && way; ++k) {
@@ -972,7 +1019,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
                             any = true;
                         }
                     }
-                    if (any) e = hipMemcpy(fp->items, dev_items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice);
+                    if (any) e = plan_memcpy(fp->items, dev_items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice);
                 }
             }
             if (d_mono) (void)hipFree(d_mono);
@@ -980,7 +1027,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             if (no_claim) {  // how many there are (flatgfa_dev_plan_describe: no_claim_items)
                 if (dev_items.empty()) {
                     dev_items.resize(items.size());
-                    FAST_TRY(hipMemcpy(dev_items.data(), fp->items, items.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+                    FAST_TRY(plan_memcpy(dev_items.data(), fp->items, items.size() * sizeof(uint4), hipMemcpyDeviceToHost));
                 }
                 for (const uint4 &it : dev_items) fp->n_noclaim += it.z >> 31;
             }
@@ -1020,25 +1067,25 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
     }
     if (!short_items.empty()) {
         FAST_TRY(hipMalloc(&fp->short_items, short_items.size() * sizeof(uint4)));
-        FAST_TRY(hipMemcpy(fp->short_items, short_items.data(), short_items.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        FAST_TRY(plan_memcpy(fp->short_items, short_items.data(), short_items.size() * sizeof(uint4), hipMemcpyHostToDevice));
     }
     if (!medium_items.empty()) {
         FAST_TRY(hipMalloc(&fp->medium_items, medium_items.size() * sizeof(uint4)));
-        FAST_TRY(hipMemcpy(fp->medium_items, medium_items.data(), medium_items.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        FAST_TRY(plan_memcpy(fp->medium_items, medium_items.data(), medium_items.size() * sizeof(uint4), hipMemcpyHostToDevice));
     }
     if (!tiny_items.empty()) {
         FAST_TRY(hipMalloc(&fp->tiny_items, tiny_items.size() * sizeof(uint4)));
-        FAST_TRY(hipMemcpy(fp->tiny_items, tiny_items.data(), tiny_items.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        FAST_TRY(plan_memcpy(fp->tiny_items, tiny_items.data(), tiny_items.size() * sizeof(uint4), hipMemcpyHostToDevice));
     }
     {
-        std::vector<uint32_t> other;
+        Vec<uint32_t> other;
         for (const uint4 &it : short_items) other.push_back(it.w);
         for (const uint4 &it : medium_items) other.push_back(it.w);
         for (const uint4 &it : tiny_items) other.push_back(it.w);
         fp->n_other = (uint32_t)other.size();
         if (!other.empty()) {
             FAST_TRY(hipMalloc(&fp->other_ids, other.size() * 4));
-            FAST_TRY(hipMemcpy(fp->other_ids, other.data(), other.size() * 4, hipMemcpyHostToDevice));
+            FAST_TRY(plan_memcpy(fp->other_ids, other.data(), other.size() * 4, hipMemcpyHostToDevice));
         }
     }
     // (the attribute belongs to the kernel, not to the plan: set once per device by the translation unit that holds it)
@@ -1079,6 +1126,7 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         FAST_TRY(hipMalloc(&fp->pair_flag, (size_t)n_win * 4));
         FAST_TRY(hipMemset(fp->pair_flag, 0, (size_t)n_win * 4));
     }
+    if (fp->dense || fp->dense_maybe) fp->can_pack = false;
     if (want_packed && (fp->dense || fp->dense_maybe)) {  // (pass 1 by partition keeps the even layout)
         want_packed = false;
         const int rc = alloc_buckets(fp, std::max<uint64_t>(cap, 4));
@@ -1104,12 +1152,12 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         const uint32_t lds_even = fp->lds_bytes_scan;
         fp->lds_bytes_scan = scan_lds_bytes(fp->nwp, true, true);
         const int rc = run_range(*fp, g, nullptr, nullptr, d_status, nullptr, nullptr, true);
-        std::vector<uint32_t> cnt(slots);
+        Vec<uint32_t> cnt(slots);
         hipError_t e = rc == FLATGFA_OK ? hipDeviceSynchronize() : hipErrorUnknown;
-        if (e == hipSuccess) e = hipMemcpy(cnt.data(), fp->counts, slots * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = plan_memcpy(cnt.data(), fp->counts, slots * 4, hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipMemset(fp->counts, 0, slots * 4);
         uint32_t st = 0;
-        if (e == hipSuccess) e = hipMemcpy(&st, d_status, 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = plan_memcpy(&st, d_status, 4, hipMemcpyDeviceToHost);
         (void)hipFree(d_status);
         fp->eligible = false;
         FAST_TRY(e);
@@ -1120,9 +1168,9 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
         }
         plan_tick("range: packed buckets: the counting call");
         const bool countable = !(st & kStBackOverflow);  // (blocks without any runs do not fit a packed call's queues: the even layout)
-        std::vector<uint32_t> off(row * fp->n_slots);
-        std::vector<uint64_t> base(fp->n_slots);
-        std::vector<uint2> pk(slots);
+        Vec<uint32_t> off(row * fp->n_slots);
+        Vec<uint64_t> base(fp->n_slots);
+        Vec<uint2> pk(slots);
         uint64_t total = 0, deepest = 0;
         bool fits = true;
         for (uint32_t gq = 0; gq < fp->n_slots; ++gq) {
@@ -1163,10 +1211,10 @@ static bool create_range(const flatgfa_dev_graph_t &g, const uint32_t *hb, const
             fp->bucket_records = (slots + fp->n_slots) * (uint64_t)fp->cap;
         } else {
             FAST_TRY(hipMalloc(&fp->buckets, std::max<uint64_t>(total, 64) * 4));
-            FAST_TRY(hipMemcpy(fp->pk_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
-            FAST_TRY(hipMemcpy(fp->pk_base, base.data(), base.size() * 8, hipMemcpyHostToDevice));
+            FAST_TRY(plan_memcpy(fp->pk_off, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+            FAST_TRY(plan_memcpy(fp->pk_base, base.data(), base.size() * 8, hipMemcpyHostToDevice));
             FAST_TRY(hipMalloc(&fp->pk, slots * sizeof(uint2)));
-            FAST_TRY(hipMemcpy(fp->pk, pk.data(), slots * sizeof(uint2), hipMemcpyHostToDevice));
+            FAST_TRY(plan_memcpy(fp->pk, pk.data(), slots * sizeof(uint2), hipMemcpyHostToDevice));
             fp->cap = (uint32_t)std::max<uint64_t>(deepest, 4);  // (what describe() reports: the deepest sub-bucket)
             fp->bucket_records = total;
         }
@@ -1223,6 +1271,7 @@ static bool fast_plan_create_impl(const flatgfa_dev_graph_t &g, const uint32_t *
 bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *hb, const uint32_t *he, FastPlan *fp, uint32_t scan_workgroups, bool prefer_packed) {
     t_scan_workgroups = scan_workgroups;
     t_prefer_packed = prefer_packed;
+    TempScope temporaries;  // (what the ranges' creation takes from the thread's arena is taken back when the next plan is made)
     const bool ok = fast_plan_create_impl(g, hb, he, fp);
     t_scan_workgroups = 0;
     t_prefer_packed = false;
@@ -1254,7 +1303,7 @@ static bool fast_plan_create_impl(const flatgfa_dev_graph_t &g, const uint32_t *
         groups_ok = want_groups != 0;
         want_groups = std::max(1u, std::min(64u, want_groups));
     }
-    std::vector<uint32_t> busy;  // the paths that have steps
+    Vec<uint32_t> busy;  // the paths that have steps
     for (uint32_t p = 0; p < g.n_paths; ++p)
         if (he[p] > hb[p]) busy.push_back(p);
     // (max_win, force_wb) by preference: 4096 windows of the graph's own size; the same with 4096-segment
@@ -1360,7 +1409,7 @@ static bool fast_plan_create_impl(const flatgfa_dev_graph_t &g, const uint32_t *
             n_groups = std::max(n_groups, 2u);
             for (; n_groups <= 64 && n_groups <= busy.size(); n_groups *= 2) {
                 bool g_all = true, g_many = false, hip_ok = true;
-                std::vector<uint32_t> hbk(g.n_paths), hek(g.n_paths);
+                Vec<uint32_t> hbk(g.n_paths), hek(g.n_paths);
                 for (uint32_t k = 0; k < n_groups && g_all && hip_ok; ++k) {
                     const size_t lo = busy.size() * k / n_groups, hi = busy.size() * (k + 1) / n_groups;
                     for (uint32_t p = 0; p < g.n_paths; ++p) hbk[p] = hek[p] = hb[p];  // (a path outside the group: no steps)
@@ -1469,7 +1518,7 @@ void fast_marks_finish(FastPlan *fp, MarksJob *job) {
     if (!job->active) return;
     unsigned long long cnt[4] = {0, 0, 0, 0};
     hipError_t e = hipEventSynchronize(job->done);
-    if (e == hipSuccess) e = hipMemcpy(cnt, job->cnt, 32, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = plan_memcpy(cnt, job->cnt, 32, hipMemcpyDeviceToHost);
     const unsigned long long flagged = cnt[2];
     // (worth it from half of the chunks: pass 2's build with the no-claim test costs the claiming records 4 %, k_scan's with the
     // marks 1-10 % (short items most), and the claims are two fifths of pass 2 -- contigs of ten blocks with a third of
@@ -1611,7 +1660,7 @@ bool fast_plan_grow(FastPlan *fp, bool ahead_of_need) {
     const auto wants = [&](FastPlan *q) {
         if (!ahead_of_need || !q->taken) return true;
         uint32_t v = 0;
-        if (hipMemcpy(&v, q->taken + q->n_slots, 4, hipMemcpyDeviceToHost) != hipSuccess) return true;
+        if (plan_memcpy(&v, q->taken + q->n_slots, 4, hipMemcpyDeviceToHost) != hipSuccess) return true;
         if (v) (void)hipMemset(q->taken + q->n_slots, 0, 4);
         return v > (q->cap >> 1);
     };
@@ -1788,7 +1837,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
         constexpr size_t kRow = kTprofRow;
         std::vector<unsigned long long> raw(kRow * (size_t)fp.n_slots);
         (void)hipStreamSynchronize(stream);
-        (void)hipMemcpy(raw.data(), sa.tprof, raw.size() * 8, hipMemcpyDeviceToHost);
+        (void)plan_memcpy(raw.data(), sa.tprof, raw.size() * 8, hipMemcpyDeviceToHost);
         (void)hipFree(sa.tprof);
         unsigned long long t0 = ~0ull;
         for (uint32_t i = 0; i < grid; ++i) t0 = std::min(t0, raw[kRow * i]);
@@ -1823,7 +1872,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     if (aa.tprof) {  // diagnostic: where the waves of pass 2 spend their time
         std::vector<uint32_t> raw(tprof_words);
         (void)hipStreamSynchronize(stream);
-        (void)hipMemcpy(raw.data(), aa.tprof, tprof_words * 4, hipMemcpyDeviceToHost);
+        (void)plan_memcpy(raw.data(), aa.tprof, tprof_words * 4, hipMemcpyDeviceToHost);
         (void)hipFree(aa.tprof);
         const size_t waves = tprof_words / 16;
         double sum[16] = {}, mx[16] = {};
@@ -1840,7 +1889,7 @@ static int run_range(const FastPlan &fp, const flatgfa_dev_graph_t &g, uint32_t 
     if (fp.dbg & kDbgTime) {  // diagnostic: where the waves of k_scan spend their cycles
         unsigned long long acc[8] = {};
         (void)hipStreamSynchronize(stream);
-        (void)hipMemcpy(acc, status + 8, sizeof acc, hipMemcpyDeviceToHost);
+        (void)plan_memcpy(acc, status + 8, sizeof acc, hipMemcpyDeviceToHost);
         (void)hipMemset(status + 8, 0, sizeof acc);
         const double waves = (double)grid * kWaves;
         fprintf(stderr, "k_scan cycles per wave: wait_block %.0f  epoch_wait %.0f  passA+B %.0f  drain %.0f  other %.0f  item switch %.0f\n",

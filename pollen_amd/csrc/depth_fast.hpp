@@ -59,6 +59,7 @@ struct FastPlan {
     // plan is made, k_scan dealing its items in a fixed order from then on), a workgroup's sub-buckets back to back.
     uint64_t mall_steps = 0;       // the steps below this index are read without the nt hint: they stay in the Infinity Cache from call to call (plan_create decides)
     bool packed = false;
+    bool can_pack = false;         // create_range: the plan could have packed buckets (tagged, all records k_scan's, ...): whether making it again for them can lead anywhere
     uint32_t *pk_off = nullptr;    // u32[n_slots][n_win + 1] sub-bucket starts within the workgroup's region; the last entry is its sink
     uint64_t *pk_base = nullptr;   // u64[n_slots] where each workgroup's region starts
     void *pk = nullptr;            // uint2[n_win][n_slots] {start in the array, room} for pass 2

@@ -1665,7 +1665,7 @@ def test_counting_kernel_in_pieces_finds_the_same_facts(monkeypatch):
             plan = DepthPlan(graph, first=(d, u))
             # (what the sizing and timing runs decide -- which pass 1 was faster, how deep the fullest sub-bucket got with the items dealt
             # as they came -- is not the counting kernel's business)
-            seen[pieces] = re.sub(r" (pass1|bucket_cap|scratch_mb)=\S+", "", plan.describe())
+            seen[pieces] = re.sub(r" (pass1|bucket_cap|scratch_mb)=\S+|\(one-item shortcut\)| bitset_owners=tracked", "", plan.describe())
             assert (d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all(), (pieces, seen[pieces])
             plan.seg_depth(d, u)
             plan.status()
