@@ -137,6 +137,16 @@ int flatgfa_device_count(void);
  * maps or parses its graph (`fgfa` does); everything it does would otherwise happen inside the
  * first flatgfa_to_device.  Returns 0, or FLATGFA_ERR_NO_DEVICE / FLATGFA_ERR_HIP. */
 int flatgfa_warm_device(int device);
+/* Host memory policy of the PROCESS (glibc's malloc; a no-op elsewhere): with `on`, freed host memory stays with the process --
+ * nothing is unmapped, the heap is not trimmed -- instead of going back to the system.  Why a GPU library has this: on the
+ * amdgpu/KFD driver a process that unmaps host memory has its GPU queues quiesced and restored by a delayed work item, and
+ * the next kernel launch or copy then waits 10-30 ms (in steps of the kernel's timer tick; a second now and then) where it
+ * would take 0.1 -- measured: a first query 20 ms instead of 0.9, a plan over a million paths 49 ms instead of 12
+ * (profiles/NOTES.md R6.6c).  The library keeps its own large temporaries; what the host application frees around its
+ * queries -- a parsed GFA, result vectors, a table -- is the application's to keep, or this switch's.  Not applied by the
+ * library itself: `fgfa` and the Python package call it at start-up (FLATGFA_KEEP_HOST_MEMORY=0 in the environment keeps
+ * them from it).  Returns 0. */
+int flatgfa_keep_host_memory(int on);
 /* Copy the graph's structure-of-arrays image (steps, path spans, segment lengths) into the
  * HBM of `device` and keep it resident until flatgfa_free.  Depth calls do this lazily on
  * device 0 if it has not been done. */

@@ -52,6 +52,7 @@ SIGNATURES = {
     "flatgfa_find_path": (c_int64, [c_void_p, c_char_p, c_size_t]),
     "flatgfa_device_count": (c_int, []),
     "flatgfa_warm_device": (c_int, [c_int]),
+    "flatgfa_keep_host_memory": (c_int, [c_int]),
     "flatgfa_to_device": (c_int, [c_void_p, c_int]),
     "flatgfa_residency_ms": (c_int, [c_void_p, POINTER(c_double), POINTER(c_double)]),
     "flatgfa_seg_depth": (c_int, [c_void_p, c_void_p, c_void_p]),
@@ -124,6 +125,10 @@ def lib() -> ctypes.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = cdll
+    # Freed host memory stays with the process (include/flatgfa.h: flatgfa_keep_host_memory): on this driver a process that
+    # unmaps host memory pays 10-30 ms on its next kernel launch or copy.  FLATGFA_KEEP_HOST_MEMORY=0 leaves malloc as it is.
+    if os.environ.get("FLATGFA_KEEP_HOST_MEMORY", "1") != "0":
+        cdll.flatgfa_keep_host_memory(1)
     return _lib
 
 

@@ -16,8 +16,13 @@
 #include <thread>
 #include <vector>
 
+#include <malloc.h>
+
+#include <climits>
+
 #include "../../include/flatgfa.h"
 #include "device_common.hpp"
+#include "temp_arena.hpp"
 #include "flatgfa_core.hpp"
 
 using fgfa_dev::set_error;
@@ -74,6 +79,7 @@ struct CStore {
     bool first_answer = false;
     int first_rc = 0;
     std::vector<uint32_t> h_path_begin, h_path_end;
+    std::vector<uint32_t> h_soa;  // the host image of the small arrays (spans, segment lengths) that was uploaded: kept, not unmapped behind the upload
     flatgfa_dev_plan_t *plan = nullptr;
     hipStream_t stream = nullptr;
     // the prepared query of the last flatgfa_seg_depth_subset call, reused while the subset is the same
@@ -460,6 +466,17 @@ static hipError_t upload(void *dst, const void *src, size_t bytes, hipStream_t s
     return (hipError_t)failed.load();
 }
 
+int flatgfa_keep_host_memory(int on) {
+#ifdef __GLIBC__
+    // (never map: large blocks come from the heap and go back to its free lists; never trim: the heap's top stays)
+    (void)mallopt(M_MMAP_MAX, on ? 0 : 65536);
+    (void)mallopt(M_TRIM_THRESHOLD, on ? INT_MAX : 128 * 1024);
+#else
+    (void)on;
+#endif
+    return FLATGFA_OK;
+}
+
 int flatgfa_warm_device(int device) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -580,7 +597,7 @@ static int ensure_device(CStore *cs, int device) {
     tick("span arrays on the host (beside the upload)");
     if (P || S) {
         CAPI_HIP(hipMalloc(&im.small, (2 * Pa + 3 * Sa + 4 * Pa) * 4));  // (the last 4 * Pa words: two u64 sums per path)
-        CAPI_HIP(hipMemcpy(im.small, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+        CAPI_HIP(fgfa_dev::plan_memcpy(im.small, host.data(), host.size() * 4, hipMemcpyHostToDevice));  // (through pinned staging, like the steps: pages the runtime pins for a copy cost the next dispatch when the host drops them, NOTES R6.6c)
         im.pb = im.small;
         im.pe = im.small + Pa;
         im.seg_len = im.small + 2 * Pa;
@@ -611,6 +628,7 @@ static int ensure_device(CStore *cs, int device) {
     cs->d_sums = reinterpret_cast<uint64_t *>(im.sums);
     cs->h_path_begin.assign(h_pb, h_pb + P);
     cs->h_path_end.assign(h_pe, h_pe + P);
+    cs->h_soa.swap(host);  // (kept until the handle goes: four megabytes unmapped here would be ten milliseconds on the first query's copy)
     cs->plan = im.plan;
     cs->first_answer = S != 0;
     cs->first_rc = first_rc;
@@ -686,10 +704,19 @@ int flatgfa_seg_depth(flatgfa_t gfa, uint64_t *depth_out, uint64_t *uniq_out) {
     if (!uniq_out) return fetch_widen(gfa, gfa->d_depth, depth_out);
     const size_t S = gfa->view.segs.len;
     if (!S) return FLATGFA_OK;
-    return with_both_u32(gfa, [&](const uint32_t *d32, const uint32_t *u32) {  // widened on two threads: Vec<usize>
-        std::thread other([&] { for (size_t i = 0; i < S; ++i) uniq_out[i] = u32[i]; });
-        for (size_t i = 0; i < S; ++i) depth_out[i] = d32[i];
-        other.join();
+    return with_both_u32(gfa, [&](const uint32_t *d32, const uint32_t *u32) {  // widened to Vec<usize> on a few threads
+        // (the caller's vectors are as a rule fresh pages: 16 MB of first touches for a million segments, which is what the threads share)
+        const unsigned per = S >= (1u << 18) ? 4u : 1u;
+        std::vector<std::thread> others;
+        const auto widen = [&](unsigned k) {
+            const uint32_t *src = k < per ? d32 : u32;
+            uint64_t *dst = k < per ? depth_out : uniq_out;
+            const unsigned j = k % per;
+            for (size_t i = S * j / per, e = S * (j + 1) / per; i < e; ++i) dst[i] = src[i];
+        };
+        for (unsigned k = 1; k < 2 * per; ++k) others.emplace_back(widen, k);
+        widen(0);
+        for (auto &t : others) t.join();
         return (int)FLATGFA_OK;
     });
 }

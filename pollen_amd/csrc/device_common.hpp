@@ -5,7 +5,7 @@
 
 // Environment variables reach this library in two kinds.  The handful a user may set -- FLATGFA_DEPTH_PATH, FLATGFA_MALL_MB,
 // FLATGFA_PACKED, FLATGFA_BUCKET_GB, FLATGFA_UPLOAD_THREADS, FLATGFA_PARSE_THREADS, FLATGFA_TIMING, FLATGFA_CHECK_NO_CLAIM,
-// FLATGFA_SHARD_FORCE_RCCL, FLATGFA_NO_WARM: INTEGRATION.md section 6 -- are read with getenv where they apply; none of them
+// FLATGFA_SHARD_FORCE_RCCL, FLATGFA_NO_WARM, FLATGFA_KEEP_HOST_MEMORY (the CLI and the Python package): INTEGRATION.md section 6 -- are read with getenv where they apply; none of them
 // changes a result.  Everything else is a TEST HOOK: the parity suite forces every device path of the shipped library
 // (tests/test_gpu_depth.py: `device_path`, tools/fuzz_gpu.py: ENVS) by shaping the plan -- piece sizes, window sizes, bucket
 // capacities, which kernel walks which path -- and reads two diagnostics (FLATGFA_SCAN_TIME, FLATGFA_ACC_TIME).  They go through

@@ -114,6 +114,8 @@ int main(int argc, char **argv) {
     bool pinned = false;
     for (const char *v : {"ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"}) pinned = pinned || getenv(v) != nullptr;
     if (wants_device && !pinned) (void)setenv("ROCR_VISIBLE_DEVICES", "0", 0);
+    // (freed host memory stays with the process: an unmapped buffer costs the next launch or copy 10-30 ms on this driver, flatgfa.h)
+    if (const char *k = getenv("FLATGFA_KEEP_HOST_MEMORY"); !(k && k[0] == '0')) (void)flatgfa_keep_host_memory(1);
     std::thread warm;
     if (wants_device && !getenv("FLATGFA_NO_WARM")) warm = std::thread([] { (void)flatgfa_warm_device(0); });
 
