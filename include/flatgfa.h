@@ -318,6 +318,11 @@ flatgfa_dev_plan_t *flatgfa_dev_plan_create_first(const flatgfa_dev_graph_t *g, 
                                                   const uint32_t *host_path_end, uint32_t *depth_out, uint32_t *uniq_out,
                                                   int *first_status);
 void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *plan);
+/* A plan that goes leaves its record buckets (the one large device allocation it had: half a gigabyte at cfg-L) with the library for
+ * the next plan of the device to take, because allocating and freeing gigabytes of device memory in a row is what the driver does worst
+ * (a plan made beside five that stay: 5 ms, or every other time 80-300 ms; with the array kept 4.8 ms every time).  One array per
+ * device, the largest seen, at most 8 GB.  This gives them back to the device; call it when no plan will be made for a while. */
+void flatgfa_dev_release_scratch(void);
 /* The step values (not the spans) of the plan's graph image were changed by the caller: waits for
  * `stream` (the plan's), then makes the plan's launch plan and scratch again from the steps as they
  * are -- which kernel walks which path, the reversed copies, which paths and blocks need no claim,

@@ -86,6 +86,7 @@ SIGNATURES = {
     "flatgfa_dev_plan_steps_changed": (c_int, [c_void_p, c_void_p]),
     "flatgfa_dev_pipeline_steps_changed": (c_int, [c_void_p]),
     "flatgfa_dev_plan_destroy": (None, [c_void_p]),
+    "flatgfa_dev_release_scratch": (None, []),
     "flatgfa_dev_plan_describe": (c_int, [c_void_p, c_char_p, c_int]),
     "flatgfa_dev_pipeline_create": (c_void_p, [POINTER(flatgfa_dev_graph_t), c_void_p, c_void_p, c_int]),
     "flatgfa_dev_pipeline_destroy": (None, [c_void_p]),

@@ -885,6 +885,8 @@ extern "C" int flatgfa_dev_plan_steps_changed(flatgfa_dev_plan_t *pl, void *stre
     return ok ? FLATGFA_OK : FLATGFA_ERR_HIP;
 }
 
+extern "C" void flatgfa_dev_release_scratch(void) { fgfa_dev::fast_release_scratch(); }
+
 extern "C" void flatgfa_dev_plan_destroy(flatgfa_dev_plan_t *pl) {
     if (!pl) return;
     plan_release_fast(pl);  // (pl->side is the device's, not the plan's: it stays)

@@ -47,6 +47,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstdio>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -394,6 +395,58 @@ __global__ __launch_bounds__(256) void k_block_flags(const uint4 *__restrict__ i
 // quarter of the device memory that is free, 64 GB at most (FLATGFA_BUCKET_GB; the diagnostic build
 // of k_scan keeps the 32-bit offsets).
 // Returns 1 when it is allocated, 0 when the capacity would be too small to be useful, -1 on a HIP error.
+// The bucket array of the last plan that went, kept per device for the next one that comes (flatgfa_dev_release_scratch gives it
+// back): allocating and freeing gigabytes of device memory in a row is what the driver does worst -- a plan made and dropped
+// beside five that stay took 5.4 ms or, every other time, 80-300 ms (tools/flow_probe2.py: all 4.8 ms with the array kept) --
+// and plans are made again in earnest: flatgfa_dev_plan_steps_changed, a pipeline's lanes, a handle per request.
+struct BucketCache {
+    uint32_t *p = nullptr;
+    uint64_t bytes = 0;
+};
+static BucketCache g_bucket_cache[64];
+static std::mutex g_bucket_cache_mu;
+static uint32_t *bucket_cache_take(uint64_t bytes) {
+    std::lock_guard<std::mutex> lk(g_bucket_cache_mu);
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return nullptr; }
+    BucketCache &c = g_bucket_cache[dev];
+    if (c.p && c.bytes >= bytes && c.bytes <= 2 * bytes) {  // (an array up to twice the size asked for will do: the capacity is a floor)
+        uint32_t *p = c.p;
+        c = BucketCache();
+        return p;
+    }
+    return nullptr;
+}
+static void bucket_cache_give(uint32_t *p, uint64_t bytes) {
+    uint32_t *drop = p;
+    {
+        std::lock_guard<std::mutex> lk(g_bucket_cache_mu);
+        int dev = -1;
+        hipPointerAttribute_t at;  // (the array's own device: the calling thread's current one may be another)
+        if (hipPointerGetAttributes(&at, p) == hipSuccess) dev = at.device;
+        if (dev >= 0 && dev < 64 && bytes <= (8ull << 30) && bytes >= g_bucket_cache[dev].bytes) {
+            drop = g_bucket_cache[dev].p;  // (the larger of the two stays)
+            g_bucket_cache[dev] = BucketCache{p, bytes};
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    if (drop) (void)hipFree(drop);
+}
+}  // namespace
+void fast_release_scratch() {
+    std::lock_guard<std::mutex> lk(g_bucket_cache_mu);
+    int cur = -1;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    for (int dev = 0; dev < 64; ++dev) {
+        if (!g_bucket_cache[dev].p) continue;
+        if (hipSetDevice(dev) == hipSuccess) (void)hipFree(g_bucket_cache[dev].p);
+        g_bucket_cache[dev] = BucketCache();
+    }
+    if (have) (void)hipSetDevice(cur);
+    (void)hipGetLastError();
+}
+namespace {
 int alloc_buckets(FastPlan *fp, uint64_t want_cap) {
     const uint64_t slots = (uint64_t)fp->n_win * fp->n_slots;
     uint64_t max_cap = ((1ull << 30) - 1) / ((uint64_t)(fp->n_win + 1) * fp->n_slots);
@@ -410,14 +463,14 @@ int alloc_buckets(FastPlan *fp, uint64_t want_cap) {
     cap &= cap >= 64 ? ~31ull : ~3ull;  // sub-buckets start on 128-byte lines: neighbours (other workgroups, other XCDs) never share one
     if (cap < 4) return 0;
     if (fp->buckets && cap <= fp->cap) return 1;  // (at its limit: the array stays as it is)
-    uint32_t *fresh = nullptr;
-    const hipError_t e = hipMalloc(&fresh, (slots + fp->n_slots) * cap * 4);  // (the new one first: a plan that cannot grow keeps what it has)
+    uint32_t *fresh = bucket_cache_take((slots + fp->n_slots) * cap * 4);
+    const hipError_t e = fresh ? hipSuccess : hipMalloc(&fresh, (slots + fp->n_slots) * cap * 4);  // (the new one first: a plan that cannot grow keeps what it has)
     if (e != hipSuccess) {
         (void)hipGetLastError();
         set_error(std::string("hipMalloc(buckets): ") + hipGetErrorString(e));
         return fp->buckets ? 1 : -1;
     }
-    if (fp->buckets) (void)hipFree(fp->buckets);
+    if (fp->buckets) bucket_cache_give(fp->buckets, (slots + fp->n_slots) * (uint64_t)fp->cap * 4);
     fp->buckets = fresh;
     fp->cap = (uint32_t)cap;
     return 1;
@@ -1675,6 +1728,10 @@ void fast_plan_destroy(FastPlan *fp) {
     for (uint32_t r = 0; r < fp->n_more; ++r) fast_plan_destroy(&fp->more[r]);
     delete[] fp->more;
     // (perm, elist, wave_off, fat_off and fat_woff lie in lists_slab)
+    if (fp->buckets && !fp->packed && fp->cap) {
+        bucket_cache_give(fp->buckets, ((uint64_t)fp->n_win + 1) * fp->n_slots * (uint64_t)fp->cap * 4);
+        fp->buckets = nullptr;
+    }
     for (void *p : {(void *)fp->counts, (void *)fp->counts0, (void *)fp->buckets, (void *)fp->dir, (void *)fp->islot, (void *)fp->lists_slab,
                     (void *)fp->items, (void *)fp->short_items,
                     (void *)fp->medium_items, (void *)fp->tiny_items, (void *)fp->rev_steps, (void *)fp->work_counter, (void *)fp->other_ids, (void *)fp->psum_part,

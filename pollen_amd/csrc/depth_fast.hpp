@@ -161,6 +161,8 @@ bool fast_plan_create(const flatgfa_dev_graph_t &g, const uint32_t *host_path_be
 void fast_plan_destroy(FastPlan *fp);
 // After a call whose records did not fit their sub-buckets (status bit 4): quadruple the capacity.
 // Returns false -- and marks the plan ineligible -- when that is not possible.
+// gives back the bucket arrays kept for the next plan (one per device)
+void fast_release_scratch();
 bool fast_plan_grow(FastPlan *fp, bool ahead_of_need = false);  // ahead_of_need: a plan that cannot grow stays eligible
 // Per-path sums of measure_path (depth.rs:116-131), accumulated by pass 2 of a seg_depth call for
 // the paths k_scan walks (plan.other_ids lists the rest): u64[n_paths] each, zeroed by the caller.

@@ -24,3 +24,10 @@ TOL = 64.0  # MiB: allocator slack, not a leak
 if seen[39] - seen[2] > TOL or after - seen[39] > TOL:
     print("LEAK: device memory grew by more than", TOL, "MiB")
     sys.exit(1)
+# the bucket array the library keeps for the next plan (include/flatgfa.h: flatgfa_dev_release_scratch) goes back on request
+dev._lib.lib().flatgfa_dev_release_scratch()
+released = used()
+print("after flatgfa_dev_release_scratch", round(released, 1), "MiB in use")
+if released > after:
+    print("flatgfa_dev_release_scratch gave nothing back")
+    sys.exit(1)
