@@ -1826,3 +1826,33 @@ def test_one_step_back_wherever_it_lies_keeps_a_path_from_going_without_claims(L
         plan.status()
         assert (d.cpu().numpy().view(np.uint32) == wd).all() and (u.cpu().numpy().view(np.uint32) == wu).all(), (pieces, desc)
         plan.close()
+
+
+def test_a_plan_that_goes_leaves_its_buckets_for_the_next_and_release_gives_them_back():
+    """flatgfa_dev_release_scratch (include/flatgfa.h): the bucket array of a destroyed plan stays with the library (device memory in use
+    does not drop), the next plan of the same graph takes it (no growth over ten plans made and dropped), and the release gives it back."""
+    from pollen_amd.device import DepthPlan, DeviceGraph, _lib
+    import torch
+    S = 1_000_000
+    g = pa.synth(9, S, 200, 50_000, "pangenome", False)
+    steps, pb, pe, _ = g.soa()
+    want_d, want_u = fo.seg_depth_with_uniq(pools_of(g))
+    graph = DeviceGraph(steps, pb, pe, S)
+    d = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    u = torch.zeros(S, dtype=torch.int32, device="cuda:0")
+    def used():
+        torch.cuda.synchronize()
+        f, t = torch.cuda.mem_get_info()
+        return (t - f) / 2**20
+    _lib.lib().flatgfa_dev_release_scratch()
+    base = used()
+    seen = []
+    for _ in range(10):
+        plan = DepthPlan(graph, first=(d, u))
+        assert (d.cpu().numpy().view(np.uint32) == want_d).all() and (u.cpu().numpy().view(np.uint32) == want_u).all()
+        plan.close()
+        seen.append(used())
+    assert seen[0] > base + 16, (base, seen)          # (the array stayed: tens of megabytes at this size)
+    assert max(seen) - min(seen) < 16, seen            # (and was taken again, not added to)
+    _lib.lib().flatgfa_dev_release_scratch()
+    assert used() < seen[-1] - 16, (base, seen, used())

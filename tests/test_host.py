@@ -424,3 +424,20 @@ def test_translate_prealloc_overflow_parse_errors_and_threads(tmp_path, monkeypa
     want = fo.dump_flatgfa_prealloc(fo.parse_gfa(odd), fo.estimate_toc(odd))
     pa.translate_prealloc(odd, out)
     assert open(out, "rb").read() == want
+
+
+def test_keep_host_memory_is_a_host_call_and_leaves_malloc_working():
+    """flatgfa_keep_host_memory (include/flatgfa.h) touches glibc's malloc parameters only -- no device -- and the Python package has
+    called it once at import; large buffers still come and go after it, on and off."""
+    import ctypes
+    from pollen_amd import _lib
+    lib = _lib.lib()
+    for on in (1, 0, 1):
+        assert lib.flatgfa_keep_host_memory(on) == 0
+        bufs = [bytearray(48 << 20) for _ in range(3)]   # (beyond any mmap threshold)
+        bufs[1][-1] = 7
+        assert bufs[1][-1] == 7
+        del bufs
+        g = pa.synth(3, 2000, 20, 300, "pangenome", False)
+        assert len(g.segments) == 2000
+        g.close()
